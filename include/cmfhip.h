@@ -1,0 +1,152 @@
+/*
+ * cmfhip.h -- C ABI of libcmfhip.so: the MI355X (gfx950) factor-update engine
+ * for collective matrix factorisation  X ~ f(U V^T),  Y ~ f(V Z^T).
+ *
+ * The reference (smn-ailab/PyCMF) has no FFI on this path: its seam is the
+ * Python solver object built at pycmf/cmf.py:437-451 and driven through
+ * `fit_iterative_update` (pycmf/cmf.py:454 -> pycmf/cmf_solvers.py:132-195),
+ * whose body is `update_step` (:172).  The closest thing to a native ABI is the
+ * (dead) Cython module pycmf/cmf_newton_solver.pyx (`_newton_update_left`
+ * :240-292, `_newton_update_V` :295-362).  The entry points below are what a
+ * binding for that seam needs; each cites the reference code it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a CMF_E* code; the message is
+ *     available from cmf_last_error() (thread-local).
+ *   - host matrices are caller-owned, any element strides (in elements), read
+ *     only unless stated.  Device state is owned by the context.
+ *   - arithmetic on the device is float32 (north_star); host I/O is float64
+ *     or float32.
+ *   - one context drives one GPU from one host thread; contexts are not
+ *     thread-safe.  With several GPUs use one process + one context per GPU
+ *     and the *_partials / *_apply pair around an all-reduce (section "sharded").
+ */
+#ifndef CMFHIP_H
+#define CMFHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cmf_ctx cmf_ctx;
+
+enum {
+    CMF_OK = 0,
+    CMF_EINVAL = 1,   /* bad argument / wrong call order            */
+    CMF_EHIP = 2,     /* a HIP runtime call failed                  */
+    CMF_ENOMEM = 3,   /* device or host allocation failed           */
+    CMF_ENODEV = 4,   /* no usable gfx950 device                    */
+    CMF_EUNSUPPORTED = 5
+};
+
+enum { CMF_U = 0, CMF_V = 1, CMF_Z = 2 };           /* factor selector          */
+enum { CMF_LINK_LINEAR = 0, CMF_LINK_LOGIT = 1 };   /* cmf_solvers.py:27-33     */
+enum { CMF_UPD_U = 1, CMF_UPD_V = 2, CMF_UPD_Z = 4 }; /* update_U/V/Z, :252-261 */
+enum { CMF_NN_U = 1, CMF_NN_V = 2, CMF_NN_Z = 4 };  /* *_non_negative, :321-326 */
+
+/* kernel classes for cmf_kernel_time() */
+enum {
+    CMF_K_GEMM_NN = 0,   /* C = A   B : X V, Y Z, F G          */
+    CMF_K_GEMM_TN = 1,   /* C = A^T B : X^T U, Y^T V, Grams    */
+    CMF_K_GEMM_NT = 2,   /* f(L R^T) - T : residual / error    */
+    CMF_K_ELEMWISE = 3,  /* slab sums, MU ratio, row updates   */
+    CMF_K_EIGEN = 4,     /* batched symmetric Jacobi           */
+    CMF_K_COUNT = 5
+};
+
+const char *cmf_last_error(void);
+int cmf_device_count(int *count);
+
+/* ---- context ---------------------------------------------------------- */
+/* `stream` is a hipStream_t the caller already owns (e.g. torch's current
+ * stream) or NULL for a context-private stream.                            */
+int cmf_ctx_create(cmf_ctx **out, int device, void *stream);
+int cmf_ctx_destroy(cmf_ctx *ctx);
+int cmf_sync(cmf_ctx *ctx);
+
+/* ---- problem ---------------------------------------------------------- */
+/* Local shard sizes: X is m x d, Y is d x p, factors have k columns.
+ * (pycmf/cmf_solvers.py:132-160 argument shapes).  Allocates device state. */
+int cmf_set_problem(cmf_ctx *ctx, int64_t m, int64_t d, int64_t p, int k);
+
+/* Dense uploads; element (i,j) is at ptr[i*rs + j*cs].  which: 0 = X, 1 = Y.
+ * Replaces the implicit "X, Y are ndarrays" of cmf_solvers.py:132.          */
+int cmf_set_data_f64(cmf_ctx *ctx, int which, const double *ptr, int64_t rs, int64_t cs);
+int cmf_set_data_f32(cmf_ctx *ctx, int which, const float *ptr, int64_t rs, int64_t cs);
+/* CSR upload (scipy layout), accept_sparse=('csr','csc') of pycmf/cmf.py:679;
+ * CSC is converted by the caller.                                            */
+int cmf_set_data_csr(cmf_ctx *ctx, int which, const int64_t *indptr, const int32_t *indices,
+                     const double *data, int64_t nnz);
+/* Synthetic |N(0,1)| fill on the device (counter-based; value of element
+ * (gi,gj) depends only on seed and its GLOBAL coordinates, so a shard can be
+ * generated in place): rows [row0,row0+rows) x cols [col0,col0+cols) of the
+ * global matrix land in the local matrix.  Used by bench.py.                 */
+int cmf_fill_data_synthetic(cmf_ctx *ctx, int which, uint64_t seed, int64_t row0, int64_t col0);
+int cmf_fill_factor_synthetic(cmf_ctx *ctx, int which, uint64_t seed, int64_t row0, double scale);
+/* read back a block of X or Y (tests) */
+int cmf_get_data_f32(cmf_ctx *ctx, int which, float *ptr, int64_t rs, int64_t cs);
+
+/* Factors (in/out, pycmf/cmf_solvers.py:195 "return U, V, Z" after in-place
+ * mutation :255,:259,:263,:324).                                             */
+int cmf_set_factor_f64(cmf_ctx *ctx, int which, const double *ptr, int64_t rs, int64_t cs);
+int cmf_get_factor_f64(cmf_ctx *ctx, int which, double *ptr, int64_t rs, int64_t cs);
+
+/* ---- MU solver: MUSolver.update_step, pycmf/cmf_solvers.py:248-263 ----- */
+int cmf_mu_step(cmf_ctx *ctx, double l1, double l2, int update_mask);
+
+/* sharded form: rank g holds rows of X/U and columns of
+ * Y/Z, V replicated.  buf is a DEVICE buffer of cmf_v_buf_elems() floats:
+ *   [ X_g^T U_g + Y_g Z_g  (d_pad x k_pad) | U_g^T U_g + Z_g^T Z_g (k_pad x k_pad) ]
+ * The caller all-reduces it (RCCL) between the two calls.
+ * cmf_solvers.py:242-246 (V numerator/denominator).                        */
+int cmf_v_buf_elems(cmf_ctx *ctx, int64_t *n);
+int cmf_mu_v_partials(cmf_ctx *ctx, float *dev_buf);
+int cmf_mu_v_apply(cmf_ctx *ctx, const float *dev_buf, double l1, double l2);
+int cmf_mu_uz_update(cmf_ctx *ctx, double l1, double l2, int update_mask);
+
+/* ---- Newton solver: NewtonSolver.update_step, cmf_solvers.py:510-522 --- */
+/* sample index lists (parity mode): for sg_ratio < 1 the caller passes the
+ * indices the reference would have drawn (cmf_solvers.py:328-344), row after
+ * row, as int32: u_idx[m][su] over d, z_idx[p][su] over d,
+ * vx_idx[d][sm] over m, vy_idx[d][sp] over p.  NULL when sg_ratio == 1.     */
+int cmf_newton_step(cmf_ctx *ctx, double alpha, double l1, double l2,
+                    int x_link, int y_link, int nn_mask, int update_mask,
+                    double hessian_pertubation, double sg_ratio,
+                    const int32_t *u_idx, const int32_t *z_idx,
+                    const int32_t *vx_idx, const int32_t *vy_idx);
+
+/* sharded Newton, linear links and sg_ratio == 1 only (same buffer shape as
+ * the MU pair: gradient partial | Gram partial).                            */
+int cmf_newton_uz_update(cmf_ctx *ctx, double alpha, double l1, double l2,
+                         int nn_mask, int update_mask, double hessian_pertubation);
+int cmf_newton_v_partials(cmf_ctx *ctx, double alpha, float *dev_buf);
+int cmf_newton_v_apply(cmf_ctx *ctx, const float *dev_buf, double l1, double l2,
+                       int nn_mask, double hessian_pertubation);
+
+/* ---- error metric: compute_factorization_error, cmf_solvers.py:36-42 --- */
+/* squared Frobenius residuals of the local shard:
+ *   *ex2 = ||X - f(U V^T)||^2, *ey2 = ||Y - f(V Z^T)||^2                    */
+int cmf_residual_sq(cmf_ctx *ctx, int x_link, int y_link, double *ex2, double *ey2);
+int cmf_data_sq(cmf_ctx *ctx, double *x2, double *y2);  /* ||X||^2, ||Y||^2 */
+
+/* ---- batched safe inverse (exposed for tests): _safe_invert :346-356 --- */
+/* H: n symmetric k x k float64 matrices (host), out: Q diag(1/max(|l|,pert)) Q^T */
+int cmf_safe_invert_batch(cmf_ctx *ctx, const double *H, double *out, int n, int k, double pert);
+
+/* ---- measurement ------------------------------------------------------ */
+/* when enabled every kernel launch is bracketed by hipEvents on the context's
+ * stream; cmf_kernel_time returns accumulated ms and launch count per class. */
+int cmf_kernel_timing(cmf_ctx *ctx, int enable);
+int cmf_kernel_time(cmf_ctx *ctx, int kernel_class, double *ms, int64_t *launches);
+int cmf_kernel_timing_reset(cmf_ctx *ctx);
+/* padded device geometry (m_pad, d_pad, p_pad, k_pad) */
+int cmf_get_geometry(cmf_ctx *ctx, int64_t *m_pad, int64_t *d_pad, int64_t *p_pad, int *k_pad);
+/* device pointers of the factor blocks (float32, row-major, ld = k_pad) */
+int cmf_factor_dev_ptr(cmf_ctx *ctx, int which, float **ptr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMFHIP_H */

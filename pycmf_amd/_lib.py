@@ -1,0 +1,258 @@
+"""ctypes binding of libcmfhip.so (C ABI in include/cmfhip.h).
+
+There is deliberately no CPU fallback: if the shared library has not been built
+or no MI355X is visible, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcmfhip.so")
+
+CMF_U, CMF_V, CMF_Z = 0, 1, 2
+LINKS = {"linear": 0, "logit": 1}
+UPD_U, UPD_V, UPD_Z = 1, 2, 4
+K_GEMM_NN, K_GEMM_TN, K_GEMM_NT, K_ELEMWISE, K_EIGEN = 0, 1, 2, 3, 4
+KERNEL_CLASSES = {"gemm_nn": 0, "gemm_tn": 1, "gemm_nt": 2, "elementwise": 3, "eigen": 4}
+
+_ERR = {1: ValueError, 2: RuntimeError, 3: MemoryError, 4: RuntimeError, 5: NotImplementedError}
+
+_i64, _i32, _dbl, _vp = C.c_int64, C.c_int, C.c_double, C.c_void_p
+_pd = C.POINTER(C.c_double)
+_pf = C.POINTER(C.c_float)
+_pi32 = C.POINTER(C.c_int32)
+_pi64 = C.POINTER(C.c_int64)
+
+# name -> (argtypes) ; every function returns int except cmf_last_error
+PROTOTYPES = {
+    "cmf_device_count": [C.POINTER(C.c_int)],
+    "cmf_ctx_create": [C.POINTER(_vp), _i32, _vp],
+    "cmf_ctx_destroy": [_vp],
+    "cmf_sync": [_vp],
+    "cmf_set_problem": [_vp, _i64, _i64, _i64, _i32],
+    "cmf_set_data_f64": [_vp, _i32, _pd, _i64, _i64],
+    "cmf_set_data_f32": [_vp, _i32, _pf, _i64, _i64],
+    "cmf_set_data_csr": [_vp, _i32, _pi64, _pi32, _pd, _i64],
+    "cmf_fill_data_synthetic": [_vp, _i32, C.c_uint64, _i64, _i64],
+    "cmf_fill_factor_synthetic": [_vp, _i32, C.c_uint64, _i64, _dbl],
+    "cmf_get_data_f32": [_vp, _i32, _pf, _i64, _i64],
+    "cmf_set_factor_f64": [_vp, _i32, _pd, _i64, _i64],
+    "cmf_get_factor_f64": [_vp, _i32, _pd, _i64, _i64],
+    "cmf_mu_step": [_vp, _dbl, _dbl, _i32],
+    "cmf_v_buf_elems": [_vp, _pi64],
+    "cmf_mu_v_partials": [_vp, _vp],
+    "cmf_mu_v_apply": [_vp, _vp, _dbl, _dbl],
+    "cmf_mu_uz_update": [_vp, _dbl, _dbl, _i32],
+    "cmf_newton_step": [_vp, _dbl, _dbl, _dbl, _i32, _i32, _i32, _i32, _dbl, _dbl,
+                        _pi32, _pi32, _pi32, _pi32],
+    "cmf_newton_uz_update": [_vp, _dbl, _dbl, _dbl, _i32, _i32, _dbl],
+    "cmf_newton_v_partials": [_vp, _dbl, _vp],
+    "cmf_newton_v_apply": [_vp, _vp, _dbl, _dbl, _i32, _dbl],
+    "cmf_residual_sq": [_vp, _i32, _i32, _pd, _pd],
+    "cmf_data_sq": [_vp, _pd, _pd],
+    "cmf_safe_invert_batch": [_vp, _pd, _pd, _i32, _i32, _dbl],
+    "cmf_kernel_timing": [_vp, _i32],
+    "cmf_kernel_time": [_vp, _i32, _pd, _pi64],
+    "cmf_kernel_timing_reset": [_vp],
+    "cmf_get_geometry": [_vp, _pi64, _pi64, _pi64, C.POINTER(C.c_int)],
+    "cmf_factor_dev_ptr": [_vp, _i32, C.POINTER(_pf)],
+}
+
+_lib = None
+
+
+def load():
+    """Load libcmfhip.so (once) and attach prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "pycmf_amd: %s is missing -- build it with `python -m pycmf_amd.build` "
+            "(hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.cmf_last_error.restype = C.c_char_p
+    lib.cmf_last_error.argtypes = []
+    for name, args in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().cmf_last_error().decode("utf-8", "replace")
+        raise _ERR.get(rc, RuntimeError)("libcmfhip: " + msg)
+
+
+def device_count():
+    n = C.c_int(0)
+    check(load().cmf_device_count(C.byref(n)))
+    return n.value
+
+
+def _strides(a):
+    return a.strides[0] // a.itemsize, a.strides[1] // a.itemsize
+
+
+class Context:
+    """Owns one cmf_ctx (one GPU).  Thin, typed wrapper over the C ABI."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = load()
+        self._h = _vp()
+        check(self._lib.cmf_ctx_create(C.byref(self._h), int(device), _vp(stream or 0)))
+        self.shape = None
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            self._lib.cmf_ctx_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- problem / data
+    def set_problem(self, m, d, p, k):
+        check(self._lib.cmf_set_problem(self._h, m, d, p, k))
+        self.shape = (int(m), int(d), int(p), int(k))
+
+    def set_data(self, which, A):
+        """Upload X (which=0) or Y (which=1): ndarray (any strides) or scipy CSR/CSC."""
+        import scipy.sparse as sp
+        if sp.issparse(A):
+            A = A.tocsr()
+            A.sum_duplicates()
+            indptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+            indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+            data = np.ascontiguousarray(A.data, dtype=np.float64)
+            check(self._lib.cmf_set_data_csr(self._h, which, indptr.ctypes.data_as(_pi64),
+                                             indices.ctypes.data_as(_pi32),
+                                             data.ctypes.data_as(_pd), A.nnz))
+            return
+        A = np.asarray(A)
+        if A.dtype == np.float32:
+            rs, cs = _strides(A)
+            check(self._lib.cmf_set_data_f32(self._h, which, A.ctypes.data_as(_pf), rs, cs))
+        else:
+            A = A if A.dtype == np.float64 else A.astype(np.float64)
+            rs, cs = _strides(A)
+            check(self._lib.cmf_set_data_f64(self._h, which, A.ctypes.data_as(_pd), rs, cs))
+
+    def get_data(self, which):
+        m, d, p, _ = self.shape
+        out = np.empty((m, d) if which == 0 else (d, p), dtype=np.float32)
+        check(self._lib.cmf_get_data_f32(self._h, which, out.ctypes.data_as(_pf), out.shape[1], 1))
+        return out
+
+    def fill_data_synthetic(self, which, seed, row0=0, col0=0):
+        check(self._lib.cmf_fill_data_synthetic(self._h, which, seed, row0, col0))
+
+    def fill_factor_synthetic(self, which, seed, row0=0, scale=1.0):
+        check(self._lib.cmf_fill_factor_synthetic(self._h, which, seed, row0, scale))
+
+    def set_factor(self, which, F):
+        F = np.asarray(F)
+        if F.dtype != np.float64:
+            F = F.astype(np.float64)
+        rs, cs = _strides(F)
+        check(self._lib.cmf_set_factor_f64(self._h, which, F.ctypes.data_as(_pd), rs, cs))
+
+    def get_factor_into(self, which, F):
+        """Write the device factor back into the caller's float64 array, in place."""
+        assert F.dtype == np.float64
+        rs, cs = _strides(F)
+        check(self._lib.cmf_get_factor_f64(self._h, which, F.ctypes.data_as(_pd), rs, cs))
+
+    def get_factor(self, which):
+        m, d, p, k = self.shape
+        out = np.empty(((m, d, p)[which], k))
+        self.get_factor_into(which, out)
+        return out
+
+    # ---- MU
+    def mu_step(self, l1, l2, mask=7):
+        check(self._lib.cmf_mu_step(self._h, l1, l2, mask))
+
+    def v_buf_elems(self):
+        n = C.c_int64(0)
+        check(self._lib.cmf_v_buf_elems(self._h, C.byref(n)))
+        return n.value
+
+    def mu_v_partials(self, dev_ptr):
+        check(self._lib.cmf_mu_v_partials(self._h, _vp(dev_ptr)))
+
+    def mu_v_apply(self, dev_ptr, l1, l2):
+        check(self._lib.cmf_mu_v_apply(self._h, _vp(dev_ptr), l1, l2))
+
+    def mu_uz_update(self, l1, l2, mask=7):
+        check(self._lib.cmf_mu_uz_update(self._h, l1, l2, mask))
+
+    # ---- Newton
+    def newton_step(self, alpha, l1, l2, x_link, y_link, nn_mask, upd_mask, pert, ratio,
+                    u_idx=None, z_idx=None, vx_idx=None, vy_idx=None):
+        def ptr(a):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.int32)
+            self._keep.append(a)
+            return a.ctypes.data_as(_pi32)
+        self._keep = []
+        check(self._lib.cmf_newton_step(self._h, alpha, l1, l2, LINKS[x_link], LINKS[y_link],
+                                        nn_mask, upd_mask, pert, ratio,
+                                        ptr(u_idx), ptr(z_idx), ptr(vx_idx), ptr(vy_idx)))
+        self._keep = []
+
+    def newton_uz_update(self, alpha, l1, l2, nn_mask, upd_mask, pert):
+        check(self._lib.cmf_newton_uz_update(self._h, alpha, l1, l2, nn_mask, upd_mask, pert))
+
+    def newton_v_partials(self, alpha, dev_ptr):
+        check(self._lib.cmf_newton_v_partials(self._h, alpha, _vp(dev_ptr)))
+
+    def newton_v_apply(self, dev_ptr, l1, l2, nn_mask, pert):
+        check(self._lib.cmf_newton_v_apply(self._h, _vp(dev_ptr), l1, l2, nn_mask, pert))
+
+    # ---- metrics
+    def residual_sq(self, x_link="linear", y_link="linear"):
+        ex, ey = C.c_double(0), C.c_double(0)
+        check(self._lib.cmf_residual_sq(self._h, LINKS[x_link], LINKS[y_link], C.byref(ex), C.byref(ey)))
+        return ex.value, ey.value
+
+    def data_sq(self):
+        x2, y2 = C.c_double(0), C.c_double(0)
+        check(self._lib.cmf_data_sq(self._h, C.byref(x2), C.byref(y2)))
+        return x2.value, y2.value
+
+    def safe_invert_batch(self, H, pert):
+        H = np.ascontiguousarray(H, dtype=np.float64)
+        n, k, _ = H.shape
+        out = np.empty_like(H)
+        check(self._lib.cmf_safe_invert_batch(self._h, H.ctypes.data_as(_pd), out.ctypes.data_as(_pd), n, k, pert))
+        return out
+
+    def sync(self):
+        check(self._lib.cmf_sync(self._h))
+
+    def kernel_timing(self, enable):
+        check(self._lib.cmf_kernel_timing(self._h, 1 if enable else 0))
+
+    def kernel_timing_reset(self):
+        check(self._lib.cmf_kernel_timing_reset(self._h))
+
+    def kernel_time(self, cls):
+        ms, n = C.c_double(0), C.c_int64(0)
+        check(self._lib.cmf_kernel_time(self._h, KERNEL_CLASSES.get(cls, cls), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def geometry(self):
+        a, b, c_, k = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int(0)
+        check(self._lib.cmf_get_geometry(self._h, C.byref(a), C.byref(b), C.byref(c_), C.byref(k)))
+        return a.value, b.value, c_.value, k.value

@@ -1,0 +1,55 @@
+"""Build libcmfhip.so (gfx950 only) in-tree with hipcc.
+
+    python -m pycmf_amd.build [--force] [--verbose]
+
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only build
+container.  The .so stays next to this file (git-ignored) so that it travels
+with the working tree to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libcmfhip.so")
+SOURCES = ["cmf_api.hip"]
+DEPS = ["cmf_api.hip", "cmf_kernels.hip.h", "cmf_newton.hip.h", "cmf_eigen.hip.h",
+        os.path.join(ROOT, "include", "cmfhip.h")]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; libcmfhip.so cannot be built")
+    return exe
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    for d in DEPS:
+        p = d if os.path.isabs(d) else os.path.join(CSRC, d)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I", os.path.join(ROOT, "include"), "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
+    print(LIB)

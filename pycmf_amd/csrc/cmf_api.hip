@@ -1,0 +1,737 @@
+// cmf_api.hip -- C ABI (include/cmfhip.h) over the gfx950 kernels.
+// Host-side orchestration of the alternating U/V/Z factor updates
+// (reference: pycmf/cmf_solvers.py:248-263 MU, :510-522 Newton, :36-42 error).
+#include "../../include/cmfhip.h"
+#include "cmf_kernels.hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace cmfk;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? CMF_ENOMEM : CMF_EHIP, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                 \
+    } while (0)
+#define CHK(expr)                 \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != CMF_OK) return rc_; \
+    } while (0)
+
+static inline int64_t rup(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct EvPair {
+    hipEvent_t a, b;
+    int cls;
+};
+
+struct cmf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 256;
+
+    int64_t m = 0, d = 0, p = 0;
+    int k = 0;
+    int64_t mp = 0, dp = 0, pp = 0;
+    int kp = 0;
+    bool have_problem = false;
+
+    float *X = nullptr, *Y = nullptr; // dense, row-major, ld = dp / pp
+    float *F[3] = {nullptr, nullptr, nullptr};
+    int64_t frows[3] = {0, 0, 0}, frows_pad[3] = {0, 0, 0};
+
+    // workspaces
+    float *num = nullptr, *den = nullptr; // max(mp,dp,pp) x kp
+    float *G = nullptr, *G2 = nullptr, *Hm = nullptr, *Hinv = nullptr; // kp x kp
+    float *vbuf = nullptr;                // dp*kp + kp*kp
+    DevBuf slabs;                         // split-K partial tiles (grow-only)
+    DevBuf resid;                         // Newton residual / weights scratch (grow-only)
+    DevBuf resid2;
+    DevBuf dpart;                         // double partial sums
+    double *dscalar = nullptr;            // 4 doubles
+    std::vector<void *> owned;
+
+    // timing
+    bool timing = false;
+    std::vector<EvPair> pending;
+    std::vector<hipEvent_t> evpool;
+    double ms[CMF_K_COUNT] = {0};
+    int64_t launches[CMF_K_COUNT] = {0};
+};
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        (void)hipGetDevice(&prev);
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// ------------------------------------------------------------------ timing helpers
+static int ev_get(cmf_ctx *c, hipEvent_t *e) {
+    if (!c->evpool.empty()) {
+        *e = c->evpool.back();
+        c->evpool.pop_back();
+        return CMF_OK;
+    }
+    HIPCHK(hipEventCreate(e));
+    return CMF_OK;
+}
+struct Timed {
+    cmf_ctx *c;
+    int cls;
+    hipEvent_t a = nullptr, b = nullptr;
+    bool on = false;
+    Timed(cmf_ctx *c_, int cls_) : c(c_), cls(cls_) {
+        if (c->timing && ev_get(c, &a) == CMF_OK && ev_get(c, &b) == CMF_OK) {
+            on = true;
+            (void)hipEventRecord(a, c->stream);
+        }
+    }
+    ~Timed() {
+        if (on) {
+            (void)hipEventRecord(b, c->stream);
+            c->pending.push_back({a, b, cls});
+        } else {
+            c->launches[cls] += 0;
+        }
+    }
+};
+static int flush_timing(cmf_ctx *c) {
+    if (c->pending.empty()) return CMF_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto &e : c->pending) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+        c->ms[e.cls] += ms;
+        c->launches[e.cls] += 1;
+        c->evpool.push_back(e.a);
+        c->evpool.push_back(e.b);
+    }
+    c->pending.clear();
+    return CMF_OK;
+}
+
+// ------------------------------------------------------------------ memory helpers
+static int dev_alloc(cmf_ctx *c, void **p, size_t bytes, bool zero = true) {
+    HIPCHK(hipMalloc(p, bytes ? bytes : 16));
+    c->owned.push_back(*p);
+    if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes ? bytes : 16, c->stream));
+    return CMF_OK;
+}
+static void dev_free(cmf_ctx *c, void *p) {
+    if (!p) return;
+    auto it = std::find(c->owned.begin(), c->owned.end(), p);
+    if (it != c->owned.end()) c->owned.erase(it);
+    (void)hipFree(p);
+}
+static int ensure(cmf_ctx *c, DevBuf &b, size_t bytes) {
+    if (b.bytes >= bytes) return CMF_OK;
+    if (b.p) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        dev_free(c, b.p);
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    CHK(dev_alloc(c, &b.p, bytes, false));
+    b.bytes = bytes;
+    return CMF_OK;
+}
+
+// ------------------------------------------------------------------ GEMM launcher
+struct GemmPlan {
+    int bn;
+    int ntiles_n;
+    int64_t tiles_m;
+    int nsplit;
+    int64_t klen;
+};
+
+static GemmPlan plan_gemm(const cmf_ctx *c, int64_t mout, int64_t n, int64_t kred, bool allow_split) {
+    GemmPlan pl;
+    pl.bn = n >= 256 ? 256 : (int)n; // n in {32,64,128} or a multiple of 256
+    pl.ntiles_n = (int)(n / pl.bn);
+    pl.tiles_m = (mout + 255) / 256;
+    const int64_t tiles = pl.tiles_m * pl.ntiles_n;
+    int64_t s = 1;
+    if (allow_split && tiles < (int64_t)(c->num_cu * 3) / 4) {
+        s = (c->num_cu + tiles / 2) / tiles;
+        const int64_t maxs = std::max<int64_t>(1, kred / 128);
+        s = std::max<int64_t>(1, std::min(s, maxs));
+    }
+    pl.klen = rup((kred + s - 1) / s, 32);
+    pl.nsplit = (int)((kred + pl.klen - 1) / pl.klen);
+    return pl;
+}
+
+template <int MODE>
+static int launch_gemm_mode(cmf_ctx *c, const GemmArgs &a, const GemmPlan &pl) {
+    dim3 grid((unsigned)pl.tiles_m, (unsigned)pl.ntiles_n, (unsigned)pl.nsplit);
+    dim3 block(512);
+#define CMF_LAUNCH(BN_)                                                                          \
+    do {                                                                                         \
+        using Cfg = GemmCfg<MODE, BN_>;                                                          \
+        static bool attr_set = false;                                                            \
+        if (!attr_set) {                                                                         \
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<MODE, BN_>),  \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,               \
+                                       (int)Cfg::LDS_BYTES));                                    \
+            attr_set = true;                                                                     \
+        }                                                                                        \
+        hipLaunchKernelGGL((gemm_kernel<MODE, BN_>), grid, block, Cfg::LDS_BYTES, c->stream, a); \
+    } while (0)
+    if constexpr (MODE == MODE_NT) {
+        if (pl.bn != 128) return fail(CMF_EINVAL, "NT tile width must be 128");
+        CMF_LAUNCH(128);
+    } else {
+        switch (pl.bn) {
+        case 256: CMF_LAUNCH(256); break;
+        case 128: CMF_LAUNCH(128); break;
+        case 64: CMF_LAUNCH(64); break;
+        case 32: CMF_LAUNCH(32); break;
+        default: return fail(CMF_EINVAL, "unsupported tile width %d", pl.bn);
+        }
+    }
+#undef CMF_LAUNCH
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
+static int sum_slabs(cmf_ctx *c, float *dst, const float *src, int64_t n, int nslab, int64_t stride,
+                     bool accumulate) {
+    Timed tm(c, CMF_K_ELEMWISE);
+    const int64_t n4 = n / 4;
+    const int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 2048);
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, c->stream, dst, src, n4, nslab, stride,
+                       accumulate ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
+// C[mout x n] (+)= op(A) * B.  mode NN: A is [mout_pad x kred]; TN: A is [kred x >=mout].
+// Result lands in `out` (ld = n); split-K partials go through the slab workspace.
+static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *B, int64_t ldb, float *out,
+                int64_t mout, int64_t n, int64_t kred, bool accumulate = false) {
+    if (kred % 32 || n % 32) return fail(CMF_EINVAL, "gemm: unpadded extent (k=%lld n=%lld)", (long long)kred, (long long)n);
+    GemmPlan pl = plan_gemm(c, mout, n, kred, true);
+    GemmArgs a;
+    memset(&a, 0, sizeof a);
+    a.A = A; a.lda = lda; a.B = B; a.ldb = ldb;
+    a.ldc = n;
+    a.Mout = (mode == MODE_TN) ? mout : rup(mout, 256);
+    a.Kred = kred; a.klen = pl.klen;
+    const int64_t rows_store = (mode == MODE_TN) ? mout : rup(mout, 256);
+    const bool direct = (pl.nsplit == 1 && !accumulate);
+    if (direct) {
+        a.C = out;
+        a.slab_stride = 0;
+    } else {
+        const size_t need = (size_t)pl.nsplit * rows_store * n * sizeof(float);
+        CHK(ensure(c, c->slabs, need));
+        a.C = (float *)c->slabs.p;
+        a.slab_stride = rows_store * n;
+    }
+    {
+        Timed tm(c, mode == MODE_NN ? CMF_K_GEMM_NN : CMF_K_GEMM_TN);
+        if (mode == MODE_NN) CHK(launch_gemm_mode<MODE_NN>(c, a, pl));
+        else CHK(launch_gemm_mode<MODE_TN>(c, a, pl));
+    }
+    if (!direct) CHK(sum_slabs(c, out, (const float *)c->slabs.p, rows_store * n, pl.nsplit, a.slab_stride, accumulate));
+    return CMF_OK;
+}
+
+struct NtOut {
+    const float *T = nullptr; int64_t ldt = 0;
+    float *R = nullptr; float *W = nullptr; int64_t ldr = 0;
+    const uint8_t *mask = nullptr; int64_t ldm = 0;
+    double *sq = nullptr; // device scalar receiving the total
+    float scale_r = 1.f, scale_w = 1.f;
+    int link = 0, w_is_slope = 0;
+};
+
+// S = L[rows x kp] * Rt[cols x kp]^T with fused epilogue
+static int gemm_nt(cmf_ctx *c, const float *L, int64_t rows_pad, int64_t rows_valid, const float *Rt,
+                   int64_t cols_pad, int64_t cols_valid, const NtOut &o) {
+    GemmPlan pl;
+    pl.bn = 128; pl.ntiles_n = (int)(cols_pad / 128); pl.tiles_m = rows_pad / 256; pl.nsplit = 1; pl.klen = c->kp;
+    GemmArgs a;
+    memset(&a, 0, sizeof a);
+    a.A = L; a.lda = c->kp; a.B = Rt; a.ldb = c->kp;
+    a.Kred = c->kp; a.klen = c->kp; a.Mout = rows_pad;
+    a.T = o.T; a.ldt = o.ldt; a.R = o.R; a.W = o.W; a.ldr = o.ldr; a.mask = o.mask; a.ldm = o.ldm;
+    a.Mvalid = rows_valid; a.Nvalid = cols_valid;
+    a.scale_r = o.scale_r; a.scale_w = o.scale_w; a.link = o.link; a.w_is_slope = o.w_is_slope;
+    const int64_t nwg = pl.tiles_m * pl.ntiles_n;
+    if (o.sq) {
+        CHK(ensure(c, c->dpart, (size_t)nwg * sizeof(double)));
+        a.sq_out = (double *)c->dpart.p;
+    }
+    {
+        Timed tm(c, CMF_K_GEMM_NT);
+        CHK(launch_gemm_mode<MODE_NT>(c, a, pl));
+    }
+    if (o.sq) {
+        Timed tm(c, CMF_K_ELEMWISE);
+        hipLaunchKernelGGL(sum_doubles_kernel, dim3(1), dim3(256), 0, c->stream, (const double *)c->dpart.p, nwg, o.sq);
+        HIPCHK(hipGetLastError());
+    }
+    return CMF_OK;
+}
+
+static int mu_apply(cmf_ctx *c, float *F, const float *num, const float *den, int64_t n, double l1, double l2) {
+    Timed tm(c, CMF_K_ELEMWISE);
+    const int64_t n4 = n / 4;
+    const int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 2048);
+    hipLaunchKernelGGL(mu_apply_kernel, dim3(blocks), dim3(256), 0, c->stream, F, num, den, n4, (float)l1, (float)l2,
+                       1.1920928955078125e-07f);
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
+// ------------------------------------------------------------------ C ABI: basics
+extern "C" const char *cmf_last_error(void) { return g_err.c_str(); }
+
+extern "C" int cmf_device_count(int *count) {
+    if (!count) return fail(CMF_EINVAL, "null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return CMF_OK;
+}
+
+extern "C" int cmf_ctx_create(cmf_ctx **out, int device, void *stream) {
+    if (!out) return fail(CMF_EINVAL, "null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(CMF_ENODEV, "no HIP device visible: libcmfhip needs an MI355X (gfx950); there is no CPU fallback");
+    if (device < 0 || device >= n) return fail(CMF_EINVAL, "device %d out of range (have %d)", device, n);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(CMF_ENODEV, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+    cmf_ctx *c = new cmf_ctx();
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            return fail(CMF_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        }
+        c->own_stream = true;
+    }
+    void *ds = nullptr;
+    int rc = dev_alloc(c, &ds, 8 * sizeof(double));
+    if (rc != CMF_OK) {
+        delete c;
+        return rc;
+    }
+    c->dscalar = (double *)ds;
+    *out = c;
+    return CMF_OK;
+}
+
+static void release_problem(cmf_ctx *c) {
+    (void)hipStreamSynchronize(c->stream);
+    for (void *p : c->owned)
+        if (p != (void *)c->dscalar) (void)hipFree(p);
+    c->owned.clear();
+    c->owned.push_back(c->dscalar);
+    c->X = c->Y = nullptr;
+    c->F[0] = c->F[1] = c->F[2] = nullptr;
+    c->num = c->den = c->G = c->G2 = c->Hm = c->Hinv = c->vbuf = nullptr;
+    c->slabs = DevBuf(); c->resid = DevBuf(); c->resid2 = DevBuf(); c->dpart = DevBuf();
+    c->have_problem = false;
+}
+
+extern "C" int cmf_ctx_destroy(cmf_ctx *c) {
+    if (!c) return CMF_OK;
+    DeviceGuard dg(c->device);
+    release_problem(c);
+    (void)hipFree(c->dscalar);
+    for (auto &e : c->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto e : c->evpool) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return CMF_OK;
+}
+
+extern "C" int cmf_sync(cmf_ctx *c) {
+    if (!c) return fail(CMF_EINVAL, "null context");
+    DeviceGuard dg(c->device);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CMF_OK;
+}
+
+static int pad_k(int k) {
+    if (k <= 32) return 32;
+    if (k <= 64) return 64;
+    if (k <= 128) return 128;
+    return (int)rup(k, 256);
+}
+
+extern "C" int cmf_set_problem(cmf_ctx *c, int64_t m, int64_t d, int64_t p, int k) {
+    if (!c) return fail(CMF_EINVAL, "null context");
+    if (m < 0 || d < 0 || p < 0 || k <= 0) return fail(CMF_EINVAL, "bad problem size m=%lld d=%lld p=%lld k=%d", (long long)m, (long long)d, (long long)p, k);
+    DeviceGuard dg(c->device);
+    release_problem(c);
+    c->m = m; c->d = d; c->p = p; c->k = k;
+    c->mp = rup(std::max<int64_t>(m, 1), 256);
+    c->dp = rup(std::max<int64_t>(d, 1), 256);
+    c->pp = rup(std::max<int64_t>(p, 1), 256);
+    c->kp = pad_k(k);
+    const int64_t rows[3] = {m, d, p}, rowsp[3] = {c->mp, c->dp, c->pp};
+    for (int f = 0; f < 3; ++f) {
+        c->frows[f] = rows[f];
+        c->frows_pad[f] = rowsp[f];
+        CHK(dev_alloc(c, (void **)&c->F[f], (size_t)rowsp[f] * c->kp * sizeof(float)));
+    }
+    const int64_t rmax = std::max(c->mp, std::max(c->dp, c->pp));
+    CHK(dev_alloc(c, (void **)&c->num, (size_t)rmax * c->kp * sizeof(float)));
+    CHK(dev_alloc(c, (void **)&c->den, (size_t)rmax * c->kp * sizeof(float)));
+    const size_t kk = (size_t)c->kp * c->kp * sizeof(float);
+    CHK(dev_alloc(c, (void **)&c->G, kk));
+    CHK(dev_alloc(c, (void **)&c->G2, kk));
+    CHK(dev_alloc(c, (void **)&c->Hm, kk));
+    CHK(dev_alloc(c, (void **)&c->Hinv, kk));
+    CHK(dev_alloc(c, (void **)&c->vbuf, (size_t)c->dp * c->kp * sizeof(float) + kk));
+    c->have_problem = true;
+    return CMF_OK;
+}
+
+#define NEED_PROBLEM(c)                                                       \
+    do {                                                                      \
+        if (!(c)) return fail(CMF_EINVAL, "null context");                    \
+        if (!(c)->have_problem) return fail(CMF_EINVAL, "cmf_set_problem has not been called"); \
+    } while (0)
+
+static int data_dims(cmf_ctx *c, int which, int64_t *rows, int64_t *cols, int64_t *rowsp, int64_t *colsp, float ***slot) {
+    if (which == 0) { *rows = c->m; *cols = c->d; *rowsp = c->mp; *colsp = c->dp; *slot = &c->X; }
+    else if (which == 1) { *rows = c->d; *cols = c->p; *rowsp = c->dp; *colsp = c->pp; *slot = &c->Y; }
+    else return fail(CMF_EINVAL, "which must be 0 (X) or 1 (Y)");
+    return CMF_OK;
+}
+
+static int ensure_dense(cmf_ctx *c, int which) {
+    int64_t r, cc, rp, cp; float **slot;
+    CHK(data_dims(c, which, &r, &cc, &rp, &cp, &slot));
+    if (!*slot) CHK(dev_alloc(c, (void **)slot, (size_t)rp * cp * sizeof(float)));
+    return CMF_OK;
+}
+
+template <typename T>
+static int upload_strided(cmf_ctx *c, float *dst, int64_t ld, int64_t rows, int64_t cols, const T *src, int64_t rs, int64_t cs) {
+    if (rows == 0 || cols == 0) return CMF_OK;
+    const int64_t chunk_rows = std::max<int64_t>(1, std::min<int64_t>(rows, (int64_t)(64 << 20) / (cols * (int64_t)sizeof(float))));
+    std::vector<float> stage((size_t)chunk_rows * cols);
+    for (int64_t r0 = 0; r0 < rows; r0 += chunk_rows) {
+        const int64_t nr = std::min(chunk_rows, rows - r0);
+        for (int64_t i = 0; i < nr; ++i) {
+            const T *srow = src + (r0 + i) * rs;
+            float *drow = stage.data() + i * cols;
+            if (cs == 1) for (int64_t j = 0; j < cols; ++j) drow[j] = (float)srow[j];
+            else for (int64_t j = 0; j < cols; ++j) drow[j] = (float)srow[j * cs];
+        }
+        HIPCHK(hipMemcpy2DAsync(dst + r0 * ld, ld * sizeof(float), stage.data(), cols * sizeof(float), cols * sizeof(float), nr,
+                                hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return CMF_OK;
+}
+
+template <typename T>
+static int set_data(cmf_ctx *c, int which, const T *ptr, int64_t rs, int64_t cs) {
+    NEED_PROBLEM(c);
+    if (!ptr) return fail(CMF_EINVAL, "null data pointer");
+    DeviceGuard dg(c->device);
+    int64_t r, cc, rp, cp; float **slot;
+    CHK(data_dims(c, which, &r, &cc, &rp, &cp, &slot));
+    CHK(ensure_dense(c, which));
+    HIPCHK(hipMemsetAsync(*slot, 0, (size_t)rp * cp * sizeof(float), c->stream));
+    return upload_strided<T>(c, *slot, cp, r, cc, ptr, rs, cs);
+}
+
+extern "C" int cmf_set_data_f64(cmf_ctx *c, int which, const double *ptr, int64_t rs, int64_t cs) { return set_data<double>(c, which, ptr, rs, cs); }
+extern "C" int cmf_set_data_f32(cmf_ctx *c, int which, const float *ptr, int64_t rs, int64_t cs) { return set_data<float>(c, which, ptr, rs, cs); }
+
+extern "C" int cmf_set_data_csr(cmf_ctx *c, int which, const int64_t *indptr, const int32_t *indices, const double *data, int64_t nnz) {
+    NEED_PROBLEM(c);
+    if (!indptr || (nnz > 0 && (!indices || !data))) return fail(CMF_EINVAL, "null CSR pointer");
+    DeviceGuard dg(c->device);
+    // round 1: CSR input is expanded to the dense device layout (the Newton path of the
+    // reference densifies too, cmf_solvers.py:389-404); a native SpMM path is the next step.
+    int64_t r, cc, rp, cp; float **slot;
+    CHK(data_dims(c, which, &r, &cc, &rp, &cp, &slot));
+    if ((double)rp * (double)cp * 4.0 > 200e9) return fail(CMF_EUNSUPPORTED, "CSR input too large to expand densely (%lld x %lld)", (long long)r, (long long)cc);
+    CHK(ensure_dense(c, which));
+    HIPCHK(hipMemsetAsync(*slot, 0, (size_t)rp * cp * sizeof(float), c->stream));
+    const int64_t chunk_rows = std::max<int64_t>(1, std::min<int64_t>(r, (int64_t)(64 << 20) / (std::max<int64_t>(cc, 1) * 4)));
+    std::vector<float> stage((size_t)chunk_rows * cc);
+    for (int64_t r0 = 0; r0 < r; r0 += chunk_rows) {
+        const int64_t nr = std::min(chunk_rows, r - r0);
+        std::fill(stage.begin(), stage.begin() + nr * cc, 0.f);
+        for (int64_t i = 0; i < nr; ++i)
+            for (int64_t q = indptr[r0 + i]; q < indptr[r0 + i + 1]; ++q) {
+                if (indices[q] < 0 || indices[q] >= cc) return fail(CMF_EINVAL, "CSR column index out of range");
+                stage[i * cc + indices[q]] += (float)data[q]; // duplicates sum, as scipy does
+            }
+        HIPCHK(hipMemcpy2DAsync(*slot + r0 * cp, cp * sizeof(float), stage.data(), cc * sizeof(float), cc * sizeof(float), nr,
+                                hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return CMF_OK;
+}
+
+extern "C" int cmf_get_data_f32(cmf_ctx *c, int which, float *ptr, int64_t rs, int64_t cs) {
+    NEED_PROBLEM(c);
+    DeviceGuard dg(c->device);
+    int64_t r, cc, rp, cp; float **slot;
+    CHK(data_dims(c, which, &r, &cc, &rp, &cp, &slot));
+    if (!*slot) return fail(CMF_EINVAL, "data %d not set", which);
+    std::vector<float> host((size_t)r * cc);
+    HIPCHK(hipMemcpy2DAsync(host.data(), cc * sizeof(float), *slot, cp * sizeof(float), cc * sizeof(float), r, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < r; ++i)
+        for (int64_t j = 0; j < cc; ++j) ptr[i * rs + j * cs] = host[i * cc + j];
+    return CMF_OK;
+}
+
+static int launch_fill(cmf_ctx *c, float *A, int64_t ld, int64_t rows, int64_t cols, uint64_t seed, int64_t row0, int64_t col0, float scale) {
+    Timed tm(c, CMF_K_ELEMWISE);
+    const int64_t total = rows * ((cols + 3) / 4);
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
+    if (total == 0) return CMF_OK;
+    hipLaunchKernelGGL(fill_absnormal_kernel, dim3(blocks), dim3(256), 0, c->stream, A, ld, rows, cols, seed, row0, col0, scale);
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
+extern "C" int cmf_fill_data_synthetic(cmf_ctx *c, int which, uint64_t seed, int64_t row0, int64_t col0) {
+    NEED_PROBLEM(c);
+    DeviceGuard dg(c->device);
+    int64_t r, cc, rp, cp; float **slot;
+    CHK(data_dims(c, which, &r, &cc, &rp, &cp, &slot));
+    CHK(ensure_dense(c, which));
+    HIPCHK(hipMemsetAsync(*slot, 0, (size_t)rp * cp * sizeof(float), c->stream));
+    return launch_fill(c, *slot, cp, r, cc, seed, row0, col0, 1.0f);
+}
+
+extern "C" int cmf_fill_factor_synthetic(cmf_ctx *c, int which, uint64_t seed, int64_t row0, double scale) {
+    NEED_PROBLEM(c);
+    if (which < 0 || which > 2) return fail(CMF_EINVAL, "bad factor id");
+    DeviceGuard dg(c->device);
+    HIPCHK(hipMemsetAsync(c->F[which], 0, (size_t)c->frows_pad[which] * c->kp * sizeof(float), c->stream));
+    return launch_fill(c, c->F[which], c->kp, c->frows[which], c->k, seed, row0, 0, (float)scale);
+}
+
+extern "C" int cmf_set_factor_f64(cmf_ctx *c, int which, const double *ptr, int64_t rs, int64_t cs) {
+    NEED_PROBLEM(c);
+    if (which < 0 || which > 2 || !ptr) return fail(CMF_EINVAL, "bad factor argument");
+    DeviceGuard dg(c->device);
+    HIPCHK(hipMemsetAsync(c->F[which], 0, (size_t)c->frows_pad[which] * c->kp * sizeof(float), c->stream));
+    return upload_strided<double>(c, c->F[which], c->kp, c->frows[which], c->k, ptr, rs, cs);
+}
+
+extern "C" int cmf_get_factor_f64(cmf_ctx *c, int which, double *ptr, int64_t rs, int64_t cs) {
+    NEED_PROBLEM(c);
+    if (which < 0 || which > 2 || !ptr) return fail(CMF_EINVAL, "bad factor argument");
+    DeviceGuard dg(c->device);
+    const int64_t r = c->frows[which];
+    std::vector<float> host((size_t)std::max<int64_t>(r, 1) * c->k);
+    if (r > 0) {
+        HIPCHK(hipMemcpy2DAsync(host.data(), c->k * sizeof(float), c->F[which], c->kp * sizeof(float), c->k * sizeof(float), r,
+                                hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < r; ++i)
+        for (int j = 0; j < c->k; ++j) ptr[i * rs + j * cs] = (double)host[i * c->k + j];
+    return CMF_OK;
+}
+
+extern "C" int cmf_get_geometry(cmf_ctx *c, int64_t *mp, int64_t *dp, int64_t *pp, int *kp) {
+    NEED_PROBLEM(c);
+    if (mp) *mp = c->mp;
+    if (dp) *dp = c->dp;
+    if (pp) *pp = c->pp;
+    if (kp) *kp = c->kp;
+    return CMF_OK;
+}
+
+extern "C" int cmf_factor_dev_ptr(cmf_ctx *c, int which, float **ptr) {
+    NEED_PROBLEM(c);
+    if (which < 0 || which > 2 || !ptr) return fail(CMF_EINVAL, "bad factor argument");
+    *ptr = c->F[which];
+    return CMF_OK;
+}
+
+extern "C" int cmf_v_buf_elems(cmf_ctx *c, int64_t *n) {
+    NEED_PROBLEM(c);
+    if (!n) return fail(CMF_EINVAL, "null argument");
+    *n = c->dp * c->kp + (int64_t)c->kp * c->kp;
+    return CMF_OK;
+}
+
+// ------------------------------------------------------------------ MU solver
+// V numerator/Gram partials of this shard: cmf_solvers.py:244-245
+extern "C" int cmf_mu_v_partials(cmf_ctx *c, float *buf) {
+    NEED_PROBLEM(c);
+    if (!buf) return fail(CMF_EINVAL, "null buffer");
+    if (!c->X || !c->Y) return fail(CMF_EINVAL, "X and Y must be set before a V update");
+    DeviceGuard dg(c->device);
+    float *P = buf, *Gs = buf + c->dp * c->kp;
+    // P = X^T U + Y Z
+    CHK(gemm(c, MODE_TN, c->X, c->dp, c->F[CMF_U], c->kp, P, c->dp, c->kp, c->mp));
+    CHK(gemm(c, MODE_NN, c->Y, c->pp, c->F[CMF_Z], c->kp, P, c->dp, c->kp, c->pp, true));
+    // G = U^T U + Z^T Z
+    CHK(gemm(c, MODE_TN, c->F[CMF_U], c->kp, c->F[CMF_U], c->kp, Gs, c->kp, c->kp, c->mp));
+    CHK(gemm(c, MODE_TN, c->F[CMF_Z], c->kp, c->F[CMF_Z], c->kp, Gs, c->kp, c->kp, c->pp, true));
+    return CMF_OK;
+}
+
+// V *= P / reg(V G): cmf_solvers.py:245, :212-228, :253-255
+extern "C" int cmf_mu_v_apply(cmf_ctx *c, const float *buf, double l1, double l2) {
+    NEED_PROBLEM(c);
+    if (!buf) return fail(CMF_EINVAL, "null buffer");
+    DeviceGuard dg(c->device);
+    const float *P = buf, *Gs = buf + c->dp * c->kp;
+    CHK(gemm(c, MODE_NN, c->F[CMF_V], c->kp, Gs, c->kp, c->den, c->dp, c->kp, c->kp));
+    CHK(mu_apply(c, c->F[CMF_V], P, c->den, c->dp * c->kp, l1, l2));
+    return CMF_OK;
+}
+
+// U *= X V / reg(U V^T V), Z *= Y^T V / reg(Z V^T V): cmf_solvers.py:230-240, :257-263.
+// (U V^T) V is evaluated as U (V^T V): same value, 2mk^2 instead of 4mdk flops.
+extern "C" int cmf_mu_uz_update(cmf_ctx *c, double l1, double l2, int mask) {
+    NEED_PROBLEM(c);
+    DeviceGuard dg(c->device);
+    if (!(mask & (CMF_UPD_U | CMF_UPD_Z))) return CMF_OK;
+    CHK(gemm(c, MODE_TN, c->F[CMF_V], c->kp, c->F[CMF_V], c->kp, c->G2, c->kp, c->kp, c->dp));
+    if (mask & CMF_UPD_U) {
+        if (!c->X) return fail(CMF_EINVAL, "X must be set before a U update");
+        CHK(gemm(c, MODE_NN, c->X, c->dp, c->F[CMF_V], c->kp, c->num, c->mp, c->kp, c->dp));
+        CHK(gemm(c, MODE_NN, c->F[CMF_U], c->kp, c->G2, c->kp, c->den, c->mp, c->kp, c->kp));
+        CHK(mu_apply(c, c->F[CMF_U], c->num, c->den, c->mp * c->kp, l1, l2));
+    }
+    if (mask & CMF_UPD_Z) {
+        if (!c->Y) return fail(CMF_EINVAL, "Y must be set before a Z update");
+        CHK(gemm(c, MODE_TN, c->Y, c->pp, c->F[CMF_V], c->kp, c->num, c->pp, c->kp, c->dp));
+        CHK(gemm(c, MODE_NN, c->F[CMF_Z], c->kp, c->G2, c->kp, c->den, c->pp, c->kp, c->kp));
+        CHK(mu_apply(c, c->F[CMF_Z], c->num, c->den, c->pp * c->kp, l1, l2));
+    }
+    return CMF_OK;
+}
+
+extern "C" int cmf_mu_step(cmf_ctx *c, double l1, double l2, int mask) {
+    NEED_PROBLEM(c);
+    if (mask & CMF_UPD_V) {
+        CHK(cmf_mu_v_partials(c, c->vbuf));
+        CHK(cmf_mu_v_apply(c, c->vbuf, l1, l2));
+    }
+    return cmf_mu_uz_update(c, l1, l2, mask);
+}
+
+// ------------------------------------------------------------------ error metric
+extern "C" int cmf_residual_sq(cmf_ctx *c, int x_link, int y_link, double *ex2, double *ey2) {
+    NEED_PROBLEM(c);
+    DeviceGuard dg(c->device);
+    double host[2] = {0, 0};
+    HIPCHK(hipMemsetAsync(c->dscalar, 0, 2 * sizeof(double), c->stream));
+    if (ex2 && c->X) {
+        NtOut o; o.T = c->X; o.ldt = c->dp; o.sq = c->dscalar; o.link = x_link;
+        CHK(gemm_nt(c, c->F[CMF_U], c->mp, c->m, c->F[CMF_V], c->dp, c->d, o));
+    }
+    if (ey2 && c->Y) {
+        NtOut o; o.T = c->Y; o.ldt = c->pp; o.sq = c->dscalar + 1; o.link = y_link;
+        CHK(gemm_nt(c, c->F[CMF_V], c->dp, c->d, c->F[CMF_Z], c->pp, c->p, o));
+    }
+    HIPCHK(hipMemcpyAsync(host, c->dscalar, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (ex2) *ex2 = host[0];
+    if (ey2) *ey2 = host[1];
+    return CMF_OK;
+}
+
+extern "C" int cmf_data_sq(cmf_ctx *c, double *x2, double *y2) {
+    NEED_PROBLEM(c);
+    DeviceGuard dg(c->device);
+    double host[2] = {0, 0};
+    HIPCHK(hipMemsetAsync(c->dscalar, 0, 2 * sizeof(double), c->stream));
+    const float *src[2] = {c->X, c->Y};
+    const int64_t n[2] = {c->mp * c->dp, c->dp * c->pp};
+    for (int w = 0; w < 2; ++w) {
+        if (!src[w]) continue;
+        const int blocks = 1024;
+        CHK(ensure(c, c->dpart, blocks * sizeof(double)));
+        Timed tm(c, CMF_K_ELEMWISE);
+        hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, c->stream, src[w], n[w] / 4, (double *)c->dpart.p);
+        hipLaunchKernelGGL(sum_doubles_kernel, dim3(1), dim3(256), 0, c->stream, (const double *)c->dpart.p, (int64_t)blocks, c->dscalar + w);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(host, c->dscalar, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (x2) *x2 = host[0];
+    if (y2) *y2 = host[1];
+    return CMF_OK;
+}
+
+// ------------------------------------------------------------------ timing API
+extern "C" int cmf_kernel_timing(cmf_ctx *c, int enable) {
+    if (!c) return fail(CMF_EINVAL, "null context");
+    DeviceGuard dg(c->device);
+    CHK(flush_timing(c));
+    c->timing = enable != 0;
+    return CMF_OK;
+}
+extern "C" int cmf_kernel_time(cmf_ctx *c, int cls, double *ms, int64_t *launches) {
+    if (!c || cls < 0 || cls >= CMF_K_COUNT) return fail(CMF_EINVAL, "bad kernel class");
+    DeviceGuard dg(c->device);
+    CHK(flush_timing(c));
+    if (ms) *ms = c->ms[cls];
+    if (launches) *launches = c->launches[cls];
+    return CMF_OK;
+}
+extern "C" int cmf_kernel_timing_reset(cmf_ctx *c) {
+    if (!c) return fail(CMF_EINVAL, "null context");
+    DeviceGuard dg(c->device);
+    CHK(flush_timing(c));
+    for (int i = 0; i < CMF_K_COUNT; ++i) { c->ms[i] = 0; c->launches[i] = 0; }
+    return CMF_OK;
+}
+
+#include "cmf_newton.hip.h"

@@ -1,0 +1,445 @@
+// cmf_kernels.hip.h -- gfx950 (MI355X / CDNA4) device kernels of the CMF update engine.
+//
+// Everything heavy is phrased as one of three fp32-MFMA GEMM forms built on
+// v_mfma_f32_32x32x2_f32 (exact f32 fma chain, 64 FLOP/clk/SIMD):
+//   NN : C[M x N]  = A[M x K]   * B[K x N]      X V, Y Z, F (V^T V), W KR(V)
+//   TN : C[Kc x N] = A[K x Kc]^T * B[K x N]     X^T U, Y^T V, Grams, W^T KR(U)
+//   NT : S[M x N]  = A[M x K]   * B[N x K]^T    U V^T / V Z^T with a fused
+//        epilogue (residual f(S)-T, sigma'(S) weights, or sum of squares)
+// One 512-thread workgroup (8 waves, 2 per SIMD) owns a 256 x BN output tile
+// and walks the reduction in 32-deep steps through double-buffered LDS.
+// Reference arithmetic being replaced: pycmf/cmf_solvers.py:232-245 (MU
+// contractions), :399-400/:436-440 (Newton residual products), :36-42 (error).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cmfk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+enum { MODE_NN = 0, MODE_TN = 1, MODE_NT = 2 };
+
+struct GemmArgs {
+    const float *A;
+    int64_t lda;
+    const float *B;
+    int64_t ldb;
+    float *C;            // NN/TN: slab base; NT: unused
+    int64_t ldc;
+    int64_t slab_stride; // elements between split-K slabs
+    int64_t Mout;        // valid output rows (TN: guards A columns / C rows)
+    int64_t Kred;        // reduction length, multiple of 32
+    int64_t klen;        // reduction length per split, multiple of 32
+    // ---- NT epilogue ----
+    const float *T;      // target (X or Y), row-major ldt, may be null (treated as 0)
+    int64_t ldt;
+    float *R;            // residual out  scale_r * (f(S) - T) * mask      (nullable)
+    float *W;            // weight out    scale_w * w(S) * mask            (nullable)
+    int64_t ldr;
+    const uint8_t *mask; // 0/1 bytes, row-major ldm                       (nullable)
+    int64_t ldm;
+    double *sq_out;      // per-workgroup sum of squares of (T - f(S))     (nullable)
+    int64_t Mvalid, Nvalid; // true (unpadded) extent for sq / logit masking
+    float scale_r, scale_w;
+    int link;            // 0 linear, 1 logit
+    int w_is_slope;      // W = scale_w * sigma'(S) (1) or scale_w (0)
+};
+
+template <int MODE, int BN>
+struct GemmCfg {
+    static constexpr int BM = 256, BK = 32, PADK = 36, NT = 512;
+    static constexpr bool A_KC = (MODE != MODE_TN);
+    static constexpr bool B_KC = (MODE == MODE_NT);
+    static constexpr int A_ELEMS = A_KC ? BM * PADK : BK * BM;
+    static constexpr int B_ELEMS = B_KC ? BN * PADK : BK * BN;
+    static constexpr int STAGE = A_ELEMS + B_ELEMS;
+    static constexpr int WN = (BN >= 64) ? 2 : 1;
+    static constexpr int WM = 8 / WN;
+    static constexpr int WTM = BM / WM, WTN = BN / WN;
+    static constexpr int TM = WTM / 32, TN = WTN / 32;
+    static constexpr int A_LD = 4;                                  // float4 per thread
+    static constexpr int B_F4 = B_KC ? BN * BK / 4 : BK * BN / 4;   // float4 in B tile
+    static constexpr int B_LD = (B_F4 + NT - 1) / NT;
+    static constexpr size_t LDS_BYTES = 2 * STAGE * sizeof(float);
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+template <int N>
+struct VecLoad;
+template <>
+struct VecLoad<1> {
+    static __device__ __forceinline__ void ld(const float *p, float *o) { o[0] = p[0]; }
+};
+template <>
+struct VecLoad<2> {
+    static __device__ __forceinline__ void ld(const float *p, float *o) {
+        f32x2 v = *reinterpret_cast<const f32x2 *>(p);
+        o[0] = v[0]; o[1] = v[1];
+    }
+};
+template <>
+struct VecLoad<4> {
+    static __device__ __forceinline__ void ld(const float *p, float *o) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(p);
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+    }
+};
+
+template <int MODE, int BN>
+__global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
+    using C = GemmCfg<MODE, BN>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wid = t >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wid / C::WN, wn = wid % C::WN;
+    const int wrow0 = wm * C::WTM, wcol0 = wn * C::WTN;
+
+    const int64_t row0 = (int64_t)blockIdx.x * C::BM; // output-row tile origin
+    const int64_t n0 = (int64_t)blockIdx.y * BN;      // output-col tile origin
+    const int64_t kbeg = (int64_t)blockIdx.z * g.klen;
+    int64_t kend = kbeg + g.klen;
+    if (kend > g.Kred) kend = g.Kred;
+    const int nkt = (int)((kend - kbeg) / C::BK);
+
+    f32x16 acc[C::TM][C::TN];
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    f32x4 ra[C::A_LD], rb[C::B_LD];
+
+    auto gload = [&](int64_t k0) {
+#pragma unroll
+        for (int p = 0; p < C::A_LD; ++p) {
+            const int idx = t + C::NT * p;
+            if constexpr (C::A_KC) {
+                const int r = idx >> 3, c4 = idx & 7;
+                ra[p] = *reinterpret_cast<const f32x4 *>(g.A + (row0 + r) * g.lda + k0 + 4 * c4);
+            } else {
+                const int r = idx >> 6, c4 = idx & 63;
+                const int64_t col = row0 + 4 * c4;
+                if (col < g.Mout)
+                    ra[p] = *reinterpret_cast<const f32x4 *>(g.A + (k0 + r) * g.lda + col);
+                else
+                    ra[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < C::B_LD; ++p) {
+            const int idx = t + C::NT * p;
+            if (C::B_F4 >= C::NT || idx < C::B_F4) {
+                if constexpr (C::B_KC) {
+                    const int r = idx >> 3, c4 = idx & 7;
+                    rb[p] = *reinterpret_cast<const f32x4 *>(g.B + (n0 + r) * g.ldb + k0 + 4 * c4);
+                } else {
+                    constexpr int F4R = BN / 4;
+                    const int r = idx / F4R, c4 = idx % F4R;
+                    rb[p] = *reinterpret_cast<const f32x4 *>(g.B + (k0 + r) * g.ldb + n0 + 4 * c4);
+                }
+            }
+        }
+    };
+    auto lstore = [&](float *As, float *Bs) {
+#pragma unroll
+        for (int p = 0; p < C::A_LD; ++p) {
+            const int idx = t + C::NT * p;
+            if constexpr (C::A_KC) {
+                const int r = idx >> 3, c4 = idx & 7;
+                *reinterpret_cast<f32x4 *>(As + r * C::PADK + 4 * c4) = ra[p];
+            } else {
+                const int r = idx >> 6, c4 = idx & 63;
+                *reinterpret_cast<f32x4 *>(As + r * C::BM + 4 * c4) = ra[p];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < C::B_LD; ++p) {
+            const int idx = t + C::NT * p;
+            if (C::B_F4 >= C::NT || idx < C::B_F4) {
+                if constexpr (C::B_KC) {
+                    const int r = idx >> 3, c4 = idx & 7;
+                    *reinterpret_cast<f32x4 *>(Bs + r * C::PADK + 4 * c4) = rb[p];
+                } else {
+                    constexpr int F4R = BN / 4;
+                    const int r = idx / F4R, c4 = idx % F4R;
+                    *reinterpret_cast<f32x4 *>(Bs + r * BN + 4 * c4) = rb[p];
+                }
+            }
+        }
+    };
+    auto compute = [&](const float *As, const float *Bs) {
+        if constexpr (C::A_KC) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 a[C::TM];
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i)
+                    a[i] = *reinterpret_cast<const f32x4 *>(As + (wrow0 + 32 * i + l31) * C::PADK + 4 * (2 * q + lh));
+                if constexpr (C::B_KC) {
+                    f32x4 b[C::TN];
+#pragma unroll
+                    for (int j = 0; j < C::TN; ++j)
+                        b[j] = *reinterpret_cast<const f32x4 *>(Bs + (wcol0 + 32 * j + l31) * C::PADK + 4 * (2 * q + lh));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < C::TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int kk = 8 * q + 4 * lh + e;
+                        float b[C::TN];
+                        VecLoad<C::TN>::ld(Bs + kk * BN + wcol0 + C::TN * l31, b);
+#pragma unroll
+                        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < C::TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int kk = 2 * s + lh;
+                float a[C::TM], b[C::TN];
+                VecLoad<C::TM>::ld(As + kk * C::BM + wrow0 + C::TM * l31, a);
+                VecLoad<C::TN>::ld(Bs + kk * BN + wcol0 + C::TN * l31, b);
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    if (nkt > 0) {
+        gload(kbeg);
+        lstore(smem, smem + C::A_ELEMS);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            float *cur = smem + (kt & 1) * C::STAGE;
+            float *nxt = smem + ((kt + 1) & 1) * C::STAGE;
+            const bool more = (kt + 1 < nkt);
+            if (more) gload(kbeg + (int64_t)(kt + 1) * C::BK);
+            compute(cur, cur + C::A_ELEMS);
+            if (more) lstore(nxt, nxt + C::A_ELEMS);
+            __syncthreads();
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    if constexpr (MODE != MODE_NT) {
+        float *Cs = g.C + (int64_t)blockIdx.z * g.slab_stride;
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int64_t row = row0 + wrow0 + (C::A_KC ? (32 * i + rr) : (C::TM * rr + i));
+                if (row < g.Mout) {
+                    float *dst = Cs + row * g.ldc + n0 + wcol0 + C::TN * l31;
+                    if constexpr (C::TN == 4) {
+                        *reinterpret_cast<f32x4 *>(dst) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+                    } else if constexpr (C::TN == 2) {
+                        *reinterpret_cast<f32x2 *>(dst) = f32x2{acc[i][0][r], acc[i][1][r]};
+                    } else {
+                        dst[0] = acc[i][0][r];
+                    }
+                }
+            }
+    } else {
+        float sq = 0.0f;
+        // per-lane origin (row of register 0, this lane's column); every element is then a
+        // wave-uniform offset away, so the address arithmetic stays on the scalar unit
+        const int64_t rbase = row0 + wrow0 + 4 * lh;
+        const int64_t cbase = n0 + wcol0 + l31;
+        const float *Tp = g.T ? g.T + rbase * g.ldt + cbase : nullptr;
+        float *Rp = g.R ? g.R + rbase * g.ldr + cbase : nullptr;
+        float *Wp = g.W ? g.W + rbase * g.ldr + cbase : nullptr;
+        const uint8_t *Mp = g.mask ? g.mask + rbase * g.ldm + cbase : nullptr;
+        const int ldt = (int)g.ldt, ldr = (int)g.ldr, ldm = (int)g.ldm;
+        const int rlim = (int)min((int64_t)1 << 20, g.Mvalid - rbase); // valid iff rr < rlim
+        const int clim = (int)min((int64_t)1 << 20, g.Nvalid - cbase);
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = 32 * i + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j) {
+                    const float s = acc[i][j][r];
+                    const float f = g.link ? sigmoidf_(s) : s;
+                    const float tv = Tp ? Tp[rr * ldt + 32 * j] : 0.0f;
+                    float mk = (rr < rlim && 32 * j < clim) ? 1.0f : 0.0f;
+                    if (Mp) mk *= (float)Mp[rr * ldm + 32 * j];
+                    const float res = f - tv;
+                    if (g.sq_out) sq += mk * res * res;
+                    if (Rp) Rp[rr * ldr + 32 * j] = g.scale_r * mk * res;
+                    if (Wp) {
+                        const float w = g.w_is_slope ? f * (1.0f - f) : 1.0f;
+                        Wp[rr * ldr + 32 * j] = g.scale_w * mk * w;
+                    }
+                }
+            }
+        if (g.sq_out) {
+            double v = (double)sq;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            __syncthreads();
+            double *red = reinterpret_cast<double *>(smem);
+            if (lane == 0) red[wid] = v;
+            __syncthreads();
+            if (t == 0) {
+                double tot = 0.0;
+                for (int w = 0; w < 8; ++w) tot += red[w];
+                g.sq_out[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ elementwise
+// dst[i] = (accumulate ? dst[i] : 0) + sum_s src[s*stride + i]      (float4 lanes)
+__global__ void sum_slabs_kernel(float *dst, const float *src, int64_t n4, int nslab,
+                                 int64_t stride, int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 a = accumulate ? reinterpret_cast<f32x4 *>(dst)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < nslab; ++s) a += reinterpret_cast<const f32x4 *>(src + (int64_t)s * stride)[i];
+        reinterpret_cast<f32x4 *>(dst)[i] = a;
+    }
+}
+
+// F *= num / reg(den)   -- MUSolver._regularized_delta, cmf_solvers.py:212-228
+__global__ void mu_apply_kernel(float *F, const float *num, const float *den, int64_t n4,
+                                float l1, float l2, float eps) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 f = reinterpret_cast<f32x4 *>(F)[i];
+        const f32x4 nu = reinterpret_cast<const f32x4 *>(num)[i];
+        f32x4 de = reinterpret_cast<const f32x4 *>(den)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float d = de[e];
+            if (l1 > 0.f) d += l1;
+            if (l2 > 0.f) d = d + l2 * f[e];
+            if (d == 0.f) d = eps;
+            f[e] = f[e] * (nu[e] / d);
+        }
+        reinterpret_cast<f32x4 *>(F)[i] = f;
+    }
+}
+
+// Newton gradient assembly + shared-inverse step pieces
+// grad = a*P + b*Q + l1*sign(F) + l2*F          (cmf_solvers.py:400, :438)
+__global__ void newton_grad_kernel(float *grad, const float *P, float a, const float *Q, float b,
+                                   const float *F, float l1, float l2, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float f = F[i];
+        float gval = a * P[i];
+        if (Q) gval += b * Q[i];
+        const float sg = (f > 0.f) ? 1.f : ((f < 0.f) ? -1.f : 0.f);
+        grad[i] = gval + l1 * sg + l2 * f;
+    }
+}
+
+// F <- F - step ; clamp (cmf_solvers.py:321-326); rows >= rows_valid stay 0
+__global__ void newton_apply_kernel(float *F, const float *step, int64_t rows_valid, int kp, int kvalid,
+                                    int64_t n, int non_negative) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / kp;
+        const int c = (int)(i % kp);
+        float v = 0.f;
+        if (r < rows_valid && c < kvalid) {
+            v = F[i] - step[i];
+            if (non_negative && v < 0.f) v = 0.f;
+        }
+        F[i] = v;
+    }
+}
+
+__global__ void axpby_diag_kernel(float *H, const float *A, float a, const float *B, float b, float diag,
+                                  int kp, int kvalid) {
+    // H = a*A + b*B + diag*I on the valid k x k block; identity on the padding
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= kp * kp) return;
+    const int r = i / kp, c = i % kp;
+    float v = a * A[i] + (B ? b * B[i] : 0.f);
+    if (r == c) v += diag;
+    if (r >= kvalid || c >= kvalid) v = (r == c) ? 1.0f : 0.0f;
+    H[i] = v;
+}
+
+__global__ void sum_doubles_kernel(const double *in, int64_t n, double *out) {
+    __shared__ double red[256];
+    double v = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) v += in[i];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+
+__global__ void sumsq_kernel(const float *A, int64_t n4, double *partials) {
+    double v = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 a = reinterpret_cast<const f32x4 *>(A)[i];
+        v += (double)a[0] * a[0] + (double)a[1] * a[1] + (double)a[2] * a[2] + (double)a[3] * a[3];
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+// ------------------------------------------------------------------ synthetic data
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// |N(0,1)| at global coordinate (gi, gj): depends on (seed, gi, gj) only
+__device__ __forceinline__ float absnormal_at(uint64_t seed, uint64_t gi, uint64_t gj) {
+    const uint64_t h = mix64(mix64(seed ^ (gi * 0xD1342543DE82EF95ull)) ^ gj);
+    const float u1 = ((float)((h >> 40) + 1)) * (1.0f / 16777217.0f);          // (0,1]
+    const float u2 = ((float)((h >> 8) & 0xFFFFFF)) * (1.0f / 16777216.0f);    // [0,1)
+    const float r = sqrtf(-2.0f * __logf(u1));
+    return fabsf(r * __cosf(6.28318530718f * u2));
+}
+__global__ void fill_absnormal_kernel(float *A, int64_t ld, int64_t rows, int64_t cols, uint64_t seed,
+                                      int64_t row0, int64_t col0, float scale) {
+    const int64_t c4n = (cols + 3) / 4;
+    const int64_t total = rows * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c4n, c = (i % c4n) * 4;
+        for (int e = 0; e < 4 && c + e < cols; ++e)
+            A[r * ld + c + e] = scale * absnormal_at(seed, (uint64_t)(row0 + r), (uint64_t)(col0 + c + e));
+    }
+}
+
+} // namespace cmfk

@@ -1,0 +1,218 @@
+"""Host-side solver objects: the drop-in seam of the reference.
+
+The reference's driver builds a solver object and calls exactly one method on it,
+``fit_iterative_update(X, Y, U, V, Z) -> (U, V, Z, n_iter)``
+(pycmf/cmf.py:437-454).  ``HipMUSolver`` and ``HipNewtonSolver`` accept the same
+constructor keywords as the reference classes (pycmf/cmf_solvers.py:98-103) and
+expose the same three methods (``fit_iterative_update`` :132, ``update_step``
+:124, ``compute_error`` :128), but every flop of the update runs in
+libcmfhip.so on the GPU:  X and Y are uploaded once, the factors stay resident
+for the whole loop, and one scalar comes back per convergence check.
+
+Semantics kept from the reference:
+* U, V, Z are mutated in place and also returned (:195, :255, :324).
+* the convergence test runs every 10th iteration when tol > 0 (:175-187) with
+  the same verbose print format (:178-181, :190-193).
+* constructing a solver with ``random_state`` seeds NumPy's *global* RNG
+  (:121-122); stochastic Newton draws its per-row samples from that stream in
+  the reference's order so that results are reproducible against it.
+* MU ignores alpha (its error metric uses the constructor default 0.5, :99).
+"""
+import time
+
+import numpy as np
+
+from . import _lib
+
+
+def _as_f64(a):
+    return a if (isinstance(a, np.ndarray) and a.dtype == np.float64) else np.asarray(a, dtype=np.float64)
+
+
+class _HipIterativeSolver:
+    def __init__(self, max_iter=200, tol=1e-4, beta_loss="frobenius",
+                 l1_reg=0, l2_reg=0, alpha=0.5, verbose=0,
+                 U_non_negative=True, V_non_negative=True, Z_non_negative=True,
+                 update_U=True, update_V=True, update_Z=True,
+                 x_link="linear", y_link="linear", hessian_pertubation=0.2,
+                 sg_sample_ratio=1., random_state=None, device=0, stream=None):
+        if beta_loss not in ("frobenius", 2, 2.0):
+            # the reference parses other losses but only implements Frobenius (:166)
+            raise ValueError("Invalid beta_loss parameter: only 'frobenius' is implemented, got %r" % (beta_loss,))
+        self.max_iter = max_iter
+        self.tol = tol
+        self.beta_loss = 2.0
+        self.l1_reg = l1_reg
+        self.l2_reg = l2_reg
+        self.alpha = alpha
+        self.verbose = verbose
+        self.U_non_negative = U_non_negative
+        self.V_non_negative = V_non_negative
+        self.Z_non_negative = Z_non_negative
+        self.update_U = update_U
+        self.update_V = update_V
+        self.update_Z = update_Z
+        self.x_link = x_link
+        self.y_link = y_link
+        self.hessian_pertubation = hessian_pertubation
+        self.sg_sample_ratio = sg_sample_ratio
+        self.device = device
+        self.stream = stream
+        self._ctx = None
+        self._bound = None
+        if random_state is not None:
+            np.random.seed(random_state)
+
+    # ------------------------------------------------------------------ device state
+    def _update_mask(self):
+        return (_lib.UPD_U if self.update_U else 0) | (_lib.UPD_V if self.update_V else 0) | \
+            (_lib.UPD_Z if self.update_Z else 0)
+
+    def _nn_mask(self):
+        return (1 if self.U_non_negative else 0) | (2 if self.V_non_negative else 0) | \
+            (4 if self.Z_non_negative else 0)
+
+    def _bind(self, X, Y, U, V, Z):
+        """Upload X, Y (once per distinct pair) and size the device problem."""
+        m, k = U.shape
+        d = V.shape[0]
+        p = Z.shape[0]
+        key = (id(X), id(Y), m, d, p, k)
+        if self._ctx is None:
+            self._ctx = _lib.Context(self.device, self.stream)
+        if self._bound != key:
+            self._ctx.set_problem(m, d, p, k)
+            if X is not None:
+                if X.shape != (m, d):
+                    raise ValueError("X has shape %s, factors imply %s" % (X.shape, (m, d)))
+                self._ctx.set_data(0, X)
+            if Y is not None:
+                if Y.shape != (d, p):
+                    raise ValueError("Y has shape %s, factors imply %s" % (Y.shape, (d, p)))
+                self._ctx.set_data(1, Y)
+            self._bound = key
+            self._XY = (X, Y)  # keep ids alive
+        return self._ctx
+
+    def _push_factors(self, U, V, Z):
+        self._ctx.set_factor(_lib.CMF_U, U)
+        self._ctx.set_factor(_lib.CMF_V, V)
+        self._ctx.set_factor(_lib.CMF_Z, Z)
+
+    def _pull_factors(self, U, V, Z):
+        for which, F in ((_lib.CMF_U, U), (_lib.CMF_V, V), (_lib.CMF_Z, Z)):
+            if isinstance(F, np.ndarray) and F.dtype == np.float64 and F.flags.writeable:
+                self._ctx.get_factor_into(which, F)
+            else:
+                F[...] = self._ctx.get_factor(which)
+
+    def release(self):
+        if self._ctx is not None:
+            self._ctx.close()
+        self._ctx = None
+        self._bound = None
+
+    # ------------------------------------------------------------------ reference API
+    def _device_step(self, l1_reg, l2_reg, alpha):
+        raise NotImplementedError("Implement in concrete subclass to use")
+
+    def update_step(self, X, Y, U, V, Z, l1_reg, l2_reg, alpha):
+        """One sweep over all factors, in place on U, V, Z (cmf_solvers.py:124)."""
+        self._bind(X, Y, U, V, Z)
+        self._push_factors(U, V, Z)
+        self._device_step(l1_reg, l2_reg, alpha)
+        self._pull_factors(U, V, Z)
+
+    def _device_error(self):
+        ex2, ey2 = self._ctx.residual_sq(self.x_link, self.y_link)
+        X, Y = self._XY
+        ex = np.sqrt(ex2) if X is not None else 0.0
+        ey = np.sqrt(ey2) if Y is not None else 0.0
+        return ex, ey
+
+    def compute_error(self, X, Y, U, V, Z):
+        """alpha*||X - f(UV^T)||_F + (1-alpha)*||Y - f(VZ^T)||_F (cmf_solvers.py:128-130)."""
+        self._bind(X, Y, U, V, Z)
+        self._push_factors(U, V, Z)
+        ex, ey = self._device_error()
+        return self.alpha * ex + (1 - self.alpha) * ey
+
+    def reconstruction_error(self):
+        """||X - f(UV^T)||_F + ||Y - f(VZ^T)||_F with the factors currently on the
+        device (pycmf/cmf.py:697-698)."""
+        ex, ey = self._device_error()
+        return ex + ey
+
+    def fit_iterative_update(self, X, Y, U, V, Z):
+        """Alternating minimisation loop (cmf_solvers.py:132-195)."""
+        start_time = time.time()
+        self._bind(X, Y, U, V, Z)
+        self._push_factors(U, V, Z)
+        ex, ey = self._device_error()
+        previous_error = error_at_init = self.alpha * ex + (1 - self.alpha) * ey
+
+        n_iter = 0
+        for n_iter in range(1, self.max_iter + 1):
+            self._device_step(self.l1_reg, self.l2_reg, self.alpha)
+            if self.tol > 0 and n_iter % 10 == 0:
+                ex, ey = self._device_error()
+                error = self.alpha * ex + (1 - self.alpha) * ey
+                if self.verbose:
+                    print("Epoch %02d reached after %.3f seconds, error: %f" %
+                          (n_iter, time.time() - start_time, error))
+                if (previous_error - error) / error_at_init < self.tol:
+                    break
+                previous_error = error
+
+        if self.verbose and (self.tol == 0 or n_iter % 10 != 0):
+            self._ctx.sync()
+            print("Epoch %02d reached after %.3f seconds." % (n_iter, time.time() - start_time))
+
+        self._pull_factors(U, V, Z)
+        return U, V, Z, n_iter
+
+
+class HipMUSolver(_HipIterativeSolver):
+    """Multiplicative updates V -> U -> Z (pycmf/cmf_solvers.py:198-263) on the GPU."""
+
+    def _device_step(self, l1_reg, l2_reg, alpha):
+        self._ctx.mu_step(l1_reg, l2_reg, self._update_mask())
+
+
+class HipNewtonSolver(_HipIterativeSolver):
+    """Row-wise Newton-Raphson sweeps U -> Z -> V (pycmf/cmf_solvers.py:318-522) on the GPU.
+
+    With ``sg_sample_ratio < 1`` the per-row samples are drawn on the host from
+    NumPy's global RNG in the reference's order (:328-344: U rows, Z rows, then for
+    every V row a U-sample followed by a Z-sample) and handed to the device as
+    index lists ("parity mode").
+    """
+
+    def _draw(self, rows, n, ratio):
+        size = int(n * ratio)
+        out = np.empty((rows, size), dtype=np.int32)
+        ar = np.arange(n)
+        for i in range(rows):
+            out[i] = np.random.permutation(ar)[:size]
+        return out
+
+    def _device_step(self, l1_reg, l2_reg, alpha):
+        m, d, p, _ = self._ctx.shape
+        ratio = self.sg_sample_ratio
+        u_idx = z_idx = vx_idx = vy_idx = None
+        if ratio < 1.:
+            if self.update_U:
+                u_idx = self._draw(m, d, ratio)
+            if self.update_Z:
+                z_idx = self._draw(p, d, ratio)
+            if self.update_V:
+                sm, sp_ = int(m * ratio), int(p * ratio)
+                vx_idx = np.empty((d, sm), dtype=np.int32)
+                vy_idx = np.empty((d, sp_), dtype=np.int32)
+                am, ap = np.arange(m), np.arange(p)
+                for i in range(d):
+                    vx_idx[i] = np.random.permutation(am)[:sm]
+                    vy_idx[i] = np.random.permutation(ap)[:sp_]
+        self._ctx.newton_step(alpha, l1_reg, l2_reg, self.x_link, self.y_link,
+                              self._nn_mask(), self._update_mask(),
+                              self.hessian_pertubation, ratio, u_idx, z_idx, vx_idx, vy_idx)

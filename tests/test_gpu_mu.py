@@ -1,0 +1,123 @@
+"""GPU parity tests for the MU path: HIP (through the C ABI) vs the CPU oracle and
+the golden vectors minted from the reference.  Run with -m gpu on an MI355X."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pycmf_amd import _lib
+    if _lib.device_count() < 1:
+        pytest.fail("no GPU visible: the gpu-marked tests need an MI355X")
+    return _lib
+
+
+def _step(lib, X, Y, U, V, Z, l1=0.0, l2=0.0, iters=1, mask=7):
+    ctx = lib.Context(0)
+    m, k = U.shape
+    ctx.set_problem(m, V.shape[0], Z.shape[0], k)
+    ctx.set_data(0, X)
+    ctx.set_data(1, Y)
+    for w, F in enumerate((U, V, Z)):
+        ctx.set_factor(w, F)
+    for _ in range(iters):
+        ctx.mu_step(l1, l2, mask)
+    out = [ctx.get_factor(w) for w in range(3)]
+    ctx.close()
+    return out
+
+
+@pytest.mark.parametrize("tag,l1,l2", [("plain", 0.0, 0.0), ("reg", 0.3, 0.7)])
+@pytest.mark.parametrize("fmt", ["dense", "csr"])
+@pytest.mark.parametrize("iters", [1, 10])
+def test_mu_golden_steps(lib, tag, l1, l2, fmt, iters):
+    g = load_golden("g2_mu_steps")
+    X = sp.csr_matrix(g["X"]) if fmt == "csr" else g["X"]
+    U, V, Z = _step(lib, X, g["Y"], g["U0"], g["V0"], g["Z0"], l1, l2, iters)
+    tol = 2e-5 if iters == 1 else 2e-4  # float32 device arithmetic vs float64 reference
+    for n, a in (("U", U), ("V", V), ("Z", Z)):
+        np.testing.assert_allclose(a, g["%s_%s_%s%d" % (tag, fmt, n, iters)], rtol=tol, atol=1e-6)
+
+
+def test_mu_signed_zero_den_partial(lib):
+    g = load_golden("g2_mu_steps")
+    U, V, Z = _step(lib, g["sX"], g["sY"], g["sU0"], g["sV0"], g["sZ0"])
+    for n, a in (("U", U), ("V", V), ("Z", Z)):
+        np.testing.assert_allclose(a, g["s%s1" % n], rtol=1e-3, atol=1e-4)  # signed data: cancellation
+    U, V, Z = _step(lib, g["zX"], g["zY"], g["zU0"], g["zV0"], g["zZ0"])
+    for n, a in (("U", U), ("V", V), ("Z", Z)):
+        np.testing.assert_allclose(a, g["z%s1" % n], rtol=2e-5, atol=1e-6)
+    U, V, Z = _step(lib, g["X"], g["Y"], g["U0"], g["V0"], g["Z0"], mask=1)
+    for n, a in (("U", U), ("V", V), ("Z", Z)):
+        np.testing.assert_allclose(a, g["p%s1" % n], rtol=2e-5, atol=1e-6)
+
+
+def _problem(seed, m, d, p, k):
+    rng = np.random.RandomState(seed)
+    X, Y = np.abs(rng.randn(m, d)), np.abs(rng.randn(d, p))
+    s = np.sqrt(X.mean() / k)
+    return X, Y, s * np.abs(rng.randn(m, k)), s * np.abs(rng.randn(d, k)), s * np.abs(rng.randn(p, k))
+
+
+def test_mu_midsize_residual_parity(lib):
+    """G6: 256x192 / 192x96, k=32, 20 iterations; north_star tolerance: residuals within
+    1e-4 relative of the float64 reference."""
+    g = load_golden("g6_mid_mu")
+    rng = np.random.RandomState(42)
+    X, Y = np.abs(rng.randn(256, 192)), np.abs(rng.randn(192, 96))
+    U0, V0, Z0 = np.abs(rng.randn(256, 32)), np.abs(rng.randn(192, 32)), np.abs(rng.randn(96, 32))
+    s = np.sqrt(X.mean() / 32)
+    U, V, Z = _step(lib, X, Y, U0 * s, V0 * s, Z0 * s, iters=20)
+    ex, ey = np.linalg.norm(X - U @ V.T), np.linalg.norm(Y - V @ Z.T)
+    rx, ry = g["errs"][-1]
+    assert abs(ex - rx) <= 1e-4 * rx
+    assert abs(ey - ry) <= 1e-4 * ry
+    np.testing.assert_allclose(U, g["U"], rtol=2e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("m,d,p,k", [(5, 4, 1, 4), (300, 260, 70, 5), (513, 257, 255, 37),
+                                      (700, 300, 520, 130), (1024, 768, 512, 256), (64, 2000, 40, 64)])
+def test_mu_vs_oracle_ragged(lib, m, d, p, k):
+    from oracle import cmf_oracle as O
+    X, Y, U0, V0, Z0 = _problem(m + k, m, d, p, k)
+    U, V, Z = _step(lib, X, Y, U0, V0, Z0, 0.01, 0.02, iters=3)
+    Ur, Vr, Zr = U0.copy(), V0.copy(), Z0.copy()
+    for _ in range(3):
+        O.mu_update_step(X, Y, Ur, Vr, Zr, 0.01, 0.02)
+    for a, b in ((U, Ur), (V, Vr), (Z, Zr)):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("link", ["linear", "logit"])
+def test_residual_sq(lib, link):
+    from oracle import cmf_oracle as O
+    X, Y, U, V, Z = _problem(3, 333, 270, 129, 20)
+    if link == "logit":
+        X, Y = 1 / (1 + np.exp(-X)), 1 / (1 + np.exp(-Y))
+        U, V, Z = U - U.mean(), V - V.mean(), Z - Z.mean()
+    ctx = lib.Context(0)
+    ctx.set_problem(333, 270, 129, 20)
+    ctx.set_data(0, X); ctx.set_data(1, Y)
+    for w, F in enumerate((U, V, Z)):
+        ctx.set_factor(w, F)
+    ex2, ey2 = ctx.residual_sq(link, link)
+    x2, y2 = ctx.data_sq()
+    Xd = ctx.get_data(0)
+    ctx.close()
+    np.testing.assert_allclose(np.sqrt(ex2), O.factorization_error(X, U, V.T, link), rtol=1e-5)
+    np.testing.assert_allclose(np.sqrt(ey2), O.factorization_error(Y, V, Z.T, link), rtol=1e-5)
+    np.testing.assert_allclose(x2, np.sum(X.astype(np.float32).astype(np.float64) ** 2), rtol=1e-6)
+    np.testing.assert_array_equal(Xd, X.astype(np.float32))
+
+
+def test_strided_and_fortran_inputs(lib):
+    X, Y, U0, V0, Z0 = _problem(9, 40, 30, 20, 6)
+    ref = _step(lib, X, Y, U0, V0, Z0)
+    got = _step(lib, np.asfortranarray(X), Y.T.copy().T, np.asfortranarray(U0), V0[::1], Z0.T.copy().T)
+    for a, b in zip(ref, got):
+        np.testing.assert_array_equal(a, b)
