@@ -137,9 +137,10 @@ int cmf_safe_invert_batch(cmf_ctx *ctx, const double *H, double *out, int n, int
 
 /* ---- measurement ------------------------------------------------------ */
 /* when enabled every kernel launch is bracketed by hipEvents on the context's
- * stream; cmf_kernel_time returns accumulated ms and launch count per class. */
+ * stream; cmf_kernel_time returns accumulated ms, launch count and algorithmic
+ * flops (2*M*N*K of every GEMM launched, 0 for the other classes) per class.  */
 int cmf_kernel_timing(cmf_ctx *ctx, int enable);
-int cmf_kernel_time(cmf_ctx *ctx, int kernel_class, double *ms, int64_t *launches);
+int cmf_kernel_time(cmf_ctx *ctx, int kernel_class, double *ms, int64_t *launches, double *flops);
 int cmf_kernel_timing_reset(cmf_ctx *ctx);
 /* padded device geometry (m_pad, d_pad, p_pad, k_pad) */
 int cmf_get_geometry(cmf_ctx *ctx, int64_t *m_pad, int64_t *d_pad, int64_t *p_pad, int *k_pad);

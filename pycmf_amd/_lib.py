@@ -54,7 +54,7 @@ PROTOTYPES = {
     "cmf_data_sq": [_vp, _pd, _pd],
     "cmf_safe_invert_batch": [_vp, _pd, _pd, _i32, _i32, _dbl],
     "cmf_kernel_timing": [_vp, _i32],
-    "cmf_kernel_time": [_vp, _i32, _pd, _pi64],
+    "cmf_kernel_time": [_vp, _i32, _pd, _pi64, _pd],
     "cmf_kernel_timing_reset": [_vp],
     "cmf_get_geometry": [_vp, _pi64, _pi64, _pi64, C.POINTER(C.c_int)],
     "cmf_factor_dev_ptr": [_vp, _i32, C.POINTER(_pf)],
@@ -248,9 +248,10 @@ class Context:
         check(self._lib.cmf_kernel_timing_reset(self._h))
 
     def kernel_time(self, cls):
-        ms, n = C.c_double(0), C.c_int64(0)
-        check(self._lib.cmf_kernel_time(self._h, KERNEL_CLASSES.get(cls, cls), C.byref(ms), C.byref(n)))
-        return ms.value, n.value
+        """(accumulated ms, launches, algorithmic flops) of one kernel class."""
+        ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
+        check(self._lib.cmf_kernel_time(self._h, KERNEL_CLASSES.get(cls, cls), C.byref(ms), C.byref(n), C.byref(fl)))
+        return ms.value, n.value, fl.value
 
     def geometry(self):
         a, b, c_, k = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int(0)

@@ -51,6 +51,7 @@ struct DevBuf {
 struct EvPair {
     hipEvent_t a, b;
     int cls;
+    double flops;
 };
 
 struct cmf_ctx {
@@ -86,6 +87,7 @@ struct cmf_ctx {
     std::vector<hipEvent_t> evpool;
     double ms[CMF_K_COUNT] = {0};
     int64_t launches[CMF_K_COUNT] = {0};
+    double flops[CMF_K_COUNT] = {0};
 };
 
 struct DeviceGuard {
@@ -115,7 +117,8 @@ struct Timed {
     int cls;
     hipEvent_t a = nullptr, b = nullptr;
     bool on = false;
-    Timed(cmf_ctx *c_, int cls_) : c(c_), cls(cls_) {
+    double flops = 0.0;
+    Timed(cmf_ctx *c_, int cls_, double flops_ = 0.0) : c(c_), cls(cls_), flops(flops_) {
         if (c->timing && ev_get(c, &a) == CMF_OK && ev_get(c, &b) == CMF_OK) {
             on = true;
             (void)hipEventRecord(a, c->stream);
@@ -124,9 +127,7 @@ struct Timed {
     ~Timed() {
         if (on) {
             (void)hipEventRecord(b, c->stream);
-            c->pending.push_back({a, b, cls});
-        } else {
-            c->launches[cls] += 0;
+            c->pending.push_back({a, b, cls, flops});
         }
     }
 };
@@ -138,6 +139,7 @@ static int flush_timing(cmf_ctx *c) {
         HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
         c->ms[e.cls] += ms;
         c->launches[e.cls] += 1;
+        c->flops[e.cls] += e.flops;
         c->evpool.push_back(e.a);
         c->evpool.push_back(e.b);
     }
@@ -265,7 +267,7 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
         a.slab_stride = rows_store * n;
     }
     {
-        Timed tm(c, mode == MODE_NN ? CMF_K_GEMM_NN : CMF_K_GEMM_TN);
+        Timed tm(c, mode == MODE_NN ? CMF_K_GEMM_NN : CMF_K_GEMM_TN, 2.0 * (double)mout * (double)n * (double)kred);
         if (mode == MODE_NN) CHK(launch_gemm_mode<MODE_NN>(c, a, pl));
         else CHK(launch_gemm_mode<MODE_TN>(c, a, pl));
     }
@@ -300,7 +302,7 @@ static int gemm_nt(cmf_ctx *c, const float *L, int64_t rows_pad, int64_t rows_va
         a.sq_out = (double *)c->dpart.p;
     }
     {
-        Timed tm(c, CMF_K_GEMM_NT);
+        Timed tm(c, CMF_K_GEMM_NT, 2.0 * (double)rows_valid * (double)cols_valid * (double)c->kp);
         CHK(launch_gemm_mode<MODE_NT>(c, a, pl));
     }
     if (o.sq) {
@@ -718,19 +720,20 @@ extern "C" int cmf_kernel_timing(cmf_ctx *c, int enable) {
     c->timing = enable != 0;
     return CMF_OK;
 }
-extern "C" int cmf_kernel_time(cmf_ctx *c, int cls, double *ms, int64_t *launches) {
+extern "C" int cmf_kernel_time(cmf_ctx *c, int cls, double *ms, int64_t *launches, double *flops) {
     if (!c || cls < 0 || cls >= CMF_K_COUNT) return fail(CMF_EINVAL, "bad kernel class");
     DeviceGuard dg(c->device);
     CHK(flush_timing(c));
     if (ms) *ms = c->ms[cls];
     if (launches) *launches = c->launches[cls];
+    if (flops) *flops = c->flops[cls];
     return CMF_OK;
 }
 extern "C" int cmf_kernel_timing_reset(cmf_ctx *c) {
     if (!c) return fail(CMF_EINVAL, "null context");
     DeviceGuard dg(c->device);
     CHK(flush_timing(c));
-    for (int i = 0; i < CMF_K_COUNT; ++i) { c->ms[i] = 0; c->launches[i] = 0; }
+    for (int i = 0; i < CMF_K_COUNT; ++i) { c->ms[i] = 0; c->launches[i] = 0; c->flops[i] = 0; }
     return CMF_OK;
 }
 

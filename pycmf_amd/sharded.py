@@ -1,0 +1,77 @@
+"""Multi-GPU data-parallel driver: one process per GPU, one all-reduce per iteration.
+
+Partitioning:  rank g owns a row block of X and U and the
+matching column block of Y and rows of Z; V is replicated.  The V update needs
+sums over all of m and p, so every rank forms its partial
+
+    buf_g = [ X_g^T U_g + Y_g Z_g  (d x k) | U_g^T U_g + Z_g^T Z_g  (k x k) ]
+
+and a single ``all_reduce(sum)`` (RCCL over xGMI through torch.distributed)
+turns it into the global numerator/Gram of pycmf/cmf_solvers.py:244-245; every
+rank then applies the identical V epilogue and updates its own U_g, Z_g locally.
+
+The local compute is a *backend* object with three methods so that the host
+logic (partition arithmetic, collective placement) can be exercised on CPU with
+the gloo backend and a test double, while production uses ``HipShardBackend``:
+
+    partials(buf)            fill buf with this shard's partial
+    apply_v(buf, l1, l2)     V update from the reduced buffer
+    update_uz(l1, l2, mask)  local U / Z update
+"""
+import numpy as np
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous, balanced partition of range(n): first n % world shards get one extra."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class HipShardBackend:
+    """Local shard on one MI355X through libcmfhip (no CPU fallback)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def buf_elems(self):
+        return self.ctx.v_buf_elems()
+
+    def partials(self, buf):
+        self.ctx.mu_v_partials(buf.data_ptr())
+
+    def apply_v(self, buf, l1, l2):
+        self.ctx.mu_v_apply(buf.data_ptr(), l1, l2)
+
+    def update_uz(self, l1, l2, mask):
+        self.ctx.mu_uz_update(l1, l2, mask)
+
+
+class ShardedMU:
+    """One MU iteration across ``world`` ranks (order V -> U -> Z, cmf_solvers.py:248-263)."""
+
+    def __init__(self, backend, buf, world=1, all_reduce=None):
+        self.backend = backend
+        self.buf = buf
+        self.world = world
+        self.all_reduce = all_reduce
+
+    def step(self, l1=0.0, l2=0.0, mask=7):
+        if mask & 2:
+            self.backend.partials(self.buf)
+            if self.world > 1:
+                self.all_reduce(self.buf)  # the single collective of the iteration
+            self.backend.apply_v(self.buf, l1, l2)
+        self.backend.update_uz(l1, l2, mask)
+
+
+def make_torch_sharded_mu(ctx, world, device):
+    """Wire a HIP context to torch.distributed (backend 'nccl' = RCCL)."""
+    import torch
+    import torch.distributed as dist
+    backend = HipShardBackend(ctx)
+    buf = torch.zeros(backend.buf_elems(), dtype=torch.float32, device=device)
+
+    def all_reduce(t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return ShardedMU(backend, buf, world, all_reduce if world > 1 else None)
