@@ -3,6 +3,7 @@
 // (reference: pycmf/cmf_solvers.py:248-263 MU, :510-522 Newton, :36-42 error).
 #include "../../include/cmfhip.h"
 #include "cmf_kernels.hip.h"
+#include "cmf_eigen.hip.h"
 
 #include <hip/hip_runtime.h>
 
@@ -76,7 +77,12 @@ struct cmf_ctx {
     float *vbuf = nullptr;                // dp*kp + kp*kp
     DevBuf slabs;                         // split-K partial tiles (grow-only)
     DevBuf resid;                         // Newton residual / weights scratch (grow-only)
-    DevBuf resid2;
+    DevBuf resid2, resid3;                // sigma' / sample weights (X side, Y side)
+    DevBuf kr1, kr2;                      // Khatri-Rao squares of factors
+    DevBuf hrows;                         // chunk of per-row Hessians / inverses
+    DevBuf mask1, mask2;                  // stochastic sample masks (bytes)
+    DevBuf idxbuf;                        // uploaded sample index lists
+    DevBuf eigws;                         // Jacobi workspace when k_pad > 128
     DevBuf dpart;                         // double partial sums
     double *dscalar = nullptr;            // 4 doubles
     std::vector<void *> owned;
@@ -378,7 +384,9 @@ static void release_problem(cmf_ctx *c) {
     c->X = c->Y = nullptr;
     c->F[0] = c->F[1] = c->F[2] = nullptr;
     c->num = c->den = c->G = c->G2 = c->Hm = c->Hinv = c->vbuf = nullptr;
-    c->slabs = DevBuf(); c->resid = DevBuf(); c->resid2 = DevBuf(); c->dpart = DevBuf();
+    c->slabs = DevBuf(); c->resid = DevBuf(); c->resid2 = DevBuf(); c->resid3 = DevBuf(); c->dpart = DevBuf();
+    c->kr1 = DevBuf(); c->kr2 = DevBuf(); c->hrows = DevBuf(); c->mask1 = DevBuf(); c->mask2 = DevBuf();
+    c->idxbuf = DevBuf(); c->eigws = DevBuf();
     c->have_problem = false;
 }
 

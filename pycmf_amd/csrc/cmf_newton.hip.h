@@ -1,22 +1,355 @@
-// cmf_newton.hip.h -- Newton solver entry points (included by cmf_api.hip)
-extern "C" int cmf_newton_step(cmf_ctx *c, double, double, double, int, int, int, int, double, double,
-                               const int32_t *, const int32_t *, const int32_t *, const int32_t *) {
-    NEED_PROBLEM(c);
-    return fail(CMF_EUNSUPPORTED, "newton step not built yet");
+// cmf_newton.hip.h -- Newton-Raphson sweeps U -> Z -> V (included by cmf_api.hip).
+//
+// Reference: NewtonSolver.update_step and helpers, pycmf/cmf_solvers.py:318-522
+// (the live pure-Python path; the Cython twin pycmf/cmf_newton_solver.pyx:240-362
+// computes the same quantities).  Every sweep is row-parallel (each row reads only
+// its own pre-sweep value and the other, frozen factors), so a sweep becomes a
+// handful of batched operations:
+//   * "shared" form (linear link, no sampling): one k x k Hessian for all rows,
+//       grad = s (F G - T O) + l1 sign F + l2 F,  F <- F - grad H^-1      (:396-410)
+//   * "per-row" form (logit link and/or sg_sample_ratio < 1):
+//       R = s m (f(F O^T) - T), W = s m w(F O^T)   one NT GEMM with fused epilogue
+//       grad = R O + reg                            big NN/TN GEMM
+//       H_i  = sum_j W_ij o_j o_j^T  (+ l2 I)       GEMM against the Khatri-Rao
+//                                                   square KR(O)[j] = o_j (x) o_j
+//       H_i^-1 by batched Jacobi, step_i = g_i H_i^-1                     (:412-430)
+//   m is the 0/1 sample mask built from the index lists the host drew (:328-344).
+
+template <typename... Args>
+static int launch_ew(cmf_ctx *c, void (*kern)(Args...), int64_t n, Args... args) {
+    Timed tm(c, CMF_K_ELEMWISE);
+    if (n <= 0) return CMF_OK;
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, c->stream, args...);
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
 }
-extern "C" int cmf_newton_uz_update(cmf_ctx *c, double, double, double, int, int, double) {
-    NEED_PROBLEM(c);
-    return fail(CMF_EUNSUPPORTED, "newton step not built yet");
+
+// Hout_i = safe_inverse(Hin_i) for nmat k_pad x k_pad matrices (valid order c->k)
+static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat, int n, int kp, double pert) {
+    if (nmat <= 0) return CMF_OK;
+    const int64_t stride = (int64_t)kp * kp;
+    const size_t lds_need = (size_t)(2 * n * n + n) * sizeof(float);
+    Timed tm(c, CMF_K_EIGEN);
+    if (lds_need <= 150 * 1024) {
+        static bool attr = false;
+        if (!attr) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&jacobi_safe_inverse_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr = true;
+        }
+        hipLaunchKernelGGL((jacobi_safe_inverse_kernel<true>), dim3(nmat), dim3(256), lds_need, c->stream, Hin, Hout,
+                           (float *)nullptr, n, kp, stride, (float)pert, nmat, 30);
+    } else {
+        CHK(ensure(c, c->eigws, (size_t)nmat * 2 * stride * sizeof(float)));
+        hipLaunchKernelGGL((jacobi_safe_inverse_kernel<false>), dim3(nmat), dim3(256), (size_t)n * sizeof(float), c->stream,
+                           Hin, Hout, (float *)c->eigws.p, n, kp, stride, (float)pert, nmat, 30);
+    }
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
 }
-extern "C" int cmf_newton_v_partials(cmf_ctx *c, double, float *) {
-    NEED_PROBLEM(c);
-    return fail(CMF_EUNSUPPORTED, "newton step not built yet");
+
+extern "C" int cmf_safe_invert_batch(cmf_ctx *c, const double *H, double *out, int n, int k, double pert) {
+    if (!c || !H || !out || n < 0 || k <= 0) return fail(CMF_EINVAL, "bad argument");
+    DeviceGuard dg(c->device);
+    const int kp = pad_k(k);
+    const size_t elems = (size_t)n * kp * kp;
+    std::vector<float> host(elems, 0.f);
+    for (int i = 0; i < n; ++i)
+        for (int r = 0; r < k; ++r)
+            for (int q = 0; q < k; ++q) host[((size_t)i * kp + r) * kp + q] = (float)H[((size_t)i * k + r) * k + q];
+    float *dH = nullptr;
+    HIPCHK(hipMalloc((void **)&dH, std::max<size_t>(elems, 4) * sizeof(float)));
+    int rc = CMF_OK;
+    do {
+        if (hipMemcpyAsync(dH, host.data(), elems * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(CMF_EHIP, "H2D failed"); break; }
+        rc = safe_inverse_dev(c, dH, dH, n, k, kp, pert);
+        if (rc != CMF_OK) break;
+        if (hipMemcpyAsync(host.data(), dH, elems * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail(CMF_EHIP, "D2H failed"); break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CMF_EHIP, "sync failed"); break; }
+    } while (0);
+    (void)hipFree(dH);
+    if (rc != CMF_OK) return rc;
+    for (int i = 0; i < n; ++i)
+        for (int r = 0; r < k; ++r)
+            for (int q = 0; q < k; ++q) out[((size_t)i * k + r) * k + q] = (double)host[((size_t)i * kp + r) * kp + q];
+    return CMF_OK;
 }
-extern "C" int cmf_newton_v_apply(cmf_ctx *c, const float *, double, double, int, double) {
-    NEED_PROBLEM(c);
-    return fail(CMF_EUNSUPPORTED, "newton step not built yet");
+
+// ---- shared-Hessian building blocks ------------------------------------------------------
+// F <- clamp(F - grad * safe_inverse(Hm)); grad lives in c->den, scratch in c->num
+static int shared_step(cmf_ctx *c, int which, double pert, bool non_negative) {
+    const int64_t rows = c->frows_pad[which];
+    CHK(safe_inverse_dev(c, c->Hm, c->Hinv, 1, c->k, c->kp, pert));
+    CHK(gemm(c, MODE_NN, c->den, c->kp, c->Hinv, c->kp, c->num, rows, c->kp, c->kp));
+    return launch_ew(c, newton_apply_kernel, rows * c->kp, c->F[which], (const float *)c->num, c->frows[which], c->kp, c->k,
+                     rows * c->kp, non_negative ? 1 : 0);
 }
-extern "C" int cmf_safe_invert_batch(cmf_ctx *c, const double *, double *, int, int, double) {
-    if (!c) return fail(CMF_EINVAL, "null context");
-    return fail(CMF_EUNSUPPORTED, "eigen solver not built yet");
+
+// U (left=true: T = X, rows m) or Z (left=false: T = Y^T, rows p) with a shared Hessian
+static int sweep_side_shared(cmf_ctx *c, bool is_u, double scale, double l1, double l2, double pert, bool nn) {
+    const int which = is_u ? CMF_U : CMF_Z;
+    const int64_t rows = c->frows_pad[which];
+    float *F = c->F[which], *V = c->F[CMF_V];
+    CHK(gemm(c, MODE_TN, V, c->kp, V, c->kp, c->G2, c->kp, c->kp, c->dp)); // V^T V
+    if (is_u) CHK(gemm(c, MODE_NN, c->X, c->dp, V, c->kp, c->num, c->mp, c->kp, c->dp)); // X V
+    else CHK(gemm(c, MODE_TN, c->Y, c->pp, V, c->kp, c->num, c->pp, c->kp, c->dp));     // Y^T V
+    CHK(gemm(c, MODE_NN, F, c->kp, c->G2, c->kp, c->den, rows, c->kp, c->kp));           // F (V^T V)
+    CHK(launch_ew(c, newton_grad_kernel, rows * c->kp, c->den, (const float *)c->den, (float)scale, (const float *)c->num,
+                  (float)-scale, (const float *)F, (float)l1, (float)l2, rows * c->kp));
+    CHK(launch_ew(c, axpby_diag_kernel, (int64_t)c->kp * c->kp, c->Hm, (const float *)c->G2, (float)scale,
+                  (const float *)nullptr, 0.f, (float)l2, c->kp, c->k));
+    return shared_step(c, which, pert, nn);
+}
+
+extern "C" int cmf_newton_v_partials(cmf_ctx *c, double alpha, float *buf) {
+    NEED_PROBLEM(c);
+    if (!buf) return fail(CMF_EINVAL, "null buffer");
+    if (!c->X || !c->Y) return fail(CMF_EINVAL, "X and Y must be set before a V update");
+    DeviceGuard dg(c->device);
+    float *P = buf, *Gs = buf + c->dp * c->kp;
+    CHK(gemm(c, MODE_TN, c->X, c->dp, c->F[CMF_U], c->kp, c->num, c->dp, c->kp, c->mp)); // X^T U
+    CHK(gemm(c, MODE_NN, c->Y, c->pp, c->F[CMF_Z], c->kp, c->den, c->dp, c->kp, c->pp)); // Y Z
+    CHK(launch_ew(c, axpby_kernel, c->dp * c->kp, P, (const float *)c->num, (float)alpha, (const float *)c->den,
+                  (float)(1.0 - alpha), c->dp * c->kp));
+    CHK(gemm(c, MODE_TN, c->F[CMF_U], c->kp, c->F[CMF_U], c->kp, c->G, c->kp, c->kp, c->mp));
+    CHK(gemm(c, MODE_TN, c->F[CMF_Z], c->kp, c->F[CMF_Z], c->kp, c->G2, c->kp, c->kp, c->pp));
+    return launch_ew(c, axpby_kernel, (int64_t)c->kp * c->kp, Gs, (const float *)c->G, (float)alpha, (const float *)c->G2,
+                     (float)(1.0 - alpha), (int64_t)c->kp * c->kp);
+}
+
+extern "C" int cmf_newton_v_apply(cmf_ctx *c, const float *buf, double l1, double l2, int nn_mask, double pert) {
+    NEED_PROBLEM(c);
+    if (!buf) return fail(CMF_EINVAL, "null buffer");
+    DeviceGuard dg(c->device);
+    const float *P = buf, *Gs = buf + c->dp * c->kp;
+    float *V = c->F[CMF_V];
+    CHK(gemm(c, MODE_NN, V, c->kp, Gs, c->kp, c->den, c->dp, c->kp, c->kp)); // V Gmix
+    CHK(launch_ew(c, newton_grad_kernel, c->dp * c->kp, c->den, (const float *)c->den, 1.0f, P, -1.0f, (const float *)V,
+                  (float)l1, (float)l2, c->dp * c->kp));
+    CHK(launch_ew(c, axpby_diag_kernel, (int64_t)c->kp * c->kp, c->Hm, Gs, 1.0f, (const float *)nullptr, 0.f, (float)l2,
+                  c->kp, c->k));
+    return shared_step(c, CMF_V, pert, (nn_mask & CMF_NN_V) != 0);
+}
+
+extern "C" int cmf_newton_uz_update(cmf_ctx *c, double alpha, double l1, double l2, int nn_mask, int upd, double pert) {
+    NEED_PROBLEM(c);
+    DeviceGuard dg(c->device);
+    if (upd & CMF_UPD_U) {
+        if (!c->X) return fail(CMF_EINVAL, "X must be set before a U update");
+        CHK(sweep_side_shared(c, true, alpha, l1, l2, pert, (nn_mask & CMF_NN_U) != 0));
+    }
+    if (upd & CMF_UPD_Z) {
+        if (!c->Y) return fail(CMF_EINVAL, "Y must be set before a Z update");
+        CHK(sweep_side_shared(c, false, 1.0 - alpha, l1, l2, pert, (nn_mask & CMF_NN_Z) != 0));
+    }
+    return CMF_OK;
+}
+
+// ---- per-row machinery --------------------------------------------------------------------
+static int build_mask(cmf_ctx *c, DevBuf &mb, int64_t rows_pad, int64_t cols_pad, const int32_t *idx, int64_t nlists,
+                      int64_t per, bool by_row) {
+    CHK(ensure(c, mb, (size_t)rows_pad * cols_pad));
+    HIPCHK(hipMemsetAsync(mb.p, 0, (size_t)rows_pad * cols_pad, c->stream));
+    if (nlists * per == 0) return CMF_OK;
+    CHK(ensure(c, c->idxbuf, (size_t)nlists * per * sizeof(int32_t)));
+    HIPCHK(hipMemcpyAsync(c->idxbuf.p, idx, (size_t)nlists * per * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream)); // idx is caller memory: do not outlive the call
+    return launch_ew(c, scatter_mask_kernel, nlists * per, (uint8_t *)mb.p, cols_pad, (const int32_t *)c->idxbuf.p, nlists, per,
+                     by_row ? 1 : 0);
+}
+
+static int khatri_rao(cmf_ctx *c, DevBuf &kb, const float *F, int64_t rows_pad) {
+    const size_t bytes = (size_t)rows_pad * c->kp * c->kp * sizeof(float);
+    if (bytes > ((size_t)96 << 30))
+        return fail(CMF_EUNSUPPORTED, "per-row Hessian path: Khatri-Rao image of %lld x %d^2 floats exceeds the 96 GiB budget",
+                    (long long)rows_pad, c->kp);
+    CHK(ensure(c, kb, bytes));
+    return launch_ew(c, khatri_rao_kernel, rows_pad * c->kp * (c->kp / 4), (float *)kb.p, F, rows_pad, c->kp);
+}
+
+static int64_t hessian_chunk_rows(const cmf_ctx *c, int64_t rows_pad) {
+    const int64_t per = (int64_t)c->kp * c->kp * sizeof(float);
+    int64_t ch = (((int64_t)2 << 30) / per) / 256 * 256;
+    ch = std::max<int64_t>(256, ch);
+    return std::min(ch, rows_pad);
+}
+
+// residual / weight images of one data matrix: S = L Rt^T in the data's own layout
+static int residual_images(cmf_ctx *c, bool x_side, int link, double scale, const uint8_t *mask, float *R, float *W,
+                           bool w_slope) {
+    NtOut o;
+    o.link = link; o.scale_r = (float)scale; o.scale_w = (float)scale; o.w_is_slope = w_slope ? 1 : 0;
+    o.R = R; o.W = W; o.mask = mask;
+    if (x_side) {
+        o.T = c->X; o.ldt = c->dp; o.ldr = c->dp; o.ldm = c->dp;
+        return gemm_nt(c, c->F[CMF_U], c->mp, c->m, c->F[CMF_V], c->dp, c->d, o);
+    }
+    o.T = c->Y; o.ldt = c->pp; o.ldr = c->pp; o.ldm = c->pp;
+    return gemm_nt(c, c->F[CMF_V], c->dp, c->d, c->F[CMF_Z], c->pp, c->p, o);
+}
+
+// finish a per-row sweep: for every chunk of rows build H_i, invert, step; then apply
+struct RowHess {
+    // H_i = [tn ? A1^T : A1] KR1  (+ A2 KR2)  + S + diag I
+    const float *A1 = nullptr; int64_t lda1 = 0; bool a1_tn = false; const float *KR1 = nullptr; int64_t kred1 = 0;
+    const float *A2 = nullptr; int64_t lda2 = 0; bool a2_tn = false; const float *KR2 = nullptr; int64_t kred2 = 0;
+    const float *S = nullptr;
+    double diag = 0.0;
+};
+
+static int per_row_finish(cmf_ctx *c, int which, const RowHess &h, double pert, bool nn) {
+    const int64_t rows_pad = c->frows_pad[which], rows = c->frows[which];
+    const int64_t kk = (int64_t)c->kp * c->kp;
+    const int64_t chunk = hessian_chunk_rows(c, rows_pad);
+    CHK(ensure(c, c->hrows, (size_t)chunk * kk * sizeof(float)));
+    float *Hc = (float *)c->hrows.p;
+    float *grad = c->num, *step = c->den;
+    for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
+        const int64_t nr_pad = std::min(chunk, rows_pad - r0);
+        const int64_t nr = std::min(nr_pad, rows - r0);
+        bool have = false;
+        if (h.A1) {
+            const float *A = h.a1_tn ? h.A1 + r0 : h.A1 + r0 * h.lda1;
+            CHK(gemm(c, h.a1_tn ? MODE_TN : MODE_NN, A, h.lda1, h.KR1, kk, Hc, nr_pad, kk, h.kred1));
+            have = true;
+        }
+        if (h.A2) {
+            const float *A = h.a2_tn ? h.A2 + r0 : h.A2 + r0 * h.lda2;
+            CHK(gemm(c, h.a2_tn ? MODE_TN : MODE_NN, A, h.lda2, h.KR2, kk, Hc, nr_pad, kk, h.kred2, have));
+            have = true;
+        }
+        CHK(launch_ew(c, hessian_finalize_kernel, nr_pad * kk, Hc, h.S, (float)h.diag, nr_pad, c->kp, c->k, have ? 1 : 0));
+        CHK(safe_inverse_dev(c, Hc, Hc, (int)nr, c->k, c->kp, pert));
+        {
+            Timed tm(c, CMF_K_ELEMWISE);
+            hipLaunchKernelGGL(rowvec_mat_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, c->stream, step + r0 * c->kp,
+                               (const float *)(grad + r0 * c->kp), (const float *)Hc, nr, c->kp, c->k);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    return launch_ew(c, newton_apply_kernel, rows_pad * c->kp, c->F[which], (const float *)step, rows, c->kp, c->k,
+                     rows_pad * c->kp, nn ? 1 : 0);
+}
+
+// U sweep (cmf_solvers.py:394-430) / Z sweep (:488-508) in per-row form
+static int sweep_side_rows(cmf_ctx *c, bool is_u, int link, double scale, double l1, double l2, double pert, bool nn,
+                           const int32_t *idx, int64_t per) {
+    const int which = is_u ? CMF_U : CMF_Z;
+    const int64_t rows_pad = c->frows_pad[which];
+    const int64_t img = is_u ? c->mp * c->dp : c->dp * c->pp;
+    const uint8_t *mask = nullptr;
+    if (idx) {
+        // U: list i = columns (over d) of X row i;  Z: list i = rows (over d) of Y column i
+        CHK(build_mask(c, c->mask1, is_u ? c->mp : c->dp, is_u ? c->dp : c->pp, idx, c->frows[which], per, is_u));
+        mask = (const uint8_t *)c->mask1.p;
+    }
+    CHK(ensure(c, c->resid, (size_t)img * sizeof(float)));
+    CHK(ensure(c, c->resid2, (size_t)img * sizeof(float)));
+    float *R = (float *)c->resid.p, *W = (float *)c->resid2.p;
+    CHK(residual_images(c, is_u, link, scale, mask, R, W, link == CMF_LINK_LOGIT));
+    float *V = c->F[CMF_V];
+    if (is_u) CHK(gemm(c, MODE_NN, R, c->dp, V, c->kp, c->num, c->mp, c->kp, c->dp));
+    else CHK(gemm(c, MODE_TN, R, c->pp, V, c->kp, c->num, c->pp, c->kp, c->dp));
+    CHK(launch_ew(c, newton_grad_kernel, rows_pad * c->kp, c->num, (const float *)c->num, 1.0f, (const float *)nullptr, 0.f,
+                  (const float *)c->F[which], (float)l1, (float)l2, rows_pad * c->kp));
+    CHK(khatri_rao(c, c->kr1, V, c->dp));
+    RowHess h;
+    h.A1 = W; h.lda1 = is_u ? c->dp : c->pp; h.a1_tn = !is_u; h.KR1 = (const float *)c->kr1.p; h.kred1 = c->dp;
+    // the logit Hessian of U carries no l2 term (:427-428); Z always does (:501-506)
+    h.diag = (is_u && link == CMF_LINK_LOGIT) ? 0.0 : l2;
+    return per_row_finish(c, which, h, pert, nn);
+}
+
+// V sweep in per-row form (cmf_solvers.py:432-486)
+static int sweep_v_rows(cmf_ctx *c, double alpha, double l1, double l2, int x_link, int y_link, double pert, bool nn,
+                        const int32_t *vx_idx, int64_t per_x, const int32_t *vy_idx, int64_t per_y) {
+    const uint8_t *mx = nullptr, *my = nullptr;
+    if (vx_idx) { // list i = rows (over m) of X column i
+        CHK(build_mask(c, c->mask1, c->mp, c->dp, vx_idx, c->d, per_x, false));
+        mx = (const uint8_t *)c->mask1.p;
+    }
+    if (vy_idx) { // list i = columns (over p) of Y row i
+        CHK(build_mask(c, c->mask2, c->dp, c->pp, vy_idx, c->d, per_y, true));
+        my = (const uint8_t *)c->mask2.p;
+    }
+    const bool x_shared = (x_link == CMF_LINK_LINEAR && !mx); // H_U = U^T U for every row
+    const bool y_shared = (y_link == CMF_LINK_LINEAR && !my);
+    const int64_t imgx = c->mp * c->dp, imgy = c->dp * c->pp;
+    CHK(ensure(c, c->resid, (size_t)std::max(imgx, imgy) * sizeof(float)));
+    float *R = (float *)c->resid.p, *WX = nullptr, *WY = nullptr;
+    if (!x_shared) { CHK(ensure(c, c->resid2, (size_t)imgx * sizeof(float))); WX = (float *)c->resid2.p; }
+    if (!y_shared) { CHK(ensure(c, c->resid3, (size_t)imgy * sizeof(float))); WY = (float *)c->resid3.p; }
+    // gradient: alpha R_X^T U + (1-alpha) R_Y Z + reg
+    CHK(residual_images(c, true, x_link, alpha, mx, R, WX, x_link == CMF_LINK_LOGIT));
+    CHK(gemm(c, MODE_TN, R, c->dp, c->F[CMF_U], c->kp, c->num, c->dp, c->kp, c->mp));
+    CHK(residual_images(c, false, y_link, 1.0 - alpha, my, R, WY, y_link == CMF_LINK_LOGIT));
+    CHK(gemm(c, MODE_NN, R, c->pp, c->F[CMF_Z], c->kp, c->num, c->dp, c->kp, c->pp, true));
+    CHK(launch_ew(c, newton_grad_kernel, c->dp * c->kp, c->num, (const float *)c->num, 1.0f, (const float *)nullptr, 0.f,
+                  (const float *)c->F[CMF_V], (float)l1, (float)l2, c->dp * c->kp));
+    RowHess h;
+    h.diag = l2;
+    const float *Gu = nullptr, *Gz = nullptr;
+    if (x_shared) { CHK(gemm(c, MODE_TN, c->F[CMF_U], c->kp, c->F[CMF_U], c->kp, c->G, c->kp, c->kp, c->mp)); Gu = c->G; }
+    if (y_shared) { CHK(gemm(c, MODE_TN, c->F[CMF_Z], c->kp, c->F[CMF_Z], c->kp, c->G2, c->kp, c->kp, c->pp)); Gz = c->G2; }
+    if (Gu || Gz) {
+        const float *A = Gu ? Gu : Gz;
+        const float a = Gu ? (float)alpha : (float)(1.0 - alpha);
+        const float *B = (Gu && Gz) ? Gz : nullptr;
+        CHK(launch_ew(c, axpby_kernel, (int64_t)c->kp * c->kp, c->Hm, A, a, B, (float)(1.0 - alpha), (int64_t)c->kp * c->kp));
+        h.S = c->Hm;
+    }
+    if (!x_shared) {
+        CHK(khatri_rao(c, c->kr1, c->F[CMF_U], c->mp));
+        h.A1 = WX; h.lda1 = c->dp; h.a1_tn = true; h.KR1 = (const float *)c->kr1.p; h.kred1 = c->mp;
+    }
+    if (!y_shared) {
+        CHK(khatri_rao(c, c->kr2, c->F[CMF_Z], c->pp));
+        const float **A = h.A1 ? &h.A2 : &h.A1;
+        if (h.A1) { h.A2 = WY; h.lda2 = c->pp; h.a2_tn = false; h.KR2 = (const float *)c->kr2.p; h.kred2 = c->pp; }
+        else { h.A1 = WY; h.lda1 = c->pp; h.a1_tn = false; h.KR1 = (const float *)c->kr2.p; h.kred1 = c->pp; }
+        (void)A;
+    }
+    return per_row_finish(c, CMF_V, h, pert, nn);
+}
+
+extern "C" int cmf_newton_step(cmf_ctx *c, double alpha, double l1, double l2, int x_link, int y_link, int nn_mask, int upd,
+                               double pert, double ratio, const int32_t *u_idx, const int32_t *z_idx, const int32_t *vx_idx,
+                               const int32_t *vy_idx) {
+    NEED_PROBLEM(c);
+    if ((x_link != 0 && x_link != 1) || (y_link != 0 && y_link != 1)) return fail(CMF_EINVAL, "bad link id");
+    DeviceGuard dg(c->device);
+    const bool sampled = ratio < 1.0;
+    const int64_t su = (int64_t)((double)c->d * ratio);  // int(n * ratio), cmf_solvers.py:331
+    const int64_t sm = (int64_t)((double)c->m * ratio), sp = (int64_t)((double)c->p * ratio);
+    if (sampled) {
+        if (((upd & CMF_UPD_U) && !u_idx) || ((upd & CMF_UPD_Z) && !z_idx) || ((upd & CMF_UPD_V) && (!vx_idx || !vy_idx)))
+            return fail(CMF_EINVAL, "sg_sample_ratio < 1 needs the sample index lists of every updated factor");
+    }
+    if (upd & CMF_UPD_U) {
+        if (!c->X) return fail(CMF_EINVAL, "X must be set before a U update");
+        if (x_link == CMF_LINK_LINEAR && !sampled)
+            CHK(sweep_side_shared(c, true, alpha, l1, l2, pert, (nn_mask & CMF_NN_U) != 0));
+        else
+            CHK(sweep_side_rows(c, true, x_link, alpha, l1, l2, pert, (nn_mask & CMF_NN_U) != 0, sampled ? u_idx : nullptr, su));
+    }
+    if (upd & CMF_UPD_Z) {
+        if (!c->Y) return fail(CMF_EINVAL, "Y must be set before a Z update");
+        if (y_link == CMF_LINK_LINEAR && !sampled)
+            CHK(sweep_side_shared(c, false, 1.0 - alpha, l1, l2, pert, (nn_mask & CMF_NN_Z) != 0));
+        else
+            CHK(sweep_side_rows(c, false, y_link, 1.0 - alpha, l1, l2, pert, (nn_mask & CMF_NN_Z) != 0,
+                                sampled ? z_idx : nullptr, su));
+    }
+    if (upd & CMF_UPD_V) {
+        if (!c->X || !c->Y) return fail(CMF_EINVAL, "X and Y must be set before a V update");
+        if (x_link == CMF_LINK_LINEAR && y_link == CMF_LINK_LINEAR && !sampled) {
+            CHK(cmf_newton_v_partials(c, alpha, c->vbuf));
+            CHK(cmf_newton_v_apply(c, c->vbuf, l1, l2, nn_mask, pert));
+        } else {
+            CHK(sweep_v_rows(c, alpha, l1, l2, x_link, y_link, pert, (nn_mask & CMF_NN_V) != 0, sampled ? vx_idx : nullptr, sm,
+                             sampled ? vy_idx : nullptr, sp));
+        }
+    }
+    return CMF_OK;
 }

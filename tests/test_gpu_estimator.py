@@ -1,0 +1,254 @@
+"""End-to-end contracts of the drop-in API on the GPU, mirroring the reference's own test
+suite (tests/test_cmf.py of smn-ailab/PyCMF; line numbers below refer to it) plus fit-level
+parity against golden values minted from the reference."""
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+from sklearn.base import clone
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+solvers = ["mu", "newton"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    from pycmf_amd import _lib
+    if _lib.device_count() < 1:
+        pytest.fail("no GPU visible: the gpu-marked tests need an MI355X")
+
+
+def CMF(**kw):
+    from pycmf_amd import CMF as C
+    return C(**kw)
+
+
+def test_input_shape_compatibility_check():  # :28-34
+    X, Y = np.ones((5, 2)), np.ones((5, 2))
+    msg = "Expected X.shape[1] == Y.shape[0], found X.shape = {}, Y.shape = {}".format(X.shape, Y.shape)
+    with pytest.raises(ValueError) as e:
+        CMF(solver='mu', beta_loss=2).fit(X, Y)
+    assert msg in str(e.value)
+
+
+@pytest.mark.parametrize("solver", solvers)
+def test_fit_nn_output(solver):  # :38-52
+    X = np.c_[5 * np.ones(5) - np.arange(1, 6), 5 * np.ones(5) + np.arange(1, 6)]
+    Y = X.T.copy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for init in (None, 'nndsvd', 'nndsvda', 'nndsvdar', 'random'):
+            U, V, Z = CMF(n_components=2, solver=solver, x_init=init, y_init=init, random_state=0).fit_transform(X, Y)
+            assert not ((U < 0).any() or (V < 0).any() or (Z < 0).any())
+
+
+@pytest.mark.parametrize("solver", solvers)
+def test_fit_close(solver):  # :55-64
+    rng = np.random.mtrand.RandomState(42)
+    X, Y = np.abs(rng.randn(6, 5)), np.abs(rng.randn(5, 6))
+    m = CMF(n_components=5, solver=solver, x_init='nndsvdar', y_init='nndsvdar', random_state=0, max_iter=1000)
+    assert m.fit(X, Y).reconstruction_err_ < 0.1
+
+
+@pytest.mark.parametrize("solver", solvers)
+def test_fit_level_parity_with_reference(solver):
+    """Same custom start as the golden run: iteration count and final error of the reference."""
+    g = load_golden("g4_fit_level")
+    m = CMF(n_components=5, solver=solver, x_init="custom", y_init="custom", random_state=0, max_iter=1000)
+    U, V, Z = m.fit_transform(g["fc_X"], g["fc_Y"], U=g["fc_U0"].copy(), V=g["fc_V0"].copy(), Z=g["fc_Z0"].copy())
+    ref_iter, ref_err = int(g["fc_%s_n_iter" % solver]), float(g["fc_%s_err" % solver])
+    assert abs(m.n_iter_ - ref_iter) <= 10  # the stopping test runs every 10th iteration
+    ex = np.linalg.norm(g["fc_X"] - U @ V.T) + np.linalg.norm(g["fc_Y"] - V @ Z.T)
+    np.testing.assert_allclose(m.reconstruction_err_, ex, rtol=1e-4)
+    assert abs(m.reconstruction_err_ - ref_err) <= 0.05 * ref_err + 1e-4
+
+
+def test_readme_smoke():
+    g = load_golden("g1_readme")
+    m = CMF(n_components=4, random_state=0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        U, V, Z = m.fit_transform(g["X"], g["Y"])
+    assert m.reconstruction_err_ < 0.1
+    assert np.linalg.norm(g["X"] - U @ V.T) / np.linalg.norm(g["X"]) < 0.05
+
+
+def test_n_components_greater_n_features():  # :104-109
+    rng = np.random.mtrand.RandomState(42)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        CMF(n_components=15, random_state=0, tol=1e-2).fit(np.abs(rng.randn(30, 10)), np.abs(rng.randn(10, 5)))
+
+
+@pytest.mark.parametrize("solver", solvers)
+def test_recover_low_rank_matrix(solver):  # :112-123
+    rng = np.random.mtrand.RandomState(42)
+    U, V, Z = np.abs(rng.randn(10, 5)), np.abs(rng.randn(8, 5)), np.abs(rng.randn(6, 5))
+    m = CMF(n_components=5, solver=solver, x_init='nndsvdar', y_init='nndsvdar', random_state=0, max_iter=1000)
+    assert m.fit(U @ V.T, V @ Z.T).reconstruction_err_ < 1.0
+
+
+def test_loss_decreasing():  # :126-162
+    from pycmf_amd import collective_matrix_factorization
+    from pycmf_amd.factor_init import initialize_mf
+    rng = np.random.mtrand.RandomState(42)
+    X, Y = np.abs(rng.randn(20, 15)), np.abs(rng.randn(15, 10))
+    U0, V0 = initialize_mf(X, 10, init='random', random_state=42, non_negative=True)
+    V0_, Z0 = initialize_mf(Y, 10, init='random', random_state=42, non_negative=True)
+    U, V, Z = U0.copy(), ((V0 + V0_) / 2).copy(), Z0.copy()
+    px, py = np.sum((X - U @ V.T) ** 2) / 2, np.sum((Y - V @ Z.T) ** 2) / 2
+    for _ in range(30):
+        U, V, Z, _ = collective_matrix_factorization(X, Y, U, V, Z, x_init='custom', y_init='custom',
+                                                     n_components=10, max_iter=1, solver='mu', tol=0., random_state=0)
+        lx, ly = np.sum((X - U @ V.T) ** 2) / 2, np.sum((Y - V @ Z.T) ** 2) / 2
+        assert max(px - lx, py - ly) > 0
+        px, py = lx, ly
+
+
+@pytest.mark.parametrize("solver", solvers)
+def test_l1_regularization(solver):  # :165-195
+    rng = np.random.mtrand.RandomState(42)
+    X, Y = np.abs(rng.randn(6, 5)), np.abs(rng.randn(5, 4))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        reg = CMF(n_components=3, solver=solver, l1_reg=2., random_state=42).fit_transform(X, Y)
+        plain = CMF(n_components=3, solver=solver, l1_reg=0., random_state=42).fit_transform(X, Y)
+    assert sum(F[F == 0].size for F in reg) > sum(F[F == 0].size for F in plain)
+
+
+@pytest.mark.parametrize("solver", solvers)
+def test_l2_regularization(solver):  # :198-217
+    rng = np.random.mtrand.RandomState(42)
+    X, Y = np.abs(rng.randn(6, 5)), np.abs(rng.randn(5, 4))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plain = CMF(n_components=3, solver=solver, l2_reg=0., random_state=42).fit_transform(X, Y)
+        reg = CMF(n_components=3, solver=solver, l2_reg=2., random_state=42).fit_transform(X, Y)
+    for Fm, Fr in zip(plain, reg):
+        assert Fm.mean() > Fr.mean()
+
+
+def test_nonnegative_condition_for_newton_solver():  # :220-236
+    rng = np.random.mtrand.RandomState(42)
+    X, Y = np.abs(rng.randn(6, 5)), np.abs(rng.randn(5, 4))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        U, V, Z = CMF(n_components=3, solver="newton", l2_reg=0., random_state=42, U_non_negative=False,
+                      V_non_negative=False, Z_non_negative=False).fit_transform(X, Y)
+    assert U.min() < 0 and V.min() < 0 and Z.min() < 0
+
+
+def test_logit_link_optimization():  # :239-250
+    rng = np.random.mtrand.RandomState(42)
+    X = 1 / (1 + np.exp(-rng.randn(6, 5)))
+    Y = 1 / (1 + np.exp(-rng.randn(5, 4)))
+    m = CMF(n_components=5, solver="newton", l2_reg=0., random_state=42, x_link="logit", y_link="logit",
+            U_non_negative=False, V_non_negative=False, Z_non_negative=False)
+    m.fit_transform(X, Y)
+    assert m.reconstruction_err_ < 0.1
+
+
+def test_logit_link_non_negative_optimization():  # :253-267
+    rng = np.random.mtrand.RandomState(42)
+    X = rng.randn(6, 5)
+    X[X < 0] = 0
+    Y = 1 / (1 + np.exp(-rng.randn(5, 4)))
+    m = CMF(n_components=5, solver="newton", l2_reg=0., random_state=42, y_link="logit",
+            U_non_negative=True, V_non_negative=True, Z_non_negative=False,
+            hessian_pertubation=0.2, max_iter=1000)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.fit_transform(X, Y)
+    assert m.reconstruction_err_ < 0.1
+
+
+def test_logit_fit_matches_reference_error():
+    """golden lg_*: x linear / y logit, signed factors, 'random' init from random_state=42."""
+    g = load_golden("g4_fit_level")
+    m = CMF(n_components=5, solver="newton", y_link="logit", random_state=42, max_iter=200,
+            U_non_negative=False, V_non_negative=False, Z_non_negative=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.fit(g["lg_X"], g["lg_Y"])
+    ref = float(g["lg_err"])
+    assert abs(m.n_iter_ - int(g["lg_n_iter"])) <= 10
+    assert abs(m.reconstruction_err_ - ref) <= 0.05 * ref + 1e-3
+
+
+@pytest.mark.parametrize("solver", solvers)
+def test_sparse_input(solver):  # :270-291
+    rng = np.random.mtrand.RandomState(42)
+    X = np.abs(rng.randn(10, 8)); X[:, 2 * np.arange(4)] = 0
+    Y = np.abs(rng.randn(8, 5))
+    est = CMF(n_components=4, solver=solver, random_state=0, x_init="random", y_init="random", max_iter=50, tol=0)
+    a = est.fit_transform(X, Y)
+    b = clone(est).fit_transform(sp.csr_matrix(X), Y)
+    c = clone(est).fit_transform(sp.csc_matrix(X), sp.csr_matrix(Y))
+    for F, G, H in zip(a, b, c):
+        np.testing.assert_array_almost_equal(F, G, 6)
+        np.testing.assert_array_almost_equal(F, H, 6)
+
+
+def _sg_model():
+    return CMF(n_components=5, solver="newton", x_init='svd', y_init='svd', U_non_negative=False,
+               V_non_negative=False, Z_non_negative=False, alpha=0.5, sg_sample_ratio=0.5,
+               random_state=0, max_iter=1000)
+
+
+def test_stochastic_newton_solver():  # :292-300
+    rng = np.random.mtrand.RandomState(42)
+    X, Y = rng.randn(6, 5), rng.randn(5, 6)
+    assert _sg_model().fit(X, Y).reconstruction_err_ < 0.1
+
+
+def test_stochastic_newton_solver_sparse_input_close():  # :303-314
+    rng = np.random.mtrand.RandomState(42)
+    A, B = rng.randn(6, 5), rng.randn(5, 6)
+    assert _sg_model().fit(sp.csr_matrix(A), sp.csr_matrix(B)).reconstruction_err_ < 0.1
+
+
+def test_stochastic_newton_solver_sparse_input():  # :317-338 (dense == sparse, identical RNG stream)
+    rng = np.random.mtrand.RandomState(36)
+    A = np.abs(rng.randn(10, 10)); A[:, 2 * np.arange(5)] = 0
+    B = np.abs(rng.randn(10, 5)); B[2 * np.arange(5), :] = 0
+    est1 = CMF(n_components=5, solver="newton", x_init='svd', y_init='svd', U_non_negative=False,
+               V_non_negative=False, Z_non_negative=False, sg_sample_ratio=0.5, random_state=0, max_iter=1000)
+    est2 = clone(est1)
+    a = est1.fit_transform(A, B)
+    b = est2.fit_transform(sp.csr_matrix(A), sp.csr_matrix(B))
+    for F, G in zip(a, b):
+        np.testing.assert_array_almost_equal(F, G)
+
+
+def test_auto_compute_alpha():  # :354-371
+    rng = np.random.mtrand.RandomState(42)
+    X, Y = np.abs(rng.randn(20, 6)), np.abs(rng.randn(6, 2))
+    kw = dict(n_components=3, solver="newton", random_state=0, max_iter=100, x_init="random", y_init="random")
+    U1, V1, Z1 = CMF(alpha="auto", **kw).fit_transform(X, Y)
+    U2, V2, Z2 = CMF(alpha=0.5, **kw).fit_transform(X, Y)
+    assert np.linalg.norm(Y - V1 @ Z1.T) < np.linalg.norm(Y - V2 @ Z2.T)
+    assert np.linalg.norm(X - U1 @ V1.T) > np.linalg.norm(X - U2 @ V2.T)
+
+
+@pytest.mark.parametrize("solver", solvers)
+def test_transform_after_fit(solver):  # :374-408
+    g = load_golden("g4_fit_level")
+    X, Y = g["tr_X"], g["tr_Y"]
+    m = CMF(n_components=3, solver=solver, x_init="random", y_init="random", random_state=0, max_iter=60)
+    U, V, Z = m.fit_transform(X, Y)
+    np.testing.assert_allclose(V, g["tr_%s_V" % solver], rtol=5e-3, atol=5e-3)
+    Ut, Vt, Zt = m.transform(X, None)
+    np.testing.assert_array_equal(Vt, V)           # V untouched when Y is None
+    np.testing.assert_allclose(Ut, g["tr_%s_Ut" % solver], rtol=5e-3, atol=5e-3)
+    assert clone(m).get_params()["solver"] == solver
+
+
+def test_missing_library_is_loud(monkeypatch):
+    from pycmf_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libcmfhip.so")
+    with pytest.raises(RuntimeError):
+        _lib.load()

@@ -1,0 +1,92 @@
+"""GPU parity tests for the Newton path (HIP through the C ABI) vs golden vectors minted
+from the reference and vs the CPU oracle.  Run with -m gpu on an MI355X."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import load_golden
+from test_oracle_golden import NEWTON_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pycmf_amd import _lib
+    if _lib.device_count() < 1:
+        pytest.fail("no GPU visible: the gpu-marked tests need an MI355X")
+    return _lib
+
+
+def test_safe_invert_batch(lib):
+    from oracle import cmf_oracle as O
+    rng = np.random.RandomState(0)
+    ctx = lib.Context(0)
+    for k in (1, 2, 3, 7, 16, 33, 64, 100, 128, 200, 256):
+        n = 5 if k <= 128 else 2
+        A = rng.randn(n, k, k + 3)
+        H = A @ A.transpose(0, 2, 1) / k
+        H[0] *= 0.01          # everything below the perturbation
+        if n > 1:
+            H[1] -= 0.8 * np.eye(k)  # indefinite: |lambda| branch
+        if n > 2:
+            H[2][:, -1] = 0; H[2][-1, :] = 0  # singular
+        got = ctx.safe_invert_batch(H, 0.2)
+        for i in range(n):
+            ref = O.safe_invert(H[i], 0.2)
+            np.testing.assert_allclose(got[i], ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max())
+    ctx.close()
+
+
+def _solver(name, seed):
+    from pycmf_amd.solver_shell import HipNewtonSolver
+    xl, yl, nn, ratio, _, l1, l2, signed = NEWTON_CASES[name]
+    return HipNewtonSolver(alpha=0.3, l1_reg=l1, l2_reg=l2, x_link=xl, y_link=yl,
+                           U_non_negative=nn, V_non_negative=nn, Z_non_negative=nn,
+                           hessian_pertubation=0.2, sg_sample_ratio=ratio, random_state=seed)
+
+
+@pytest.mark.parametrize("name", sorted(NEWTON_CASES))
+@pytest.mark.parametrize("fmt", ["dense", "csr"])
+def test_newton_golden_steps(lib, name, fmt):
+    xl, yl, nn, ratio, seed, l1, l2, signed = NEWTON_CASES[name]
+    g = load_golden("g3_newton_steps")
+    X = g["Xlog"] if xl == "logit" else g["X"]
+    Y = g["Ylog"] if yl == "logit" else g["Y"]
+    if fmt == "csr":
+        X = sp.csr_matrix(X)
+    sfx = "s" if signed else "p"
+    U, V, Z = g["U0" + sfx].copy(), g["V0" + sfx].copy(), g["Z0" + sfx].copy()
+    s = _solver(name, seed)
+    for it in range(1, 4):
+        s.update_step(X, Y, U, V, Z, l1, l2, 0.3)
+        if it in (1, 3):
+            tol = 5e-4 if it == 1 else 5e-3
+            for n, a in (("U", U), ("V", V), ("Z", Z)):
+                ref = g["%s_%s_%s%d" % (name, fmt, n, it)]
+                np.testing.assert_allclose(a, ref, rtol=tol, atol=tol * max(1.0, np.abs(ref).max()))
+    s.release()
+
+
+@pytest.mark.parametrize("xl,yl,ratio,k", [("linear", "linear", 1.0, 12), ("logit", "linear", 1.0, 9),
+                                          ("linear", "logit", 0.5, 20), ("logit", "logit", 0.7, 33)])
+def test_newton_vs_oracle_midsize(lib, xl, yl, ratio, k):
+    """Sizes that span several 256-row tiles and a padded k; identical host-drawn samples."""
+    from oracle import cmf_oracle as O
+    from pycmf_amd.solver_shell import HipNewtonSolver
+    m, d, p = 300, 270, 130
+    rng = np.random.RandomState(k)
+    X = rng.rand(m, d) if xl == "logit" else np.abs(rng.randn(m, d))
+    Y = rng.rand(d, p) if yl == "logit" else np.abs(rng.randn(d, p))
+    U0, V0, Z0 = 0.3 * rng.randn(m, k), 0.3 * rng.randn(d, k), 0.3 * rng.randn(p, k)
+    kw = dict(alpha=0.4, l1_reg=0.01, l2_reg=0.05, x_link=xl, y_link=yl, U_non_negative=False,
+              V_non_negative=False, Z_non_negative=False, hessian_pertubation=0.2, sg_sample_ratio=ratio)
+    s = HipNewtonSolver(random_state=5, **kw)
+    U, V, Z = U0.copy(), V0.copy(), Z0.copy()
+    s.update_step(X, Y, U, V, Z, 0.01, 0.05, 0.4)
+    s.release()
+    o = O.OracleSolver("newton", random_state=5, **kw)
+    Ur, Vr, Zr = U0.copy(), V0.copy(), Z0.copy()
+    o.update_step(X, Y, Ur, Vr, Zr)
+    for a, b in ((U, Ur), (V, Vr), (Z, Zr)):
+        np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-3 * np.abs(b).max())
