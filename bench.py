@@ -137,7 +137,7 @@ def main():
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             elapsed = float(te.item())
 
-        classes = {c: ctx.kernel_time(c) for c in ("gemm_nn", "gemm_tn", "gemm_nt", "elementwise")}
+        classes = {c: ctx.kernel_time(c) for c in ("gemm_nn", "gemm_tn", "gemm_small", "gemm_nt", "elementwise")}
         ctx.kernel_timing(False)
         ex2, ey2 = ctx.residual_sq()
         x2, y2 = ctx.data_sq()
@@ -180,12 +180,15 @@ def main():
                                   "1 RCCL all-reduce of (d+k)*k f32 per iteration" % world},
         "roofline": {
             "bound": "mfma",
-            "kernel": "cmfk::gemm_kernel<%s,%d>" % ("MODE_NN" if dom == "gemm_nn" else "MODE_TN", 256 if k >= 256 else k),
+            "kernel": "cmfk::gemm_kernel<%d, %d, 0>  (%s data pass)" % (0 if dom == "gemm_nn" else 1, 256 if k >= 256 else k,
+                                                                     "NN: X V / Y Z" if dom == "gemm_nn" else "TN: X^T U / Y^T V"),
             "achieved": achieved,
             "peak": FP32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
             "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/traffic_%s.json)" % args.workload,
+            "algorithmic_flops_per_launch": dfl / max(dn, 1),
             "avg_launch_ms": dms / max(dn, 1),
             "launches": dn,
             "per_class_ms_per_step": {c: v[0] / args.steps for c, v in classes.items()},

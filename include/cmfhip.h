@@ -48,12 +48,13 @@ enum { CMF_NN_U = 1, CMF_NN_V = 2, CMF_NN_Z = 4 };  /* *_non_negative, :321-326 
 
 /* kernel classes for cmf_kernel_time() */
 enum {
-    CMF_K_GEMM_NN = 0,   /* C = A   B : X V, Y Z, F G          */
-    CMF_K_GEMM_TN = 1,   /* C = A^T B : X^T U, Y^T V, Grams    */
+    CMF_K_GEMM_NN = 0,   /* C = A   B over a data-sized A: X V, Y Z, R V, W KR   */
+    CMF_K_GEMM_TN = 1,   /* C = A^T B over a data-sized A: X^T U, Y^T V, R^T U   */
     CMF_K_GEMM_NT = 2,   /* f(L R^T) - T : residual / error    */
     CMF_K_ELEMWISE = 3,  /* slab sums, MU ratio, row updates   */
     CMF_K_EIGEN = 4,     /* batched symmetric Jacobi           */
-    CMF_K_COUNT = 5
+    CMF_K_GEMM_SMALL = 5,/* factor-side products: Grams, F G, grad H^-1 */
+    CMF_K_COUNT = 6
 };
 
 const char *cmf_last_error(void);

@@ -15,7 +15,7 @@ CMF_U, CMF_V, CMF_Z = 0, 1, 2
 LINKS = {"linear": 0, "logit": 1}
 UPD_U, UPD_V, UPD_Z = 1, 2, 4
 K_GEMM_NN, K_GEMM_TN, K_GEMM_NT, K_ELEMWISE, K_EIGEN = 0, 1, 2, 3, 4
-KERNEL_CLASSES = {"gemm_nn": 0, "gemm_tn": 1, "gemm_nt": 2, "elementwise": 3, "eigen": 4}
+KERNEL_CLASSES = {"gemm_nn": 0, "gemm_tn": 1, "gemm_nt": 2, "elementwise": 3, "eigen": 4, "gemm_small": 5}
 
 _ERR = {1: ValueError, 2: RuntimeError, 3: MemoryError, 4: RuntimeError, 5: NotImplementedError}
 
@@ -63,6 +63,30 @@ PROTOTYPES = {
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so and
+    ask for it by its unversioned name, so if libcmfhip.so pulled in /opt/rocm's copy first, a
+    later ``import torch`` would load a second runtime that finds no GPU.  When torch is
+    installed (not necessarily imported) its bundled runtime is loaded first; libcmfhip's
+    ``libamdhip64.so.7`` dependency then resolves to that same image."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load libcmfhip.so (once) and attach prototypes."""
     global _lib
@@ -72,6 +96,7 @@ def load():
         raise RuntimeError(
             "pycmf_amd: %s is missing -- build it with `python -m pycmf_amd.build` "
             "(hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
+    _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     lib.cmf_last_error.restype = C.c_char_p
     lib.cmf_last_error.argtypes = []

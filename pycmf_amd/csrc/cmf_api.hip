@@ -205,7 +205,7 @@ static GemmPlan plan_gemm(const cmf_ctx *c, int64_t mout, int64_t n, int64_t kre
     return pl;
 }
 
-template <int MODE>
+template <int MODE, int ROLE>
 static int launch_gemm_mode(cmf_ctx *c, const GemmArgs &a, const GemmPlan &pl) {
     dim3 grid((unsigned)pl.tiles_m, (unsigned)pl.ntiles_n, (unsigned)pl.nsplit);
     dim3 block(512);
@@ -214,12 +214,12 @@ static int launch_gemm_mode(cmf_ctx *c, const GemmArgs &a, const GemmPlan &pl) {
         using Cfg = GemmCfg<MODE, BN_>;                                                          \
         static bool attr_set = false;                                                            \
         if (!attr_set) {                                                                         \
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<MODE, BN_>),  \
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<MODE, BN_, ROLE>), \
                                        hipFuncAttributeMaxDynamicSharedMemorySize,               \
                                        (int)Cfg::LDS_BYTES));                                    \
             attr_set = true;                                                                     \
         }                                                                                        \
-        hipLaunchKernelGGL((gemm_kernel<MODE, BN_>), grid, block, Cfg::LDS_BYTES, c->stream, a); \
+        hipLaunchKernelGGL((gemm_kernel<MODE, BN_, ROLE>), grid, block, Cfg::LDS_BYTES, c->stream, a); \
     } while (0)
     if constexpr (MODE == MODE_NT) {
         if (pl.bn != 128) return fail(CMF_EINVAL, "NT tile width must be 128");
@@ -251,8 +251,11 @@ static int sum_slabs(cmf_ctx *c, float *dst, const float *src, int64_t n, int ns
 
 // C[mout x n] (+)= op(A) * B.  mode NN: A is [mout_pad x kred]; TN: A is [kred x >=mout].
 // Result lands in `out` (ld = n); split-K partials go through the slab workspace.
+// `A` is a factor-sized operand when lda == k_pad (Grams, F*G, step products): those launches
+// use the ROLE=1 symbol and the CMF_K_GEMM_SMALL timing class.
 static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *B, int64_t ldb, float *out,
                 int64_t mout, int64_t n, int64_t kred, bool accumulate = false) {
+    const bool data_pass = (lda != c->kp);
     if (kred % 32 || n % 32) return fail(CMF_EINVAL, "gemm: unpadded extent (k=%lld n=%lld)", (long long)kred, (long long)n);
     GemmPlan pl = plan_gemm(c, mout, n, kred, true);
     GemmArgs a;
@@ -273,9 +276,15 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
         a.slab_stride = rows_store * n;
     }
     {
-        Timed tm(c, mode == MODE_NN ? CMF_K_GEMM_NN : CMF_K_GEMM_TN, 2.0 * (double)mout * (double)n * (double)kred);
-        if (mode == MODE_NN) CHK(launch_gemm_mode<MODE_NN>(c, a, pl));
-        else CHK(launch_gemm_mode<MODE_TN>(c, a, pl));
+        Timed tm(c, !data_pass ? CMF_K_GEMM_SMALL : (mode == MODE_NN ? CMF_K_GEMM_NN : CMF_K_GEMM_TN),
+                 2.0 * (double)mout * (double)n * (double)kred);
+        if (mode == MODE_NN) {
+            if (data_pass) CHK((launch_gemm_mode<MODE_NN, 0>(c, a, pl)));
+            else CHK((launch_gemm_mode<MODE_NN, 1>(c, a, pl)));
+        } else {
+            if (data_pass) CHK((launch_gemm_mode<MODE_TN, 0>(c, a, pl)));
+            else CHK((launch_gemm_mode<MODE_TN, 1>(c, a, pl)));
+        }
     }
     if (!direct) CHK(sum_slabs(c, out, (const float *)c->slabs.p, rows_store * n, pl.nsplit, a.slab_stride, accumulate));
     return CMF_OK;
@@ -309,7 +318,7 @@ static int gemm_nt(cmf_ctx *c, const float *L, int64_t rows_pad, int64_t rows_va
     }
     {
         Timed tm(c, CMF_K_GEMM_NT, 2.0 * (double)rows_valid * (double)cols_valid * (double)c->kp);
-        CHK(launch_gemm_mode<MODE_NT>(c, a, pl));
+        CHK((launch_gemm_mode<MODE_NT, 0>(c, a, pl)));
     }
     if (o.sq) {
         Timed tm(c, CMF_K_ELEMWISE);

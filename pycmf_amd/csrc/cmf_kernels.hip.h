@@ -89,7 +89,9 @@ struct VecLoad<4> {
     }
 };
 
-template <int MODE, int BN>
+// ROLE only separates the symbols: 0 = pass over a data-sized operand (X, Y, residual or
+// weight image), 1 = factor-side product (Gram, F*G, step); profiles then report them apart.
+template <int MODE, int BN, int ROLE = 0>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
     using C = GemmCfg<MODE, BN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];

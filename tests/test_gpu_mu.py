@@ -121,3 +121,55 @@ def test_strided_and_fortran_inputs(lib):
     got = _step(lib, np.asfortranarray(X), Y.T.copy().T, np.asfortranarray(U0), V0[::1], Z0.T.copy().T)
     for a, b in zip(ref, got):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_protocol_matches_unsharded(lib, world):
+    """run `world` shards as separate contexts on this one GPU, emulate the
+    all-reduce by summing their partial buffers on the device, and compare with the
+    unsharded step (same kernels, different partition)."""
+    import torch
+    from pycmf_amd.sharded import ShardedMU, HipShardBackend, shard_bounds
+    m, d, p, k = 700, 300, 530, 24
+    X, Y, U0, V0, Z0 = _problem(77, m, d, p, k)
+    ref = _step(lib, X, Y, U0, V0, Z0, 0.01, 0.02, iters=2)
+    ctxs, bufs, bounds = [], [], []
+    for r in range(world):
+        r0, r1 = shard_bounds(m, world, r)
+        c0, c1 = shard_bounds(p, world, r)
+        ctx = lib.Context(0)
+        ctx.set_problem(r1 - r0, d, c1 - c0, k)
+        ctx.set_data(0, X[r0:r1]); ctx.set_data(1, Y[:, c0:c1])
+        ctx.set_factor(0, U0[r0:r1]); ctx.set_factor(1, V0); ctx.set_factor(2, Z0[c0:c1])
+        ctxs.append(ctx); bounds.append((r0, r1, c0, c1))
+        bufs.append(torch.zeros(ctx.v_buf_elems(), dtype=torch.float32, device="cuda:0"))
+    for _ in range(2):
+        for ctx, b in zip(ctxs, bufs):
+            ctx.mu_v_partials(b.data_ptr())
+            ctx.sync()
+        total = torch.stack(bufs).sum(0)
+        for ctx, b in zip(ctxs, bufs):
+            b.copy_(total)
+            torch.cuda.synchronize()
+            ctx.mu_v_apply(b.data_ptr(), 0.01, 0.02)
+            ctx.mu_uz_update(0.01, 0.02, 7)
+            ctx.sync()
+    for ctx, (r0, r1, c0, c1) in zip(ctxs, bounds):
+        np.testing.assert_allclose(ctx.get_factor(1), ref[1], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(ctx.get_factor(0), ref[0][r0:r1], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(ctx.get_factor(2), ref[2][c0:c1], rtol=1e-5, atol=1e-7)
+        ctx.close()
+
+
+def test_synthetic_fill_is_partition_independent(lib):
+    """bench.py's generator: a shard filled with global offsets equals the slice of the
+    full matrix."""
+    full = lib.Context(0); full.set_problem(300, 200, 120, 8)
+    full.fill_data_synthetic(0, 42); full.fill_data_synthetic(1, 43)
+    Xf, Yf = full.get_data(0), full.get_data(1)
+    part = lib.Context(0); part.set_problem(100, 200, 40, 8)
+    part.fill_data_synthetic(0, 42, 150, 0); part.fill_data_synthetic(1, 43, 0, 60)
+    np.testing.assert_array_equal(part.get_data(0), Xf[150:250])
+    np.testing.assert_array_equal(part.get_data(1), Yf[:, 60:100])
+    assert Xf.min() >= 0 and abs(Xf.mean() - 0.7979) < 0.02 and abs((Xf ** 2).mean() - 1.0) < 0.03
+    full.close(); part.close()

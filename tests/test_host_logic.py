@@ -1,0 +1,216 @@
+"""CPU-only tests of the host side: initialisers vs reference fixtures, the C ABI surface,
+shard arithmetic, and the N>1 protocol over gloo with a test-double backend."""
+import ctypes
+import os
+import re
+import socket
+import subprocess
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, ROOT
+
+
+# ------------------------------------------------------------------ initialisers (H3)
+@pytest.mark.parametrize("init", ["random", "nndsvd", "nndsvda", "nndsvdar"])
+def test_init_nonneg_matches_reference(init):
+    from pycmf_amd.factor_init import initialize_mf
+    g = load_golden("g5_init")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        A, B = initialize_mf(g["M"], 4, init=init, random_state=3, non_negative=True)
+    np.testing.assert_allclose(A, g["%s_nn_A" % init], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(B, g["%s_nn_B" % init], rtol=1e-10, atol=1e-12)
+    assert B.flags.f_contiguous  # second factor is a transposed view, like the reference
+
+
+@pytest.mark.parametrize("init", ["random", "svd"])
+def test_init_free_matches_reference(init):
+    from pycmf_amd.factor_init import initialize_mf
+    g = load_golden("g5_init")
+    A, B = initialize_mf(g["Ms"], 4, init=init, random_state=3, non_negative=False)
+    np.testing.assert_allclose(A, g["%s_free_A" % init], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(B, g["%s_free_B" % init], rtol=1e-10, atol=1e-12)
+
+
+def test_init_svd_padding_and_errors():
+    from pycmf_amd.factor_init import initialize_mf, init_custom
+    g = load_golden("g5_init")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        A, B = initialize_mf(g["Ms"], 9, init="svd", random_state=3)
+    np.testing.assert_allclose(A, g["svd_pad_A"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(B, g["svd_pad_B"], rtol=1e-10, atol=1e-12)
+    with pytest.raises(ValueError):
+        initialize_mf(g["M"], 4, init="svd", non_negative=True)
+    with pytest.raises(ValueError):
+        initialize_mf(g["M"], 4, init="bogus")
+    with pytest.raises(ValueError):
+        init_custom(np.ones((3, 3)), g["M"], 4, 0)
+    with pytest.raises(ValueError):
+        init_custom(np.zeros((12, 4)), g["M"], 4, 0, non_negative=True)
+
+
+def test_driver_validation_messages():
+    """Validation happens before any GPU call (pycmf/cmf.py:390-399, :453)."""
+    from pycmf_amd import CMF, collective_matrix_factorization
+    X, Y = np.ones((5, 2)), np.ones((5, 2))
+    with pytest.raises(ValueError, match=re.escape("Expected X.shape[1] == Y.shape[0], found X.shape = (5, 2), Y.shape = (5, 2)")):
+        CMF(solver='mu', beta_loss=2).fit(X, Y)
+    Y = np.ones((2, 3))
+    with pytest.raises(ValueError, match="No such link foo for x_link"):
+        collective_matrix_factorization(X, Y, n_components=2, x_link="foo")
+    with pytest.raises(ValueError, match="No such link bar for y_link"):
+        collective_matrix_factorization(X, Y, n_components=2, y_link="bar")
+    with pytest.raises(ValueError, match="No such solver: cd"):
+        collective_matrix_factorization(X, Y, n_components=2, solver="cd", x_init="random", y_init="random")
+    with pytest.raises(ValueError, match="Invalid beta_loss"):
+        collective_matrix_factorization(X, Y, n_components=2, beta_loss="nope")
+
+
+def test_estimator_params_roundtrip():
+    from sklearn.base import clone
+    from pycmf_amd import CMF
+    m = CMF(n_components=7, solver="newton", alpha=0.25, sg_sample_ratio=0.5, hessian_pertubation=0.3, device=1)
+    p = clone(m).get_params()
+    assert p["n_components"] == 7 and p["solver"] == "newton" and p["alpha"] == 0.25
+    assert p["sg_sample_ratio"] == 0.5 and p["hessian_pertubation"] == 0.3 and p["device"] == 1
+    d = CMF().get_params()  # reference defaults, pycmf/cmf.py:620-624
+    assert (d["solver"], d["alpha"], d["tol"], d["max_iter"]) == ("mu", "auto", 1e-4, 600)
+    assert d["x_link"] == d["y_link"] == "linear" and d["hessian_pertubation"] == 0.2 and d["sg_sample_ratio"] == 1.
+
+
+# ------------------------------------------------------------------ C ABI surface
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cmfhip.h")).read()
+    return sorted(set(re.findall(r"\b(cmf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pycmf_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from pycmf_amd import build
+        build.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "libcmfhip.so does not export %s" % n
+    # and the ctypes table covers the header
+    assert set(_lib.PROTOTYPES) | {"cmf_last_error"} == set(names)
+
+
+def test_no_device_is_a_loud_error():
+    from pycmf_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback"):
+        _lib.Context(0)
+    from pycmf_amd import CMF
+    with pytest.raises(RuntimeError):
+        CMF(n_components=2, x_init="random", y_init="random").fit(np.ones((4, 3)), np.ones((3, 2)))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "pycmf_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("no CPU fallback", ""), f
+
+
+# ------------------------------------------------------------------ sharding
+def test_shard_bounds_cover_and_balance():
+    from pycmf_amd.sharded import shard_bounds
+    for n in (0, 1, 7, 8, 65536, 100003):
+        for w in (1, 2, 3, 8):
+            parts = [shard_bounds(n, w, r) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from pycmf_amd.sharded import ShardedMU, shard_bounds
+from oracle import cmf_oracle as O
+
+class OracleShard:
+    """test double for HipShardBackend: float64 NumPy arithmetic on one shard"""
+    def __init__(self, X, Y, U, V, Z):
+        self.X, self.Y, self.U, self.V, self.Z = X, Y, U, V, Z
+        self.d, self.k = V.shape
+    def buf_elems(self):
+        return self.d * self.k + self.k * self.k
+    def partials(self, buf):
+        P = self.X.T @ self.U + self.Y @ self.Z
+        G = self.U.T @ self.U + self.Z.T @ self.Z
+        buf[:] = torch.from_numpy(np.concatenate([P.ravel(), G.ravel()]))
+    def apply_v(self, buf, l1, l2):
+        b = buf.numpy()
+        P = b[: self.d * self.k].reshape(self.d, self.k)
+        G = b[self.d * self.k:].reshape(self.k, self.k)
+        self.V *= O.mu_ratio(P, self.V @ G, l1, l2, self.V)
+    def update_uz(self, l1, l2, mask):
+        O.mu_update_step(self.X, self.Y, self.U, self.V, self.Z, l1, l2, update_V=False,
+                         update_U=bool(mask & 1), update_Z=bool(mask & 4))
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+rng = np.random.RandomState(0)
+m, d, p, k = 23, 11, 9, 4
+X, Y = np.abs(rng.randn(m, d)), np.abs(rng.randn(d, p))
+U, V, Z = np.abs(rng.randn(m, k)), np.abs(rng.randn(d, k)), np.abs(rng.randn(p, k))
+r0, r1 = shard_bounds(m, world, rank)
+c0, c1 = shard_bounds(p, world, rank)
+be = OracleShard(X[r0:r1], Y[:, c0:c1], U[r0:r1].copy(), V.copy(), Z[c0:c1].copy())
+buf = torch.zeros(be.buf_elems(), dtype=torch.float64)
+calls = []
+def allreduce(t):
+    calls.append(1)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+drv = ShardedMU(be, buf, world, allreduce)
+for _ in range(3):
+    drv.step(0.1, 0.2, 7)
+assert len(calls) == 3, "exactly one collective per iteration"
+Ur, Vr, Zr = U.copy(), V.copy(), Z.copy()
+for _ in range(3):
+    O.mu_update_step(X, Y, Ur, Vr, Zr, 0.1, 0.2)
+np.testing.assert_allclose(be.V, Vr, rtol=1e-10)
+np.testing.assert_allclose(be.U, Ur[r0:r1], rtol=1e-10)
+np.testing.assert_allclose(be.Z, Zr[c0:c1], rtol=1e-10)
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_sharded_mu_world2_gloo(tmp_path):
+    """Two ranks, gloo on CPU: the sharded step (partials -> one all-reduce -> identical V
+    epilogue -> local U/Z) reproduces the unsharded reference step."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
+        assert "rank %d ok" % r in o

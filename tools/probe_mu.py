@@ -24,7 +24,7 @@ def run(m, d, p, k, steps=5, warm=2):
     ctx.kernel_timing_reset()
     for _ in range(steps):
         ctx.mu_step(0.0, 0.0, 7)
-    for cls in ("gemm_nn", "gemm_tn", "gemm_nt", "elementwise"):
+    for cls in ("gemm_nn", "gemm_tn", "gemm_small", "gemm_nt", "elementwise"):
         ms, n, fl = ctx.kernel_time(cls)
         print("   %-12s %9.3f ms/iter  (%d launches/iter)  %.1f TF/s" % (cls, ms / steps, n // steps, fl / max(ms, 1e-9) / 1e9))
     ex2, ey2 = ctx.residual_sq()
