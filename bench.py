@@ -180,7 +180,7 @@ def main():
                                   "1 RCCL all-reduce of (d+k)*k f32 per iteration" % world},
         "roofline": {
             "bound": "mfma",
-            "kernel": "cmfk::gemm_kernel<%d, %d, 0>  (%s data pass)" % (0 if dom == "gemm_nn" else 1, 256 if k >= 256 else k,
+            "kernel": "cmfk::gemm_kernel<%d, %d, 0, 4>  (%s data pass)" % (0 if dom == "gemm_nn" else 1, 256 if k >= 256 else k,
                                                                      "NN: X V / Y Z" if dom == "gemm_nn" else "TN: X^T U / Y^T V"),
             "achieved": achieved,
             "peak": FP32_MFMA_PEAK_TFLOPS,

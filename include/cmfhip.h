@@ -66,6 +66,9 @@ int cmf_device_count(int *count);
 int cmf_ctx_create(cmf_ctx **out, int device, void *stream);
 int cmf_ctx_destroy(cmf_ctx *ctx);
 int cmf_sync(cmf_ctx *ctx);
+/* tuning knobs (A/B measurements in one process): "gemm_pipe" 0|1|2 = staging schedule of
+ * the data-pass GEMM kernels, "gemm_split" n = force the split-K factor (<= 0: heuristic) */
+int cmf_set_option(cmf_ctx *ctx, const char *name, int64_t value);
 
 /* ---- problem ---------------------------------------------------------- */
 /* Local shard sizes: X is m x d, Y is d x p, factors have k columns.

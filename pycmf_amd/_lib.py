@@ -31,6 +31,7 @@ PROTOTYPES = {
     "cmf_ctx_create": [C.POINTER(_vp), _i32, _vp],
     "cmf_ctx_destroy": [_vp],
     "cmf_sync": [_vp],
+    "cmf_set_option": [_vp, C.c_char_p, _i64],
     "cmf_set_problem": [_vp, _i64, _i64, _i64, _i32],
     "cmf_set_data_f64": [_vp, _i32, _pd, _i64, _i64],
     "cmf_set_data_f32": [_vp, _i32, _pf, _i64, _i64],
@@ -262,6 +263,9 @@ class Context:
         out = np.empty_like(H)
         check(self._lib.cmf_safe_invert_batch(self._h, H.ctypes.data_as(_pd), out.ctypes.data_as(_pd), n, k, pert))
         return out
+
+    def set_option(self, name, value):
+        check(self._lib.cmf_set_option(self._h, name.encode(), int(value)))
 
     def sync(self):
         check(self._lib.cmf_sync(self._h))

@@ -66,6 +66,8 @@ struct cmf_ctx {
     int64_t mp = 0, dp = 0, pp = 0;
     int kp = 0;
     bool have_problem = false;
+    int opt_pipe = 4;      // GEMM staging schedule (see gemm_kernel PIPE); 4 measured best (tools/ab_gemm.py)
+    int opt_split = -1;    // force split-K factor (<=0: heuristic)
 
     float *X = nullptr, *Y = nullptr; // dense, row-major, ld = dp / pp
     float *F[3] = {nullptr, nullptr, nullptr};
@@ -195,7 +197,9 @@ static GemmPlan plan_gemm(const cmf_ctx *c, int64_t mout, int64_t n, int64_t kre
     pl.tiles_m = (mout + 255) / 256;
     const int64_t tiles = pl.tiles_m * pl.ntiles_n;
     int64_t s = 1;
-    if (allow_split && tiles < (int64_t)(c->num_cu * 3) / 4) {
+    if (allow_split && c->opt_split > 0) {
+        s = std::min<int64_t>(c->opt_split, std::max<int64_t>(1, kred / 32));
+    } else if (allow_split && tiles < (int64_t)(c->num_cu * 3) / 4) {
         s = (c->num_cu + tiles / 2) / tiles;
         const int64_t maxs = std::max<int64_t>(1, kred / 128);
         s = std::max<int64_t>(1, std::min(s, maxs));
@@ -205,8 +209,8 @@ static GemmPlan plan_gemm(const cmf_ctx *c, int64_t mout, int64_t n, int64_t kre
     return pl;
 }
 
-template <int MODE, int ROLE>
-static int launch_gemm_mode(cmf_ctx *c, const GemmArgs &a, const GemmPlan &pl) {
+template <int MODE, int ROLE, int PIPE>
+static int launch_gemm_pipe(cmf_ctx *c, const GemmArgs &a, const GemmPlan &pl) {
     dim3 grid((unsigned)pl.tiles_m, (unsigned)pl.ntiles_n, (unsigned)pl.nsplit);
     dim3 block(512);
 #define CMF_LAUNCH(BN_)                                                                          \
@@ -214,12 +218,12 @@ static int launch_gemm_mode(cmf_ctx *c, const GemmArgs &a, const GemmPlan &pl) {
         using Cfg = GemmCfg<MODE, BN_>;                                                          \
         static bool attr_set = false;                                                            \
         if (!attr_set) {                                                                         \
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<MODE, BN_, ROLE>), \
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<MODE, BN_, ROLE, PIPE>), \
                                        hipFuncAttributeMaxDynamicSharedMemorySize,               \
                                        (int)Cfg::LDS_BYTES));                                    \
             attr_set = true;                                                                     \
         }                                                                                        \
-        hipLaunchKernelGGL((gemm_kernel<MODE, BN_, ROLE>), grid, block, Cfg::LDS_BYTES, c->stream, a); \
+        hipLaunchKernelGGL((gemm_kernel<MODE, BN_, ROLE, PIPE>), grid, block, Cfg::LDS_BYTES, c->stream, a); \
     } while (0)
     if constexpr (MODE == MODE_NT) {
         if (pl.bn != 128) return fail(CMF_EINVAL, "NT tile width must be 128");
@@ -236,6 +240,17 @@ static int launch_gemm_mode(cmf_ctx *c, const GemmArgs &a, const GemmPlan &pl) {
 #undef CMF_LAUNCH
     HIPCHK(hipGetLastError());
     return CMF_OK;
+}
+
+template <int MODE, int ROLE>
+static int launch_gemm_mode(cmf_ctx *c, const GemmArgs &a, const GemmPlan &pl) {
+    if (ROLE == 0 && MODE != MODE_NT) {
+        if (c->opt_pipe == 1) return launch_gemm_pipe<MODE, ROLE, (ROLE == 0 && MODE != MODE_NT) ? 1 : 0>(c, a, pl);
+        if (c->opt_pipe == 2) return launch_gemm_pipe<MODE, ROLE, (ROLE == 0 && MODE != MODE_NT) ? 2 : 0>(c, a, pl);
+        if (c->opt_pipe == 3) return launch_gemm_pipe<MODE, ROLE, (ROLE == 0 && MODE != MODE_NT) ? 3 : 0>(c, a, pl);
+        if (c->opt_pipe == 4) return launch_gemm_pipe<MODE, ROLE, (ROLE == 0 && MODE != MODE_NT) ? 4 : 0>(c, a, pl);
+    }
+    return launch_gemm_pipe<MODE, ROLE, 0>(c, a, pl);
 }
 
 static int sum_slabs(cmf_ctx *c, float *dst, const float *src, int64_t n, int nslab, int64_t stride,
@@ -408,6 +423,19 @@ extern "C" int cmf_ctx_destroy(cmf_ctx *c) {
     for (auto e : c->evpool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    return CMF_OK;
+}
+
+extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
+    if (!c || !name) return fail(CMF_EINVAL, "null argument");
+    if (!strcmp(name, "gemm_pipe")) {
+        if (value < 0 || value > 4) return fail(CMF_EINVAL, "gemm_pipe must be 0..4");
+        c->opt_pipe = (int)value;
+    } else if (!strcmp(name, "gemm_split")) {
+        c->opt_split = (int)value;
+    } else {
+        return fail(CMF_EINVAL, "unknown option %s", name);
+    }
     return CMF_OK;
 }
 

@@ -91,7 +91,13 @@ struct VecLoad<4> {
 
 // ROLE only separates the symbols: 0 = pass over a data-sized operand (X, Y, residual or
 // weight image), 1 = factor-side product (Gram, F*G, step); profiles then report them apart.
-template <int MODE, int BN, int ROLE = 0>
+// PIPE selects the staging schedule inside a K-step (A/B-able in one process, cmf_set_option):
+//   0: global loads of tile t+1 at group 0, all LDS writes as a burst after group 15
+//   1: LDS writes of tile t+1 one piece per group in groups 0..7, loads of tile t+2 at group 8
+//   2: LDS writes two pieces per group in groups 0..3, loads of tile t+2 at group 4
+//   3: LDS writes four pieces per group in groups 0..1, loads of tile t+2 at group 2
+//   4: all eight LDS writes in group 0, loads of tile t+2 at group 1
+template <int MODE, int BN, int ROLE = 0, int PIPE = 0>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
     using C = GemmCfg<MODE, BN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -127,12 +133,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
                 const int r = idx >> 3, c4 = idx & 7;
                 ra[p] = *reinterpret_cast<const f32x4 *>(g.A + (row0 + r) * g.lda + k0 + 4 * c4);
             } else {
+                // branch-free: a conditional load makes hipcc wait for the loads it has just
+                // issued (it must assume the skipped path); out-of-range columns are clamped
+                // here and zeroed when the tile is written to LDS
                 const int r = idx >> 6, c4 = idx & 63;
-                const int64_t col = row0 + 4 * c4;
-                if (col < g.Mout)
-                    ra[p] = *reinterpret_cast<const f32x4 *>(g.A + (k0 + r) * g.lda + col);
-                else
-                    ra[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                int64_t col = row0 + 4 * c4;
+                if (ROLE == 1 && col > g.Mout - 4) col = g.Mout - 4;
+                ra[p] = *reinterpret_cast<const f32x4 *>(g.A + (k0 + r) * g.lda + col);
             }
         }
 #pragma unroll
@@ -150,79 +157,141 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
             }
         }
     };
-    auto lstore = [&](float *As, float *Bs) {
-#pragma unroll
-        for (int p = 0; p < C::A_LD; ++p) {
+    // one 16-byte piece of the staged tile -> LDS (p < A_LD: A tile, else B tile)
+    auto lstore_piece = [&](float *As, float *Bs, int p) {
+        if (p < C::A_LD) {
             const int idx = t + C::NT * p;
             if constexpr (C::A_KC) {
                 const int r = idx >> 3, c4 = idx & 7;
                 *reinterpret_cast<f32x4 *>(As + r * C::PADK + 4 * c4) = ra[p];
             } else {
                 const int r = idx >> 6, c4 = idx & 63;
-                *reinterpret_cast<f32x4 *>(As + r * C::BM + 4 * c4) = ra[p];
+                f32x4 v = ra[p];
+                if (ROLE == 1 && row0 + 4 * c4 >= g.Mout) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4 *>(As + r * C::BM + 4 * c4) = v;
             }
-        }
-#pragma unroll
-        for (int p = 0; p < C::B_LD; ++p) {
-            const int idx = t + C::NT * p;
+        } else if (p - C::A_LD < C::B_LD) {
+            const int pb = p - C::A_LD;
+            const int idx = t + C::NT * pb;
             if (C::B_F4 >= C::NT || idx < C::B_F4) {
                 if constexpr (C::B_KC) {
                     const int r = idx >> 3, c4 = idx & 7;
-                    *reinterpret_cast<f32x4 *>(Bs + r * C::PADK + 4 * c4) = rb[p];
+                    *reinterpret_cast<f32x4 *>(Bs + r * C::PADK + 4 * c4) = rb[pb];
                 } else {
                     constexpr int F4R = BN / 4;
                     const int r = idx / F4R, c4 = idx % F4R;
-                    *reinterpret_cast<f32x4 *>(Bs + r * BN + 4 * c4) = rb[p];
+                    *reinterpret_cast<f32x4 *>(Bs + r * BN + 4 * c4) = rb[pb];
                 }
             }
         }
     };
-    auto compute = [&](const float *As, const float *Bs) {
-        if constexpr (C::A_KC) {
+    auto lstore = [&](float *As, float *Bs) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 a[C::TM];
+        for (int p = 0; p < C::A_LD + C::B_LD; ++p) lstore_piece(As, Bs, p);
+    };
+
+    // One K-step = 16 MFMA groups (one per k-pair).  Software pipeline inside the step:
+    //  * fragment reads of group s+1 are issued before the MFMAs of group s (register double
+    //    buffer), so LDS latency sits under 8-16 MFMAs of 64 cycles;
+    //  * the staged registers of tile t+1 (loaded during step t-1) are written to the other LDS
+    //    buffer one 16-byte piece per group in groups 0..7, i.e. under MFMAs instead of as a
+    //    burst in front of the barrier;
+    //  * the global loads of tile t+2 are issued at group 8 into the registers just drained.
+    // sched_barrier(0) pins that order (hipcc otherwise re-serialises reads and MFMAs).
+    auto compute = [&](const float *As, const float *Bs, float *nAs, float *nBs, bool do_write, bool do_load,
+                       int64_t next_k0) {
+        auto side = [&](int sidx) {
+            if constexpr (PIPE == 0) {
+                if (sidx == 0 && do_load) gload(next_k0);
+            } else {
+                constexpr int WPG = 1 << (PIPE - 1); // LDS-write pieces per group: 1, 2 or 4
+                constexpr int NG = 8 / WPG;          // groups that carry writes; loads go at group NG
+                if (sidx < NG) {
+                    if (do_write) {
+#pragma unroll
+                        for (int w = 0; w < WPG; ++w) lstore_piece(nAs, nBs, WPG * sidx + w);
+                    }
+                } else if (sidx == NG) {
+                    if (do_load) gload(next_k0);
+                }
+            }
+        };
+        if constexpr (C::A_KC) {
+            f32x4 a[2][C::TM];
+            auto lda_frag = [&](int q, f32x4 *dst) {
 #pragma unroll
                 for (int i = 0; i < C::TM; ++i)
-                    a[i] = *reinterpret_cast<const f32x4 *>(As + (wrow0 + 32 * i + l31) * C::PADK + 4 * (2 * q + lh));
-                if constexpr (C::B_KC) {
-                    f32x4 b[C::TN];
+                    dst[i] = *reinterpret_cast<const f32x4 *>(As + (wrow0 + 32 * i + l31) * C::PADK + 4 * (2 * q + lh));
+            };
+            if constexpr (C::B_KC) {
+                f32x4 b[2][C::TN];
+                auto ldb_frag = [&](int q, f32x4 *dst) {
 #pragma unroll
                     for (int j = 0; j < C::TN; ++j)
-                        b[j] = *reinterpret_cast<const f32x4 *>(Bs + (wcol0 + 32 * j + l31) * C::PADK + 4 * (2 * q + lh));
+                        dst[j] = *reinterpret_cast<const f32x4 *>(Bs + (wcol0 + 32 * j + l31) * C::PADK + 4 * (2 * q + lh));
+                };
+                lda_frag(0, a[0]);
+                ldb_frag(0, b[0]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-                            for (int j = 0; j < C::TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int kk = 8 * q + 4 * lh + e;
-                        float b[C::TN];
-                        VecLoad<C::TN>::ld(Bs + kk * BN + wcol0 + C::TN * l31, b);
-#pragma unroll
-                        for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-                            for (int j = 0; j < C::TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j], acc[i][j], 0, 0, 0);
+                for (int sidx = 0; sidx < 16; ++sidx) {
+                    const int q = sidx >> 2, e = sidx & 3;
+                    if (e == 0 && q + 1 < 4) {
+                        lda_frag(q + 1, a[(q + 1) & 1]);
+                        ldb_frag(q + 1, b[(q + 1) & 1]);
                     }
+                    side(sidx);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][i][e], b[q & 1][j][e], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                float b[2][C::TN];
+                auto ldb_frag = [&](int sidx, float *dst) { // sidx = 4*q + e
+                    const int kk = 8 * (sidx >> 2) + 4 * lh + (sidx & 3);
+                    VecLoad<C::TN>::ld(Bs + kk * BN + wcol0 + C::TN * l31, dst);
+                };
+                lda_frag(0, a[0]);
+                ldb_frag(0, b[0]);
+#pragma unroll
+                for (int sidx = 0; sidx < 16; ++sidx) {
+                    const int q = sidx >> 2, e = sidx & 3;
+                    if (sidx + 1 < 16) {
+                        ldb_frag(sidx + 1, b[(sidx + 1) & 1]);
+                        if (e == 0 && q + 1 < 4) lda_frag(q + 1, a[(q + 1) & 1]);
+                    }
+                    side(sidx);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][i][e], b[sidx & 1][j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         } else {
+            float a[2][C::TM], b[2][C::TN];
+            auto ld_frag = [&](int sidx, float *da, float *db) {
+                const int kk = 2 * sidx + lh;
+                VecLoad<C::TM>::ld(As + kk * C::BM + wrow0 + C::TM * l31, da);
+                VecLoad<C::TN>::ld(Bs + kk * BN + wcol0 + C::TN * l31, db);
+            };
+            ld_frag(0, a[0], b[0]);
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int kk = 2 * s + lh;
-                float a[C::TM], b[C::TN];
-                VecLoad<C::TM>::ld(As + kk * C::BM + wrow0 + C::TM * l31, a);
-                VecLoad<C::TN>::ld(Bs + kk * BN + wcol0 + C::TN * l31, b);
+            for (int sidx = 0; sidx < 16; ++sidx) {
+                if (sidx + 1 < 16) ld_frag(sidx + 1, a[(sidx + 1) & 1], b[(sidx + 1) & 1]);
+                side(sidx);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < C::TM; ++i)
 #pragma unroll
                     for (int j = 0; j < C::TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sidx & 1][i], b[sidx & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -230,14 +299,19 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
     if (nkt > 0) {
         gload(kbeg);
         lstore(smem, smem + C::A_ELEMS);
+        if (PIPE != 0 && nkt > 1) gload(kbeg + C::BK); // tile 1 waits in registers
         __syncthreads();
         for (int kt = 0; kt < nkt; ++kt) {
             float *cur = smem + (kt & 1) * C::STAGE;
             float *nxt = smem + ((kt + 1) & 1) * C::STAGE;
-            const bool more = (kt + 1 < nkt);
-            if (more) gload(kbeg + (int64_t)(kt + 1) * C::BK);
-            compute(cur, cur + C::A_ELEMS);
-            if (more) lstore(nxt, nxt + C::A_ELEMS);
+            if constexpr (PIPE == 0) {
+                const bool more = kt + 1 < nkt;
+                compute(cur, cur + C::A_ELEMS, nxt, nxt + C::A_ELEMS, false, more, kbeg + (int64_t)(kt + 1) * C::BK);
+                if (more) lstore(nxt, nxt + C::A_ELEMS);
+            } else {
+                compute(cur, cur + C::A_ELEMS, nxt, nxt + C::A_ELEMS, kt + 1 < nkt, kt + 2 < nkt,
+                        kbeg + (int64_t)(kt + 2) * C::BK);
+            }
             __syncthreads();
         }
     }

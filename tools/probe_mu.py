@@ -1,6 +1,6 @@
 """Quick perf probe: time cmf_mu_step at a given shape with per-kernel-class timing."""
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pycmf_amd import _lib
 
 def run(m, d, p, k, steps=5, warm=2):
