@@ -54,7 +54,8 @@ enum {
     CMF_K_ELEMWISE = 3,  /* slab sums, MU ratio, row updates   */
     CMF_K_EIGEN = 4,     /* batched symmetric Jacobi           */
     CMF_K_GEMM_SMALL = 5,/* factor-side products: Grams, F G, grad H^-1 */
-    CMF_K_COUNT = 6
+    CMF_K_SPMM = 6,      /* native CSR: A F, A^T F, sum_nnz a_ij (l_i . r_j)  */
+    CMF_K_COUNT = 7
 };
 
 const char *cmf_last_error(void);
@@ -66,8 +67,9 @@ int cmf_device_count(int *count);
 int cmf_ctx_create(cmf_ctx **out, int device, void *stream);
 int cmf_ctx_destroy(cmf_ctx *ctx);
 int cmf_sync(cmf_ctx *ctx);
-/* tuning knobs (A/B measurements in one process): "gemm_pipe" 0|1|2 = staging schedule of
- * the data-pass GEMM kernels, "gemm_split" n = force the split-K factor (<= 0: heuristic) */
+/* tuning knobs (A/B measurements in one process): "gemm_pipe" 0..4 = staging schedule of the
+ * data-pass GEMM kernels, "gemm_split" n = force the split-K factor (<= 0: heuristic),
+ * "sparse_mode" 0 auto | 1 dense | 2 native CSR (set before cmf_set_data_csr)       */
 int cmf_set_option(cmf_ctx *ctx, const char *name, int64_t value);
 
 /* ---- problem ---------------------------------------------------------- */
@@ -80,7 +82,10 @@ int cmf_set_problem(cmf_ctx *ctx, int64_t m, int64_t d, int64_t p, int k);
 int cmf_set_data_f64(cmf_ctx *ctx, int which, const double *ptr, int64_t rs, int64_t cs);
 int cmf_set_data_f32(cmf_ctx *ctx, int which, const float *ptr, int64_t rs, int64_t cs);
 /* CSR upload (scipy layout), accept_sparse=('csr','csc') of pycmf/cmf.py:679;
- * CSC is converted by the caller.                                            */
+ * CSC is converted by the caller.  Large, genuinely sparse inputs (density < 2 %,
+ * dense image > 1 GB) stay CSR on the device (A and A^T images, SpMM kernels);
+ * others are expanded to the dense layout.  cmf_set_option("sparse_mode", 1|2)
+ * forces dense | native.                                                     */
 int cmf_set_data_csr(cmf_ctx *ctx, int which, const int64_t *indptr, const int32_t *indices,
                      const double *data, int64_t nnz);
 /* Synthetic |N(0,1)| fill on the device (counter-based; value of element

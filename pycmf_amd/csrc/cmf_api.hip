@@ -4,6 +4,7 @@
 #include "../../include/cmfhip.h"
 #include "cmf_kernels.hip.h"
 #include "cmf_eigen.hip.h"
+#include "cmf_sparse.hip.h"
 
 #include <hip/hip_runtime.h>
 
@@ -49,6 +50,13 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
+struct CsrDev {
+    int64_t *indptr = nullptr;
+    int32_t *idx = nullptr;
+    float *val = nullptr;
+    int64_t rows = 0, cols = 0, nnz = 0;
+};
+
 struct EvPair {
     hipEvent_t a, b;
     int cls;
@@ -68,8 +76,13 @@ struct cmf_ctx {
     bool have_problem = false;
     int opt_pipe = 4;      // GEMM staging schedule (see gemm_kernel PIPE); 4 measured best (tools/ab_gemm.py)
     int opt_split = -1;    // force split-K factor (<=0: heuristic)
+    int opt_chol = 1;      // Cholesky fast path of the safe inverse (0: always Jacobi)
 
-    float *X = nullptr, *Y = nullptr; // dense, row-major, ld = dp / pp
+    float *X = nullptr, *Y = nullptr; // dense, row-major, ld = dp / pp (null while a sparse input stays native)
+    CsrDev sp[2][2];                  // [X|Y][A | A^T] native CSR images
+    bool sparse[2] = {false, false};
+    double sp_sq[2] = {0.0, 0.0};     // sum of squares of the stored values
+    int opt_sparse = 0;               // 0 auto, 1 always expand to dense, 2 always native CSR
     float *F[3] = {nullptr, nullptr, nullptr};
     int64_t frows[3] = {0, 0, 0}, frows_pad[3] = {0, 0, 0};
 
@@ -85,6 +98,7 @@ struct cmf_ctx {
     DevBuf mask1, mask2;                  // stochastic sample masks (bytes)
     DevBuf idxbuf;                        // uploaded sample index lists
     DevBuf eigws;                         // Jacobi workspace when k_pad > 128
+    DevBuf eigflag, eigcopy;              // Cholesky fast path: per-matrix fallback flags, input copy
     DevBuf dpart;                         // double partial sums
     double *dscalar = nullptr;            // 4 doubles
     std::vector<void *> owned;
@@ -353,6 +367,8 @@ static int mu_apply(cmf_ctx *c, float *F, const float *num, const float *den, in
     return CMF_OK;
 }
 
+#include "cmf_sparse_host.hip.h"
+
 // ------------------------------------------------------------------ C ABI: basics
 extern "C" const char *cmf_last_error(void) { return g_err.c_str(); }
 
@@ -410,8 +426,13 @@ static void release_problem(cmf_ctx *c) {
     c->num = c->den = c->G = c->G2 = c->Hm = c->Hinv = c->vbuf = nullptr;
     c->slabs = DevBuf(); c->resid = DevBuf(); c->resid2 = DevBuf(); c->resid3 = DevBuf(); c->dpart = DevBuf();
     c->kr1 = DevBuf(); c->kr2 = DevBuf(); c->hrows = DevBuf(); c->mask1 = DevBuf(); c->mask2 = DevBuf();
-    c->idxbuf = DevBuf(); c->eigws = DevBuf();
+    c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf();
     c->have_problem = false;
+    for (int w = 0; w < 2; ++w) {
+        c->sparse[w] = false;
+        c->sp_sq[w] = 0.0;
+        for (int t = 0; t < 2; ++t) c->sp[w][t] = CsrDev();
+    }
 }
 
 extern "C" int cmf_ctx_destroy(cmf_ctx *c) {
@@ -433,6 +454,11 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_pipe = (int)value;
     } else if (!strcmp(name, "gemm_split")) {
         c->opt_split = (int)value;
+    } else if (!strcmp(name, "safe_inverse_cholesky")) {
+        c->opt_chol = value != 0;
+    } else if (!strcmp(name, "sparse_mode")) {
+        if (value < 0 || value > 2) return fail(CMF_EINVAL, "sparse_mode must be 0 (auto), 1 (dense) or 2 (native CSR)");
+        c->opt_sparse = (int)value;
     } else {
         return fail(CMF_EINVAL, "unknown option %s", name);
     }
@@ -530,6 +556,7 @@ static int set_data(cmf_ctx *c, int which, const T *ptr, int64_t rs, int64_t cs)
     int64_t r, cc, rp, cp; float **slot;
     CHK(data_dims(c, which, &r, &cc, &rp, &cp, &slot));
     CHK(ensure_dense(c, which));
+    c->sparse[which] = false;
     HIPCHK(hipMemsetAsync(*slot, 0, (size_t)rp * cp * sizeof(float), c->stream));
     return upload_strided<T>(c, *slot, cp, r, cc, ptr, rs, cs);
 }
@@ -541,11 +568,17 @@ extern "C" int cmf_set_data_csr(cmf_ctx *c, int which, const int64_t *indptr, co
     NEED_PROBLEM(c);
     if (!indptr || (nnz > 0 && (!indices || !data))) return fail(CMF_EINVAL, "null CSR pointer");
     DeviceGuard dg(c->device);
-    // round 1: CSR input is expanded to the dense device layout (the Newton path of the
-    // reference densifies too, cmf_solvers.py:389-404); a native SpMM path is the next step.
     int64_t r, cc, rp, cp; float **slot;
     CHK(data_dims(c, which, &r, &cc, &rp, &cp, &slot));
-    if ((double)rp * (double)cp * 4.0 > 200e9) return fail(CMF_EUNSUPPORTED, "CSR input too large to expand densely (%lld x %lld)", (long long)r, (long long)cc);
+    // native CSR (SpMM / SDDMM kernels) when the matrix is genuinely sparse and large, or on
+    // request; otherwise expand into the dense layout and use the MFMA path
+    const double dense_bytes = (double)rp * (double)cp * 4.0;
+    const double density = (r > 0 && cc > 0) ? (double)nnz / ((double)r * (double)cc) : 1.0;
+    const bool native = c->opt_sparse == 2 || (c->opt_sparse == 0 && density < 0.02 && dense_bytes > 1e9);
+    if (*slot) { HIPCHK(hipStreamSynchronize(c->stream)); dev_free(c, *slot); *slot = nullptr; }
+    c->sparse[which] = false;
+    if (native) return set_data_csr_native(c, which, indptr, indices, data, nnz, r, cc);
+    if (dense_bytes > 200e9) return fail(CMF_EUNSUPPORTED, "CSR input too large to expand densely (%lld x %lld)", (long long)r, (long long)cc);
     CHK(ensure_dense(c, which));
     HIPCHK(hipMemsetAsync(*slot, 0, (size_t)rp * cp * sizeof(float), c->stream));
     const int64_t chunk_rows = std::max<int64_t>(1, std::min<int64_t>(r, (int64_t)(64 << 20) / (std::max<int64_t>(cc, 1) * 4)));
@@ -570,6 +603,7 @@ extern "C" int cmf_get_data_f32(cmf_ctx *c, int which, float *ptr, int64_t rs, i
     DeviceGuard dg(c->device);
     int64_t r, cc, rp, cp; float **slot;
     CHK(data_dims(c, which, &r, &cc, &rp, &cp, &slot));
+    if (!*slot && c->sparse[which]) CHK(need_dense(c, which));
     if (!*slot) return fail(CMF_EINVAL, "data %d not set", which);
     std::vector<float> host((size_t)r * cc);
     HIPCHK(hipMemcpy2DAsync(host.data(), cc * sizeof(float), *slot, cp * sizeof(float), cc * sizeof(float), r, hipMemcpyDeviceToHost, c->stream));
@@ -659,12 +693,12 @@ extern "C" int cmf_v_buf_elems(cmf_ctx *c, int64_t *n) {
 extern "C" int cmf_mu_v_partials(cmf_ctx *c, float *buf) {
     NEED_PROBLEM(c);
     if (!buf) return fail(CMF_EINVAL, "null buffer");
-    if (!c->X || !c->Y) return fail(CMF_EINVAL, "X and Y must be set before a V update");
+    if (!have_data(c, 0) || !have_data(c, 1)) return fail(CMF_EINVAL, "X and Y must be set before a V update");
     DeviceGuard dg(c->device);
     float *P = buf, *Gs = buf + c->dp * c->kp;
     // P = X^T U + Y Z
-    CHK(gemm(c, MODE_TN, c->X, c->dp, c->F[CMF_U], c->kp, P, c->dp, c->kp, c->mp));
-    CHK(gemm(c, MODE_NN, c->Y, c->pp, c->F[CMF_Z], c->kp, P, c->dp, c->kp, c->pp, true));
+    CHK(data_times(c, 0, true, c->F[CMF_U], P));
+    CHK(data_times(c, 1, false, c->F[CMF_Z], P, true));
     // G = U^T U + Z^T Z
     CHK(gemm(c, MODE_TN, c->F[CMF_U], c->kp, c->F[CMF_U], c->kp, Gs, c->kp, c->kp, c->mp));
     CHK(gemm(c, MODE_TN, c->F[CMF_Z], c->kp, c->F[CMF_Z], c->kp, Gs, c->kp, c->kp, c->pp, true));
@@ -690,14 +724,14 @@ extern "C" int cmf_mu_uz_update(cmf_ctx *c, double l1, double l2, int mask) {
     if (!(mask & (CMF_UPD_U | CMF_UPD_Z))) return CMF_OK;
     CHK(gemm(c, MODE_TN, c->F[CMF_V], c->kp, c->F[CMF_V], c->kp, c->G2, c->kp, c->kp, c->dp));
     if (mask & CMF_UPD_U) {
-        if (!c->X) return fail(CMF_EINVAL, "X must be set before a U update");
-        CHK(gemm(c, MODE_NN, c->X, c->dp, c->F[CMF_V], c->kp, c->num, c->mp, c->kp, c->dp));
+        if (!have_data(c, 0)) return fail(CMF_EINVAL, "X must be set before a U update");
+        CHK(data_times(c, 0, false, c->F[CMF_V], c->num));
         CHK(gemm(c, MODE_NN, c->F[CMF_U], c->kp, c->G2, c->kp, c->den, c->mp, c->kp, c->kp));
         CHK(mu_apply(c, c->F[CMF_U], c->num, c->den, c->mp * c->kp, l1, l2));
     }
     if (mask & CMF_UPD_Z) {
-        if (!c->Y) return fail(CMF_EINVAL, "Y must be set before a Z update");
-        CHK(gemm(c, MODE_TN, c->Y, c->pp, c->F[CMF_V], c->kp, c->num, c->pp, c->kp, c->dp));
+        if (!have_data(c, 1)) return fail(CMF_EINVAL, "Y must be set before a Z update");
+        CHK(data_times(c, 1, true, c->F[CMF_V], c->num));
         CHK(gemm(c, MODE_NN, c->F[CMF_Z], c->kp, c->G2, c->kp, c->den, c->pp, c->kp, c->kp));
         CHK(mu_apply(c, c->F[CMF_Z], c->num, c->den, c->pp * c->kp, l1, l2));
     }
@@ -719,13 +753,23 @@ extern "C" int cmf_residual_sq(cmf_ctx *c, int x_link, int y_link, double *ex2, 
     DeviceGuard dg(c->device);
     double host[2] = {0, 0};
     HIPCHK(hipMemsetAsync(c->dscalar, 0, 2 * sizeof(double), c->stream));
-    if (ex2 && c->X) {
-        NtOut o; o.T = c->X; o.ldt = c->dp; o.sq = c->dscalar; o.link = x_link;
-        CHK(gemm_nt(c, c->F[CMF_U], c->mp, c->m, c->F[CMF_V], c->dp, c->d, o));
+    if (ex2 && have_data(c, 0)) {
+        if (!c->X && x_link == CMF_LINK_LINEAR) {
+            CHK(sparse_residual_sq(c, 0, c->dscalar));
+        } else {
+            CHK(need_dense(c, 0));
+            NtOut o; o.T = c->X; o.ldt = c->dp; o.sq = c->dscalar; o.link = x_link;
+            CHK(gemm_nt(c, c->F[CMF_U], c->mp, c->m, c->F[CMF_V], c->dp, c->d, o));
+        }
     }
-    if (ey2 && c->Y) {
-        NtOut o; o.T = c->Y; o.ldt = c->pp; o.sq = c->dscalar + 1; o.link = y_link;
-        CHK(gemm_nt(c, c->F[CMF_V], c->dp, c->d, c->F[CMF_Z], c->pp, c->p, o));
+    if (ey2 && have_data(c, 1)) {
+        if (!c->Y && y_link == CMF_LINK_LINEAR) {
+            CHK(sparse_residual_sq(c, 1, c->dscalar + 1));
+        } else {
+            CHK(need_dense(c, 1));
+            NtOut o; o.T = c->Y; o.ldt = c->pp; o.sq = c->dscalar + 1; o.link = y_link;
+            CHK(gemm_nt(c, c->F[CMF_V], c->dp, c->d, c->F[CMF_Z], c->pp, c->p, o));
+        }
     }
     HIPCHK(hipMemcpyAsync(host, c->dscalar, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -741,8 +785,12 @@ extern "C" int cmf_data_sq(cmf_ctx *c, double *x2, double *y2) {
     HIPCHK(hipMemsetAsync(c->dscalar, 0, 2 * sizeof(double), c->stream));
     const float *src[2] = {c->X, c->Y};
     const int64_t n[2] = {c->mp * c->dp, c->dp * c->pp};
+    double sparse_sq[2] = {-1.0, -1.0};
     for (int w = 0; w < 2; ++w) {
-        if (!src[w]) continue;
+        if (!src[w]) {
+            if (c->sparse[w]) sparse_sq[w] = c->sp_sq[w];
+            continue;
+        }
         const int blocks = 1024;
         CHK(ensure(c, c->dpart, blocks * sizeof(double)));
         Timed tm(c, CMF_K_ELEMWISE);
@@ -752,6 +800,8 @@ extern "C" int cmf_data_sq(cmf_ctx *c, double *x2, double *y2) {
     }
     HIPCHK(hipMemcpyAsync(host, c->dscalar, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (sparse_sq[0] >= 0) host[0] = sparse_sq[0];
+    if (sparse_sq[1] >= 0) host[1] = sparse_sq[1];
     if (x2) *x2 = host[0];
     if (y2) *y2 = host[1];
     return CMF_OK;

@@ -25,10 +25,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 // n = valid order (<= kp).  Only the leading n x n block is read; Hout's padding is zeroed.
 template <bool USE_LDS>
 __global__ __launch_bounds__(256) void jacobi_safe_inverse_kernel(const float *Hin, float *Hout, float *ws, int n, int kp,
-                                                                  int64_t stride, float pert, int nmat, int max_sweeps) {
+                                                                  int64_t stride, float pert, int nmat, int max_sweeps,
+                                                                  const int *need) {
     extern __shared__ __attribute__((aligned(16))) float esm[];
     const int mat = blockIdx.x;
     if (mat >= nmat) return;
+    if (need && !need[mat]) return; // already inverted by the Cholesky fast path
     const float *H = Hin + (int64_t)mat * stride;
     float *O = Hout + (int64_t)mat * stride;
     const int ld = n;
@@ -121,6 +123,119 @@ __global__ __launch_bounds__(256) void jacobi_safe_inverse_kernel(const float *H
         float acc = 0.f;
         if (r < n && c < n) {
             for (int j = 0; j < n; ++j) acc += inv[j] * Vt[j * ld + r] * Vt[j * ld + c];
+        }
+        O[idx] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Cholesky fast path of the safe inverse.  When every eigenvalue of the (symmetric) H is
+// >= pert, the clamp of _safe_invert is the identity and the result is simply H^-1.  That is
+// decided exactly by trying to factor H - pert*I: it is positive definite iff lambda_min > pert.
+// If so, H = L L^T is factored in a packed lower triangle held in LDS (n(n+1)/2 floats: 131.6 KB
+// at n = 256), L is inverted in place and H^-1 = L^-T L^-1 is written out.  Otherwise
+// need_jacobi[mat] is set and the Jacobi kernel (which skips matrices whose flag is 0) does the
+// general |lambda| / clamp computation.  One workgroup per matrix.
+__device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; } // j <= i
+
+__device__ bool chol_packed(float *Lp, int n, float floor_) {
+    // right-looking Cholesky on the packed lower triangle; returns false on a non-positive pivot
+    __shared__ int ok;
+    const int t = threadIdx.x;
+    if (t == 0) ok = 1;
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        const float dj = Lp[tri(j, j)];
+        if (!(dj > floor_)) {
+            if (t == 0) ok = 0;
+            break; // uniform: every thread reads the same dj
+        }
+        const float ljj = sqrtf(dj);
+        const float inv = 1.0f / ljj;
+        __syncthreads();
+        for (int i = j + t; i < n; i += 256) Lp[tri(i, j)] = (i == j) ? ljj : Lp[tri(i, j)] * inv;
+        __syncthreads();
+        for (int i = j + 1 + t; i < n; i += 256) {
+            const float lij = Lp[tri(i, j)];
+            float *row = Lp + tri(i, 0);
+            for (int c = j + 1; c <= i; ++c) row[c] -= lij * Lp[tri(c, j)];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    return ok != 0;
+}
+
+__global__ __launch_bounds__(256) void chol_safe_inverse_kernel(const float *Hin, float *Hout, int *need_jacobi, int n, int kp,
+                                                                 int64_t stride, float pert, int nmat) {
+    extern __shared__ __attribute__((aligned(16))) float esm[];
+    const int mat = blockIdx.x;
+    if (mat >= nmat) return;
+    const float *H = Hin + (int64_t)mat * stride;
+    float *O = Hout + (int64_t)mat * stride;
+    float *Lp = esm;
+    const int t = threadIdx.x;
+    const int ntri = n * (n + 1) / 2;
+    // scale-aware pivot floor: a pivot must clear rounding noise of the largest diagonal entry
+    float dmax = 0.f;
+    for (int i = t; i < n; i += 256) dmax = fmaxf(dmax, fabsf(H[i * kp + i]));
+    __shared__ float red[4];
+    for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+    if ((t & 63) == 0) red[t >> 6] = dmax;
+    __syncthreads();
+    dmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float floor_ = 4.0e-6f * dmax;
+
+    // 1) is H - pert*I positive definite?
+    for (int idx = t; idx < ntri; idx += 256) {
+        int i = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
+        while (tri(i + 1, 0) <= idx) ++i;
+        while (tri(i, 0) > idx) --i;
+        const int j = idx - tri(i, 0);
+        Lp[idx] = H[i * kp + j] - (i == j ? pert : 0.f);
+    }
+    __syncthreads();
+    const bool pd = chol_packed(Lp, n, floor_);
+    if (!pd) {
+        if (t == 0) need_jacobi[mat] = 1;
+        return;
+    }
+    if (t == 0) need_jacobi[mat] = 0;
+    // 2) factor H itself
+    __syncthreads();
+    for (int idx = t; idx < ntri; idx += 256) {
+        int i = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
+        while (tri(i + 1, 0) <= idx) ++i;
+        while (tri(i, 0) > idx) --i;
+        const int j = idx - tri(i, 0);
+        Lp[idx] = H[i * kp + j];
+    }
+    __syncthreads();
+    (void)chol_packed(Lp, n, 0.0f);
+    // 3) X = L^-1 in place (lower): column j from the already inverted trailing block
+    for (int j = n - 1; j >= 0; --j) {
+        const float xjj = 1.0f / Lp[tri(j, j)];
+        float mine[1 + 255 / 256 + 1]; // rows handled by this thread: i = j+1+t, j+1+t+256 (n <= 512)
+        int cnt = 0;
+        for (int i = j + 1 + t; i < n; i += 256) {
+            float sacc = 0.f;
+            const float *row = Lp + tri(i, 0);
+            for (int c = j + 1; c <= i; ++c) sacc += row[c] * Lp[tri(c, j)];
+            mine[cnt++] = -sacc * xjj;
+        }
+        __syncthreads();
+        cnt = 0;
+        for (int i = j + 1 + t; i < n; i += 256) Lp[tri(i, j)] = mine[cnt++];
+        if (t == 0) Lp[tri(j, j)] = xjj;
+        __syncthreads();
+    }
+    // 4) H^-1 = X^T X (symmetric), zero on the padding
+    for (int idx = t; idx < kp * kp; idx += 256) {
+        const int a = idx / kp, b = idx % kp;
+        float acc = 0.f;
+        if (a < n && b < n) {
+            const int lo = a > b ? a : b;
+            for (int j = lo; j < n; ++j) acc += Lp[tri(j, a)] * Lp[tri(j, b)];
         }
         O[idx] = acc;
     }

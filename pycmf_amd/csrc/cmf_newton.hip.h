@@ -25,12 +25,36 @@ static int launch_ew(cmf_ctx *c, void (*kern)(Args...), int64_t n, Args... args)
     return CMF_OK;
 }
 
-// Hout_i = safe_inverse(Hin_i) for nmat k_pad x k_pad matrices (valid order c->k)
+// Hout_i = safe_inverse(Hin_i) for nmat k_pad x k_pad matrices (valid order n).
+// Cholesky fast path first (exact when lambda_min >= pert), Jacobi for the flagged rest.
 static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat, int n, int kp, double pert) {
     if (nmat <= 0) return CMF_OK;
     const int64_t stride = (int64_t)kp * kp;
-    const size_t lds_need = (size_t)(2 * n * n + n) * sizeof(float);
     Timed tm(c, CMF_K_EIGEN);
+    const int *need = nullptr;
+    const size_t tri_bytes = (size_t)n * (n + 1) / 2 * sizeof(float);
+    const bool inplace = (Hin == Hout);
+    if (c->opt_chol && tri_bytes <= 150 * 1024 && n <= 512) {
+        CHK(ensure(c, c->eigflag, (size_t)nmat * sizeof(int)));
+        const float *src = Hin;
+        if (inplace) { // the fast path overwrites its output: keep the input for the Jacobi fallback
+            CHK(ensure(c, c->eigcopy, (size_t)nmat * stride * sizeof(float)));
+            HIPCHK(hipMemcpyAsync(c->eigcopy.p, Hin, (size_t)nmat * stride * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            src = (const float *)c->eigcopy.p;
+        }
+        static bool attr_c = false;
+        if (!attr_c) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_safe_inverse_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_c = true;
+        }
+        hipLaunchKernelGGL(chol_safe_inverse_kernel, dim3(nmat), dim3(256), tri_bytes, c->stream, src, Hout, (int *)c->eigflag.p, n, kp,
+                           stride, (float)pert, nmat);
+        HIPCHK(hipGetLastError());
+        need = (const int *)c->eigflag.p;
+        Hin = src;
+    }
+    const size_t lds_need = (size_t)(2 * n * n + n) * sizeof(float);
     if (lds_need <= 150 * 1024) {
         static bool attr = false;
         if (!attr) {
@@ -39,11 +63,11 @@ static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat,
             attr = true;
         }
         hipLaunchKernelGGL((jacobi_safe_inverse_kernel<true>), dim3(nmat), dim3(256), lds_need, c->stream, Hin, Hout,
-                           (float *)nullptr, n, kp, stride, (float)pert, nmat, 30);
+                           (float *)nullptr, n, kp, stride, (float)pert, nmat, 30, need);
     } else {
         CHK(ensure(c, c->eigws, (size_t)nmat * 2 * stride * sizeof(float)));
         hipLaunchKernelGGL((jacobi_safe_inverse_kernel<false>), dim3(nmat), dim3(256), (size_t)n * sizeof(float), c->stream,
-                           Hin, Hout, (float *)c->eigws.p, n, kp, stride, (float)pert, nmat, 30);
+                           Hin, Hout, (float *)c->eigws.p, n, kp, stride, (float)pert, nmat, 30, need);
     }
     HIPCHK(hipGetLastError());
     return CMF_OK;
@@ -92,8 +116,8 @@ static int sweep_side_shared(cmf_ctx *c, bool is_u, double scale, double l1, dou
     const int64_t rows = c->frows_pad[which];
     float *F = c->F[which], *V = c->F[CMF_V];
     CHK(gemm(c, MODE_TN, V, c->kp, V, c->kp, c->G2, c->kp, c->kp, c->dp)); // V^T V
-    if (is_u) CHK(gemm(c, MODE_NN, c->X, c->dp, V, c->kp, c->num, c->mp, c->kp, c->dp)); // X V
-    else CHK(gemm(c, MODE_TN, c->Y, c->pp, V, c->kp, c->num, c->pp, c->kp, c->dp));     // Y^T V
+    if (is_u) CHK(data_times(c, 0, false, V, c->num)); // X V
+    else CHK(data_times(c, 1, true, V, c->num));       // Y^T V
     CHK(gemm(c, MODE_NN, F, c->kp, c->G2, c->kp, c->den, rows, c->kp, c->kp));           // F (V^T V)
     CHK(launch_ew(c, newton_grad_kernel, rows * c->kp, c->den, (const float *)c->den, (float)scale, (const float *)c->num,
                   (float)-scale, (const float *)F, (float)l1, (float)l2, rows * c->kp));
@@ -105,11 +129,11 @@ static int sweep_side_shared(cmf_ctx *c, bool is_u, double scale, double l1, dou
 extern "C" int cmf_newton_v_partials(cmf_ctx *c, double alpha, float *buf) {
     NEED_PROBLEM(c);
     if (!buf) return fail(CMF_EINVAL, "null buffer");
-    if (!c->X || !c->Y) return fail(CMF_EINVAL, "X and Y must be set before a V update");
+    if (!have_data(c, 0) || !have_data(c, 1)) return fail(CMF_EINVAL, "X and Y must be set before a V update");
     DeviceGuard dg(c->device);
     float *P = buf, *Gs = buf + c->dp * c->kp;
-    CHK(gemm(c, MODE_TN, c->X, c->dp, c->F[CMF_U], c->kp, c->num, c->dp, c->kp, c->mp)); // X^T U
-    CHK(gemm(c, MODE_NN, c->Y, c->pp, c->F[CMF_Z], c->kp, c->den, c->dp, c->kp, c->pp)); // Y Z
+    CHK(data_times(c, 0, true, c->F[CMF_U], c->num));  // X^T U
+    CHK(data_times(c, 1, false, c->F[CMF_Z], c->den)); // Y Z
     CHK(launch_ew(c, axpby_kernel, c->dp * c->kp, P, (const float *)c->num, (float)alpha, (const float *)c->den,
                   (float)(1.0 - alpha), c->dp * c->kp));
     CHK(gemm(c, MODE_TN, c->F[CMF_U], c->kp, c->F[CMF_U], c->kp, c->G, c->kp, c->kp, c->mp));
@@ -136,11 +160,11 @@ extern "C" int cmf_newton_uz_update(cmf_ctx *c, double alpha, double l1, double 
     NEED_PROBLEM(c);
     DeviceGuard dg(c->device);
     if (upd & CMF_UPD_U) {
-        if (!c->X) return fail(CMF_EINVAL, "X must be set before a U update");
+        if (!have_data(c, 0)) return fail(CMF_EINVAL, "X must be set before a U update");
         CHK(sweep_side_shared(c, true, alpha, l1, l2, pert, (nn_mask & CMF_NN_U) != 0));
     }
     if (upd & CMF_UPD_Z) {
-        if (!c->Y) return fail(CMF_EINVAL, "Y must be set before a Z update");
+        if (!have_data(c, 1)) return fail(CMF_EINVAL, "Y must be set before a Z update");
         CHK(sweep_side_shared(c, false, 1.0 - alpha, l1, l2, pert, (nn_mask & CMF_NN_Z) != 0));
     }
     return CMF_OK;
@@ -327,14 +351,16 @@ extern "C" int cmf_newton_step(cmf_ctx *c, double alpha, double l1, double l2, i
             return fail(CMF_EINVAL, "sg_sample_ratio < 1 needs the sample index lists of every updated factor");
     }
     if (upd & CMF_UPD_U) {
-        if (!c->X) return fail(CMF_EINVAL, "X must be set before a U update");
+        if (!have_data(c, 0)) return fail(CMF_EINVAL, "X must be set before a U update");
+        if (!(x_link == CMF_LINK_LINEAR && !sampled)) CHK(need_dense(c, 0));
         if (x_link == CMF_LINK_LINEAR && !sampled)
             CHK(sweep_side_shared(c, true, alpha, l1, l2, pert, (nn_mask & CMF_NN_U) != 0));
         else
             CHK(sweep_side_rows(c, true, x_link, alpha, l1, l2, pert, (nn_mask & CMF_NN_U) != 0, sampled ? u_idx : nullptr, su));
     }
     if (upd & CMF_UPD_Z) {
-        if (!c->Y) return fail(CMF_EINVAL, "Y must be set before a Z update");
+        if (!have_data(c, 1)) return fail(CMF_EINVAL, "Y must be set before a Z update");
+        if (!(y_link == CMF_LINK_LINEAR && !sampled)) CHK(need_dense(c, 1));
         if (y_link == CMF_LINK_LINEAR && !sampled)
             CHK(sweep_side_shared(c, false, 1.0 - alpha, l1, l2, pert, (nn_mask & CMF_NN_Z) != 0));
         else
@@ -342,7 +368,11 @@ extern "C" int cmf_newton_step(cmf_ctx *c, double alpha, double l1, double l2, i
                                 sampled ? z_idx : nullptr, su));
     }
     if (upd & CMF_UPD_V) {
-        if (!c->X || !c->Y) return fail(CMF_EINVAL, "X and Y must be set before a V update");
+        if (!have_data(c, 0) || !have_data(c, 1)) return fail(CMF_EINVAL, "X and Y must be set before a V update");
+        if (!(x_link == CMF_LINK_LINEAR && y_link == CMF_LINK_LINEAR && !sampled)) {
+            CHK(need_dense(c, 0));
+            CHK(need_dense(c, 1));
+        }
         if (x_link == CMF_LINK_LINEAR && y_link == CMF_LINK_LINEAR && !sampled) {
             CHK(cmf_newton_v_partials(c, alpha, c->vbuf));
             CHK(cmf_newton_v_apply(c, c->vbuf, l1, l2, nn_mask, pert));

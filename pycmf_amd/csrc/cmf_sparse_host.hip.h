@@ -1,0 +1,153 @@
+// cmf_sparse_host.hip.h -- host side of the native CSR path (included by cmf_api.hip)
+
+static int csr_upload(cmf_ctx *c, CsrDev &dst, const int64_t *indptr, const int32_t *indices, const float *vals, int64_t rows,
+                      int64_t cols, int64_t nnz) {
+    dst.rows = rows; dst.cols = cols; dst.nnz = nnz;
+    CHK(dev_alloc(c, (void **)&dst.indptr, (size_t)(rows + 1) * sizeof(int64_t), false));
+    CHK(dev_alloc(c, (void **)&dst.idx, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t), false));
+    CHK(dev_alloc(c, (void **)&dst.val, (size_t)std::max<int64_t>(nnz, 1) * sizeof(float), false));
+    HIPCHK(hipMemcpyAsync(dst.indptr, indptr, (size_t)(rows + 1) * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    if (nnz > 0) {
+        HIPCHK(hipMemcpyAsync(dst.idx, indices, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(dst.val, vals, (size_t)nnz * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CMF_OK;
+}
+
+// keep A as CSR and as CSR of A^T (counting sort on the host, O(nnz))
+static int set_data_csr_native(cmf_ctx *c, int which, const int64_t *indptr, const int32_t *indices, const double *data, int64_t nnz,
+                               int64_t rows, int64_t cols) {
+    std::vector<float> vals((size_t)std::max<int64_t>(nnz, 1));
+    double sq = 0.0;
+    for (int64_t q = 0; q < nnz; ++q) {
+        if (indices[q] < 0 || indices[q] >= cols) return fail(CMF_EINVAL, "CSR column index out of range");
+        vals[q] = (float)data[q];
+        sq += (double)vals[q] * (double)vals[q];
+    }
+    CHK(csr_upload(c, c->sp[which][0], indptr, indices, vals.data(), rows, cols, nnz));
+    // transpose
+    std::vector<int64_t> tptr((size_t)cols + 1, 0);
+    for (int64_t q = 0; q < nnz; ++q) tptr[indices[q] + 1]++;
+    for (int64_t j = 0; j < cols; ++j) tptr[j + 1] += tptr[j];
+    std::vector<int32_t> tidx((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<float> tval((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<int64_t> fill(tptr.begin(), tptr.end() - 1);
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t q = indptr[r]; q < indptr[r + 1]; ++q) {
+            const int64_t pos = fill[indices[q]]++;
+            tidx[pos] = (int32_t)r;
+            tval[pos] = vals[q];
+        }
+    CHK(csr_upload(c, c->sp[which][1], tptr.data(), tidx.data(), tval.data(), cols, rows, nnz));
+    c->sparse[which] = true;
+    c->sp_sq[which] = sq;
+    return CMF_OK;
+}
+
+template <int GL, int CH>
+static void launch_spmm(cmf_ctx *c, const CsrView &v, const float *F, float *out, bool accumulate) {
+    constexpr int RPW = 64 / GL;
+    const int64_t waves = (v.rows + RPW - 1) / RPW;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    if (blocks) hipLaunchKernelGGL((spmm_csr_kernel<GL, CH>), dim3(blocks), dim3(256), 0, c->stream, v, F, c->kp, out, accumulate ? 1 : 0);
+}
+
+// out[rows x kp] (+)= A F for a device CSR matrix A
+static int spmm(cmf_ctx *c, const CsrDev &A, const float *F, float *out, int64_t rows_pad, bool accumulate) {
+    if (!accumulate && rows_pad > A.rows)
+        HIPCHK(hipMemsetAsync(out + A.rows * c->kp, 0, (size_t)(rows_pad - A.rows) * c->kp * sizeof(float), c->stream));
+    CsrView v{A.indptr, A.idx, A.val, A.rows};
+    Timed tm(c, CMF_K_SPMM, 2.0 * (double)A.nnz * (double)c->kp);
+    switch (c->kp) {
+    case 32: launch_spmm<8, 1>(c, v, F, out, accumulate); break;
+    case 64: launch_spmm<16, 1>(c, v, F, out, accumulate); break;
+    case 128: launch_spmm<32, 1>(c, v, F, out, accumulate); break;
+    case 256: launch_spmm<64, 1>(c, v, F, out, accumulate); break;
+    case 512: launch_spmm<64, 2>(c, v, F, out, accumulate); break;
+    case 768: launch_spmm<64, 3>(c, v, F, out, accumulate); break;
+    case 1024: launch_spmm<64, 4>(c, v, F, out, accumulate); break;
+    default: return fail(CMF_EUNSUPPORTED, "native CSR path supports n_components <= 1024 (k_pad=%d)", c->kp);
+    }
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
+// expand a natively-sparse data matrix into the dense layout (per-row Newton images need it)
+static int need_dense(cmf_ctx *c, int which) {
+    float **slot = which == 0 ? &c->X : &c->Y;
+    if (*slot) return CMF_OK;
+    if (!c->sparse[which]) return fail(CMF_EINVAL, "%s has not been set", which == 0 ? "X" : "Y");
+    const int64_t rp = which == 0 ? c->mp : c->dp, cp = which == 0 ? c->dp : c->pp;
+    if ((double)rp * (double)cp * 4.0 > 128e9)
+        return fail(CMF_EUNSUPPORTED, "this solver configuration needs a dense %lld x %lld image of a sparse input (logit link or "
+                                      "sg_sample_ratio < 1); it does not fit", (long long)rp, (long long)cp);
+    CHK(dev_alloc(c, (void **)slot, (size_t)rp * cp * sizeof(float)));
+    const CsrDev &A = c->sp[which][0];
+    CsrView v{A.indptr, A.idx, A.val, A.rows};
+    Timed tm(c, CMF_K_ELEMWISE);
+    const unsigned blocks = (unsigned)((A.rows + 3) / 4);
+    if (blocks) hipLaunchKernelGGL(csr_to_dense_kernel, dim3(blocks), dim3(256), 0, c->stream, v, *slot, cp);
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
+// data-times-factor products of the update steps:
+//   which = 0: X (m x d)   trans = false: X B (B has d rows) -> m rows ; true: X^T B (B has m rows) -> d rows
+//   which = 1: Y (d x p)   trans = false: Y B (B has p rows) -> d rows ; true: Y^T B (B has d rows) -> p rows
+static int data_times(cmf_ctx *c, int which, bool trans, const float *B, float *out, bool accumulate = false) {
+    const int64_t rp = which == 0 ? c->mp : c->dp, cp = which == 0 ? c->dp : c->pp;
+    if (c->sparse[which] && !(which == 0 ? c->X : c->Y)) return spmm(c, c->sp[which][trans ? 1 : 0], B, out, trans ? cp : rp, accumulate);
+    const float *A = which == 0 ? c->X : c->Y;
+    if (!A) return fail(CMF_EINVAL, "%s has not been set", which == 0 ? "X" : "Y");
+    if (!trans) return gemm(c, MODE_NN, A, cp, B, c->kp, out, rp, c->kp, cp, accumulate);
+    return gemm(c, MODE_TN, A, cp, B, c->kp, out, cp, c->kp, rp, accumulate);
+}
+
+static bool have_data(const cmf_ctx *c, int which) { return (which == 0 ? c->X : c->Y) != nullptr || c->sparse[which]; }
+
+template <int GL, int CH>
+static void launch_sddmm(cmf_ctx *c, const CsrView &v, const float *L, const float *R, double *partials, unsigned blocks) {
+    hipLaunchKernelGGL((sddmm_cross_kernel<GL, CH>), dim3(blocks), dim3(256), 0, c->stream, v, L, R, c->kp, partials);
+}
+
+// ||A - L R^T||^2 = ||A||^2 - 2 sum_nnz a_ij (l_i . r_j) + <L^T L, R^T R>   (linear link, native CSR)
+static int sparse_residual_sq(cmf_ctx *c, int which, double *dev_out) {
+    const CsrDev &A = c->sp[which][0];
+    const float *L = which == 0 ? c->F[CMF_U] : c->F[CMF_V];
+    const float *R = which == 0 ? c->F[CMF_V] : c->F[CMF_Z];
+    const int64_t lrows = which == 0 ? c->mp : c->dp, rrows = which == 0 ? c->dp : c->pp;
+    CHK(gemm(c, MODE_TN, L, c->kp, L, c->kp, c->G, c->kp, c->kp, lrows));
+    CHK(gemm(c, MODE_TN, R, c->kp, R, c->kp, c->G2, c->kp, c->kp, rrows));
+    const int gl = std::min(64, c->kp / 4);
+    const int rpw = 64 / gl;
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, ((A.rows + rpw - 1) / rpw + 3) / 4);
+    CHK(ensure(c, c->dpart, (size_t)blocks * sizeof(double)));
+    CsrView v{A.indptr, A.idx, A.val, A.rows};
+    {
+        Timed tm(c, CMF_K_SPMM, 2.0 * (double)A.nnz * (double)c->kp);
+        switch (c->kp) {
+        case 32: launch_sddmm<8, 1>(c, v, L, R, (double *)c->dpart.p, blocks); break;
+        case 64: launch_sddmm<16, 1>(c, v, L, R, (double *)c->dpart.p, blocks); break;
+        case 128: launch_sddmm<32, 1>(c, v, L, R, (double *)c->dpart.p, blocks); break;
+        case 256: launch_sddmm<64, 1>(c, v, L, R, (double *)c->dpart.p, blocks); break;
+        case 512: launch_sddmm<64, 2>(c, v, L, R, (double *)c->dpart.p, blocks); break;
+        case 768: launch_sddmm<64, 3>(c, v, L, R, (double *)c->dpart.p, blocks); break;
+        case 1024: launch_sddmm<64, 4>(c, v, L, R, (double *)c->dpart.p, blocks); break;
+        default: return fail(CMF_EUNSUPPORTED, "native CSR path supports n_components <= 1024");
+        }
+        HIPCHK(hipGetLastError());
+    }
+    Timed tm(c, CMF_K_ELEMWISE);
+    hipLaunchKernelGGL(sum_doubles_kernel, dim3(1), dim3(256), 0, c->stream, (const double *)c->dpart.p, (int64_t)blocks, c->dscalar + 4);
+    hipLaunchKernelGGL(frob_inner_kernel, dim3(1), dim3(256), 0, c->stream, (const float *)c->G, (const float *)c->G2, c->kp * c->kp, c->dscalar + 5);
+    HIPCHK(hipGetLastError());
+    double h[2];
+    HIPCHK(hipMemcpyAsync(h, c->dscalar + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double r2 = c->sp_sq[which] - 2.0 * h[0] + h[1];
+    if (r2 < 0) r2 = 0; // rounding of the expansion near a perfect fit
+    HIPCHK(hipMemcpyAsync(dev_out, &r2, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CMF_OK;
+}

@@ -18,6 +18,7 @@ Semantics kept from the reference:
   the reference's order so that results are reproducible against it.
 * MU ignores alpha (its error metric uses the constructor default 0.5, :99).
 """
+import os
 import time
 
 import numpy as np
@@ -36,9 +37,10 @@ class _HipIterativeSolver:
                  update_U=True, update_V=True, update_Z=True,
                  x_link="linear", y_link="linear", hessian_pertubation=0.2,
                  sg_sample_ratio=1., random_state=None, device=0, stream=None):
-        if beta_loss not in ("frobenius", 2, 2.0):
-            # the reference parses other losses but only implements Frobenius (:166)
-            raise ValueError("Invalid beta_loss parameter: only 'frobenius' is implemented, got %r" % (beta_loss,))
+        # like the reference, any beta_loss sklearn can parse is accepted and then ignored: only the
+        # Frobenius objective is implemented by either solver (cmf_solvers.py:106, :166)
+        if isinstance(beta_loss, str) and beta_loss not in ("frobenius", "kullback-leibler", "itakura-saito"):
+            raise ValueError("Invalid beta_loss parameter: got %r" % (beta_loss,))
         self.max_iter = max_iter
         self.tol = tol
         self.beta_loss = 2.0
@@ -80,6 +82,9 @@ class _HipIterativeSolver:
         key = (id(X), id(Y), m, d, p, k)
         if self._ctx is None:
             self._ctx = _lib.Context(self.device, self.stream)
+            mode = os.environ.get("PYCMF_AMD_SPARSE_MODE")  # "dense" | "native": override the auto choice
+            if mode:
+                self._ctx.set_option("sparse_mode", {"auto": 0, "dense": 1, "native": 2}[mode])
         if self._bound != key:
             self._ctx.set_problem(m, d, p, k)
             if X is not None:

@@ -1,0 +1,104 @@
+"""Native CSR path (SpMM / SDDMM kernels) vs golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import load_golden
+from test_oracle_golden import NEWTON_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pycmf_amd import _lib
+    if _lib.device_count() < 1:
+        pytest.fail("no GPU visible: the gpu-marked tests need an MI355X")
+    return _lib
+
+
+def _ctx(lib, X, Y, U, V, Z, mode=2):
+    ctx = lib.Context(0)
+    ctx.set_option("sparse_mode", mode)
+    ctx.set_problem(U.shape[0], V.shape[0], Z.shape[0], U.shape[1])
+    ctx.set_data(0, X); ctx.set_data(1, Y)
+    for w, F in enumerate((U, V, Z)):
+        ctx.set_factor(w, F)
+    return ctx
+
+
+@pytest.mark.parametrize("tag,l1,l2", [("plain", 0.0, 0.0), ("reg", 0.3, 0.7)])
+def test_native_csr_mu_golden(lib, tag, l1, l2):
+    g = load_golden("g2_mu_steps")
+    ctx = _ctx(lib, sp.csr_matrix(g["X"]), sp.csr_matrix(g["Y"]), g["U0"], g["V0"], g["Z0"])
+    for it in range(1, 11):
+        ctx.mu_step(l1, l2, 7)
+        if it in (1, 10):
+            tol = 2e-5 if it == 1 else 2e-4
+            for w, n in enumerate("UVZ"):
+                np.testing.assert_allclose(ctx.get_factor(w), g["%s_csr_%s%d" % (tag, n, it)], rtol=tol, atol=1e-6)
+    ctx.close()
+
+
+def _sparse_problem(seed, m, d, p, k, density):
+    rng = np.random.RandomState(seed)
+    X = sp.random(m, d, density=density, random_state=rng, format="csr", data_rvs=lambda n: np.abs(rng.randn(n)) + 0.1)
+    Y = sp.random(d, p, density=min(1.0, 4 * density), random_state=rng, format="csr", data_rvs=lambda n: np.abs(rng.randn(n)) + 0.1)
+    s = 0.3
+    return X, Y, s * np.abs(rng.randn(m, k)), s * np.abs(rng.randn(d, k)), s * np.abs(rng.randn(p, k))
+
+
+@pytest.mark.parametrize("m,d,p,k", [(3000, 2000, 300, 20), (1500, 2500, 70, 130), (900, 1100, 257, 256), (700, 650, 64, 300)])
+def test_native_csr_mu_vs_oracle(lib, m, d, p, k):
+    from oracle import cmf_oracle as O
+    X, Y, U0, V0, Z0 = _sparse_problem(k, m, d, p, k, 0.01)
+    ctx = _ctx(lib, X, Y, U0, V0, Z0)
+    for _ in range(2):
+        ctx.mu_step(0.01, 0.02, 7)
+    got = [ctx.get_factor(w) for w in range(3)]
+    ex2, ey2 = ctx.residual_sq("linear", "linear")
+    x2, y2 = ctx.data_sq()
+    ctx.close()
+    U, V, Z = U0.copy(), V0.copy(), Z0.copy()
+    for _ in range(2):
+        O.mu_update_step(X, Y, U, V, Z, 0.01, 0.02)
+    for a, b in zip(got, (U, V, Z)):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(np.sqrt(ex2), O.factorization_error(X, U, V.T, "linear"), rtol=2e-4)
+    np.testing.assert_allclose(np.sqrt(ey2), O.factorization_error(Y, V, Z.T, "linear"), rtol=2e-4)
+    np.testing.assert_allclose(x2, X.multiply(X).sum(), rtol=1e-5)
+
+
+def test_native_equals_dense_expansion(lib):
+    X, Y, U0, V0, Z0 = _sparse_problem(5, 1200, 900, 130, 40, 0.02)
+    outs = []
+    for mode in (1, 2):
+        ctx = _ctx(lib, X, Y, U0, V0, Z0, mode)
+        ctx.mu_step(0.0, 0.0, 7)
+        ctx.newton_step(0.4, 0.01, 0.1, "linear", "linear", 0, 7, 0.2, 1.0)
+        outs.append([ctx.get_factor(w) for w in range(3)] + [ctx.get_data(0)])
+        ctx.close()
+    for a, b in zip(*outs):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-6)
+    np.testing.assert_array_equal(outs[0][3], X.toarray().astype(np.float32))
+
+
+@pytest.mark.parametrize("name", sorted(NEWTON_CASES))
+def test_native_csr_newton_golden(lib, name, monkeypatch):
+    """Sparse X kept native: linear/unsampled sweeps use SpMM, the others expand on demand."""
+    from pycmf_amd.solver_shell import HipNewtonSolver
+    monkeypatch.setenv("PYCMF_AMD_SPARSE_MODE", "native")
+    xl, yl, nn, ratio, seed, l1, l2, signed = NEWTON_CASES[name]
+    g = load_golden("g3_newton_steps")
+    X = sp.csr_matrix(g["Xlog"] if xl == "logit" else g["X"])
+    Y = g["Ylog"] if yl == "logit" else g["Y"]
+    sfx = "s" if signed else "p"
+    U, V, Z = g["U0" + sfx].copy(), g["V0" + sfx].copy(), g["Z0" + sfx].copy()
+    s = HipNewtonSolver(alpha=0.3, l1_reg=l1, l2_reg=l2, x_link=xl, y_link=yl, U_non_negative=nn,
+                        V_non_negative=nn, Z_non_negative=nn, hessian_pertubation=0.2,
+                        sg_sample_ratio=ratio, random_state=seed)
+    s.update_step(X, Y, U, V, Z, l1, l2, 0.3)
+    for n, a in (("U", U), ("V", V), ("Z", Z)):
+        ref = g["%s_csr_%s1" % (name, n)]
+        np.testing.assert_allclose(a, ref, rtol=5e-4, atol=5e-4 * max(1.0, np.abs(ref).max()))
+    s.release()
