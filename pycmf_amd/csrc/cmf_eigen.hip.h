@@ -241,6 +241,178 @@ __global__ __launch_bounds__(256) void chol_safe_inverse_kernel(const float *Hin
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Batched per-row Newton solve  step_i = g_i H_i^-1  through a register-resident Cholesky.
+// (cmf_solvers.py:321-326 with :346-356, for the rows whose Hessian has lambda_min >= pert, where
+// the eigenvalue clamp is the identity; the others are flagged for the Jacobi kernel.)
+// One 256-thread workgroup per matrix; thread (ti, tc) = (t & 15, t >> 4) owns the elements
+// (i, c) with i = ti (mod 16), c = tc (mod 16) of the lower triangle, i.e. NB(NB+1)/2 blocks of
+// one register each (136 VGPRs at n = 256).  A column step publishes column j through LDS,
+// every thread scales the 2x16 values it needs and applies the rank-1 update to its own
+// registers; no element of the trailing matrix ever travels through LDS.  The triangular solves
+// keep the right-hand side in LDS and reduce over the 16 consecutive lanes that own a column.
+template <int NB>
+struct CholRegs {
+    float M[NB][NB]; // only b <= a is used
+};
+
+template <int NB>
+__device__ __forceinline__ void chol_load(CholRegs<NB> &R, const float *H, int n, int kp, float shift, float *stage, int t) {
+    const int ti = t & 15, tc = t >> 4;
+#pragma unroll
+    for (int a = 0; a < NB; ++a) {
+        const int W = 16 * (a + 1);
+        for (int idx = t; idx < 16 * W; idx += 256) {
+            const int r = idx / W, cc = idx % W;
+            const int i = 16 * a + r;
+            float v = (i == cc) ? 1.0f : 0.0f; // identity outside the valid n x n block
+            if (i < n && cc < n) v = H[i * kp + cc] - (i == cc ? shift : 0.f);
+            stage[r * (16 * NB) + cc] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b <= a; ++b) R.M[a][b] = stage[ti * (16 * NB) + tc + 16 * b];
+        __syncthreads();
+    }
+}
+
+// in-register Cholesky; returns false (uniformly) on a pivot <= floor_
+template <int NB>
+__device__ __forceinline__ bool chol_factor(CholRegs<NB> &R, int n, float floor_, float *col, int t) {
+    const int ti = t & 15, tc = t >> 4;
+    bool ok = true;
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) {
+        for (int jl = 0; jl < 16; ++jl) {
+            const int j = 16 * jb + jl;
+            if (j >= n) break;
+            if (tc == jl) {
+#pragma unroll
+                for (int a = jb; a < NB; ++a) col[ti + 16 * a] = R.M[a][jb];
+            }
+            __syncthreads();
+            const float piv = col[j];
+            if (!(piv > floor_)) { ok = false; break; }
+            const float ljj = sqrtf(piv), inv = 1.0f / ljj;
+            float li[NB], lc[NB];
+#pragma unroll
+            for (int a = jb; a < NB; ++a) {
+                const int i = ti + 16 * a, c = tc + 16 * a;
+                li[a] = (i > j) ? col[i] * inv : 0.f;
+                lc[a] = (c > j) ? col[c] * inv : 0.f;
+            }
+            if (tc == jl) {
+#pragma unroll
+                for (int a = jb; a < NB; ++a) {
+                    const int i = ti + 16 * a;
+                    if (i > j) R.M[a][jb] = li[a];
+                    else if (i == j) R.M[a][jb] = ljj;
+                }
+            }
+#pragma unroll
+            for (int a = jb; a < NB; ++a)
+#pragma unroll
+                for (int b = jb; b <= a; ++b) R.M[a][b] -= li[a] * lc[b];
+            __syncthreads();
+        }
+        if (!ok) break;
+    }
+    return ok;
+}
+
+template <int NB>
+__global__ __launch_bounds__(256, 2) void chol_solve_kernel(const float *Hin, const float *grad, float *step, int *need_jacobi,
+                                                            int n, int kp, int64_t stride, float pert, int nmat) {
+    __shared__ float col[16 * NB];
+    __shared__ float vec[16 * NB];
+    __shared__ float stage[16 * 16 * NB];
+    __shared__ float red[4];
+    const int mat = blockIdx.x;
+    if (mat >= nmat) return;
+    const float *H = Hin + (int64_t)mat * stride;
+    const int t = threadIdx.x, ti = t & 15, tc = t >> 4;
+
+    float dmax = 0.f;
+    for (int i = t; i < n; i += 256) dmax = fmaxf(dmax, fabsf(H[i * kp + i]));
+    for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
+    if ((t & 63) == 0) red[t >> 6] = dmax;
+    __syncthreads();
+    dmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float floor_ = 4.0e-6f * dmax;
+
+    CholRegs<NB> R;
+    chol_load<NB>(R, H, n, kp, pert, stage, t);
+    if (!chol_factor<NB>(R, n, floor_, col, t)) { // lambda_min < pert: the clamp matters -> Jacobi
+        if (t == 0) need_jacobi[mat] = 1;
+        return;
+    }
+    if (t == 0) need_jacobi[mat] = 0;
+    __syncthreads();
+    chol_load<NB>(R, H, n, kp, 0.f, stage, t);
+    (void)chol_factor<NB>(R, n, 0.f, col, t);
+
+    // forward substitution  L y = g
+    for (int i = t; i < 16 * NB; i += 256) vec[i] = (i < n) ? grad[(int64_t)mat * kp + i] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) {
+        for (int jl = 0; jl < 16; ++jl) {
+            const int j = 16 * jb + jl;
+            if (j >= n) break;
+            if (tc == jl && ti == jl) vec[j] = vec[j] / R.M[jb][jb];
+            __syncthreads();
+            if (tc == jl) {
+                const float yj = vec[j];
+#pragma unroll
+                for (int a = jb; a < NB; ++a) {
+                    const int i = ti + 16 * a;
+                    if (i > j && i < n) vec[i] -= R.M[a][jb] * yj;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // back substitution  L^T x = y
+#pragma unroll
+    for (int jb = NB - 1; jb >= 0; --jb) {
+        for (int jl = 15; jl >= 0; --jl) {
+            const int j = 16 * jb + jl;
+            if (j >= n) continue;
+            if (tc == jl) { // the 16 consecutive lanes that own column j
+                float sacc = 0.f;
+#pragma unroll
+                for (int a = jb; a < NB; ++a) {
+                    const int i = ti + 16 * a;
+                    if (i > j && i < n) sacc += R.M[a][jb] * vec[i];
+                }
+                sacc += __shfl_xor(sacc, 8, 16);
+                sacc += __shfl_xor(sacc, 4, 16);
+                sacc += __shfl_xor(sacc, 2, 16);
+                sacc += __shfl_xor(sacc, 1, 16);
+                if (ti == jl) vec[j] = (vec[j] - sacc) / R.M[jb][jb];
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = t; i < kp; i += 256) step[(int64_t)mat * kp + i] = (i < n) ? vec[i] : 0.f;
+}
+
+// step_i = g_i * Hinv_i only for the rows flagged for the Jacobi path
+__global__ __launch_bounds__(256) void rowvec_mat_flagged_kernel(float *step, const float *grad, const float *Hinv, const int *need,
+                                                                 int64_t nrows, int kp, int kvalid) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows || !need[row]) return;
+    const float *g = grad + row * kp;
+    const float *Hm = Hinv + row * (int64_t)kp * kp;
+    for (int c = lane; c < kp; c += 64) {
+        float acc = 0.f;
+        if (c < kvalid)
+            for (int a = 0; a < kvalid; ++a) acc += g[a] * Hm[a * kp + c];
+        step[row * kp + c] = acc;
+    }
+}
+
 // KR[j][a*kp + b] = F[j][a] * F[j][b]     (row-wise Khatri-Rao square of a factor)
 __global__ void khatri_rao_kernel(float *KR, const float *F, int64_t rows, int kp) {
     const int64_t total4 = rows * kp * (kp / 4);

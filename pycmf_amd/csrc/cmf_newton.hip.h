@@ -73,6 +73,54 @@ static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat,
     return CMF_OK;
 }
 
+// step_i = grad_i * safe_inverse(H_i) for a chunk of per-row Hessians (H is clobbered):
+// register-resident Cholesky solve for the rows with lambda_min >= pert, Jacobi + row product
+// for the flagged rest.
+static int safe_solve_rows(cmf_ctx *c, float *Hc, const float *grad, float *step, int64_t nr, int n, int kp, double pert) {
+    if (nr <= 0) return CMF_OK;
+    const int64_t stride = (int64_t)kp * kp;
+    if (!c->opt_chol || n > 256) { // general path only
+        CHK(safe_inverse_dev(c, Hc, Hc, (int)nr, n, kp, pert));
+        Timed tm(c, CMF_K_ELEMWISE);
+        hipLaunchKernelGGL(rowvec_mat_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, c->stream, step, grad, (const float *)Hc, nr, kp, n);
+        HIPCHK(hipGetLastError());
+        return CMF_OK;
+    }
+    CHK(ensure(c, c->eigflag, (size_t)nr * sizeof(int)));
+    int *flags = (int *)c->eigflag.p;
+    {
+        Timed tm(c, CMF_K_EIGEN);
+        const dim3 grid((unsigned)nr), block(256);
+        if (n <= 32) hipLaunchKernelGGL((chol_solve_kernel<2>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr);
+        else if (n <= 64) hipLaunchKernelGGL((chol_solve_kernel<4>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr);
+        else if (n <= 128) hipLaunchKernelGGL((chol_solve_kernel<8>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr);
+        else hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr);
+        HIPCHK(hipGetLastError());
+        // flagged matrices: |lambda| / clamp by Jacobi, in place (the solve kernel does not modify H)
+        const size_t lds_need = (size_t)(2 * n * n + n) * sizeof(float);
+        if (lds_need <= 150 * 1024) {
+            static bool attr = false;
+            if (!attr) {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&jacobi_safe_inverse_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                attr = true;
+            }
+            hipLaunchKernelGGL((jacobi_safe_inverse_kernel<true>), dim3((unsigned)nr), dim3(256), lds_need, c->stream, (const float *)Hc, Hc,
+                               (float *)nullptr, n, kp, stride, (float)pert, (int)nr, 30, (const int *)flags);
+        } else {
+            CHK(ensure(c, c->eigws, (size_t)nr * 2 * stride * sizeof(float)));
+            hipLaunchKernelGGL((jacobi_safe_inverse_kernel<false>), dim3((unsigned)nr), dim3(256), (size_t)n * sizeof(float), c->stream,
+                               (const float *)Hc, Hc, (float *)c->eigws.p, n, kp, stride, (float)pert, (int)nr, 30, (const int *)flags);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    Timed tm(c, CMF_K_ELEMWISE);
+    hipLaunchKernelGGL(rowvec_mat_flagged_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, c->stream, step, grad, (const float *)Hc,
+                       (const int *)flags, nr, kp, n);
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
 extern "C" int cmf_safe_invert_batch(cmf_ctx *c, const double *H, double *out, int n, int k, double pert) {
     if (!c || !H || !out || n < 0 || k <= 0) return fail(CMF_EINVAL, "bad argument");
     DeviceGuard dg(c->device);
@@ -244,13 +292,7 @@ static int per_row_finish(cmf_ctx *c, int which, const RowHess &h, double pert, 
             have = true;
         }
         CHK(launch_ew(c, hessian_finalize_kernel, nr_pad * kk, Hc, h.S, (float)h.diag, nr_pad, c->kp, c->k, have ? 1 : 0));
-        CHK(safe_inverse_dev(c, Hc, Hc, (int)nr, c->k, c->kp, pert));
-        {
-            Timed tm(c, CMF_K_ELEMWISE);
-            hipLaunchKernelGGL(rowvec_mat_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, c->stream, step + r0 * c->kp,
-                               (const float *)(grad + r0 * c->kp), (const float *)Hc, nr, c->kp, c->k);
-            HIPCHK(hipGetLastError());
-        }
+        CHK(safe_solve_rows(c, Hc, grad + r0 * c->kp, step + r0 * c->kp, nr, c->k, c->kp, pert));
     }
     return launch_ew(c, newton_apply_kernel, rows_pad * c->kp, c->F[which], (const float *)step, rows, c->kp, c->k,
                      rows_pad * c->kp, nn ? 1 : 0);

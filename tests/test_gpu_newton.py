@@ -69,7 +69,8 @@ def test_newton_golden_steps(lib, name, fmt):
 
 
 @pytest.mark.parametrize("xl,yl,ratio,k", [("linear", "linear", 1.0, 12), ("logit", "linear", 1.0, 9),
-                                          ("linear", "logit", 0.5, 20), ("logit", "logit", 0.7, 33)])
+                                          ("linear", "logit", 0.5, 20), ("logit", "logit", 0.7, 33),
+                                          ("linear", "linear", 1.0, 256), ("logit", "logit", 0.6, 200)])
 def test_newton_vs_oracle_midsize(lib, xl, yl, ratio, k):
     """Sizes that span several 256-row tiles and a padded k; identical host-drawn samples."""
     from oracle import cmf_oracle as O
