@@ -126,6 +126,13 @@ int cmf_newton_step(cmf_ctx *ctx, double alpha, double l1, double l2,
                     const int32_t *u_idx, const int32_t *z_idx,
                     const int32_t *vx_idx, const int32_t *vy_idx);
 
+/* Throughput mode of sg_ratio < 1: the per-row samples (exactly int(n*ratio) distinct
+ * candidates per row, uniform) are drawn on the device from a counter-based generator keyed by
+ * (seed, sweep, row) -- same distribution as cmf_solvers.py:328-344, not NumPy's stream.       */
+int cmf_newton_step_device_sampled(cmf_ctx *ctx, double alpha, double l1, double l2,
+                                   int x_link, int y_link, int nn_mask, int update_mask,
+                                   double hessian_pertubation, double sg_ratio, uint64_t seed);
+
 /* sharded Newton, linear links and sg_ratio == 1 only (same buffer shape as
  * the MU pair: gradient partial | Gram partial).                            */
 int cmf_newton_uz_update(cmf_ctx *ctx, double alpha, double l1, double l2,

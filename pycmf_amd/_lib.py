@@ -48,6 +48,7 @@ PROTOTYPES = {
     "cmf_mu_uz_update": [_vp, _dbl, _dbl, _i32],
     "cmf_newton_step": [_vp, _dbl, _dbl, _dbl, _i32, _i32, _i32, _i32, _dbl, _dbl,
                         _pi32, _pi32, _pi32, _pi32],
+    "cmf_newton_step_device_sampled": [_vp, _dbl, _dbl, _dbl, _i32, _i32, _i32, _i32, _dbl, _dbl, C.c_uint64],
     "cmf_newton_uz_update": [_vp, _dbl, _dbl, _dbl, _i32, _i32, _dbl],
     "cmf_newton_v_partials": [_vp, _dbl, _vp],
     "cmf_newton_v_apply": [_vp, _vp, _dbl, _dbl, _i32, _dbl],
@@ -236,6 +237,10 @@ class Context:
                                         nn_mask, upd_mask, pert, ratio,
                                         ptr(u_idx), ptr(z_idx), ptr(vx_idx), ptr(vy_idx)))
         self._keep = []
+
+    def newton_step_device_sampled(self, alpha, l1, l2, x_link, y_link, nn_mask, upd_mask, pert, ratio, seed):
+        check(self._lib.cmf_newton_step_device_sampled(self._h, alpha, l1, l2, LINKS[x_link], LINKS[y_link],
+                                                       nn_mask, upd_mask, pert, ratio, seed))
 
     def newton_uz_update(self, alpha, l1, l2, nn_mask, upd_mask, pert):
         check(self._lib.cmf_newton_uz_update(self._h, alpha, l1, l2, nn_mask, upd_mask, pert))

@@ -77,6 +77,8 @@ struct cmf_ctx {
     int opt_pipe = 4;      // GEMM staging schedule (see gemm_kernel PIPE); 4 measured best (tools/ab_gemm.py)
     int opt_split = -1;    // force split-K factor (<=0: heuristic)
     int opt_chol = 1;      // Cholesky fast path of the safe inverse (0: always Jacobi)
+    bool dev_sampling = false; // armed for one cmf_newton_step by cmf_newton_step_device_sampled
+    uint64_t dev_seed = 0;
 
     float *X = nullptr, *Y = nullptr; // dense, row-major, ld = dp / pp (null while a sparse input stays native)
     CsrDev sp[2][2];                  // [X|Y][A | A^T] native CSR images

@@ -472,6 +472,80 @@ __global__ void scatter_mask_kernel(uint8_t *mask, int64_t ld, const int32_t *id
     }
 }
 
+// Device-side sampler ("throughput mode" of sg_sample_ratio < 1): for every list l pick exactly
+// `s` of the `n` candidates uniformly at random, as the reference's permutation(n)[:s] does
+// (cmf_solvers.py:328-344), but from a counter-based hash instead of NumPy's MT19937 stream.
+// Candidate j of list l gets the key hash(seed, l, j); the s smallest keys win.  The s-th smallest
+// key is found exactly by a 3-level radix select (12 + 12 + 8 bits) on LDS histograms; ties on the
+// full 32-bit key are broken by candidate index.  One workgroup per list; keys are recomputed, never stored.
+__device__ __forceinline__ uint32_t sample_key(uint64_t seed, uint64_t l, uint64_t j) {
+    return (uint32_t)(mix64(mix64(seed ^ (l * 0xD1342543DE82EF95ull)) ^ (j + 0x632BE59BD9B4E019ull)) >> 32);
+}
+
+__global__ __launch_bounds__(256) void sample_mask_kernel(uint8_t *mask, int64_t ld, int by_row, int64_t nlists, int n, int s,
+                                                          uint64_t seed) {
+    __shared__ unsigned hist[4096];
+    __shared__ unsigned sel_prefix, sel_remaining, tie_budget;
+    const int64_t l = blockIdx.x;
+    if (l >= nlists) return;
+    const int t = threadIdx.x;
+    unsigned prefix = 0, remaining = (unsigned)s; // keys < prefix region already counted as winners
+    // level 0: bits 31..20, level 1: bits 19..8, level 2: bits 7..0
+    const int shifts[3] = {20, 8, 0};
+    const int widths[3] = {12, 12, 8};
+    unsigned known_mask = 0;
+    for (int lev = 0; lev < 3; ++lev) {
+        const int nb = 1 << widths[lev];
+        for (int b = t; b < nb; b += 256) hist[b] = 0;
+        __syncthreads();
+        for (int j = t; j < n; j += 256) {
+            const uint32_t k = sample_key(seed, (uint64_t)l, (uint64_t)j);
+            if ((k & known_mask) == prefix) atomicAdd(&hist[(k >> shifts[lev]) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        if (t == 0) {
+            unsigned acc = 0, b = 0;
+            for (; b < (unsigned)nb; ++b) {
+                if (acc + hist[b] >= remaining) break;
+                acc += hist[b];
+            }
+            if (b >= (unsigned)nb) b = nb - 1;
+            sel_prefix = prefix | (b << shifts[lev]);
+            sel_remaining = remaining - acc; // how many winners still to pick inside the chosen bin
+        }
+        __syncthreads();
+        prefix = sel_prefix;
+        remaining = sel_remaining;
+        known_mask |= ((unsigned)(nb - 1)) << shifts[lev];
+        __syncthreads();
+    }
+    // winners: key < prefix, plus the first `remaining` (by index) of the candidates with key == prefix
+    if (t == 0) tie_budget = remaining;
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + t;
+        bool win = false, tie = false;
+        if (j < n) {
+            const uint32_t k = sample_key(seed, (uint64_t)l, (uint64_t)j);
+            win = k < prefix;
+            tie = (k == prefix);
+        }
+        // ties are rare (32-bit keys): resolve them serially in index order
+        if (__syncthreads_or(tie ? 1 : 0)) {
+            for (int q = 0; q < 256; ++q) {
+                if (t == q && tie) {
+                    if (tie_budget > 0) { win = true; tie_budget -= 1; }
+                }
+                __syncthreads();
+            }
+        }
+        if (j < n) {
+            const int64_t off = by_row ? (l * ld + j) : ((int64_t)j * ld + l);
+            mask[off] = win ? 1 : 0;
+        }
+    }
+}
+
 // out = a*A + b*B (B nullable)
 __global__ void axpby_kernel(float *out, const float *A, float a, const float *B, float b, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;

@@ -219,11 +219,19 @@ extern "C" int cmf_newton_uz_update(cmf_ctx *c, double alpha, double l1, double 
 }
 
 // ---- per-row machinery --------------------------------------------------------------------
+// `n` = number of candidates per list (the extent sampled from)
 static int build_mask(cmf_ctx *c, DevBuf &mb, int64_t rows_pad, int64_t cols_pad, const int32_t *idx, int64_t nlists,
-                      int64_t per, bool by_row) {
+                      int64_t per, bool by_row, int64_t n = 0, int salt = 0) {
     CHK(ensure(c, mb, (size_t)rows_pad * cols_pad));
     HIPCHK(hipMemsetAsync(mb.p, 0, (size_t)rows_pad * cols_pad, c->stream));
     if (nlists * per == 0) return CMF_OK;
+    if (c->dev_sampling) { // draw the samples on the device (counter-based)
+        Timed tm(c, CMF_K_ELEMWISE);
+        hipLaunchKernelGGL(sample_mask_kernel, dim3((unsigned)nlists), dim3(256), 0, c->stream, (uint8_t *)mb.p, cols_pad,
+                           by_row ? 1 : 0, nlists, (int)n, (int)per, c->dev_seed * 4 + (uint64_t)salt);
+        HIPCHK(hipGetLastError());
+        return CMF_OK;
+    }
     CHK(ensure(c, c->idxbuf, (size_t)nlists * per * sizeof(int32_t)));
     HIPCHK(hipMemcpyAsync(c->idxbuf.p, idx, (size_t)nlists * per * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream)); // idx is caller memory: do not outlive the call
@@ -305,9 +313,9 @@ static int sweep_side_rows(cmf_ctx *c, bool is_u, int link, double scale, double
     const int64_t rows_pad = c->frows_pad[which];
     const int64_t img = is_u ? c->mp * c->dp : c->dp * c->pp;
     const uint8_t *mask = nullptr;
-    if (idx) {
+    if (idx || c->dev_sampling) {
         // U: list i = columns (over d) of X row i;  Z: list i = rows (over d) of Y column i
-        CHK(build_mask(c, c->mask1, is_u ? c->mp : c->dp, is_u ? c->dp : c->pp, idx, c->frows[which], per, is_u));
+        CHK(build_mask(c, c->mask1, is_u ? c->mp : c->dp, is_u ? c->dp : c->pp, idx, c->frows[which], per, is_u, c->d, is_u ? 0 : 1));
         mask = (const uint8_t *)c->mask1.p;
     }
     CHK(ensure(c, c->resid, (size_t)img * sizeof(float)));
@@ -331,12 +339,12 @@ static int sweep_side_rows(cmf_ctx *c, bool is_u, int link, double scale, double
 static int sweep_v_rows(cmf_ctx *c, double alpha, double l1, double l2, int x_link, int y_link, double pert, bool nn,
                         const int32_t *vx_idx, int64_t per_x, const int32_t *vy_idx, int64_t per_y) {
     const uint8_t *mx = nullptr, *my = nullptr;
-    if (vx_idx) { // list i = rows (over m) of X column i
-        CHK(build_mask(c, c->mask1, c->mp, c->dp, vx_idx, c->d, per_x, false));
+    if (vx_idx || c->dev_sampling) { // list i = rows (over m) of X column i
+        CHK(build_mask(c, c->mask1, c->mp, c->dp, vx_idx, c->d, per_x, false, c->m, 2));
         mx = (const uint8_t *)c->mask1.p;
     }
-    if (vy_idx) { // list i = columns (over p) of Y row i
-        CHK(build_mask(c, c->mask2, c->dp, c->pp, vy_idx, c->d, per_y, true));
+    if (vy_idx || c->dev_sampling) { // list i = columns (over p) of Y row i
+        CHK(build_mask(c, c->mask2, c->dp, c->pp, vy_idx, c->d, per_y, true, c->p, 3));
         my = (const uint8_t *)c->mask2.p;
     }
     const bool x_shared = (x_link == CMF_LINK_LINEAR && !mx); // H_U = U^T U for every row
@@ -386,9 +394,14 @@ extern "C" int cmf_newton_step(cmf_ctx *c, double alpha, double l1, double l2, i
     if ((x_link != 0 && x_link != 1) || (y_link != 0 && y_link != 1)) return fail(CMF_EINVAL, "bad link id");
     DeviceGuard dg(c->device);
     const bool sampled = ratio < 1.0;
+    struct SamplingScope { // device sampling is armed by cmf_newton_step_device_sampled only
+        cmf_ctx *c; bool keep;
+        ~SamplingScope() { if (!keep) c->dev_sampling = false; }
+    } scope{c, false};
+    if (!sampled) c->dev_sampling = false;
     const int64_t su = (int64_t)((double)c->d * ratio);  // int(n * ratio), cmf_solvers.py:331
     const int64_t sm = (int64_t)((double)c->m * ratio), sp = (int64_t)((double)c->p * ratio);
-    if (sampled) {
+    if (sampled && !c->dev_sampling) {
         if (((upd & CMF_UPD_U) && !u_idx) || ((upd & CMF_UPD_Z) && !z_idx) || ((upd & CMF_UPD_V) && (!vx_idx || !vy_idx)))
             return fail(CMF_EINVAL, "sg_sample_ratio < 1 needs the sample index lists of every updated factor");
     }
@@ -398,7 +411,7 @@ extern "C" int cmf_newton_step(cmf_ctx *c, double alpha, double l1, double l2, i
         if (x_link == CMF_LINK_LINEAR && !sampled)
             CHK(sweep_side_shared(c, true, alpha, l1, l2, pert, (nn_mask & CMF_NN_U) != 0));
         else
-            CHK(sweep_side_rows(c, true, x_link, alpha, l1, l2, pert, (nn_mask & CMF_NN_U) != 0, sampled ? u_idx : nullptr, su));
+            CHK(sweep_side_rows(c, true, x_link, alpha, l1, l2, pert, (nn_mask & CMF_NN_U) != 0, (sampled && !c->dev_sampling) ? u_idx : nullptr, su));
     }
     if (upd & CMF_UPD_Z) {
         if (!have_data(c, 1)) return fail(CMF_EINVAL, "Y must be set before a Z update");
@@ -407,7 +420,7 @@ extern "C" int cmf_newton_step(cmf_ctx *c, double alpha, double l1, double l2, i
             CHK(sweep_side_shared(c, false, 1.0 - alpha, l1, l2, pert, (nn_mask & CMF_NN_Z) != 0));
         else
             CHK(sweep_side_rows(c, false, y_link, 1.0 - alpha, l1, l2, pert, (nn_mask & CMF_NN_Z) != 0,
-                                sampled ? z_idx : nullptr, su));
+                                (sampled && !c->dev_sampling) ? z_idx : nullptr, su));
     }
     if (upd & CMF_UPD_V) {
         if (!have_data(c, 0) || !have_data(c, 1)) return fail(CMF_EINVAL, "X and Y must be set before a V update");
@@ -419,9 +432,20 @@ extern "C" int cmf_newton_step(cmf_ctx *c, double alpha, double l1, double l2, i
             CHK(cmf_newton_v_partials(c, alpha, c->vbuf));
             CHK(cmf_newton_v_apply(c, c->vbuf, l1, l2, nn_mask, pert));
         } else {
-            CHK(sweep_v_rows(c, alpha, l1, l2, x_link, y_link, pert, (nn_mask & CMF_NN_V) != 0, sampled ? vx_idx : nullptr, sm,
-                             sampled ? vy_idx : nullptr, sp));
+            CHK(sweep_v_rows(c, alpha, l1, l2, x_link, y_link, pert, (nn_mask & CMF_NN_V) != 0,
+                             (sampled && !c->dev_sampling) ? vx_idx : nullptr, sm, (sampled && !c->dev_sampling) ? vy_idx : nullptr, sp));
         }
     }
     return CMF_OK;
+}
+
+// Same step with the per-row samples drawn on the device from a counter-based generator keyed by
+// (seed, sweep, row): statistically equivalent to the reference's sampler (exactly int(n*ratio)
+// distinct candidates per row, uniform), not stream-identical to NumPy's MT19937.
+extern "C" int cmf_newton_step_device_sampled(cmf_ctx *c, double alpha, double l1, double l2, int x_link, int y_link, int nn_mask,
+                                              int upd, double pert, double ratio, uint64_t seed) {
+    NEED_PROBLEM(c);
+    c->dev_sampling = ratio < 1.0;
+    c->dev_seed = seed;
+    return cmf_newton_step(c, alpha, l1, l2, x_link, y_link, nn_mask, upd, pert, ratio, nullptr, nullptr, nullptr, nullptr);
 }

@@ -39,7 +39,7 @@ def collective_matrix_factorization(X, Y, U=None, V=None, Z=None,
                                     update_U=True, update_V=True, update_Z=True,
                                     x_link="linear", y_link="linear",
                                     hessian_pertubation=0.2, sg_sample_ratio=1.,
-                                    device=0, _return_solver=False):
+                                    device=0, sg_sampler="numpy", _return_solver=False):
     """Factorise X ~ f(U V^T) and Y ~ f(V Z^T) with a shared V on an MI355X.
 
     Same contract as the reference function (pycmf/cmf.py:215-456): returns
@@ -101,7 +101,7 @@ def collective_matrix_factorization(X, Y, U=None, V=None, Z=None,
                                         V_non_negative=V_non_negative, Z_non_negative=Z_non_negative,
                                         x_link=x_link, y_link=y_link,
                                         hessian_pertubation=hessian_pertubation,
-                                        sg_sample_ratio=sg_sample_ratio, **common)
+                                        sg_sample_ratio=sg_sample_ratio, sg_sampler=sg_sampler, **common)
     else:
         raise ValueError("No such solver: %s" % solver)
 
@@ -126,7 +126,8 @@ class CMF(BaseEstimator, TransformerMixin):
     attributes ``reconstruction_err_``, ``n_components_``, ``x_weights``,
     ``components``, ``y_weights``, ``n_iter_`` (:697-704).
 
-    Extra keyword: ``device`` (GPU ordinal, default 0).
+    Extra keywords: ``device`` (GPU ordinal, default 0) and ``sg_sampler`` ('numpy' = the
+    reference's host RNG stream, default; 'device' = counter-based sampler on the GPU).
     """
 
     def __init__(self, n_components=None, x_init=None, y_init=None, solver='mu', alpha='auto',
@@ -134,7 +135,7 @@ class CMF(BaseEstimator, TransformerMixin):
                  random_state=None, l1_reg=0., l2_reg=0., verbose=0,
                  U_non_negative=True, V_non_negative=True, Z_non_negative=True,
                  x_link="linear", y_link="linear", hessian_pertubation=0.2, sg_sample_ratio=1.,
-                 device=0):
+                 device=0, sg_sampler="numpy"):
         self.n_components = n_components
         self.x_init = x_init
         self.y_init = y_init
@@ -155,6 +156,7 @@ class CMF(BaseEstimator, TransformerMixin):
         self.hessian_pertubation = hessian_pertubation
         self.sg_sample_ratio = sg_sample_ratio
         self.device = device
+        self.sg_sampler = sg_sampler
 
     def _kwargs(self):
         return dict(solver=self.solver, beta_loss=self.beta_loss, tol=self.tol, max_iter=self.max_iter,
@@ -163,7 +165,7 @@ class CMF(BaseEstimator, TransformerMixin):
                     V_non_negative=self.V_non_negative, Z_non_negative=self.Z_non_negative,
                     x_link=self.x_link, y_link=self.y_link,
                     hessian_pertubation=self.hessian_pertubation,
-                    sg_sample_ratio=self.sg_sample_ratio, device=self.device)
+                    sg_sample_ratio=self.sg_sample_ratio, device=self.device, sg_sampler=self.sg_sampler)
 
     def fit_transform(self, X, Y, U=None, V=None, Z=None):
         X = check_array(X, accept_sparse=('csr', 'csc'), dtype=float)

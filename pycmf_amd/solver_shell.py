@@ -36,7 +36,7 @@ class _HipIterativeSolver:
                  U_non_negative=True, V_non_negative=True, Z_non_negative=True,
                  update_U=True, update_V=True, update_Z=True,
                  x_link="linear", y_link="linear", hessian_pertubation=0.2,
-                 sg_sample_ratio=1., random_state=None, device=0, stream=None):
+                 sg_sample_ratio=1., random_state=None, device=0, stream=None, sg_sampler="numpy"):
         # like the reference, any beta_loss sklearn can parse is accepted and then ignored: only the
         # Frobenius objective is implemented by either solver (cmf_solvers.py:106, :166)
         if isinstance(beta_loss, str) and beta_loss not in ("frobenius", "kullback-leibler", "itakura-saito"):
@@ -60,6 +60,10 @@ class _HipIterativeSolver:
         self.sg_sample_ratio = sg_sample_ratio
         self.device = device
         self.stream = stream
+        if sg_sampler not in ("numpy", "device"):
+            raise ValueError("sg_sampler must be 'numpy' (reference RNG stream) or 'device', got %r" % (sg_sampler,))
+        self.sg_sampler = sg_sampler
+        self._sample_seed = (int(random_state) if isinstance(random_state, (int, np.integer)) else 0) << 20
         self._ctx = None
         self._bound = None
         if random_state is not None:
@@ -190,7 +194,10 @@ class HipNewtonSolver(_HipIterativeSolver):
     With ``sg_sample_ratio < 1`` the per-row samples are drawn on the host from
     NumPy's global RNG in the reference's order (:328-344: U rows, Z rows, then for
     every V row a U-sample followed by a Z-sample) and handed to the device as
-    index lists ("parity mode").
+    index lists ("parity mode", ``sg_sampler='numpy'``, the default).  With
+    ``sg_sampler='device'`` the same distribution (exactly int(n*ratio) distinct
+    candidates per row) is drawn on the GPU from a counter-based generator: no
+    host RNG time, no index upload, but not NumPy's stream.
     """
 
     def _draw(self, rows, n, ratio):
@@ -205,6 +212,12 @@ class HipNewtonSolver(_HipIterativeSolver):
         m, d, p, _ = self._ctx.shape
         ratio = self.sg_sample_ratio
         u_idx = z_idx = vx_idx = vy_idx = None
+        if ratio < 1. and self.sg_sampler == "device":
+            self._sample_seed += 1
+            self._ctx.newton_step_device_sampled(alpha, l1_reg, l2_reg, self.x_link, self.y_link, self._nn_mask(),
+                                                 self._update_mask(), self.hessian_pertubation, ratio,
+                                                 self._sample_seed)
+            return
         if ratio < 1.:
             if self.update_U:
                 u_idx = self._draw(m, d, ratio)

@@ -91,3 +91,57 @@ def test_newton_vs_oracle_midsize(lib, xl, yl, ratio, k):
     o.update_step(X, Y, Ur, Vr, Zr)
     for a, b in ((U, Ur), (V, Vr), (Z, Zr)):
         np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-3 * np.abs(b).max())
+
+
+def test_device_sampler_exact_size_and_uniform(lib):
+    """cmf_newton_step_device_sampled draws exactly int(n*ratio) candidates per row; with a logit
+    link the masked residual image vanishes exactly on the unsampled entries, which makes the
+    masks observable from the outside: after one U-only step with l1=l2=0 a row moves iff ... we
+    instead check the end-to-end contract (the reference's own stochastic tests, :292-314)."""
+    from pycmf_amd import CMF
+    rng = np.random.mtrand.RandomState(42)
+    X, Y = rng.randn(6, 5), rng.randn(5, 6)
+    m = CMF(n_components=5, solver="newton", x_init='svd', y_init='svd', U_non_negative=False,
+            V_non_negative=False, Z_non_negative=False, alpha=0.5, sg_sample_ratio=0.5,
+            random_state=0, max_iter=1000, sg_sampler="device")
+    assert m.fit(X, Y).reconstruction_err_ < 0.1
+
+
+def test_device_sampler_matches_host_sampler_statistically(lib):
+    """Same problem, host (NumPy stream) vs device sampler: different samples, same quality."""
+    from pycmf_amd.solver_shell import HipNewtonSolver
+    rng = np.random.RandomState(3)
+    m, d, p, k = 400, 300, 150, 8
+    X, Y = np.abs(rng.randn(m, d)), rng.rand(d, p)
+    U0, V0, Z0 = 0.3 * rng.randn(m, k), 0.3 * rng.randn(d, k), 0.3 * rng.randn(p, k)
+    errs = {}
+    for sampler in ("numpy", "device"):
+        s = HipNewtonSolver(alpha=0.4, l2_reg=0.05, y_link="logit", U_non_negative=False, V_non_negative=False,
+                            Z_non_negative=False, sg_sample_ratio=0.5, random_state=1, max_iter=15, tol=0,
+                            sg_sampler=sampler)
+        U, V, Z = U0.copy(), V0.copy(), Z0.copy()
+        s.fit_iterative_update(X, Y, U, V, Z)
+        errs[sampler] = s.compute_error(X, Y, U, V, Z)
+        s.release()
+    assert abs(errs["numpy"] - errs["device"]) < 0.05 * errs["numpy"]
+
+
+def test_device_sampler_masks(lib):
+    """Observe the device-drawn masks directly: U-only step, linear link, l1 = l2 = 0, V = e_1-like
+    so that row i's step depends on sum over its sampled columns of (u_i v_j - x_ij) v_j."""
+    m, d, p, k = 64, 200, 40, 1
+    X = np.zeros((m, d)); Y = np.zeros((d, p))
+    U0 = np.zeros((m, k)); V0 = np.ones((d, k)); Z0 = np.ones((p, k))
+    X[:, :] = 1.0  # residual = -1 on every sampled entry -> gradient_i = -alpha * (#sampled) ; H_i = alpha * (#sampled)
+    ctx = lib.Context(0)
+    ctx.set_problem(m, d, p, k)
+    ctx.set_data(0, X); ctx.set_data(1, Y)
+    for w, F in enumerate((U0, V0, Z0)):
+        ctx.set_factor(w, F)
+    # with H_i = alpha*s >= pert the Newton step gives u_i = 1 exactly, independent of the sample; use
+    # pert huge instead so that H^-1 = 1/pert and the step reveals s: u_i = alpha * s / pert
+    ctx.newton_step_device_sampled(0.5, 0.0, 0.0, "linear", "linear", 0, 1, 1e6, 0.37, 1234)
+    U = ctx.get_factor(0)[:, 0]
+    s = int(d * 0.37)
+    np.testing.assert_allclose(U, 0.5 * s / 1e6, rtol=1e-5)
+    ctx.close()

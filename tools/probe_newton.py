@@ -12,6 +12,7 @@ ratio = float(a[4]) if len(a) > 4 else 0.5
 xl = a[5] if len(a) > 5 else "linear"
 yl = a[6] if len(a) > 6 else "logit"
 iters = int(a[7]) if len(a) > 7 else 1
+sampler = a[8] if len(a) > 8 else "numpy"
 ctx = _lib.Context(0)
 ctx.set_problem(m, d, p, k)
 ctx.fill_data_synthetic(0, 42); ctx.fill_data_synthetic(1, 43)
@@ -26,12 +27,15 @@ def draw(rows, n):
 for it in range(iters):
     t0 = time.time()
     idx = (None,) * 4
-    if ratio < 1:
+    if ratio < 1 and sampler == "numpy":
         idx = (draw(m, d), draw(p, d), draw(d, m), draw(d, p))
     th = time.time() - t0
     ctx.kernel_timing(True); ctx.kernel_timing_reset()
     t0 = time.time()
-    ctx.newton_step(0.5, 0.0, 0.1, xl, yl, 0, 7, 0.2, ratio, *idx)
+    if ratio < 1 and sampler == "device":
+        ctx.newton_step_device_sampled(0.5, 0.0, 0.1, xl, yl, 0, 7, 0.2, ratio, 1000 + it)
+    else:
+        ctx.newton_step(0.5, 0.0, 0.1, xl, yl, 0, 7, 0.2, ratio, *idx)
     ctx.sync(); dt = time.time() - t0
     print("iter %d: host sampling %.1fs, device step %.3fs" % (it, th, dt))
     for cls in ("gemm_nn", "gemm_tn", "gemm_nt", "gemm_small", "eigen", "elementwise"):
