@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- factor-update iterations/s of the CMF MU solver on MI355X.
+"""bench.py -- factor-update iterations/s of the CMF solvers on MI355X.
 
 Metric (BASELINE.json): factor-update iterations/s (and cells/s) at
-n_components=256, 65536^2 dense.  One "step" = one full ``update_step``
-(V, U, Z multiplicative updates; pycmf/cmf_solvers.py:248-263) over synthetic
-non-negative X (m x d), Y (d x p) already resident in HBM.
+n_components=256, 65536^2 dense.  One "step" = one full ``update_step`` of the
+reference (MU: V,U,Z, pycmf/cmf_solvers.py:248-263; Newton: U,Z,V, :510-522)
+over synthetic X (m x d), Y (d x p) already resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c2|tiny]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c2|c3|c5|tiny]
+
+Default workload = C4 (the configuration the metric is quoted on; it fits one
+GPU: 34.4 GB).  c2 / c3 / c5 are the other BASELINE configs (parity-test
+shapes; same JSON contract, for the record in DESIGN.md).
 
 N > 1 is launched by torch.distributed.run (one rank per GPU).  The problem is
 FIXED (strong scaling): rank g owns rows [g*m/N, (g+1)*m/N) of X/U and the same
 fraction of Y's columns / Z's rows; V is replicated and reassembled by one RCCL
 all-reduce per iteration (pycmf_amd/sharded.py).
 
-Prints ONE JSON line on rank 0 (contract in the task description) with
-``roofline`` (dominant GEMM kernel, HIP events on the launch stream over the
-timed region) and ``cpu_baseline`` (CPU oracle, bounded sample, rank 0, N=1).
+Prints ONE JSON line on rank 0 with ``roofline`` (dominant kernel class, HIP
+events on the launch stream over the timed region) and ``cpu_baseline`` (CPU
+oracle, bounded sample, rank 0, N=1).
 """
 import argparse
 import json
@@ -27,38 +31,81 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (m, d, p, k, description)
-    "c4": (65536, 65536, 65536, 256,
-           "BASELINE configs[3]: CMF(n_components=256, solver='mu'), dense 65536x65536 X, "
-           "65536x65536 Y, non-negative synthetic"),
-    "c2": (16384, 8192, 4096, 128,
-           "BASELINE configs[1]: CMF(n_components=128, solver='mu', linear link), dense "
-           "16384x8192 X, 8192x4096 Y, non-negative synthetic"),
-    "tiny": (2048, 1024, 512, 64, "debug shape"),
+    "c4": dict(m=65536, d=65536, p=65536, k=256, solver="mu",
+               desc="BASELINE configs[3]: CMF(n_components=256, solver='mu'), dense 65536x65536 X, "
+                    "65536x65536 Y, non-negative synthetic"),
+    "c2": dict(m=16384, d=8192, p=4096, k=128, solver="mu",
+               desc="BASELINE configs[1]: CMF(n_components=128, solver='mu', linear link), dense "
+                    "16384x8192 X, 8192x4096 Y, non-negative synthetic"),
+    "c3": dict(m=32768, d=16384, p=8192, k=256, solver="newton", x_link="linear", y_link="logit", ratio=0.5,
+               desc="BASELINE configs[2]: CMF(n_components=256, solver='newton', y_link='logit', "
+                    "sg_sample_ratio=0.5, device sampler) on dense 32768x16384 X, 16384x8192 Y"),
+    "c5": dict(m=1000000, d=100000, p=64, k=256, solver="newton", x_link="linear", y_link="linear", ratio=1.0,
+               nnz_per_row=100,
+               desc="BASELINE configs[4]: CSR X 1e6 x 1e5 at 0.1% nnz (100 per row, values 1.0, native CSR), "
+                    "dense Y 1e5 x 64, n_components=256, newton solver, linear links"),
+    "tiny": dict(m=2048, d=1024, p=512, k=64, solver="mu", desc="debug shape"),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec
 
 
-def mu_algorithmic_flops(m, d, p, k):
-    """F_MU = 4 k d (m+p) + 4 k^2 (m+d+p)."""
-    return 4.0 * k * d * (m + p) + 4.0 * k * k * (m + d + p)
+def algorithmic_flops(w):
+    """SURVEY.md 8(d).  MU: 4kd(m+p) + 4k^2(m+d+p).  Newton: residual/gradient contractions
+    + per-row Hessians 2k^2(m s_d + p s_d + d(s_m+s_p)) on the sweeps that need them."""
+    m, d, p, k = w["m"], w["d"], w["p"], w["k"]
+    if "nnz_per_row" in w:  # sparse X: the X contractions cost 2 k nnz each
+        nnz = float(m) * w["nnz_per_row"]
+        base = 4.0 * k * nnz + 4.0 * k * d * p + 4.0 * k * k * (m + d + p)
+    else:
+        base = 4.0 * k * d * (m + p) + 4.0 * k * k * (m + d + p)
+    if w["solver"] == "mu":
+        return base
+    r = w.get("ratio", 1.0)
+    xl, yl = w["x_link"], w["y_link"]
+    s_d, s_m, s_p = int(d * r), int(m * r), int(p * r)
+    f = base
+    if xl == "logit" or r < 1:  # U rows
+        f += 2.0 * k * k * m * s_d + 2.0 * k * m * s_d
+    if yl == "logit" or r < 1:  # Z rows
+        f += 2.0 * k * k * p * s_d + 2.0 * k * p * s_d
+    if xl == "logit" or yl == "logit" or r < 1:  # V rows
+        hx = s_m if (xl == "logit" or r < 1) else 0
+        hy = s_p if (yl == "logit" or r < 1) else 0
+        f += 2.0 * k * k * d * (hx + hy) + 2.0 * k * d * (s_m + s_p)
+    return f
 
 
-def cpu_baseline(k, budget_s=20.0):
-    """Time the CPU oracle (reference operation order, float64, all BLAS threads) on a
-    bounded sample of the same workload and scale to the bench shape by the work ratio."""
+def cpu_baseline(w, budget_s=20.0):
+    """CPU oracle (reference operation order, float64, all BLAS threads) on a bounded sample of
+    the same workload, scaled to the bench shape by the algorithmic-work ratio."""
     import numpy as np
     from oracle import cmf_oracle as O
-    ms = ds = ps = 4096
+    k = w["k"]
+    if w["solver"] == "mu":
+        ms = ds = ps = 4096
+    else:
+        ms, ds, ps = 96, 64, 32  # per-row eigh(k x k) in Python: keep it to a few hundred rows
     rng = np.random.RandomState(42)
     X, Y = np.abs(rng.randn(ms, ds)), np.abs(rng.randn(ds, ps))
+    if w.get("y_link") == "logit":
+        Y = 1.0 / (1.0 + np.exp(-Y))
     sc = np.sqrt(X.mean() / k)
     U, V, Z = (sc * np.abs(rng.randn(n, k)) for n in (ms, ds, ps))
-    O.mu_update_step(X, Y, U, V, Z)  # warm-up
+    if w["solver"] == "mu":
+        def step():
+            O.mu_update_step(X, Y, U, V, Z)
+    else:
+        np.random.seed(0)
+
+        def step():
+            O.newton_update_step(X, Y, U, V, Z, 0.5, 0.0, 0.1, w["x_link"], w["y_link"],
+                                 False, False, False, ratio=w.get("ratio", 1.0), pert=0.2)
+    step()
     t0 = time.perf_counter()
     iters = 0
     while True:
-        O.mu_update_step(X, Y, U, V, Z)
+        step()
         iters += 1
         el = time.perf_counter() - t0
         if el > budget_s or (iters >= 3 and el > budget_s / 2):
@@ -68,7 +115,10 @@ def cpu_baseline(k, budget_s=20.0):
         threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [os.cpu_count() or 1])
     except Exception:
         threads = os.cpu_count() or 1
-    return iters / el, (ms, ds, ps), iters, el, threads
+    sample = {key: val for key, val in w.items() if key != "nnz_per_row"}
+    sample.update(m=ms, d=ds, p=ps)
+    ratio = algorithmic_flops(sample) / algorithmic_flops(w)
+    return iters / el, (ms, ds, ps), iters, el, threads, ratio
 
 
 def main():
@@ -88,10 +138,11 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
         args.gpus = world
 
+    import numpy as np
     import torch
     import torch.distributed as dist
     from pycmf_amd import _lib
-    from pycmf_amd.sharded import make_torch_sharded_mu, shard_bounds
+    from pycmf_amd.sharded import make_torch_sharded_mu, make_torch_sharded_newton, shard_bounds
 
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -99,7 +150,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    m, d, p, k, desc = WORKLOADS[args.workload]
+    w = WORKLOADS[args.workload]
+    m, d, p, k = w["m"], w["d"], w["p"], w["k"]
+    newton = w["solver"] == "newton"
+    sharded_ok = (not newton) or (w["x_link"] == "linear" and w["y_link"] == "linear" and w["ratio"] == 1.0)
+    if world > 1 and not sharded_ok:
+        raise SystemExit("workload %s (per-row Newton sweeps) is single-GPU in this round" % args.workload)
     r0, r1 = shard_bounds(m, world, rank)
     c0, c1 = shard_bounds(p, world, rank)
 
@@ -107,14 +163,41 @@ def main():
     with torch.cuda.stream(stream):
         ctx = _lib.Context(local_rank, stream.cuda_stream)
         ctx.set_problem(r1 - r0, d, c1 - c0, k)
-        # X rows [r0,r1), Y columns [c0,c1): values depend only on global coordinates
-        ctx.fill_data_synthetic(0, 42, r0, 0)
-        ctx.fill_data_synthetic(1, 43, 0, c0)
-        scale = (0.7979 / k) ** 0.5  # 'random' init rule: sqrt(mean(|N(0,1)|) / k), pycmf/cmf.py:111
+        if "nnz_per_row" in w:
+            # CSR row block generated on the host (values 1.0: binary bag-of-words like the reference's
+            # notebook) and kept native on the device
+            import scipy.sparse as sp
+            npr = w["nnz_per_row"]
+            rng = np.random.default_rng(42 + rank)
+            rows = r1 - r0
+            X = sp.csr_matrix((np.ones(rows * npr), rng.integers(0, d, size=rows * npr, dtype=np.int32),
+                               np.arange(0, rows * npr + 1, npr, dtype=np.int64)), shape=(rows, d))
+            ctx.set_option("sparse_mode", 2)
+            ctx.set_data(0, X)
+            del X
+            scale = (npr / d / k) ** 0.5
+        else:
+            ctx.fill_data_synthetic(0, 42, r0, 0)   # X rows [r0,r1): values depend only on global coordinates
+            scale = (0.7979 / k) ** 0.5             # 'random' init rule sqrt(mean / k), pycmf/cmf.py:111
+        ctx.fill_data_synthetic(1, 43, 0, c0)       # Y columns [c0,c1)
         ctx.fill_factor_synthetic(_lib.CMF_U, 101, r0, scale)
         ctx.fill_factor_synthetic(_lib.CMF_V, 102, 0, scale)
         ctx.fill_factor_synthetic(_lib.CMF_Z, 103, c0, scale)
-        drv = make_torch_sharded_mu(ctx, world, device)
+
+        if not newton:
+            drv = make_torch_sharded_mu(ctx, world, device)
+
+            def do_step(it):
+                drv.step(0.0, 0.0, 7)
+        elif sharded_ok:
+            drv = make_torch_sharded_newton(ctx, world, device, alpha=0.5, nn_mask=0, pert=0.2)
+
+            def do_step(it):
+                drv.step(0.0, 0.1, 7)
+        else:
+            def do_step(it):
+                ctx.newton_step_device_sampled(0.5, 0.0, 0.1, w["x_link"], w["y_link"], 0, 7, 0.2,
+                                               w["ratio"], 1000 + it)
 
         def sync_all():
             torch.cuda.synchronize(device)
@@ -122,14 +205,14 @@ def main():
                 dist.barrier()
                 torch.cuda.synchronize(device)
 
-        for _ in range(args.warmup):
-            drv.step(0.0, 0.0, 7)
+        for it in range(args.warmup):
+            do_step(it)
         ctx.kernel_timing(True)
         ctx.kernel_timing_reset()
         sync_all()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            drv.step(0.0, 0.0, 7)
+        for it in range(args.steps):
+            do_step(args.warmup + it)
         sync_all()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -137,10 +220,12 @@ def main():
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             elapsed = float(te.item())
 
-        classes = {c: ctx.kernel_time(c) for c in ("gemm_nn", "gemm_tn", "gemm_small", "gemm_nt", "elementwise")}
+        names = ("gemm_nn", "gemm_tn", "gemm_small", "gemm_nt", "spmm", "eigen", "elementwise")
+        classes = {c: ctx.kernel_time(c) for c in names}
         ctx.kernel_timing(False)
-        ex2, ey2 = ctx.residual_sq()
+        ex2, ey2 = ctx.residual_sq(w.get("x_link", "linear"), w.get("y_link", "linear"))
         x2, y2 = ctx.data_sq()
+        kp = ctx.geometry()[3]
 
     if rank != 0:
         if world > 1:
@@ -149,19 +234,43 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     its = args.steps / elapsed
-    # dominant kernel = GEMM class with the most device time on rank 0
-    dom = max(("gemm_nn", "gemm_tn"), key=lambda c: classes[c][0])
+    # dominant kernel class = most device time on rank 0
+    dom = max(("gemm_nn", "gemm_tn", "spmm"), key=lambda c: classes[c][0])
     dms, dn, dfl = classes[dom]
-    achieved = dfl / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-    if world == 1 and os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(dom)
-        except Exception:
-            traffic = None
+    if dom == "spmm":
+        # HBM-bound gather kernel.  Algorithmic (compulsory) bytes of one A*F product: CSR arrays once
+        # + the dense operand once + the output once; the k_pad*4-byte factor-row gather per nonzero
+        # is served by L2 / Infinity Cache and reported separately.
+        nnz = float(r1 - r0) * w["nnz_per_row"]
+        comp = nnz * 8.0 + ((r1 - r0) + d) * kp * 4.0
+        achieved = comp / (dms / max(dn, 1) * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "cmfk::spmm_csr_kernel<64, 1>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "gathered_GBps": nnz * (kp * 4.0 + 8.0) / (dms / max(dn, 1) * 1e-3) / 1e9,
+                "note": "achieved = compulsory HBM bytes (CSR + dense operand + output) / launch time; the "
+                        "per-nonzero factor-row gathers (gathered_GBps) are served by L2 / Infinity Cache",
+                "avg_launch_ms": dms / max(dn, 1), "launches": dn}
+    else:
+        achieved = dfl / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        if world == 1 and os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        roof = {"bound": "mfma",
+                "kernel": "cmfk::gemm_kernel<%d, %d, 0, 4>  (%s data pass)" % (
+                    0 if dom == "gemm_nn" else 1, 256 if k >= 256 else kp,
+                    "NN: X V / Y Z / W KR" if dom == "gemm_nn" else "TN: X^T U / Y^T V / W^T KR"),
+                "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/traffic_%s.json)" % args.workload,
+                "algorithmic_flops_per_launch": dfl / max(dn, 1),
+                "avg_launch_ms": dms / max(dn, 1), "launches": dn}
+    roof["per_class_ms_per_step"] = {c: v[0] / args.steps for c, v in classes.items() if v[1]}
     out = {
-        "metric": "factor-update iterations/s (MU solver: V,U,Z update per iteration)",
+        "metric": "factor-update iterations/s (%s solver: one full update_step per iteration)" % w["solver"],
         "value": its,
         "unit": "it/s",
         "n_gpus": world,
@@ -174,39 +283,27 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "cells_per_s": (float(m) * d + float(d) * p) * its,
-        "algorithmic_tflops": mu_algorithmic_flops(m, d, p, k) * its / 1e12,
-        "config": {"workload": desc, "m": m, "d": d, "p": p, "n_components": k, "solver": "mu",
+        "algorithmic_tflops": algorithmic_flops(w) * its / 1e12,
+        "config": {"workload": w["desc"], "m": m, "d": d, "p": p, "n_components": k, "solver": w["solver"],
                    "parallelism": "X/U row-sharded, Y/Z column-sharded x%d, V replicated, "
                                   "1 RCCL all-reduce of (d+k)*k f32 per iteration" % world},
-        "roofline": {
-            "bound": "mfma",
-            "kernel": "cmfk::gemm_kernel<%d, %d, 0, 4>  (%s data pass)" % (0 if dom == "gemm_nn" else 1, 256 if k >= 256 else k,
-                                                                     "NN: X V / Y Z" if dom == "gemm_nn" else "TN: X^T U / Y^T V"),
-            "achieved": achieved,
-            "peak": FP32_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-            "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/traffic_%s.json)" % args.workload,
-            "algorithmic_flops_per_launch": dfl / max(dn, 1),
-            "avg_launch_ms": dms / max(dn, 1),
-            "launches": dn,
-            "per_class_ms_per_step": {c: v[0] / args.steps for c, v in classes.items()},
-        },
+        "roofline": roof,
         "rel_residual": {"x": (ex2 / x2) ** 0.5 if x2 > 0 else None, "y": (ey2 / y2) ** 0.5 if y2 > 0 else None,
                          "note": "rank-0 shard, after warmup+steps iterations"},
     }
+    for key in ("x_link", "y_link", "ratio"):
+        if key in w:
+            out["config"][key] = w[key]
     if world == 1 and not args.no_cpu_baseline:
-        cits, shp, n_it, el, threads = cpu_baseline(k)
-        work_ratio = (float(shp[1]) * (shp[0] + shp[2])) / (float(d) * (m + p))
+        cits, shp, n_it, el, threads, work_ratio = cpu_baseline(w)
         out["cpu_baseline"] = {
             "value": cits * work_ratio,
             "unit": "it/s",
             "cores": threads,
             "kind": "port",
-            "sample": "oracle/cmf_oracle.mu_update_step (NumPy float64, reference operation order incl. "
-                      "(U V^T) V), m=d=p=%d k=%d, %d iterations in %.1f s = %.3f it/s, scaled to the bench "
-                      "shape by d(m+p) ratio %.3g" % (shp[0], k, n_it, el, cits, work_ratio),
+            "sample": "oracle/cmf_oracle %s step (NumPy float64, reference operation order), m,d,p=%s k=%d, "
+                      "%d iterations in %.1f s = %.3f it/s, scaled to the bench shape by the algorithmic-work ratio "
+                      "%.3g" % (w["solver"], shp, k, n_it, el, cits, work_ratio),
         }
     print(json.dumps(out))
     if world > 1:

@@ -77,6 +77,7 @@ struct cmf_ctx {
     int opt_pipe = 4;      // GEMM staging schedule (see gemm_kernel PIPE); 4 measured best (tools/ab_gemm.py)
     int opt_split = -1;    // force split-K factor (<=0: heuristic)
     int opt_chol = 1;      // Cholesky fast path of the safe inverse (0: always Jacobi)
+    double flop_scale = 1.0;   // algorithmic/executed flop ratio of the launches being issued (sampled sweeps run masked-dense)
     bool dev_sampling = false; // armed for one cmf_newton_step by cmf_newton_step_device_sampled
     uint64_t dev_seed = 0;
 
@@ -90,7 +91,7 @@ struct cmf_ctx {
 
     // workspaces
     float *num = nullptr, *den = nullptr; // max(mp,dp,pp) x kp
-    float *G = nullptr, *G2 = nullptr, *Hm = nullptr, *Hinv = nullptr; // kp x kp
+    float *G = nullptr, *G2 = nullptr, *Hm = nullptr, *Hinv = nullptr, *Eye = nullptr; // kp x kp
     float *vbuf = nullptr;                // dp*kp + kp*kp
     DevBuf slabs;                         // split-K partial tiles (grow-only)
     DevBuf resid;                         // Newton residual / weights scratch (grow-only)
@@ -308,7 +309,7 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
     }
     {
         Timed tm(c, !data_pass ? CMF_K_GEMM_SMALL : (mode == MODE_NN ? CMF_K_GEMM_NN : CMF_K_GEMM_TN),
-                 2.0 * (double)mout * (double)n * (double)kred);
+                 2.0 * (double)mout * (double)n * (double)kred * c->flop_scale);
         if (mode == MODE_NN) {
             if (data_pass) CHK((launch_gemm_mode<MODE_NN, 0>(c, a, pl)));
             else CHK((launch_gemm_mode<MODE_NN, 1>(c, a, pl)));
@@ -348,7 +349,7 @@ static int gemm_nt(cmf_ctx *c, const float *L, int64_t rows_pad, int64_t rows_va
         a.sq_out = (double *)c->dpart.p;
     }
     {
-        Timed tm(c, CMF_K_GEMM_NT, 2.0 * (double)rows_valid * (double)cols_valid * (double)c->kp);
+        Timed tm(c, CMF_K_GEMM_NT, 2.0 * (double)rows_valid * (double)cols_valid * (double)c->kp * c->flop_scale);
         CHK((launch_gemm_mode<MODE_NT, 0>(c, a, pl)));
     }
     if (o.sq) {
@@ -425,7 +426,7 @@ static void release_problem(cmf_ctx *c) {
     c->owned.push_back(c->dscalar);
     c->X = c->Y = nullptr;
     c->F[0] = c->F[1] = c->F[2] = nullptr;
-    c->num = c->den = c->G = c->G2 = c->Hm = c->Hinv = c->vbuf = nullptr;
+    c->num = c->den = c->G = c->G2 = c->Hm = c->Hinv = c->Eye = c->vbuf = nullptr;
     c->slabs = DevBuf(); c->resid = DevBuf(); c->resid2 = DevBuf(); c->resid3 = DevBuf(); c->dpart = DevBuf();
     c->kr1 = DevBuf(); c->kr2 = DevBuf(); c->hrows = DevBuf(); c->mask1 = DevBuf(); c->mask2 = DevBuf();
     c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf();
@@ -505,6 +506,7 @@ extern "C" int cmf_set_problem(cmf_ctx *c, int64_t m, int64_t d, int64_t p, int 
     CHK(dev_alloc(c, (void **)&c->G2, kk));
     CHK(dev_alloc(c, (void **)&c->Hm, kk));
     CHK(dev_alloc(c, (void **)&c->Hinv, kk));
+    CHK(dev_alloc(c, (void **)&c->Eye, kk));
     CHK(dev_alloc(c, (void **)&c->vbuf, (size_t)c->dp * c->kp * sizeof(float) + kk));
     c->have_problem = true;
     return CMF_OK;

@@ -34,7 +34,21 @@ static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat,
     const int *need = nullptr;
     const size_t tri_bytes = (size_t)n * (n + 1) / 2 * sizeof(float);
     const bool inplace = (Hin == Hout);
-    if (c->opt_chol && tri_bytes <= 150 * 1024 && n <= 512) {
+    if (c->opt_chol && nmat == 1 && n <= 256 && c->have_problem && kp == c->kp && !inplace) {
+        // one shared Hessian: let k_pad workgroups each factor it in registers and solve for one unit
+        // vector -- H^-1 row by row (H^-1 is symmetric) at the latency of a single solve
+        CHK(ensure(c, c->eigflag, (size_t)kp * sizeof(int)));
+        int *flags = (int *)c->eigflag.p;
+        hipLaunchKernelGGL(axpby_diag_kernel, dim3((kp * kp + 255) / 256), dim3(256), 0, c->stream, c->Eye, (const float *)Hin, 0.0f,
+                           (const float *)nullptr, 0.f, 1.0f, kp, n);
+        const dim3 grid((unsigned)kp), block(256);
+        if (n <= 32) hipLaunchKernelGGL((chol_solve_kernel<2>), grid, block, 0, c->stream, Hin, (const float *)c->Eye, Hout, flags, n, kp, (int64_t)0, (float)pert, kp);
+        else if (n <= 64) hipLaunchKernelGGL((chol_solve_kernel<4>), grid, block, 0, c->stream, Hin, (const float *)c->Eye, Hout, flags, n, kp, (int64_t)0, (float)pert, kp);
+        else if (n <= 128) hipLaunchKernelGGL((chol_solve_kernel<8>), grid, block, 0, c->stream, Hin, (const float *)c->Eye, Hout, flags, n, kp, (int64_t)0, (float)pert, kp);
+        else hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, Hin, (const float *)c->Eye, Hout, flags, n, kp, (int64_t)0, (float)pert, kp);
+        HIPCHK(hipGetLastError());
+        need = (const int *)flags; // flags[0]: the single matrix needs the Jacobi path
+    } else if (c->opt_chol && tri_bytes <= 150 * 1024 && n <= 512) {
         CHK(ensure(c, c->eigflag, (size_t)nmat * sizeof(int)));
         const float *src = Hin;
         if (inplace) { // the fast path overwrites its output: keep the input for the Jacobi fallback
@@ -394,6 +408,10 @@ extern "C" int cmf_newton_step(cmf_ctx *c, double alpha, double l1, double l2, i
     if ((x_link != 0 && x_link != 1) || (y_link != 0 && y_link != 1)) return fail(CMF_EINVAL, "bad link id");
     DeviceGuard dg(c->device);
     const bool sampled = ratio < 1.0;
+    struct FlopScope { // sampled sweeps execute masked-dense GEMMs: credit only the sampled share
+        cmf_ctx *c;
+        ~FlopScope() { c->flop_scale = 1.0; }
+    } fscope{c};
     struct SamplingScope { // device sampling is armed by cmf_newton_step_device_sampled only
         cmf_ctx *c; bool keep;
         ~SamplingScope() { if (!keep) c->dev_sampling = false; }
@@ -410,17 +428,23 @@ extern "C" int cmf_newton_step(cmf_ctx *c, double alpha, double l1, double l2, i
         if (!(x_link == CMF_LINK_LINEAR && !sampled)) CHK(need_dense(c, 0));
         if (x_link == CMF_LINK_LINEAR && !sampled)
             CHK(sweep_side_shared(c, true, alpha, l1, l2, pert, (nn_mask & CMF_NN_U) != 0));
-        else
+        else {
+            c->flop_scale = sampled ? ratio : 1.0;
             CHK(sweep_side_rows(c, true, x_link, alpha, l1, l2, pert, (nn_mask & CMF_NN_U) != 0, (sampled && !c->dev_sampling) ? u_idx : nullptr, su));
+            c->flop_scale = 1.0;
+        }
     }
     if (upd & CMF_UPD_Z) {
         if (!have_data(c, 1)) return fail(CMF_EINVAL, "Y must be set before a Z update");
         if (!(y_link == CMF_LINK_LINEAR && !sampled)) CHK(need_dense(c, 1));
         if (y_link == CMF_LINK_LINEAR && !sampled)
             CHK(sweep_side_shared(c, false, 1.0 - alpha, l1, l2, pert, (nn_mask & CMF_NN_Z) != 0));
-        else
+        else {
+            c->flop_scale = sampled ? ratio : 1.0;
             CHK(sweep_side_rows(c, false, y_link, 1.0 - alpha, l1, l2, pert, (nn_mask & CMF_NN_Z) != 0,
                                 (sampled && !c->dev_sampling) ? z_idx : nullptr, su));
+            c->flop_scale = 1.0;
+        }
     }
     if (upd & CMF_UPD_V) {
         if (!have_data(c, 0) || !have_data(c, 1)) return fail(CMF_EINVAL, "X and Y must be set before a V update");
@@ -432,6 +456,7 @@ extern "C" int cmf_newton_step(cmf_ctx *c, double alpha, double l1, double l2, i
             CHK(cmf_newton_v_partials(c, alpha, c->vbuf));
             CHK(cmf_newton_v_apply(c, c->vbuf, l1, l2, nn_mask, pert));
         } else {
+            c->flop_scale = sampled ? ratio : 1.0;
             CHK(sweep_v_rows(c, alpha, l1, l2, x_link, y_link, pert, (nn_mask & CMF_NN_V) != 0,
                              (sampled && !c->dev_sampling) ? vx_idx : nullptr, sm, (sampled && !c->dev_sampling) ? vy_idx : nullptr, sp));
         }

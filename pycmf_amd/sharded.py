@@ -65,6 +65,42 @@ class ShardedMU:
         self.backend.update_uz(l1, l2, mask)
 
 
+class HipNewtonShardBackend:
+    """Linear-link, unsampled Newton step on one shard (cmf_newton_uz_update / _v_partials / _v_apply)."""
+
+    def __init__(self, ctx, alpha, nn_mask=0, pert=0.2):
+        self.ctx, self.alpha, self.nn_mask, self.pert = ctx, alpha, nn_mask, pert
+
+    def buf_elems(self):
+        return self.ctx.v_buf_elems()
+
+    def update_uz(self, l1, l2, mask):
+        self.ctx.newton_uz_update(self.alpha, l1, l2, self.nn_mask, mask, self.pert)
+
+    def partials(self, buf):
+        self.ctx.newton_v_partials(self.alpha, buf.data_ptr())
+
+    def apply_v(self, buf, l1, l2):
+        self.ctx.newton_v_apply(buf.data_ptr(), l1, l2, self.nn_mask, self.pert)
+
+
+class ShardedNewtonLinear:
+    """One Newton iteration (order U -> Z -> V, cmf_solvers.py:510-522) across ranks for linear links and
+    sg_sample_ratio == 1: U and Z sweeps are local, the V sweep needs one all-reduce of
+    [alpha X^T U + (1-alpha) Y Z | alpha U^T U + (1-alpha) Z^T Z]."""
+
+    def __init__(self, backend, buf, world=1, all_reduce=None):
+        self.backend, self.buf, self.world, self.all_reduce = backend, buf, world, all_reduce
+
+    def step(self, l1=0.0, l2=0.0, mask=7):
+        self.backend.update_uz(l1, l2, mask)
+        if mask & 2:
+            self.backend.partials(self.buf)
+            if self.world > 1:
+                self.all_reduce(self.buf)
+            self.backend.apply_v(self.buf, l1, l2)
+
+
 def make_torch_sharded_mu(ctx, world, device):
     """Wire a HIP context to torch.distributed (backend 'nccl' = RCCL)."""
     import torch
@@ -75,3 +111,14 @@ def make_torch_sharded_mu(ctx, world, device):
     def all_reduce(t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return ShardedMU(backend, buf, world, all_reduce if world > 1 else None)
+
+
+def make_torch_sharded_newton(ctx, world, device, alpha, nn_mask=0, pert=0.2):
+    import torch
+    import torch.distributed as dist
+    backend = HipNewtonShardBackend(ctx, alpha, nn_mask, pert)
+    buf = torch.zeros(backend.buf_elems(), dtype=torch.float32, device=device)
+
+    def all_reduce(t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return ShardedNewtonLinear(backend, buf, world, all_reduce if world > 1 else None)
