@@ -220,7 +220,7 @@ def main():
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             elapsed = float(te.item())
 
-        names = ("gemm_nn", "gemm_tn", "gemm_small", "gemm_nt", "spmm", "eigen", "elementwise")
+        names = ("gemm_nn", "gemm_tn", "gemm_small", "gemm_nt", "spmm", "rowhess", "eigen", "elementwise")
         classes = {c: ctx.kernel_time(c) for c in names}
         ctx.kernel_timing(False)
         ex2, ey2 = ctx.residual_sq(w.get("x_link", "linear"), w.get("y_link", "linear"))
@@ -235,7 +235,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     its = args.steps / elapsed
     # dominant kernel class = most device time on rank 0
-    dom = max(("gemm_nn", "gemm_tn", "spmm"), key=lambda c: classes[c][0])
+    dom = max(("gemm_nn", "gemm_tn", "spmm", "rowhess"), key=lambda c: classes[c][0])
     dms, dn, dfl = classes[dom]
     if dom == "spmm":
         # HBM-bound gather kernel.  Algorithmic (compulsory) bytes of one A*F product: CSR arrays once
@@ -259,10 +259,14 @@ def main():
                 traffic = json.load(open(tpath)).get(dom)
             except Exception:
                 traffic = None
+        if dom == "rowhess":
+            kname = "cmfk::row_hess_kernel<%d>  (fused per-row gradient + Hessian over the sampled rows)" % kp
+        else:
+            kname = "cmfk::gemm_kernel<%d, %d, 0, 4>  (%s data pass)" % (
+                0 if dom == "gemm_nn" else 1, 256 if k >= 256 else kp,
+                "NN: X V / Y Z / W KR" if dom == "gemm_nn" else "TN: X^T U / Y^T V / W^T KR")
         roof = {"bound": "mfma",
-                "kernel": "cmfk::gemm_kernel<%d, %d, 0, 4>  (%s data pass)" % (
-                    0 if dom == "gemm_nn" else 1, 256 if k >= 256 else kp,
-                    "NN: X V / Y Z / W KR" if dom == "gemm_nn" else "TN: X^T U / Y^T V / W^T KR"),
+                "kernel": kname,
                 "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/traffic_%s.json)" % args.workload,

@@ -55,7 +55,8 @@ enum {
     CMF_K_EIGEN = 4,     /* batched symmetric Jacobi           */
     CMF_K_GEMM_SMALL = 5,/* factor-side products: Grams, F G, grad H^-1 */
     CMF_K_SPMM = 6,      /* native CSR: A F, A^T F, sum_nnz a_ij (l_i . r_j)  */
-    CMF_K_COUNT = 7
+    CMF_K_ROWHESS = 7,   /* fused per-row gradient + Hessian over the sampled rows */
+    CMF_K_COUNT = 8
 };
 
 const char *cmf_last_error(void);
@@ -69,7 +70,9 @@ int cmf_ctx_destroy(cmf_ctx *ctx);
 int cmf_sync(cmf_ctx *ctx);
 /* tuning knobs (A/B measurements in one process): "gemm_pipe" 0..4 = staging schedule of the
  * data-pass GEMM kernels, "gemm_split" n = force the split-K factor (<= 0: heuristic),
- * "sparse_mode" 0 auto | 1 dense | 2 native CSR (set before cmf_set_data_csr)       */
+ * "sparse_mode" 0 auto | 1 dense | 2 native CSR (set before cmf_set_data_csr),
+ * "row_kernel" 1 fused gather kernel | 0 masked-dense GEMMs for per-row Newton sweeps,
+ * "safe_inverse_cholesky" 1 | 0                                                      */
 int cmf_set_option(cmf_ctx *ctx, const char *name, int64_t value);
 
 /* ---- problem ---------------------------------------------------------- */

@@ -5,6 +5,7 @@
 #include "cmf_kernels.hip.h"
 #include "cmf_eigen.hip.h"
 #include "cmf_sparse.hip.h"
+#include "cmf_rowhess.hip.h"
 
 #include <hip/hip_runtime.h>
 
@@ -77,6 +78,7 @@ struct cmf_ctx {
     int opt_pipe = 4;      // GEMM staging schedule (see gemm_kernel PIPE); 4 measured best (tools/ab_gemm.py)
     int opt_split = -1;    // force split-K factor (<=0: heuristic)
     int opt_chol = 1;      // Cholesky fast path of the safe inverse (0: always Jacobi)
+    int opt_rowkernel = 1; // per-row Newton sweeps: fused gather kernel (1) or masked-dense GEMMs (0)
     double flop_scale = 1.0;   // algorithmic/executed flop ratio of the launches being issued (sampled sweeps run masked-dense)
     bool dev_sampling = false; // armed for one cmf_newton_step by cmf_newton_step_device_sampled
     uint64_t dev_seed = 0;
@@ -99,6 +101,7 @@ struct cmf_ctx {
     DevBuf kr1, kr2;                      // Khatri-Rao squares of factors
     DevBuf hrows;                         // chunk of per-row Hessians / inverses
     DevBuf mask1, mask2;                  // stochastic sample masks (bytes)
+    DevBuf lists1, lists2;                // device copies of the per-row sample index lists
     DevBuf idxbuf;                        // uploaded sample index lists
     DevBuf eigws;                         // Jacobi workspace when k_pad > 128
     DevBuf eigflag, eigcopy;              // Cholesky fast path: per-matrix fallback flags, input copy
@@ -429,6 +432,7 @@ static void release_problem(cmf_ctx *c) {
     c->num = c->den = c->G = c->G2 = c->Hm = c->Hinv = c->Eye = c->vbuf = nullptr;
     c->slabs = DevBuf(); c->resid = DevBuf(); c->resid2 = DevBuf(); c->resid3 = DevBuf(); c->dpart = DevBuf();
     c->kr1 = DevBuf(); c->kr2 = DevBuf(); c->hrows = DevBuf(); c->mask1 = DevBuf(); c->mask2 = DevBuf();
+    c->lists1 = DevBuf(); c->lists2 = DevBuf();
     c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf();
     c->have_problem = false;
     for (int w = 0; w < 2; ++w) {
@@ -457,6 +461,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_pipe = (int)value;
     } else if (!strcmp(name, "gemm_split")) {
         c->opt_split = (int)value;
+    } else if (!strcmp(name, "row_kernel")) {
+        c->opt_rowkernel = value != 0;
     } else if (!strcmp(name, "safe_inverse_cholesky")) {
         c->opt_chol = value != 0;
     } else if (!strcmp(name, "sparse_mode")) {

@@ -401,6 +401,159 @@ static int sweep_v_rows(cmf_ctx *c, double alpha, double l1, double l2, int x_li
     return per_row_finish(c, CMF_V, h, pert, nn);
 }
 
+// ---- fused per-row path (cmf_rowhess.hip.h): only the sampled rows are touched ---------------
+template <int KP>
+static int launch_row_hess_kp(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
+    using Cfg = RowHessCfg<KP>;
+    static bool attr = false;
+    if (!attr) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&row_hess_kernel<KP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)Cfg::LDS_BYTES));
+        attr = true;
+    }
+    hipLaunchKernelGGL((row_hess_kernel<KP>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
+static int launch_row_hess(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
+    if (nrows <= 0) return CMF_OK;
+    Timed tm(c, CMF_K_ROWHESS, 2.0 * (double)nrows * (double)a.s * ((double)c->kp * c->kp + 2.0 * c->kp));
+    switch (c->kp) {
+    case 32: return launch_row_hess_kp<32>(c, a, nrows);
+    case 64: return launch_row_hess_kp<64>(c, a, nrows);
+    case 128: return launch_row_hess_kp<128>(c, a, nrows);
+    case 256: return launch_row_hess_kp<256>(c, a, nrows);
+    default: return fail(CMF_EUNSUPPORTED, "fused row kernel supports k_pad <= 256");
+    }
+}
+
+// device index lists for one sweep side: from the host lists (parity mode) or from the device sampler
+static int sample_lists(cmf_ctx *c, DevBuf &lb, DevBuf &mb, const int32_t *host_idx, int64_t nlists, int64_t per, int64_t n,
+                        int salt, const int32_t **out) {
+    *out = nullptr;
+    if (nlists * per == 0) return CMF_OK;
+    CHK(ensure(c, lb, (size_t)nlists * per * sizeof(int32_t)));
+    if (c->dev_sampling) {
+        // sample into a transient byte mask [nlists x n_pad], then compact every row into an ascending list
+        const int64_t ldm = rup(n, 256);
+        CHK(ensure(c, mb, (size_t)nlists * ldm));
+        Timed tm(c, CMF_K_ELEMWISE);
+        hipLaunchKernelGGL(sample_mask_kernel, dim3((unsigned)nlists), dim3(256), 0, c->stream, (uint8_t *)mb.p, ldm, 1, nlists, (int)n,
+                           (int)per, c->dev_seed * 4 + (uint64_t)salt);
+        hipLaunchKernelGGL(mask_to_list_kernel, dim3((unsigned)nlists), dim3(256), 0, c->stream, (const uint8_t *)mb.p, ldm, 1, nlists,
+                           (int)n, (int)per, (int32_t *)lb.p);
+        HIPCHK(hipGetLastError());
+    } else {
+        HIPCHK(hipMemcpyAsync(lb.p, host_idx, (size_t)nlists * per * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream)); // host_idx is caller memory
+    }
+    *out = (const int32_t *)lb.p;
+    return CMF_OK;
+}
+
+struct RowSide {
+    bool active = false;
+    const float *O = nullptr;   // other factor
+    const int32_t *lists = nullptr;
+    int64_t per = 0;            // samples per row
+    const float *T = nullptr;
+    int64_t t_row = 0, t_col = 0;
+    double scale = 1.0;
+    int link = 0;
+};
+
+// finish a sweep of factor `which` whose per-row parts come from up to two fused sides;
+// c->num must already hold any shared-side gradient part if `grad_preloaded`
+static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const RowSide &s2, const float *S, double diag, bool grad_preloaded,
+                             double l1, double l2, double pert, bool nn) {
+    const int64_t rows_pad = c->frows_pad[which], rows = c->frows[which];
+    const int64_t kk = (int64_t)c->kp * c->kp;
+    const int64_t chunk = hessian_chunk_rows(c, rows_pad);
+    CHK(ensure(c, c->hrows, (size_t)chunk * kk * sizeof(float)));
+    float *Hc = (float *)c->hrows.p;
+    float *grad = c->num, *step = c->den;
+    for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
+        const int64_t nr = std::min(chunk, rows - r0);
+        bool have_h = false, have_g = grad_preloaded;
+        for (const RowSide *sd : {&s1, &s2}) {
+            if (!sd->active) continue;
+            RowHessArgs a;
+            memset(&a, 0, sizeof a);
+            a.O = sd->O; a.F = c->F[which];
+            a.idx = sd->lists; a.idx_stride = sd->per; a.s = (int)sd->per;
+            a.T = sd->T; a.t_row = sd->t_row; a.t_col = sd->t_col;
+            a.scale = (float)sd->scale; a.link = sd->link;
+            a.H = Hc; a.G = grad; a.accumulate = 0; a.row0 = r0; a.nrows = nr;
+            // H and G accumulate independently: encode as two flags in one int (bit0: H, bit1: G)
+            a.accumulate = (have_h ? 1 : 0) | (have_g ? 2 : 0);
+            CHK(launch_row_hess(c, a, nr));
+            have_h = have_g = true;
+        }
+        CHK(launch_ew(c, hessian_finalize_kernel, nr * kk, Hc, S, (float)diag, nr, c->kp, c->k, have_h ? 1 : 0));
+        CHK(launch_ew(c, newton_grad_kernel, nr * c->kp, grad + r0 * c->kp, (const float *)(grad + r0 * c->kp), 1.0f, (const float *)nullptr, 0.f,
+                      (const float *)(c->F[which] + r0 * c->kp), (float)l1, (float)l2, nr * c->kp));
+        CHK(safe_solve_rows(c, Hc, grad + r0 * c->kp, step + r0 * c->kp, nr, c->k, c->kp, pert));
+    }
+    return launch_ew(c, newton_apply_kernel, rows_pad * c->kp, c->F[which], (const float *)step, rows, c->kp, c->k, rows_pad * c->kp,
+                     nn ? 1 : 0);
+}
+
+static int sweep_side_fused(cmf_ctx *c, bool is_u, int link, double scale, double l1, double l2, double pert, bool nn,
+                            const int32_t *idx, int64_t per, bool sampled) {
+    const int which = is_u ? CMF_U : CMF_Z;
+    RowSide sd;
+    sd.active = true;
+    sd.O = c->F[CMF_V];
+    sd.per = sampled ? per : c->d;
+    if (sampled) CHK(sample_lists(c, c->lists1, c->mask1, idx, c->frows[which], per, c->d, is_u ? 0 : 1, &sd.lists));
+    if (is_u) { sd.T = c->X; sd.t_row = c->dp; sd.t_col = 1; }
+    else { sd.T = c->Y; sd.t_row = 1; sd.t_col = c->pp; }
+    sd.scale = scale; sd.link = link;
+    // the logit Hessian of U carries no l2 term (:427-428); Z always does (:501-506)
+    const double diag = (is_u && link == CMF_LINK_LOGIT) ? 0.0 : l2;
+    return fused_rows_finish(c, which, sd, RowSide(), nullptr, diag, false, l1, l2, pert, nn);
+}
+
+static int sweep_v_fused(cmf_ctx *c, double alpha, double l1, double l2, int x_link, int y_link, double pert, bool nn,
+                         const int32_t *vx_idx, int64_t per_x, const int32_t *vy_idx, int64_t per_y, bool sampled) {
+    const bool x_shared = (x_link == CMF_LINK_LINEAR && !sampled);
+    const bool y_shared = (y_link == CMF_LINK_LINEAR && !sampled);
+    RowSide sx, sy;
+    const float *S = nullptr;
+    bool preloaded = false;
+    float *V = c->F[CMF_V];
+    if (x_shared || y_shared) {
+        // shared side: gradient part s (V G - T-product) and Hessian part s G, like the shared sweep
+        const bool xs = x_shared;
+        const double sc = xs ? alpha : 1.0 - alpha;
+        const float *Fo = xs ? c->F[CMF_U] : c->F[CMF_Z];
+        const int64_t orow = xs ? c->mp : c->pp;
+        CHK(gemm(c, MODE_TN, Fo, c->kp, Fo, c->kp, c->G, c->kp, c->kp, orow));            // Gram of the other factor
+        CHK(data_times(c, xs ? 0 : 1, xs, Fo, c->num));                                     // X^T U  or  Y Z
+        CHK(gemm(c, MODE_NN, V, c->kp, c->G, c->kp, c->den, c->dp, c->kp, c->kp));          // V G
+        CHK(launch_ew(c, axpby_kernel, c->dp * c->kp, c->num, (const float *)c->den, (float)sc, (const float *)c->num, (float)-sc,
+                      c->dp * c->kp));
+        CHK(launch_ew(c, axpby_kernel, (int64_t)c->kp * c->kp, c->Hm, (const float *)c->G, (float)sc, (const float *)nullptr, 0.f,
+                      (int64_t)c->kp * c->kp));
+        S = c->Hm;
+        preloaded = true;
+    }
+    if (!x_shared) {
+        sx.active = true; sx.O = c->F[CMF_U];
+        sx.per = sampled ? per_x : c->m;
+        if (sampled) CHK(sample_lists(c, c->lists1, c->mask1, vx_idx, c->d, per_x, c->m, 2, &sx.lists));
+        sx.T = c->X; sx.t_row = 1; sx.t_col = c->dp; sx.scale = alpha; sx.link = x_link;
+    }
+    if (!y_shared) {
+        sy.active = true; sy.O = c->F[CMF_Z];
+        sy.per = sampled ? per_y : c->p;
+        if (sampled) CHK(sample_lists(c, c->lists2, c->mask2, vy_idx, c->d, per_y, c->p, 3, &sy.lists));
+        sy.T = c->Y; sy.t_row = c->pp; sy.t_col = 1; sy.scale = 1.0 - alpha; sy.link = y_link;
+    }
+    return fused_rows_finish(c, CMF_V, sx, sy, S, l2, preloaded, l1, l2, pert, nn);
+}
+
 extern "C" int cmf_newton_step(cmf_ctx *c, double alpha, double l1, double l2, int x_link, int y_link, int nn_mask, int upd,
                                double pert, double ratio, const int32_t *u_idx, const int32_t *z_idx, const int32_t *vx_idx,
                                const int32_t *vy_idx) {
@@ -417,6 +570,7 @@ extern "C" int cmf_newton_step(cmf_ctx *c, double alpha, double l1, double l2, i
         ~SamplingScope() { if (!keep) c->dev_sampling = false; }
     } scope{c, false};
     if (!sampled) c->dev_sampling = false;
+    const bool fused = c->opt_rowkernel && c->kp <= 256; // fused gather kernel vs masked-dense GEMMs
     const int64_t su = (int64_t)((double)c->d * ratio);  // int(n * ratio), cmf_solvers.py:331
     const int64_t sm = (int64_t)((double)c->m * ratio), sp = (int64_t)((double)c->p * ratio);
     if (sampled && !c->dev_sampling) {
@@ -428,7 +582,9 @@ extern "C" int cmf_newton_step(cmf_ctx *c, double alpha, double l1, double l2, i
         if (!(x_link == CMF_LINK_LINEAR && !sampled)) CHK(need_dense(c, 0));
         if (x_link == CMF_LINK_LINEAR && !sampled)
             CHK(sweep_side_shared(c, true, alpha, l1, l2, pert, (nn_mask & CMF_NN_U) != 0));
-        else {
+        else if (fused) {
+            CHK(sweep_side_fused(c, true, x_link, alpha, l1, l2, pert, (nn_mask & CMF_NN_U) != 0, u_idx, su, sampled));
+        } else {
             c->flop_scale = sampled ? ratio : 1.0;
             CHK(sweep_side_rows(c, true, x_link, alpha, l1, l2, pert, (nn_mask & CMF_NN_U) != 0, (sampled && !c->dev_sampling) ? u_idx : nullptr, su));
             c->flop_scale = 1.0;
@@ -439,7 +595,9 @@ extern "C" int cmf_newton_step(cmf_ctx *c, double alpha, double l1, double l2, i
         if (!(y_link == CMF_LINK_LINEAR && !sampled)) CHK(need_dense(c, 1));
         if (y_link == CMF_LINK_LINEAR && !sampled)
             CHK(sweep_side_shared(c, false, 1.0 - alpha, l1, l2, pert, (nn_mask & CMF_NN_Z) != 0));
-        else {
+        else if (fused) {
+            CHK(sweep_side_fused(c, false, y_link, 1.0 - alpha, l1, l2, pert, (nn_mask & CMF_NN_Z) != 0, z_idx, su, sampled));
+        } else {
             c->flop_scale = sampled ? ratio : 1.0;
             CHK(sweep_side_rows(c, false, y_link, 1.0 - alpha, l1, l2, pert, (nn_mask & CMF_NN_Z) != 0,
                                 (sampled && !c->dev_sampling) ? z_idx : nullptr, su));
@@ -455,6 +613,8 @@ extern "C" int cmf_newton_step(cmf_ctx *c, double alpha, double l1, double l2, i
         if (x_link == CMF_LINK_LINEAR && y_link == CMF_LINK_LINEAR && !sampled) {
             CHK(cmf_newton_v_partials(c, alpha, c->vbuf));
             CHK(cmf_newton_v_apply(c, c->vbuf, l1, l2, nn_mask, pert));
+        } else if (fused) {
+            CHK(sweep_v_fused(c, alpha, l1, l2, x_link, y_link, pert, (nn_mask & CMF_NN_V) != 0, vx_idx, sm, vy_idx, sp, sampled));
         } else {
             c->flop_scale = sampled ? ratio : 1.0;
             CHK(sweep_v_rows(c, alpha, l1, l2, x_link, y_link, pert, (nn_mask & CMF_NN_V) != 0,

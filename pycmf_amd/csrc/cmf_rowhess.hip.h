@@ -1,0 +1,234 @@
+// cmf_rowhess.hip.h -- fused per-row Newton accumulation (gfx950).
+//
+// For one row f_i of a factor and the (sampled) rows o_j, j in S_i, of the other factor it forms in
+// ONE pass over the gathered rows (pycmf/cmf_solvers.py:414-428, :455-484, :494-506):
+//     z_j = f_i . o_j            r_j = s (link(z_j) - t_ij)           w_j = s link'(z_j)   (1 if linear)
+//     g_i = sum_j r_j o_j        H_i = sum_j w_j o_j o_j^T
+// One 512-thread workgroup per row.  The 32 gathered rows of a K-step are staged through registers
+// into an LDS tile; while they are still in registers the owning lanes take the dot product with
+// f_i (butterfly over the k_pad/4 lanes that share a row), so z, r, w and the gradient cost no LDS
+// traffic.  H_i is a rank-32 MFMA update per step, both operands read from the SAME LDS tile (the A
+// fragment is scaled by w_j as it is read) -- only the sampled rows are ever touched, there is no
+// residual / weight / mask image and no Khatri-Rao matrix.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cmfk {
+
+struct RowHessArgs {
+    const float *O;       // other factor, rows x KP
+    const float *F;       // this factor, rows x KP (row i = f_i)
+    const int32_t *idx;   // [nrows x s] sample lists, or null: j = 0..s-1
+    int64_t idx_stride;   // elements between the lists of consecutive rows (= s)
+    int s;                // samples per row
+    const float *T;       // targets: t_ij = T[i*t_row + j*t_col]
+    int64_t t_row, t_col;
+    float scale;
+    int link;             // 0 linear, 1 logit
+    float *H;             // [nrows x KP x KP] out (accumulate ? += : =)
+    float *G;             // [nrows x KP] gradient part out (accumulate ? += : =)
+    int accumulate;       // bit 0: H += , bit 1: G +=
+    int64_t row0;         // first row of this launch (blockIdx.x + row0 = i)
+    int64_t nrows;        // rows in this launch; H, G are indexed by blockIdx.x (H) / i (G)
+};
+
+template <int KP>
+struct RowHessCfg {
+    static constexpr int GS = KP / 4;                      // lanes per gathered row
+    static constexpr int LD = (32 * GS + 511) / 512;       // float4 per thread per tile
+    static constexpr int WM = KP >= 128 ? 4 : (KP == 64 ? 2 : 1);
+    static constexpr int WN = KP >= 64 ? 2 : 1;
+    static constexpr int TM = KP == 256 ? 2 : 1;
+    static constexpr int TN = KP == 256 ? 4 : (KP == 128 ? 2 : 1);
+    static constexpr int TILE = 32 * KP;
+    static constexpr size_t LDS_BYTES = (2 * TILE + 2 * 64) * sizeof(float);
+};
+
+template <int KP>
+__global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
+    using C = RowHessCfg<KP>;
+    extern __shared__ __attribute__((aligned(16))) float rsm[];
+    auto tile_of = [&](int b) { return rsm + b * C::TILE; };        // two row tiles
+    auto wv_of = [&](int b) { return rsm + 2 * C::TILE + 32 * b; }; // their weights
+
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int64_t i = g.row0 + blockIdx.x;
+    const int c4 = t % C::GS;
+    const bool loader = (C::GS >= 16) || (t < 32 * C::GS);
+    const f32x4 u4 = *reinterpret_cast<const f32x4 *>(g.F + i * KP + 4 * c4);
+    const int32_t *list = g.idx ? g.idx + i * g.idx_stride : nullptr;
+    const float *Ti = g.T + i * g.t_row;
+    const int nt = (g.s + 31) / 32;
+
+    const int wm = wid / C::WN, wn = wid % C::WN;
+    const bool mfma_wave = wid < C::WM * C::WN;
+    const int wrow0 = wm * 32 * C::TM, wcol0 = wn * 32 * C::TN;
+
+    f32x16 acc[C::TM][C::TN];
+#pragma unroll
+    for (int a = 0; a < C::TM; ++a)
+#pragma unroll
+        for (int b = 0; b < C::TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    f32x4 gacc = {0.f, 0.f, 0.f, 0.f};
+
+    int jn[C::LD];      // indices of the tile about to be gathered
+    f32x4 rr[C::LD];    // gathered rows of the tile in flight
+    float tt[C::LD];    // their targets
+    bool vv[C::LD];     // sample exists (tail of the list)
+
+    auto row_of = [&](int p) { return (t + 512 * p) / C::GS; };
+    auto load_idx = [&](int tl) {
+#pragma unroll
+        for (int p = 0; p < C::LD; ++p) {
+            const int q = 32 * tl + row_of(p);
+            const int qc = q < g.s ? q : g.s - 1;
+            jn[p] = list ? list[qc] : qc;
+        }
+    };
+    auto gather = [&](int tl) {
+#pragma unroll
+        for (int p = 0; p < C::LD; ++p) {
+            const int q = 32 * tl + row_of(p);
+            vv[p] = q < g.s;
+            rr[p] = *reinterpret_cast<const f32x4 *>(g.O + (int64_t)jn[p] * KP + 4 * c4);
+            tt[p] = Ti[(int64_t)jn[p] * g.t_col];
+        }
+    };
+    // registers -> (z, r, w, gradient) -> LDS tile
+    auto stage = [&](int nb) {
+#pragma unroll
+        for (int p = 0; p < C::LD; ++p) {
+            float z = u4[0] * rr[p][0] + u4[1] * rr[p][1] + u4[2] * rr[p][2] + u4[3] * rr[p][3];
+#pragma unroll
+            for (int off = C::GS / 2; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
+            const float f = g.link ? sigmoidf_(z) : z;
+            const float valid = vv[p] ? 1.0f : 0.0f;
+            const float res = valid * g.scale * (f - tt[p]);
+            const float wgt = valid * g.scale * (g.link ? f * (1.0f - f) : 1.0f);
+            gacc += res * rr[p];
+            const int r = row_of(p);
+            if (c4 == 0) wv_of(nb)[r] = wgt;
+            *reinterpret_cast<f32x4 *>(tile_of(nb) + r * KP + 4 * c4) = rr[p];
+        }
+    };
+    auto mfma_tile = [&](int cb, bool do_stage, int nb, bool do_gather, int tl_gather, bool do_idx, int tl_idx) {
+        const float *Rt = tile_of(cb);
+        const float *Wv = wv_of(cb);
+        float a[2][C::TM], b[2][C::TN];
+        auto ld_frag = [&](int sidx, float *da, float *db) {
+            const int kk = 2 * sidx + lh;
+            const float w = Wv[kk];
+            VecLoad<C::TM>::ld(Rt + kk * KP + wrow0 + C::TM * l31, da);
+            VecLoad<C::TN>::ld(Rt + kk * KP + wcol0 + C::TN * l31, db);
+#pragma unroll
+            for (int x = 0; x < C::TM; ++x) da[x] *= w;
+        };
+        if (mfma_wave) ld_frag(0, a[0], b[0]);
+#pragma unroll
+        for (int sidx = 0; sidx < 16; ++sidx) {
+            if (mfma_wave && sidx + 1 < 16) ld_frag(sidx + 1, a[(sidx + 1) & 1], b[(sidx + 1) & 1]);
+            if (sidx == 0) {
+                if (do_stage && loader) stage(nb);
+            } else if (sidx == 1) {
+                if (do_gather && loader) gather(tl_gather);
+                if (do_idx && loader) load_idx(tl_idx);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (mfma_wave) {
+#pragma unroll
+                for (int x = 0; x < C::TM; ++x)
+#pragma unroll
+                    for (int y = 0; y < C::TN; ++y)
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sidx & 1][x], b[sidx & 1][y], acc[x][y], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (nt > 0) {
+        if (loader) {
+            load_idx(0);
+            gather(0);
+            stage(0);
+            if (nt > 1) {
+                load_idx(1);
+                gather(1);
+            }
+            if (nt > 2) load_idx(2);
+        }
+        __syncthreads();
+        for (int tl = 0; tl < nt; ++tl) {
+            // tile tl is in LDS; tile tl+1 is in registers; jn holds the indices of tile tl+2
+            mfma_tile(tl & 1, tl + 1 < nt, (tl + 1) & 1, tl + 2 < nt, tl + 2, tl + 3 < nt, tl + 3);
+            __syncthreads();
+        }
+    }
+
+    // ---- H_i tile out (rows interleaved like the TN GEMM form)
+    float *Hi = g.H + (int64_t)blockIdx.x * KP * KP;
+    if (mfma_wave) {
+#pragma unroll
+        for (int x = 0; x < C::TM; ++x)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rrw = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = wrow0 + C::TM * rrw + x;
+                float *dst = Hi + row * KP + wcol0 + C::TN * l31;
+                if constexpr (C::TN == 4) {
+                    f32x4 v = {acc[x][0][r], acc[x][1][r], acc[x][2][r], acc[x][3][r]};
+                    if (g.accumulate & 1) v += *reinterpret_cast<f32x4 *>(dst);
+                    *reinterpret_cast<f32x4 *>(dst) = v;
+                } else if constexpr (C::TN == 2) {
+                    f32x2 v = {acc[x][0][r], acc[x][1][r]};
+                    if (g.accumulate & 1) v += *reinterpret_cast<f32x2 *>(dst);
+                    *reinterpret_cast<f32x2 *>(dst) = v;
+                } else {
+                    dst[0] = acc[x][0][r] + ((g.accumulate & 1) ? dst[0] : 0.f);
+                }
+            }
+    }
+    // ---- gradient part: sum the per-thread partials that share a column chunk
+    __syncthreads();
+    constexpr int NREP = 512 / C::GS; // threads per column chunk
+    float *gr = rsm;                  // [NREP][KP] staging (the tiles are dead now); 512*4 floats <= 2*TILE
+    *reinterpret_cast<f32x4 *>(gr + (t / C::GS) * KP + 4 * c4) = loader ? gacc : f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    if (t < KP) {
+        float sacc = 0.f;
+        for (int rep = 0; rep < NREP; ++rep) sacc += gr[rep * KP + t];
+        float *dst = g.G + i * KP + t;
+        *dst = sacc + ((g.accumulate & 2) ? *dst : 0.f);
+    }
+}
+
+// compact a 0/1 byte mask row (or column) into an ascending index list of exactly `per` entries
+__global__ __launch_bounds__(256) void mask_to_list_kernel(const uint8_t *mask, int64_t ld, int by_row, int64_t nlists, int n,
+                                                           int per, int32_t *lists) {
+    __shared__ int wave_cnt[4];
+    __shared__ int base;
+    const int64_t l = blockIdx.x;
+    if (l >= nlists) return;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    if (t == 0) base = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + t;
+        const bool on = j < n && mask[by_row ? (l * ld + j) : ((int64_t)j * ld + l)] != 0;
+        const unsigned long long bal = __ballot(on);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wid] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wid; ++w) off += wave_cnt[w];
+        if (on && off + before < per) lists[l * per + off + before] = j;
+        __syncthreads();
+        if (t == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+}
+
+} // namespace cmfk

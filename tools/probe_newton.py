@@ -13,7 +13,9 @@ xl = a[5] if len(a) > 5 else "linear"
 yl = a[6] if len(a) > 6 else "logit"
 iters = int(a[7]) if len(a) > 7 else 1
 sampler = a[8] if len(a) > 8 else "numpy"
+row_kernel = int(a[9]) if len(a) > 9 else 1
 ctx = _lib.Context(0)
+ctx.set_option("row_kernel", row_kernel)
 ctx.set_problem(m, d, p, k)
 ctx.fill_data_synthetic(0, 42); ctx.fill_data_synthetic(1, 43)
 sc = (0.8 / k) ** 0.5
@@ -38,7 +40,7 @@ for it in range(iters):
         ctx.newton_step(0.5, 0.0, 0.1, xl, yl, 0, 7, 0.2, ratio, *idx)
     ctx.sync(); dt = time.time() - t0
     print("iter %d: host sampling %.1fs, device step %.3fs" % (it, th, dt))
-    for cls in ("gemm_nn", "gemm_tn", "gemm_nt", "gemm_small", "eigen", "elementwise"):
+    for cls in ("gemm_nn", "gemm_tn", "gemm_nt", "gemm_small", "rowhess", "eigen", "elementwise"):
         ms, n, fl = ctx.kernel_time(cls)
         print("   %-12s %10.2f ms  %4d launches  %.1f TF/s" % (cls, ms, n, fl / max(ms, 1e-9) / 1e9))
     ctx.kernel_timing(False)
