@@ -224,13 +224,62 @@ def test_stochastic_newton_solver_sparse_input():  # :317-338 (dense == sparse, 
 
 
 def test_auto_compute_alpha():  # :354-371
+    rng = np.random.mtrand.RandomState(36)
+    X, Y = rng.randn(10, 10), rng.randn(10, 5)
+    kw = dict(n_components=2, solver="newton", x_init='svd', y_init='svd', U_non_negative=False,
+              V_non_negative=False, Z_non_negative=False, random_state=0, max_iter=100)
+    U1, V1, Z1 = CMF(alpha=0.5, **kw).fit_transform(X, Y)
+    U2, V2, Z2 = CMF(alpha="auto", **kw).fit_transform(X, Y)
+    assert np.linalg.norm(U2 @ V2.T - X) > np.linalg.norm(U1 @ V1.T - X)
+    assert np.linalg.norm(V1 @ Z1.T - Y) > np.linalg.norm(V2 @ Z2.T - Y)
+
+
+def test_transform_custom_init():  # :67-82
+    rs = np.random.RandomState(0)
+    X, Y = np.abs(rs.randn(6, 5)), np.abs(rs.randn(5, 1))
+    avg = np.sqrt(X.mean() / 4)
+    U0, V0 = np.abs(avg * rs.randn(6, 4)), np.abs(avg * rs.randn(5, 4))
+    Z0 = np.abs(np.sqrt(Y.mean() / 4) * rs.randn(1, 4))
+    CMF(solver='newton', n_components=4, x_init='custom', y_init='custom', random_state=0).fit_transform(X, Y, U=U0, V=V0, Z=Z0)
+
+
+def test_input_method_compatibility():  # :85-101: every pair of init methods, one MU iteration
+    import itertools
+    rng = np.random.mtrand.RandomState(0)
+    X, Y = np.abs(rng.randn(6, 5)), np.abs(rng.randn(5, 6))
+    avg = np.sqrt(X.mean() / 4)
+    U0, V0 = np.abs(avg * rng.randn(6, 4)), np.abs(avg * rng.randn(5, 4))
+    Z0 = np.abs(np.sqrt(Y.mean() / 4) * rng.randn(6, 4))
+    inits = [None, 'random', 'nndsvd', 'nndsvda', 'nndsvdar', 'custom']
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for xi, yi in itertools.product(inits, inits):
+            U, V, Z = CMF(n_components=4, solver='mu', x_init=xi, y_init=yi, random_state=0,
+                          max_iter=1).fit_transform(X, Y, U=U0.copy(), V=V0.copy(), Z=Z0.copy())
+            assert np.isfinite(U).all() and np.isfinite(V).all() and np.isfinite(Z).all()
+
+
+def test_svd_ncomponents_lt_nfeatures():  # :340-351
     rng = np.random.mtrand.RandomState(42)
-    X, Y = np.abs(rng.randn(20, 6)), np.abs(rng.randn(6, 2))
-    kw = dict(n_components=3, solver="newton", random_state=0, max_iter=100, x_init="random", y_init="random")
-    U1, V1, Z1 = CMF(alpha="auto", **kw).fit_transform(X, Y)
-    U2, V2, Z2 = CMF(alpha=0.5, **kw).fit_transform(X, Y)
-    assert np.linalg.norm(Y - V1 @ Z1.T) < np.linalg.norm(Y - V2 @ Z2.T)
-    assert np.linalg.norm(X - U1 @ V1.T) > np.linalg.norm(X - U2 @ V2.T)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        CMF(n_components=3, solver="newton", x_init='svd', y_init='svd', U_non_negative=False, V_non_negative=False,
+            Z_non_negative=False, random_state=0, max_iter=1).fit(rng.randn(6, 4), rng.randn(4, 2))
+
+
+def test_analysis(capsys):  # :411-423 (the reference's own version breaks on current sklearn; ours does not)
+    from sklearn.feature_extraction.text import CountVectorizer
+    rng = np.random.mtrand.RandomState(36)
+    model = CMF(n_components=2, solver="newton", max_iter=1)
+    cv = CountVectorizer()
+    X_ = sp.csr_matrix(cv.fit_transform(["hello world", "goodbye world", "hello goodbye"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model.fit_transform(X_.T, np.abs(rng.randn(3, 1)))
+    model.print_topic_terms(cv, importances=False)
+    model.print_topic_terms(cv, importances=True)
+    out = capsys.readouterr().out
+    assert "Topic 1" in out and "Topic 2" in out and "hello" in out
 
 
 @pytest.mark.parametrize("solver", solvers)
