@@ -58,6 +58,15 @@ struct CsrDev {
     int64_t rows = 0, cols = 0, nnz = 0;
 };
 
+// A captured update step: replayed with hipGraphLaunch while the key (hyper-parameters baked into
+// kernel arguments) and every device pointer it references stay unchanged.
+struct StepGraph {
+    hipGraphExec_t exec = nullptr;
+    double key[8] = {0};
+    int warm = 0;       // eager runs with this key (the first one sizes every workspace)
+    bool failed = false;
+};
+
 struct EvPair {
     hipEvent_t a, b;
     int cls;
@@ -75,6 +84,9 @@ struct cmf_ctx {
     int64_t mp = 0, dp = 0, pp = 0;
     int kp = 0;
     bool have_problem = false;
+    int opt_graph = 0;     // replay MU / linear-Newton steps from a captured hipGraph (opt-in: measured neutral,
+                           // the ~4 us per dependent kernel boundary is device-side, not host launch cost)
+    StepGraph mu_graph, newton_graph;
     int opt_pipe = 4;      // GEMM staging schedule (see gemm_kernel PIPE); 4 measured best (tools/ab_gemm.py)
     int opt_split = -1;    // force split-K factor (<=0: heuristic)
     int opt_chol = 1;      // Cholesky fast path of the safe inverse (0: always Jacobi)
@@ -188,8 +200,18 @@ static void dev_free(cmf_ctx *c, void *p) {
     if (it != c->owned.end()) c->owned.erase(it);
     (void)hipFree(p);
 }
+static void drop_graph(StepGraph &g) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    g = StepGraph();
+}
+static void invalidate_graphs(cmf_ctx *c) {
+    drop_graph(c->mu_graph);
+    drop_graph(c->newton_graph);
+}
+
 static int ensure(cmf_ctx *c, DevBuf &b, size_t bytes) {
     if (b.bytes >= bytes) return CMF_OK;
+    invalidate_graphs(c); // a captured step may hold the old pointer
     if (b.p) {
         HIPCHK(hipStreamSynchronize(c->stream));
         dev_free(c, b.p);
@@ -423,6 +445,7 @@ extern "C" int cmf_ctx_create(cmf_ctx **out, int device, void *stream) {
 
 static void release_problem(cmf_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
+    invalidate_graphs(c);
     for (void *p : c->owned)
         if (p != (void *)c->dscalar) (void)hipFree(p);
     c->owned.clear();
@@ -456,6 +479,11 @@ extern "C" int cmf_ctx_destroy(cmf_ctx *c) {
 
 extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return fail(CMF_EINVAL, "null argument");
+    invalidate_graphs(c);
+    if (!strcmp(name, "graph")) {
+        c->opt_graph = value != 0;
+        return CMF_OK;
+    }
     if (!strcmp(name, "gemm_pipe")) {
         if (value < 0 || value > 4) return fail(CMF_EINVAL, "gemm_pipe must be 0..4");
         c->opt_pipe = (int)value;
@@ -532,6 +560,7 @@ static int data_dims(cmf_ctx *c, int which, int64_t *rows, int64_t *cols, int64_
 }
 
 static int ensure_dense(cmf_ctx *c, int which) {
+    invalidate_graphs(c);
     int64_t r, cc, rp, cp; float **slot;
     CHK(data_dims(c, which, &r, &cc, &rp, &cp, &slot));
     if (!*slot) CHK(dev_alloc(c, (void **)slot, (size_t)rp * cp * sizeof(float)));
@@ -748,13 +777,69 @@ extern "C" int cmf_mu_uz_update(cmf_ctx *c, double l1, double l2, int mask) {
     return CMF_OK;
 }
 
-extern "C" int cmf_mu_step(cmf_ctx *c, double l1, double l2, int mask) {
-    NEED_PROBLEM(c);
+// Run `eager` (a fixed sequence of launches on c->stream) directly, or capture it into a hipGraph
+// on its second call with an unchanged key and replay the graph from then on.  Launch-bound small
+// problems (the reference's own test sizes run ~25 launches of a few microseconds per iteration)
+// are then paced by one graph launch instead.
+template <typename F>
+static int run_graphed(cmf_ctx *c, StepGraph &g, const double *key, int nkey, F &&eager) {
+    if (!c->opt_graph || c->timing) return eager();
+    bool same = true;
+    for (int i = 0; i < nkey; ++i) same = same && (g.key[i] == key[i]);
+    if (!same) {
+        drop_graph(g);
+        for (int i = 0; i < nkey; ++i) g.key[i] = key[i];
+    }
+    if (g.exec) {
+        HIPCHK(hipGraphLaunch(g.exec, c->stream));
+        return CMF_OK;
+    }
+    if (g.failed || g.warm < 1) {
+        g.warm += 1;
+        return eager();
+    }
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        g.failed = true;
+        (void)hipGetLastError();
+        return eager();
+    }
+    const int rc = eager();
+    const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    if (rc != CMF_OK || e != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        g.failed = true;
+        // capture swallowed the launches: run the step for real
+        return rc != CMF_OK ? rc : eager();
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess || !exec) {
+        (void)hipGetLastError();
+        g.failed = true;
+        return eager();
+    }
+    // ensure() may have dropped the graph during capture (it must not allocate then); guard anyway
+    g.exec = exec;
+    HIPCHK(hipGraphLaunch(g.exec, c->stream));
+    return CMF_OK;
+}
+
+static int mu_step_eager(cmf_ctx *c, double l1, double l2, int mask) {
     if (mask & CMF_UPD_V) {
         CHK(cmf_mu_v_partials(c, c->vbuf));
         CHK(cmf_mu_v_apply(c, c->vbuf, l1, l2));
     }
     return cmf_mu_uz_update(c, l1, l2, mask);
+}
+
+extern "C" int cmf_mu_step(cmf_ctx *c, double l1, double l2, int mask) {
+    NEED_PROBLEM(c);
+    DeviceGuard dg(c->device);
+    const double key[3] = {l1, l2, (double)mask};
+    return run_graphed(c, c->mu_graph, key, 3, [&]() { return mu_step_eager(c, l1, l2, mask); });
 }
 
 // ------------------------------------------------------------------ error metric

@@ -554,9 +554,28 @@ static int sweep_v_fused(cmf_ctx *c, double alpha, double l1, double l2, int x_l
     return fused_rows_finish(c, CMF_V, sx, sy, S, l2, preloaded, l1, l2, pert, nn);
 }
 
+static int newton_step_impl(cmf_ctx *c, double alpha, double l1, double l2, int x_link, int y_link, int nn_mask, int upd,
+                            double pert, double ratio, const int32_t *u_idx, const int32_t *z_idx, const int32_t *vx_idx,
+                            const int32_t *vy_idx);
+
 extern "C" int cmf_newton_step(cmf_ctx *c, double alpha, double l1, double l2, int x_link, int y_link, int nn_mask, int upd,
                                double pert, double ratio, const int32_t *u_idx, const int32_t *z_idx, const int32_t *vx_idx,
                                const int32_t *vy_idx) {
+    NEED_PROBLEM(c);
+    if (x_link == CMF_LINK_LINEAR && y_link == CMF_LINK_LINEAR && ratio >= 1.0 && have_data(c, 0) && have_data(c, 1)) {
+        // all three sweeps take the shared-Hessian form: a fixed launch sequence -> graph replay
+        DeviceGuard dg(c->device);
+        const double key[6] = {alpha, l1, l2, (double)nn_mask, (double)upd, pert};
+        return run_graphed(c, c->newton_graph, key, 6, [&]() {
+            return newton_step_impl(c, alpha, l1, l2, x_link, y_link, nn_mask, upd, pert, ratio, nullptr, nullptr, nullptr, nullptr);
+        });
+    }
+    return newton_step_impl(c, alpha, l1, l2, x_link, y_link, nn_mask, upd, pert, ratio, u_idx, z_idx, vx_idx, vy_idx);
+}
+
+static int newton_step_impl(cmf_ctx *c, double alpha, double l1, double l2, int x_link, int y_link, int nn_mask, int upd,
+                            double pert, double ratio, const int32_t *u_idx, const int32_t *z_idx, const int32_t *vx_idx,
+                            const int32_t *vy_idx) {
     NEED_PROBLEM(c);
     if ((x_link != 0 && x_link != 1) || (y_link != 0 && y_link != 1)) return fail(CMF_EINVAL, "bad link id");
     DeviceGuard dg(c->device);
