@@ -162,6 +162,9 @@ int cmf_safe_invert_batch(cmf_ctx *ctx, const double *H, double *out, int n, int
 int cmf_kernel_timing(cmf_ctx *ctx, int enable);
 int cmf_kernel_time(cmf_ctx *ctx, int kernel_class, double *ms, int64_t *launches, double *flops);
 int cmf_kernel_timing_reset(cmf_ctx *ctx);
+/* diagnostic: one X*V data pass with s_memtime / s_memrealtime stamps around the main loop;
+ * median in-kernel shader clock (GHz) and main-loop duration (us) over the workgroups        */
+int cmf_debug_clock(cmf_ctx *ctx, double *ghz, double *loop_us);
 /* padded device geometry (m_pad, d_pad, p_pad, k_pad) */
 int cmf_get_geometry(cmf_ctx *ctx, int64_t *m_pad, int64_t *d_pad, int64_t *p_pad, int *k_pad);
 /* device pointers of the factor blocks (float32, row-major, ld = k_pad) */

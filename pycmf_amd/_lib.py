@@ -55,6 +55,7 @@ PROTOTYPES = {
     "cmf_residual_sq": [_vp, _i32, _i32, _pd, _pd],
     "cmf_data_sq": [_vp, _pd, _pd],
     "cmf_safe_invert_batch": [_vp, _pd, _pd, _i32, _i32, _dbl],
+    "cmf_debug_clock": [_vp, _pd, _pd],
     "cmf_kernel_timing": [_vp, _i32],
     "cmf_kernel_time": [_vp, _i32, _pd, _pi64, _pd],
     "cmf_kernel_timing_reset": [_vp],
@@ -274,6 +275,11 @@ class Context:
 
     def sync(self):
         check(self._lib.cmf_sync(self._h))
+
+    def debug_clock(self):
+        g, u = C.c_double(0), C.c_double(0)
+        check(self._lib.cmf_debug_clock(self._h, C.byref(g), C.byref(u)))
+        return g.value, u.value
 
     def kernel_timing(self, enable):
         check(self._lib.cmf_kernel_timing(self._h, 1 if enable else 0))

@@ -84,6 +84,7 @@ struct cmf_ctx {
     int64_t mp = 0, dp = 0, pp = 0;
     int kp = 0;
     bool have_problem = false;
+    unsigned long long *dbg_stamps = nullptr; // set by cmf_debug_clock for its own launches only
     int opt_graph = 0;     // replay MU / linear-Newton steps from a captured hipGraph (opt-in: measured neutral,
                            // the ~4 us per dependent kernel boundary is device-side, not host launch cost)
     StepGraph mu_graph, newton_graph;
@@ -321,6 +322,7 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
     a.ldc = n;
     a.Mout = (mode == MODE_TN) ? mout : rup(mout, 256);
     a.Kred = kred; a.klen = pl.klen;
+    a.dbg = data_pass ? c->dbg_stamps : nullptr;
     const int64_t rows_store = (mode == MODE_TN) ? mout : rup(mout, 256);
     const bool direct = (pl.nsplit == 1 && !accumulate);
     if (direct) {
@@ -903,6 +905,38 @@ extern "C" int cmf_data_sq(cmf_ctx *c, double *x2, double *y2) {
 }
 
 // ------------------------------------------------------------------ timing API
+// Diagnostic: launch the NN data pass X*V once with clock stamps; returns the median over workgroups of
+// (shader cycles / elapsed time) in GHz and of the main-loop duration in microseconds.
+extern "C" int cmf_debug_clock(cmf_ctx *c, double *ghz, double *loop_us) {
+    NEED_PROBLEM(c);
+    if (!c->X) return fail(CMF_EINVAL, "dense X required");
+    DeviceGuard dg(c->device);
+    const int64_t nwg = (c->mp / 256) * std::max(1, c->kp / 256) * 64;
+    unsigned long long *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, (size_t)nwg * 4 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(d, 0, (size_t)nwg * 4 * sizeof(unsigned long long), c->stream));
+    c->dbg_stamps = d;
+    int rc = gemm(c, MODE_NN, c->X, c->dp, c->F[CMF_V], c->kp, c->num, c->mp, c->kp, c->dp);
+    c->dbg_stamps = nullptr;
+    (void)hipStreamSynchronize(c->stream);
+    std::vector<unsigned long long> h((size_t)nwg * 4);
+    if (rc == CMF_OK && hipMemcpy(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(CMF_EHIP, "D2H failed");
+    (void)hipFree(d);
+    if (rc != CMF_OK) return rc;
+    std::vector<double> f, us;
+    for (int64_t i = 0; i < nwg; ++i) {
+        const double cyc = (double)(h[4 * i + 2] - h[4 * i + 0]), rt = (double)(h[4 * i + 3] - h[4 * i + 1]);
+        if (h[4 * i + 3] == 0 || rt <= 0) continue;
+        f.push_back(cyc / (rt * 10.0) ); // memrealtime ticks at 100 MHz: cycles / (ticks * 10 ns) = GHz
+        us.push_back(rt / 100.0);
+    }
+    if (f.empty()) return fail(CMF_EHIP, "no stamps recorded");
+    std::sort(f.begin(), f.end()); std::sort(us.begin(), us.end());
+    if (ghz) *ghz = f[f.size() / 2];
+    if (loop_us) *loop_us = us[us.size() / 2];
+    return CMF_OK;
+}
+
 extern "C" int cmf_kernel_timing(cmf_ctx *c, int enable) {
     if (!c) return fail(CMF_EINVAL, "null context");
     DeviceGuard dg(c->device);

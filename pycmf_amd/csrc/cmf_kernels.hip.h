@@ -46,6 +46,7 @@ struct GemmArgs {
     float scale_r, scale_w;
     int link;            // 0 linear, 1 logit
     int w_is_slope;      // W = scale_w * sigma'(S) (1) or scale_w (0)
+    unsigned long long *dbg; // diagnostic only: per-workgroup {memtime, memrealtime} at start and end (nullable)
 };
 
 template <int MODE, int BN>
@@ -97,6 +98,8 @@ struct VecLoad<4> {
 //   2: LDS writes two pieces per group in groups 0..3, loads of tile t+2 at group 4
 //   3: LDS writes four pieces per group in groups 0..1, loads of tile t+2 at group 2
 //   4: all eight LDS writes in group 0, loads of tile t+2 at group 1
+// (also tried and dropped: piece p written in group p and re-loaded at once: -1..-3 %; one piece in the shadow
+//  of each MFMA: -25 %, hipcc's conservative waitcnts serialise it)
 template <int MODE, int BN, int ROLE = 0, int PIPE = 0>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
     using C = GemmCfg<MODE, BN>;
@@ -122,6 +125,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
         for (int j = 0; j < C::TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int64_t wg_linear = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (g.dbg && t == 0) { // clock diagnostic (tools/probe_clock.py); never set in production launches
+        g.dbg[4 * wg_linear + 0] = __builtin_amdgcn_s_memtime();
+        g.dbg[4 * wg_linear + 1] = __builtin_amdgcn_s_memrealtime();
+    }
 
     f32x4 ra[C::A_LD], rb[C::B_LD];
 
@@ -316,6 +325,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
         }
     }
 
+    if (g.dbg && t == 0) {
+        g.dbg[4 * wg_linear + 2] = __builtin_amdgcn_s_memtime();
+        g.dbg[4 * wg_linear + 3] = __builtin_amdgcn_s_memrealtime();
+    }
     // ---------------------------------------------------------------- epilogue
     if constexpr (MODE != MODE_NT) {
         float *Cs = g.C + (int64_t)blockIdx.z * g.slab_stride;
