@@ -98,6 +98,11 @@ int cmf_set_data_csr(cmf_ctx *ctx, int which, const int64_t *indptr, const int32
  * global matrix land in the local matrix.  Used by bench.py.                 */
 int cmf_fill_data_synthetic(cmf_ctx *ctx, int which, uint64_t seed, int64_t row0, int64_t col0);
 int cmf_fill_factor_synthetic(cmf_ctx *ctx, int which, uint64_t seed, int64_t row0, double scale);
+/* out (host, rows_out x ncols, row-major float64) = op(A) * B with A = X (which 0) or Y (which 1),
+ * op = transpose when trans != 0, B host row-major float64 (b_rows x ncols).  The big products of the
+ * initialisers' randomized SVD (sklearn randomized_svd called at pycmf/cmf.py:126,:149) run through
+ * this on the data already resident on the device (dense MFMA GEMM or native CSR SpMM).            */
+int cmf_data_matmul_f64(cmf_ctx *ctx, int which, int trans, const double *B, int64_t b_rows, int ncols, double *out);
 /* read back a block of X or Y (tests) */
 int cmf_get_data_f32(cmf_ctx *ctx, int which, float *ptr, int64_t rs, int64_t cs);
 

@@ -39,6 +39,7 @@ PROTOTYPES = {
     "cmf_fill_data_synthetic": [_vp, _i32, C.c_uint64, _i64, _i64],
     "cmf_fill_factor_synthetic": [_vp, _i32, C.c_uint64, _i64, _dbl],
     "cmf_get_data_f32": [_vp, _i32, _pf, _i64, _i64],
+    "cmf_data_matmul_f64": [_vp, _i32, _i32, _pd, _i64, _i32, _pd],
     "cmf_set_factor_f64": [_vp, _i32, _pd, _i64, _i64],
     "cmf_get_factor_f64": [_vp, _i32, _pd, _i64, _i64],
     "cmf_mu_step": [_vp, _dbl, _dbl, _i32],
@@ -179,6 +180,16 @@ class Context:
         m, d, p, _ = self.shape
         out = np.empty((m, d) if which == 0 else (d, p), dtype=np.float32)
         check(self._lib.cmf_get_data_f32(self._h, which, out.ctypes.data_as(_pf), out.shape[1], 1))
+        return out
+
+    def data_matmul(self, which, trans, B):
+        """op(X|Y) @ B on the device for a host float64 matrix B; returns a host float64 array."""
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        m, d, p, _ = self.shape
+        ar, ac = ((m, d), (d, p))[which]
+        out = np.empty((ac if trans else ar, B.shape[1]))
+        check(self._lib.cmf_data_matmul_f64(self._h, which, 1 if trans else 0, B.ctypes.data_as(_pd), B.shape[0], B.shape[1],
+                                            out.ctypes.data_as(_pd)))
         return out
 
     def fill_data_synthetic(self, which, seed, row0=0, col0=0):

@@ -653,3 +653,44 @@ extern "C" int cmf_newton_step_device_sampled(cmf_ctx *c, double alpha, double l
     c->dev_seed = seed;
     return cmf_newton_step(c, alpha, l1, l2, x_link, y_link, nn_mask, upd, pert, ratio, nullptr, nullptr, nullptr, nullptr);
 }
+
+// ---- generic "data times a host matrix" product (initialisers: randomized range finder) --------------
+// out (host, float64, rows_out x ncols) = op(A) * B,  A = X (which 0) or Y (which 1), op = transpose if trans.
+extern "C" int cmf_data_matmul_f64(cmf_ctx *c, int which, int trans, const double *B, int64_t b_rows, int ncols, double *out) {
+    NEED_PROBLEM(c);
+    if ((which != 0 && which != 1) || !B || !out || ncols <= 0) return fail(CMF_EINVAL, "bad argument");
+    if (!have_data(c, which)) return fail(CMF_EINVAL, "%s has not been set", which == 0 ? "X" : "Y");
+    DeviceGuard dg(c->device);
+    const int64_t ar = which == 0 ? c->m : c->d, ac = which == 0 ? c->d : c->p;       // A is ar x ac
+    const int64_t arp = which == 0 ? c->mp : c->dp, acp = which == 0 ? c->dp : c->pp;
+    const int64_t need_rows = trans ? ar : ac, out_rows = trans ? ac : ar;
+    const int64_t need_pad = trans ? arp : acp, out_pad = trans ? acp : arp;
+    if (b_rows != need_rows) return fail(CMF_EINVAL, "operand has %lld rows, expected %lld", (long long)b_rows, (long long)need_rows);
+    const int np = ncols <= 32 ? 32 : ncols <= 64 ? 64 : ncols <= 128 ? 128 : (int)rup(ncols, 256);
+    float *dB = nullptr, *dO = nullptr;
+    HIPCHK(hipMalloc((void **)&dB, (size_t)need_pad * np * sizeof(float)));
+    if (hipMalloc((void **)&dO, (size_t)out_pad * np * sizeof(float)) != hipSuccess) { (void)hipFree(dB); return fail(CMF_ENOMEM, "out of device memory"); }
+    int rc = CMF_OK;
+    do {
+        if (hipMemsetAsync(dB, 0, (size_t)need_pad * np * sizeof(float), c->stream) != hipSuccess) { rc = fail(CMF_EHIP, "memset failed"); break; }
+        rc = upload_strided<double>(c, dB, np, need_rows, ncols, B, ncols, 1);
+        if (rc != CMF_OK) break;
+        const float *A = which == 0 ? c->X : c->Y;
+        if (!A) { // native CSR
+            rc = spmm(c, c->sp[which][trans ? 1 : 0], dB, dO, out_pad, false, np);
+        } else if (!trans) {
+            rc = gemm(c, MODE_NN, A, acp, dB, np, dO, arp, np, acp);
+        } else {
+            rc = gemm(c, MODE_TN, A, acp, dB, np, dO, acp, np, arp);
+        }
+        if (rc != CMF_OK) break;
+        std::vector<float> host((size_t)out_rows * ncols);
+        if (hipMemcpy2DAsync(host.data(), ncols * sizeof(float), dO, np * sizeof(float), ncols * sizeof(float), out_rows, hipMemcpyDeviceToHost,
+                             c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CMF_EHIP, "D2H failed"); break; }
+        for (size_t i = 0; i < host.size(); ++i) out[i] = (double)host[i];
+    } while (0);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(dB);
+    (void)hipFree(dO);
+    return rc;
+}

@@ -46,28 +46,29 @@ static int set_data_csr_native(cmf_ctx *c, int which, const int64_t *indptr, con
 }
 
 template <int GL, int CH>
-static void launch_spmm(cmf_ctx *c, const CsrView &v, const float *F, float *out, bool accumulate) {
+static void launch_spmm(cmf_ctx *c, const CsrView &v, const float *F, float *out, bool accumulate, int width) {
     constexpr int RPW = 64 / GL;
     const int64_t waves = (v.rows + RPW - 1) / RPW;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
-    if (blocks) hipLaunchKernelGGL((spmm_csr_kernel<GL, CH>), dim3(blocks), dim3(256), 0, c->stream, v, F, c->kp, out, accumulate ? 1 : 0);
+    if (blocks) hipLaunchKernelGGL((spmm_csr_kernel<GL, CH>), dim3(blocks), dim3(256), 0, c->stream, v, F, width, out, accumulate ? 1 : 0);
 }
 
-// out[rows x kp] (+)= A F for a device CSR matrix A
-static int spmm(cmf_ctx *c, const CsrDev &A, const float *F, float *out, int64_t rows_pad, bool accumulate) {
+// out[rows x width] (+)= A F for a device CSR matrix A (width = k_pad unless stated)
+static int spmm(cmf_ctx *c, const CsrDev &A, const float *F, float *out, int64_t rows_pad, bool accumulate, int width = 0) {
+    if (width <= 0) width = c->kp;
     if (!accumulate && rows_pad > A.rows)
-        HIPCHK(hipMemsetAsync(out + A.rows * c->kp, 0, (size_t)(rows_pad - A.rows) * c->kp * sizeof(float), c->stream));
+        HIPCHK(hipMemsetAsync(out + A.rows * width, 0, (size_t)(rows_pad - A.rows) * width * sizeof(float), c->stream));
     CsrView v{A.indptr, A.idx, A.val, A.rows};
-    Timed tm(c, CMF_K_SPMM, 2.0 * (double)A.nnz * (double)c->kp);
-    switch (c->kp) {
-    case 32: launch_spmm<8, 1>(c, v, F, out, accumulate); break;
-    case 64: launch_spmm<16, 1>(c, v, F, out, accumulate); break;
-    case 128: launch_spmm<32, 1>(c, v, F, out, accumulate); break;
-    case 256: launch_spmm<64, 1>(c, v, F, out, accumulate); break;
-    case 512: launch_spmm<64, 2>(c, v, F, out, accumulate); break;
-    case 768: launch_spmm<64, 3>(c, v, F, out, accumulate); break;
-    case 1024: launch_spmm<64, 4>(c, v, F, out, accumulate); break;
-    default: return fail(CMF_EUNSUPPORTED, "native CSR path supports n_components <= 1024 (k_pad=%d)", c->kp);
+    Timed tm(c, CMF_K_SPMM, 2.0 * (double)A.nnz * (double)width);
+    switch (width) {
+    case 32: launch_spmm<8, 1>(c, v, F, out, accumulate, width); break;
+    case 64: launch_spmm<16, 1>(c, v, F, out, accumulate, width); break;
+    case 128: launch_spmm<32, 1>(c, v, F, out, accumulate, width); break;
+    case 256: launch_spmm<64, 1>(c, v, F, out, accumulate, width); break;
+    case 512: launch_spmm<64, 2>(c, v, F, out, accumulate, width); break;
+    case 768: launch_spmm<64, 3>(c, v, F, out, accumulate, width); break;
+    case 1024: launch_spmm<64, 4>(c, v, F, out, accumulate, width); break;
+    default: return fail(CMF_EUNSUPPORTED, "native CSR path supports operand widths 32..1024 (got %d)", width);
     }
     HIPCHK(hipGetLastError());
     return CMF_OK;
@@ -151,3 +152,4 @@ static int sparse_residual_sq(cmf_ctx *c, int which, double *dev_out) {
     HIPCHK(hipStreamSynchronize(c->stream));
     return CMF_OK;
 }
+

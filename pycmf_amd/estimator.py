@@ -11,7 +11,7 @@ import numpy as np
 from sklearn.base import BaseEstimator, TransformerMixin
 from sklearn.utils import check_array
 
-from .factor_init import initialize_mf, init_custom
+from .factor_init import initialize_mf, init_custom, DeviceOperand, DEVICE_SVD_MIN_CELLS
 from .solver_shell import HipMUSolver, HipNewtonSolver
 from .topic_terms import print_topic_terms_from_matrix, print_topic_terms_with_importances
 
@@ -63,29 +63,6 @@ def collective_matrix_factorization(X, Y, U=None, V=None, Z=None,
     if y_link not in ("linear", "logit"):
         raise ValueError("No such link %s for y_link" % y_link)
 
-    # ---- initial factors (cmf.py:402-430)
-    if x_init == 'custom':
-        if X is not None:
-            U = init_custom(U, X, n_components, 0, non_negative=U_non_negative, random_state=random_state)
-            V = init_custom(V, X, n_components, 1, non_negative=V_non_negative, random_state=random_state)
-    else:
-        x_init = "random" if x_link == "logit" else x_init
-        U, V = initialize_mf(X, n_components, init=x_init, random_state=random_state,
-                             non_negative=(U_non_negative or V_non_negative))
-    if y_init == 'custom':
-        if Y is not None:
-            V = init_custom(V, Y, n_components, 0, non_negative=V_non_negative, random_state=random_state)
-            Z = init_custom(Z, Y, n_components, 1, non_negative=Z_non_negative, random_state=random_state)
-        V_from_y = V
-    else:
-        y_init = "random" if y_link == "logit" else y_init
-        V_from_y, Z = initialize_mf(Y, n_components, init=y_init, random_state=random_state,
-                                    non_negative=(Z_non_negative or V_non_negative))
-    if U_non_negative == Z_non_negative:
-        V = (V + V_from_y) / 2
-    elif Z_non_negative and not U_non_negative:
-        V = V_from_y
-
     # ---- solver dispatch (cmf.py:433-453)
     common = dict(max_iter=max_iter, tol=tol, verbose=verbose, update_U=update_U, update_V=update_V,
                   update_Z=update_Z, l1_reg=l1_reg, l2_reg=l2_reg, random_state=random_state, device=device)
@@ -104,6 +81,40 @@ def collective_matrix_factorization(X, Y, U=None, V=None, Z=None,
                                         sg_sample_ratio=sg_sample_ratio, sg_sampler=sg_sampler, **common)
     else:
         raise ValueError("No such solver: %s" % solver)
+
+    # Large inputs go to the GPU before the initialisers run, so that the randomized SVD behind
+    # 'svd' / 'nndsvd*' can use the device copy for its products (the solver later reuses the upload).
+    op_x = op_y = None
+    big = [M is not None and M.shape[0] * M.shape[1] >= DEVICE_SVD_MIN_CELLS for M in (X, Y)]
+    needs_svd = [i not in ('custom', 'random') for i in (x_init, y_init)]
+    if X is not None and Y is not None and any(b and n for b, n in zip(big, needs_svd)):
+        ctx = solver_object.bind_data(X, Y, n_components)
+        if ctx is not None:
+            op_x = DeviceOperand(ctx, 0, X.shape)
+            op_y = DeviceOperand(ctx, 1, Y.shape)
+
+    # ---- initial factors (cmf.py:402-430)
+    if x_init == 'custom':
+        if X is not None:
+            U = init_custom(U, X, n_components, 0, non_negative=U_non_negative, random_state=random_state)
+            V = init_custom(V, X, n_components, 1, non_negative=V_non_negative, random_state=random_state)
+    else:
+        x_init = "random" if x_link == "logit" else x_init
+        U, V = initialize_mf(X, n_components, init=x_init, random_state=random_state,
+                             non_negative=(U_non_negative or V_non_negative), operand=op_x)
+    if y_init == 'custom':
+        if Y is not None:
+            V = init_custom(V, Y, n_components, 0, non_negative=V_non_negative, random_state=random_state)
+            Z = init_custom(Z, Y, n_components, 1, non_negative=Z_non_negative, random_state=random_state)
+        V_from_y = V
+    else:
+        y_init = "random" if y_link == "logit" else y_init
+        V_from_y, Z = initialize_mf(Y, n_components, init=y_init, random_state=random_state,
+                                    non_negative=(Z_non_negative or V_non_negative), operand=op_y)
+    if U_non_negative == Z_non_negative:
+        V = (V + V_from_y) / 2
+    elif Z_non_negative and not U_non_negative:
+        V = V_from_y
 
     U, V, Z = _writable_f64(U), _writable_f64(V), _writable_f64(Z)
     U, V, Z, n_iter = solver_object.fit_iterative_update(X, Y, U, V, Z)

@@ -14,6 +14,65 @@ from sklearn.utils.extmath import randomized_svd
 from sklearn.utils.validation import check_non_negative
 
 
+# matrices with at least this many cells route the randomized SVD's big products through the GPU
+DEVICE_SVD_MIN_CELLS = 4_000_000
+
+
+class DeviceOperand:
+    """X or Y as it already sits on the GPU: ``dot(B)`` = M @ B and ``tdot(B)`` = M.T @ B computed by
+    libcmfhip (MFMA GEMM or native CSR SpMM, float32) for a host matrix B."""
+
+    def __init__(self, ctx, which, shape):
+        self.ctx, self.which, self.shape = ctx, which, shape
+
+    def dot(self, B):
+        return self.ctx.data_matmul(self.which, False, B)
+
+    def tdot(self, B):
+        return self.ctx.data_matmul(self.which, True, B)
+
+
+def randomized_svd_device(op, n_components, random_state=None, n_oversamples=10):
+    """Randomized truncated SVD (Halko, Martinsson & Tropp 2011, Alg. 4.3/4.4 + 5.1) with the same
+    defaults as ``sklearn.utils.extmath.randomized_svd`` -- n_iter 'auto' (7 when k < 0.1 min(shape),
+    else 4), LU-normalised power iterations, final QR, 'auto' transposition, u-based sign flip -- and the
+    same Gaussian test matrix for a given ``random_state``; only the products with the data matrix
+    run on the GPU (in float32), the tall-skinny LU / QR / small SVD stay on the host in float64."""
+    from scipy import linalg
+    n_samples, n_features = op.shape
+    size = n_components + n_oversamples
+    n_iter = 7 if n_components < 0.1 * min(op.shape) else 4
+    transpose = n_samples < n_features
+    fwd, bwd = (op.tdot, op.dot) if transpose else (op.dot, op.tdot)   # products with A and A.T, A = M.T if transpose
+    cols = n_samples if transpose else n_features
+    rng = check_random_state(random_state)
+    Q = rng.normal(size=(cols, size))
+    for _ in range(n_iter):
+        Q, _ = linalg.lu(fwd(Q), permute_l=True, check_finite=False)
+        Q, _ = linalg.lu(bwd(Q), permute_l=True, check_finite=False)
+    Q, _ = linalg.qr(fwd(Q), mode="economic", check_finite=False)
+    B = bwd(Q).T                                                         # Q.T @ A
+    Uhat, s, Vt = linalg.svd(B, full_matrices=False, lapack_driver="gesdd", check_finite=False)
+    U = Q @ Uhat
+    # svd_flip (u-based decision when not transposed, v-based when transposed), as sklearn does
+    if not transpose:
+        signs = np.sign(U[np.argmax(np.abs(U), axis=0), range(U.shape[1])])
+    else:
+        signs = np.sign(Vt[range(Vt.shape[0]), np.argmax(np.abs(Vt), axis=1)])
+    signs[signs == 0] = 1.0
+    U *= signs
+    Vt *= signs[:, None]
+    if transpose:
+        return Vt[:n_components, :].T, s[:n_components], U[:, :n_components].T
+    return U[:, :n_components], s[:n_components], Vt[:n_components, :]
+
+
+def _rsvd(M, k, random_state, operand):
+    if operand is not None and M.shape[0] * M.shape[1] >= DEVICE_SVD_MIN_CELLS:
+        return randomized_svd_device(operand, k, random_state=random_state)
+    return randomized_svd(M, k, random_state=random_state)
+
+
 def _l2(x):
     return sqrt(float(np.dot(x.ravel(), x.ravel())))
 
@@ -42,13 +101,13 @@ def _random_pair(M, k, random_state, non_negative):
     return A, B
 
 
-def _svd_pair(M, k, random_state):
+def _svd_pair(M, k, random_state, operand=None):
     # cmf.py:119-142; randomized_svd yields at most min(M.shape) triplets -> zero-pad
     n, f = M.shape
     if min(n, f) < k:
         warnings.warn('The number of components is smaller than the rank in svd initialization.' +
                       'The input will be padded with zeros to compensate for the lack of singular values.')
-    Us, S, Vt = randomized_svd(M, k, random_state=random_state)
+    Us, S, Vt = _rsvd(M, k, random_state, operand)
     if k > f:
         r = Us.shape[1]
         Up = np.zeros((n, k)); Up[:, :r] = Us
@@ -59,9 +118,9 @@ def _svd_pair(M, k, random_state):
     return np.dot(Us, root), np.dot(root, Vt)
 
 
-def _nndsvd_pair(M, k, variant, random_state, eps):
+def _nndsvd_pair(M, k, variant, random_state, eps, operand=None):
     # Boutsidis & Gallopoulos NNDSVD, as in cmf.py:144-197
-    Us, S, Vt = randomized_svd(M, k, random_state=random_state)
+    Us, S, Vt = _rsvd(M, k, random_state, operand)
     A = np.zeros(Us.shape)
     B = np.zeros(Vt.shape)
     A[:, 0] = np.sqrt(S[0]) * np.abs(Us[:, 0])
@@ -93,8 +152,11 @@ def _nndsvd_pair(M, k, variant, random_state, eps):
     return A, B
 
 
-def initialize_mf(M, n_components, init=None, eps=1e-6, random_state=None, non_negative=False):
-    """Initial guess M ~ A @ B;  returns (A, B.T).  pycmf/cmf.py:41-202."""
+def initialize_mf(M, n_components, init=None, eps=1e-6, random_state=None, non_negative=False, operand=None):
+    """Initial guess M ~ A @ B;  returns (A, B.T).  pycmf/cmf.py:41-202.
+
+    ``operand`` (optional :class:`DeviceOperand` for M): large matrices run the randomized SVD's
+    products on the GPU where M already resides; small ones use sklearn on the host."""
     if non_negative:
         check_non_negative(M, "MF initialization")
     n_features = M.shape[1]
@@ -109,12 +171,12 @@ def initialize_mf(M, n_components, init=None, eps=1e-6, random_state=None, non_n
     elif init == 'svd':
         if non_negative:
             raise ValueError('SVD initialization incompatible with NMF (use nndsvd instead)')
-        A, B = _svd_pair(M, n_components, random_state)
+        A, B = _svd_pair(M, n_components, random_state, operand)
     elif init in ('nndsvd', 'nndsvda', 'nndsvdar'):
         if not non_negative:
             warnings.warn('%s results in non-negative constrained factors,' % init +
                           'so SVD initialization should provide better initial estimate')
-        A, B = _nndsvd_pair(M, n_components, init, random_state, eps)
+        A, B = _nndsvd_pair(M, n_components, init, random_state, eps, operand)
     else:
         raise ValueError("Invalid init argument")
     return A, B.T

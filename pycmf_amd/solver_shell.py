@@ -78,11 +78,21 @@ class _HipIterativeSolver:
         return (1 if self.U_non_negative else 0) | (2 if self.V_non_negative else 0) | \
             (4 if self.Z_non_negative else 0)
 
+    def bind_data(self, X, Y, k):
+        """Upload X and Y ahead of the factors (the initialisers use the device copies)."""
+        m = X.shape[0] if X is not None else None
+        d = X.shape[1] if X is not None else Y.shape[0]
+        p = Y.shape[1] if Y is not None else None
+        if m is None or p is None:
+            return None
+        return self._bind_dims(X, Y, m, d, p, k)
+
     def _bind(self, X, Y, U, V, Z):
         """Upload X, Y (once per distinct pair) and size the device problem."""
         m, k = U.shape
-        d = V.shape[0]
-        p = Z.shape[0]
+        return self._bind_dims(X, Y, m, V.shape[0], Z.shape[0], k)
+
+    def _bind_dims(self, X, Y, m, d, p, k):
         key = (id(X), id(Y), m, d, p, k)
         if self._ctx is None:
             self._ctx = _lib.Context(self.device, self.stream)

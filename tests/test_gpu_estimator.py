@@ -301,3 +301,40 @@ def test_missing_library_is_loud(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libcmfhip.so")
     with pytest.raises(RuntimeError):
         _lib.load()
+
+
+def test_device_assisted_randomized_svd_matches_sklearn():
+    """above DEVICE_SVD_MIN_CELLS the initialisers' randomized SVD takes its products
+    from the GPU copy of the data; same algorithm and test matrix as sklearn -> same factors (fp32)."""
+    from sklearn.utils.extmath import randomized_svd
+    from pycmf_amd import _lib
+    from pycmf_amd.factor_init import DeviceOperand, randomized_svd_device, initialize_mf
+    rng = np.random.RandomState(0)
+    for shape in ((2600, 1700), (1500, 2900)):     # tall and wide (sklearn transposes the wide one)
+        M = np.abs(rng.randn(shape[0], 12) @ rng.randn(12, shape[1])) + 0.05 * np.abs(rng.randn(*shape))
+        Y = np.abs(rng.randn(shape[1], 5))
+        ctx = _lib.Context(0)
+        ctx.set_problem(shape[0], shape[1], 5, 8)
+        ctx.set_data(0, M); ctx.set_data(1, Y)
+        op = DeviceOperand(ctx, 0, M.shape)
+        np.testing.assert_allclose(op.dot(Y), M @ Y, rtol=2e-5)
+        np.testing.assert_allclose(op.tdot(M[:, :3]), M.T @ M[:, :3], rtol=2e-5)
+        U1, s1, V1 = randomized_svd_device(op, 8, random_state=3)
+        U0, s0, V0 = randomized_svd(M, 8, random_state=3)
+        np.testing.assert_allclose(s1, s0, rtol=1e-4)
+        np.testing.assert_allclose(U1 * s1 @ V1, U0 * s0 @ V0, rtol=0, atol=2e-3 * np.abs(M).max())
+        A1, B1 = initialize_mf(M, 8, init="nndsvd", random_state=3, non_negative=True, operand=op)
+        A0, B0 = initialize_mf(M, 8, init="nndsvd", random_state=3, non_negative=True)
+        np.testing.assert_allclose(A1 @ B1.T, A0 @ B0.T, rtol=0, atol=5e-3 * np.abs(M).max())
+        ctx.close()
+
+
+def test_fit_with_device_assisted_init():
+    rng = np.random.RandomState(1)
+    U, V, Z = np.abs(rng.randn(2400, 6)), np.abs(rng.randn(1800, 6)), np.abs(rng.randn(40, 6))
+    X, Y = U @ V.T, V @ Z.T
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = CMF(n_components=6, solver="mu", random_state=0, max_iter=200)
+        m.fit(X, Y)
+    assert m.reconstruction_err_ < 0.05 * (np.linalg.norm(X) + np.linalg.norm(Y))
