@@ -145,3 +145,54 @@ def test_device_sampler_masks(lib):
     s = int(d * 0.37)
     np.testing.assert_allclose(U, 0.5 * s / 1e6, rtol=1e-5)
     ctx.close()
+
+
+def test_newton_large_k_fallback_paths(lib):
+    """k_pad = 512: per-row sweeps take the masked-dense GEMM formulation (Khatri-Rao images) and the
+    safe inverse runs entirely on the Jacobi kernel with its global-memory workspace."""
+    from oracle import cmf_oracle as O
+    from pycmf_amd.solver_shell import HipNewtonSolver
+    m, d, p, k = 40, 36, 20, 300
+    rng = np.random.RandomState(2)
+    X, Y = rng.rand(m, d), np.abs(rng.randn(d, p))
+    U0, V0, Z0 = 0.1 * rng.randn(m, k), 0.1 * rng.randn(d, k), 0.1 * rng.randn(p, k)
+    kw = dict(alpha=0.4, l1_reg=0.0, l2_reg=0.3, x_link="logit", y_link="linear", U_non_negative=False,
+              V_non_negative=False, Z_non_negative=False, hessian_pertubation=0.2)
+    s = HipNewtonSolver(**kw)
+    U, V, Z = U0.copy(), V0.copy(), Z0.copy()
+    s.update_step(X, Y, U, V, Z, 0.0, 0.3, 0.4)
+    s.release()
+    o = O.OracleSolver("newton", **kw)
+    Ur, Vr, Zr = U0.copy(), V0.copy(), Z0.copy()
+    o.update_step(X, Y, Ur, Vr, Zr)
+    for a, b in ((U, Ur), (V, Vr), (Z, Zr)):
+        np.testing.assert_allclose(a, b, rtol=5e-3, atol=5e-3 * np.abs(b).max())
+
+
+@pytest.mark.parametrize("row_kernel", [0, 1])
+def test_row_kernel_and_gemm_formulation_agree(lib, row_kernel):
+    """The fused gather kernel and the masked-dense GEMM formulation are two evaluations of the same
+    sweep: identical host-drawn samples -> same factors."""
+    from oracle import cmf_oracle as O
+    m, d, p, k = 310, 280, 140, 40
+    rng = np.random.RandomState(8)
+    X, Y = np.abs(rng.randn(m, d)), rng.rand(d, p)
+    U0, V0, Z0 = 0.3 * rng.randn(m, k), 0.3 * rng.randn(d, k), 0.3 * rng.randn(p, k)
+    np.random.seed(4)
+    masks = {"U": [], "Z": [], "V": []}
+    Ur, Vr, Zr = U0.copy(), V0.copy(), Z0.copy()
+    O.newton_update_step(X, Y, Ur, Vr, Zr, 0.4, 0.01, 0.05, "linear", "logit", False, False, False,
+                         ratio=0.5, pert=0.2, masks=masks)
+    ctx = lib.Context(0)
+    ctx.set_option("row_kernel", row_kernel)
+    ctx.set_problem(m, d, p, k)
+    ctx.set_data(0, X); ctx.set_data(1, Y)
+    for w, F in enumerate((U0, V0, Z0)):
+        ctx.set_factor(w, F)
+    ctx.newton_step(0.4, 0.01, 0.05, "linear", "logit", 0, 7, 0.2, 0.5,
+                    np.array(masks["U"]), np.array(masks["Z"]),
+                    np.array([a for a, _ in masks["V"]]), np.array([b for _, b in masks["V"]]))
+    got = [ctx.get_factor(w) for w in range(3)]
+    ctx.close()
+    for a, b in zip(got, (Ur, Vr, Zr)):
+        np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-3 * np.abs(b).max())
