@@ -144,11 +144,19 @@ def main():
     from pycmf_amd import _lib
     from pycmf_amd.sharded import make_torch_sharded_mu, make_torch_sharded_newton, shard_bounds
 
+    # Test hooks (not used by the driver): CMF_BENCH_SAME_DEVICE=1 puts every rank on GPU 0 and
+    # CMF_BENCH_BACKEND=gloo swaps RCCL for gloo, so the N>1 code path can be exercised on a 1-GPU box.
+    if os.environ.get("CMF_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("CMF_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     w = WORKLOADS[args.workload]
     m, d, p, k = w["m"], w["d"], w["p"], w["k"]

@@ -14,6 +14,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -121,6 +122,7 @@ struct cmf_ctx {
     DevBuf dpart;                         // double partial sums
     double *dscalar = nullptr;            // 4 doubles
     std::vector<void *> owned;
+    std::set<const void *> lds_opt_in;    // kernels whose >64 KB dynamic-LDS attribute is set on THIS device
 
     // timing
     bool timing = false;
@@ -224,6 +226,14 @@ static int ensure(cmf_ctx *c, DevBuf &b, size_t bytes) {
     return CMF_OK;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember it per context, not per process
+static int allow_big_lds(cmf_ctx *c, const void *fn, int bytes) {
+    if (c->lds_opt_in.count(fn)) return CMF_OK;
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    c->lds_opt_in.insert(fn);
+    return CMF_OK;
+}
+
 // ------------------------------------------------------------------ GEMM launcher
 struct GemmPlan {
     int bn;
@@ -259,13 +269,7 @@ static int launch_gemm_pipe(cmf_ctx *c, const GemmArgs &a, const GemmPlan &pl) {
 #define CMF_LAUNCH(BN_)                                                                          \
     do {                                                                                         \
         using Cfg = GemmCfg<MODE, BN_>;                                                          \
-        static bool attr_set = false;                                                            \
-        if (!attr_set) {                                                                         \
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<MODE, BN_, ROLE, PIPE>), \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,               \
-                                       (int)Cfg::LDS_BYTES));                                    \
-            attr_set = true;                                                                     \
-        }                                                                                        \
+        CHK(allow_big_lds(c, reinterpret_cast<const void *>(&gemm_kernel<MODE, BN_, ROLE, PIPE>), (int)Cfg::LDS_BYTES)); \
         hipLaunchKernelGGL((gemm_kernel<MODE, BN_, ROLE, PIPE>), grid, block, Cfg::LDS_BYTES, c->stream, a); \
     } while (0)
     if constexpr (MODE == MODE_NT) {

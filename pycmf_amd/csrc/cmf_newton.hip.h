@@ -56,12 +56,7 @@ static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat,
             HIPCHK(hipMemcpyAsync(c->eigcopy.p, Hin, (size_t)nmat * stride * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
             src = (const float *)c->eigcopy.p;
         }
-        static bool attr_c = false;
-        if (!attr_c) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_safe_inverse_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            attr_c = true;
-        }
+        CHK(allow_big_lds(c, reinterpret_cast<const void *>(&chol_safe_inverse_kernel), 150 * 1024));
         hipLaunchKernelGGL(chol_safe_inverse_kernel, dim3(nmat), dim3(256), tri_bytes, c->stream, src, Hout, (int *)c->eigflag.p, n, kp,
                            stride, (float)pert, nmat);
         HIPCHK(hipGetLastError());
@@ -70,12 +65,7 @@ static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat,
     }
     const size_t lds_need = (size_t)(2 * n * n + n) * sizeof(float);
     if (lds_need <= 150 * 1024) {
-        static bool attr = false;
-        if (!attr) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&jacobi_safe_inverse_kernel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            attr = true;
-        }
+        CHK(allow_big_lds(c, reinterpret_cast<const void *>(&jacobi_safe_inverse_kernel<true>), 150 * 1024));
         hipLaunchKernelGGL((jacobi_safe_inverse_kernel<true>), dim3(nmat), dim3(256), lds_need, c->stream, Hin, Hout,
                            (float *)nullptr, n, kp, stride, (float)pert, nmat, 30, need);
     } else {
@@ -113,12 +103,7 @@ static int safe_solve_rows(cmf_ctx *c, float *Hc, const float *grad, float *step
         // flagged matrices: |lambda| / clamp by Jacobi, in place (the solve kernel does not modify H)
         const size_t lds_need = (size_t)(2 * n * n + n) * sizeof(float);
         if (lds_need <= 150 * 1024) {
-            static bool attr = false;
-            if (!attr) {
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&jacobi_safe_inverse_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-                attr = true;
-            }
+            CHK(allow_big_lds(c, reinterpret_cast<const void *>(&jacobi_safe_inverse_kernel<true>), 150 * 1024));
             hipLaunchKernelGGL((jacobi_safe_inverse_kernel<true>), dim3((unsigned)nr), dim3(256), lds_need, c->stream, (const float *)Hc, Hc,
                                (float *)nullptr, n, kp, stride, (float)pert, (int)nr, 30, (const int *)flags);
         } else {
@@ -405,12 +390,7 @@ static int sweep_v_rows(cmf_ctx *c, double alpha, double l1, double l2, int x_li
 template <int KP>
 static int launch_row_hess_kp(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
     using Cfg = RowHessCfg<KP>;
-    static bool attr = false;
-    if (!attr) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&row_hess_kernel<KP>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)Cfg::LDS_BYTES));
-        attr = true;
-    }
+    CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<KP>), (int)Cfg::LDS_BYTES));
     hipLaunchKernelGGL((row_hess_kernel<KP>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
     HIPCHK(hipGetLastError());
     return CMF_OK;
