@@ -75,7 +75,7 @@ def test_newton_vs_oracle_midsize(lib, xl, yl, ratio, k):
     """Sizes that span several 256-row tiles and a padded k; identical host-drawn samples."""
     from oracle import cmf_oracle as O
     from pycmf_amd.solver_shell import HipNewtonSolver
-    m, d, p = 300, 270, 130
+    m, d, p = (300, 270, 130) if k < 100 else (270, 90, 40)  # the oracle does one eigh(k x k) per row
     rng = np.random.RandomState(k)
     X = rng.rand(m, d) if xl == "logit" else np.abs(rng.randn(m, d))
     Y = rng.rand(d, p) if yl == "logit" else np.abs(rng.randn(d, p))
