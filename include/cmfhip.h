@@ -68,7 +68,7 @@ int cmf_device_count(int *count);
 int cmf_ctx_create(cmf_ctx **out, int device, void *stream);
 int cmf_ctx_destroy(cmf_ctx *ctx);
 int cmf_sync(cmf_ctx *ctx);
-/* tuning knobs (A/B measurements in one process): "gemm_pipe" 0..4 = staging schedule of the
+/* tuning knobs (A/B measurements in one process): "gemm_pipe" 0..5 | 10 = staging schedule of the
  * data-pass GEMM kernels, "gemm_split" n = force the split-K factor (<= 0: heuristic),
  * "sparse_mode" 0 auto | 1 dense | 2 native CSR (set before cmf_set_data_csr),
  * "row_kernel" 1 fused gather kernel | 0 masked-dense GEMMs for per-row Newton sweeps,

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 #include <string>
@@ -296,6 +297,8 @@ static int launch_gemm_mode(cmf_ctx *c, const GemmArgs &a, const GemmPlan &pl) {
         if (c->opt_pipe == 2) return launch_gemm_pipe<MODE, ROLE, (ROLE == 0 && MODE != MODE_NT) ? 2 : 0>(c, a, pl);
         if (c->opt_pipe == 3) return launch_gemm_pipe<MODE, ROLE, (ROLE == 0 && MODE != MODE_NT) ? 3 : 0>(c, a, pl);
         if (c->opt_pipe == 4) return launch_gemm_pipe<MODE, ROLE, (ROLE == 0 && MODE != MODE_NT) ? 4 : 0>(c, a, pl);
+        if (c->opt_pipe == 5) return launch_gemm_pipe<MODE, ROLE, (ROLE == 0 && MODE != MODE_NT) ? 5 : 0>(c, a, pl);
+        if (c->opt_pipe == 10) return launch_gemm_pipe<MODE, ROLE, (ROLE == 0 && MODE != MODE_NT) ? 10 : 0>(c, a, pl);
     }
     return launch_gemm_pipe<MODE, ROLE, 0>(c, a, pl);
 }
@@ -438,6 +441,10 @@ extern "C" int cmf_ctx_create(cmf_ctx **out, int device, void *stream) {
         }
         c->own_stream = true;
     }
+    if (const char *e = getenv("CMF_GEMM_PIPE")) { // A/B hook for the test-suite: staging schedule of the data-pass GEMMs
+        const int v = atoi(e);
+        if ((v >= 0 && v <= 5) || v == 10) c->opt_pipe = v;
+    }
     void *ds = nullptr;
     int rc = dev_alloc(c, &ds, 8 * sizeof(double));
     if (rc != CMF_OK) {
@@ -491,7 +498,7 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         return CMF_OK;
     }
     if (!strcmp(name, "gemm_pipe")) {
-        if (value < 0 || value > 4) return fail(CMF_EINVAL, "gemm_pipe must be 0..4");
+        if (value < 0 || (value > 5 && value != 10)) return fail(CMF_EINVAL, "gemm_pipe must be 0..5 or 10");
         c->opt_pipe = (int)value;
     } else if (!strcmp(name, "gemm_split")) {
         c->opt_split = (int)value;

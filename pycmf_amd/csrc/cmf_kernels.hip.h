@@ -98,6 +98,11 @@ struct VecLoad<4> {
 //   2: LDS writes two pieces per group in groups 0..3, loads of tile t+2 at group 4
 //   3: LDS writes four pieces per group in groups 0..1, loads of tile t+2 at group 2
 //   4: all eight LDS writes in group 0, loads of tile t+2 at group 1
+//   5: schedule 4 with waves 4-7 staging half a K-step later than waves 0-3 (stagger)
+//  10: direct-to-LDS loads of tile t+1 at group 0 (no staging registers, no ds_write): TN +1 %, NN -5 %
+// Diagnostic builds (not kept): no staging at all 153-154 TF/s (98 %), LDS writes only 146-147, no barrier +0.5 %:
+// the 7 % between schedule 4 and the bare MFMA+fragment loop is the 64 KB/step of LDS fill traffic and the
+// global loads themselves, not where in the step they are issued.
 // (also tried and dropped: piece p written in group p and re-loaded at once: -1..-3 %; one piece in the shadow
 //  of each MFMA: -25 %, hipcc's conservative waitcnts serialise it)
 template <int MODE, int BN, int ROLE = 0, int PIPE = 0>
@@ -207,11 +212,59 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
     //    burst in front of the barrier;
     //  * the global loads of tile t+2 are issued at group 8 into the registers just drained.
     // sched_barrier(0) pins that order (hipcc otherwise re-serialises reads and MFMAs).
+    const bool late = __builtin_amdgcn_readfirstlane(wid) >= 4; // wave-uniform by construction
+    // PIPE 10: direct-to-LDS loads (global_load_lds_dwordx4): no staging registers, no ds_write.  The LDS
+    // image must then be lane-linear, so the k-contiguous A tile of the NN form loses its row padding and is
+    // XOR-swizzled instead (16-byte chunk c of row r lives at chunk c ^ (r & 7)); the permutation is applied to
+    // the per-lane SOURCE address and again on the fragment read.
+    constexpr bool GLDS = (PIPE == 10);
+    constexpr int APK = GLDS ? C::BK : C::PADK; // floats per row of a k-contiguous A tile
+    auto glds_tile = [&](float *As, float *Bs, int64_t k0) {
+        typedef __attribute__((address_space(3))) float lds_f;
+#pragma unroll
+        for (int p = 0; p < C::A_LD; ++p) {
+            const int idx = t + C::NT * p;
+            const int wave_first = __builtin_amdgcn_readfirstlane(idx & ~63);
+            const float *src;
+            if constexpr (C::A_KC) {
+                const int r = idx >> 3, cpos = idx & 7;
+                src = g.A + (row0 + r) * g.lda + k0 + 4 * (cpos ^ (r & 7));
+            } else {
+                const int r = idx >> 6, c4 = idx & 63;
+                int64_t col = row0 + 4 * c4;
+                if (ROLE == 1 && col > g.Mout - 4) col = g.Mout - 4;
+                src = g.A + (k0 + r) * g.lda + col;
+            }
+            __builtin_amdgcn_global_load_lds(src, (lds_f *)(As + 4 * wave_first), 16, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < C::B_LD; ++p) {
+            const int idx = t + C::NT * p;
+            if (C::B_F4 >= C::NT || idx < C::B_F4) {
+                const int wave_first = __builtin_amdgcn_readfirstlane(idx & ~63);
+                constexpr int F4R = BN / 4;
+                const int r = idx / F4R, c4 = idx % F4R;
+                const float *src = g.B + (k0 + r) * g.ldb + n0 + 4 * c4;
+                __builtin_amdgcn_global_load_lds(src, (lds_f *)(Bs + 4 * wave_first), 16, 0, 0);
+            }
+        }
+    };
     auto compute = [&](const float *As, const float *Bs, float *nAs, float *nBs, bool do_write, bool do_load,
                        int64_t next_k0) {
         auto side = [&](int sidx) {
             if constexpr (PIPE == 0) {
                 if (sidx == 0 && do_load) gload(next_k0);
+            } else if constexpr (PIPE == 10) {
+                if (sidx == 0 && do_write) glds_tile(nAs, nBs, next_k0); // next_k0 = tile t+1 here
+            } else if constexpr (PIPE == 5) {
+                // schedule 4 with the two waves of every SIMD staggered by half a K-step: waves 0-3 stage in
+                // groups 0/1, waves 4-7 in groups 8/9, so one wave's staging sits beside its partner's MFMAs
+                const int g0 = late ? 8 : 0;
+                if (sidx == g0) {
+                    if (do_write) lstore(nAs, nBs);
+                } else if (sidx == g0 + 1) {
+                    if (do_load) gload(next_k0);
+                }
             } else {
                 constexpr int WPG = 1 << (PIPE - 1); // LDS-write pieces per group: 1, 2 or 4
                 constexpr int NG = 8 / WPG;          // groups that carry writes; loads go at group NG
@@ -229,8 +282,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
             f32x4 a[2][C::TM];
             auto lda_frag = [&](int q, f32x4 *dst) {
 #pragma unroll
-                for (int i = 0; i < C::TM; ++i)
-                    dst[i] = *reinterpret_cast<const f32x4 *>(As + (wrow0 + 32 * i + l31) * C::PADK + 4 * (2 * q + lh));
+                for (int i = 0; i < C::TM; ++i) {
+                    const int row = wrow0 + 32 * i + l31;
+                    const int chunk = GLDS ? ((2 * q + lh) ^ (row & 7)) : (2 * q + lh);
+                    dst[i] = *reinterpret_cast<const f32x4 *>(As + row * APK + 4 * chunk);
+                }
             };
             if constexpr (C::B_KC) {
                 f32x4 b[2][C::TN];
@@ -305,7 +361,21 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
         }
     };
 
-    if (nkt > 0) {
+    if constexpr (GLDS) {
+        static_assert(MODE != MODE_NT, "direct-to-LDS staging is wired for the NN / TN forms");
+        if (nkt > 0) {
+            glds_tile(smem, smem + C::A_ELEMS, kbeg);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int kt = 0; kt < nkt; ++kt) {
+                float *cur = smem + (kt & 1) * C::STAGE;
+                float *nxt = smem + ((kt + 1) & 1) * C::STAGE;
+                compute(cur, cur + C::A_ELEMS, nxt, nxt + C::A_ELEMS, kt + 1 < nkt, false, kbeg + (int64_t)(kt + 1) * C::BK);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+    } else if (nkt > 0) {
         gload(kbeg);
         lstore(smem, smem + C::A_ELEMS);
         if (PIPE != 0 && nkt > 1) gload(kbeg + C::BK); // tile 1 waits in registers
