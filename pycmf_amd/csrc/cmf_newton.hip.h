@@ -390,8 +390,13 @@ static int sweep_v_rows(cmf_ctx *c, double alpha, double l1, double l2, int x_li
 template <int KP>
 static int launch_row_hess_kp(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
     using Cfg = RowHessCfg<KP>;
-    CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<KP>), (int)Cfg::LDS_BYTES));
-    hipLaunchKernelGGL((row_hess_kernel<KP>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
+    if (c->opt_rowstagger) {
+        CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<KP, 1>), (int)Cfg::LDS_BYTES));
+        hipLaunchKernelGGL((row_hess_kernel<KP, 1>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
+    } else {
+        CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<KP, 0>), (int)Cfg::LDS_BYTES));
+        hipLaunchKernelGGL((row_hess_kernel<KP, 0>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
+    }
     HIPCHK(hipGetLastError());
     return CMF_OK;
 }

@@ -45,9 +45,10 @@ struct RowHessCfg {
     static constexpr size_t LDS_BYTES = (2 * TILE + 2 * 64) * sizeof(float);
 };
 
-template <int KP>
+template <int KP, int STAGGER = 1>
 __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
     using C = RowHessCfg<KP>;
+    const bool late = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >= 4;
     extern __shared__ __attribute__((aligned(16))) float rsm[];
     auto tile_of = [&](int b) { return rsm + b * C::TILE; };        // two row tiles
     auto wv_of = [&](int b) { return rsm + 2 * C::TILE + 32 * b; }; // their weights
@@ -118,32 +119,38 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
     auto mfma_tile = [&](int cb, bool do_stage, int nb, bool do_gather, int tl_gather, bool do_idx, int tl_idx) {
         const float *Rt = tile_of(cb);
         const float *Wv = wv_of(cb);
-        float a[2][C::TM], b[2][C::TN];
-        auto ld_frag = [&](int sidx, float *da, float *db) {
+        float a[2][C::TM], b[2][C::TN], wf[2];
+        // raw fragment + weight reads are prefetched one group ahead; the scaling by w_j happens right before the
+        // MFMAs that consume the fragment (multiplying at load time would expose the LDS latency every group)
+        auto ld_frag = [&](int sidx, float *da, float *db, float *dw) {
             const int kk = 2 * sidx + lh;
-            const float w = Wv[kk];
+            *dw = Wv[kk];
             VecLoad<C::TM>::ld(Rt + kk * KP + wrow0 + C::TM * l31, da);
             VecLoad<C::TN>::ld(Rt + kk * KP + wcol0 + C::TN * l31, db);
-#pragma unroll
-            for (int x = 0; x < C::TM; ++x) da[x] *= w;
         };
-        if (mfma_wave) ld_frag(0, a[0], b[0]);
+        if (mfma_wave) ld_frag(0, a[0], b[0], &wf[0]);
 #pragma unroll
         for (int sidx = 0; sidx < 16; ++sidx) {
-            if (mfma_wave && sidx + 1 < 16) ld_frag(sidx + 1, a[(sidx + 1) & 1], b[(sidx + 1) & 1]);
-            if (sidx == 0) {
+            if (mfma_wave && sidx + 1 < 16) ld_frag(sidx + 1, a[(sidx + 1) & 1], b[(sidx + 1) & 1], &wf[(sidx + 1) & 1]);
+            // the VALU-heavy staging of waves 4-7 runs half a step after that of waves 0-3, so that on every
+            // SIMD one wave's dot products / sigmoids sit beside its partner's MFMAs (STAGGER = 0: lockstep)
+            const int g0 = (STAGGER && late) ? 8 : 0;
+            if (sidx == g0) {
                 if (do_stage && loader) stage(nb);
-            } else if (sidx == 1) {
+            } else if (sidx == g0 + 1) {
                 if (do_gather && loader) gather(tl_gather);
                 if (do_idx && loader) load_idx(tl_idx);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (mfma_wave) {
+                float as[C::TM];
+#pragma unroll
+                for (int x = 0; x < C::TM; ++x) as[x] = a[sidx & 1][x] * wf[sidx & 1];
 #pragma unroll
                 for (int x = 0; x < C::TM; ++x)
 #pragma unroll
                     for (int y = 0; y < C::TN; ++y)
-                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sidx & 1][x], b[sidx & 1][y], acc[x][y], 0, 0, 0);
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[x], b[sidx & 1][y], acc[x][y], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
