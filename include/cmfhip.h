@@ -72,6 +72,8 @@ int cmf_sync(cmf_ctx *ctx);
  * data-pass GEMM kernels, "gemm_split" n = force the split-K factor (<= 0: heuristic),
  * "sparse_mode" 0 auto | 1 dense | 2 native CSR (set before cmf_set_data_csr),
  * "row_kernel" 1 fused gather kernel | 0 masked-dense GEMMs for per-row Newton sweeps,
+ * "z_logit_hessian_l2" 1 (live Python path, cmf_solvers.py:505-506) | 0 (Cython twin,
+ * cmf_newton_solver.pyx:287-290: Z's logit Hessian without l2 I),
  * "safe_inverse_cholesky" 1 | 0, "graph" 1 | 0 (replay MU / linear-Newton steps from a
  * captured hipGraph; automatically off while cmf_kernel_timing is enabled)              */
 int cmf_set_option(cmf_ctx *ctx, const char *name, int64_t value);

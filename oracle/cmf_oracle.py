@@ -226,11 +226,16 @@ def newton_sweep_U(U, V, X, alpha, l1, l2, link, non_negative, ratio, pert,
 
 
 def newton_sweep_Z(Z, V, Y, alpha, l1, l2, link, non_negative, ratio, pert,
-                   masks=None):
+                   masks=None, cython_variant=False):
     """Row-wise Newton sweep over Z            (cmf_solvers.py:488-508).
 
     Never uses a precomputed gradient or shared inverse; weight is (1-alpha);
     both link branches add l2*I (:501-506).
+
+    ``cython_variant``: the (dead) Cython path updates Z with the same routine as U,
+    ``_newton_update_left(Z, V, Y^T, 1-alpha, ...)`` (cmf_solvers.py:300-304,
+    cmf_newton_solver.pyx:240-292), whose logit Hessian carries NO l2 term
+    (pyx:287-290); everything else is identical in value.
     """
     k = Z.shape[1]
     for i in range(Z.shape[0]):
@@ -245,7 +250,9 @@ def newton_sweep_Z(Z, V, Y, alpha, l1, l2, link, non_negative, ratio, pert,
             H = (1 - alpha) * (Vs.T @ Vs) + l2 * np.eye(k)                # :501
         else:
             w = link_slope(Vs @ z)
-            H = (1 - alpha) * ((Vs.T * w) @ Vs) + l2 * np.eye(k)          # :505
+            H = (1 - alpha) * ((Vs.T * w) @ Vs)                           # :505 / pyx:289
+            if not cython_variant:
+                H = H + l2 * np.eye(k)
         _row_step(Z, i, g, safe_invert(H, pert), non_negative)
 
 
@@ -299,7 +306,7 @@ def newton_update_step(X, Y, U, V, Z, alpha, l1=0.0, l2=0.0,
                        x_link="linear", y_link="linear",
                        U_non_negative=True, V_non_negative=True, Z_non_negative=True,
                        ratio=1.0, pert=0.2,
-                       update_U=True, update_V=True, update_Z=True, masks=None):
+                       update_U=True, update_V=True, update_Z=True, masks=None, cython_variant=False):
     """One Newton sweep U -> Z -> V, in place     (cmf_solvers.py:510-522).
 
     ``masks``: optional dict {"U": [], "Z": [], "V": []} that receives the
@@ -311,7 +318,8 @@ def newton_update_step(X, Y, U, V, Z, alpha, l1=0.0, l2=0.0,
     if update_U:
         newton_sweep_U(U, V, X, alpha, l1, l2, x_link, U_non_negative, ratio, pert, mU)
     if update_Z:
-        newton_sweep_Z(Z, V, Y, alpha, l1, l2, y_link, Z_non_negative, ratio, pert, mZ)
+        newton_sweep_Z(Z, V, Y, alpha, l1, l2, y_link, Z_non_negative, ratio, pert, mZ,
+                       cython_variant=cython_variant)
     if update_V:
         newton_sweep_V(V, U, Z, X, Y, alpha, l1, l2, x_link, y_link,
                        V_non_negative, ratio, pert, mV)

@@ -330,7 +330,7 @@ static int sweep_side_rows(cmf_ctx *c, bool is_u, int link, double scale, double
     RowHess h;
     h.A1 = W; h.lda1 = is_u ? c->dp : c->pp; h.a1_tn = !is_u; h.KR1 = (const float *)c->kr1.p; h.kred1 = c->dp;
     // the logit Hessian of U carries no l2 term (:427-428); Z always does (:501-506)
-    h.diag = (is_u && link == CMF_LINK_LOGIT) ? 0.0 : l2;
+    h.diag = (link == CMF_LINK_LOGIT && (is_u || !c->opt_zlogit_l2)) ? 0.0 : l2;
     return per_row_finish(c, which, h, pert, nn);
 }
 
@@ -496,7 +496,7 @@ static int sweep_side_fused(cmf_ctx *c, bool is_u, int link, double scale, doubl
     else { sd.T = c->Y; sd.t_row = 1; sd.t_col = c->pp; }
     sd.scale = scale; sd.link = link;
     // the logit Hessian of U carries no l2 term (:427-428); Z always does (:501-506)
-    const double diag = (is_u && link == CMF_LINK_LOGIT) ? 0.0 : l2;
+    const double diag = (link == CMF_LINK_LOGIT && (is_u || !c->opt_zlogit_l2)) ? 0.0 : l2;
     return fused_rows_finish(c, which, sd, RowSide(), nullptr, diag, false, l1, l2, pert, nn);
 }
 

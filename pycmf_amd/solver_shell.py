@@ -36,7 +36,8 @@ class _HipIterativeSolver:
                  U_non_negative=True, V_non_negative=True, Z_non_negative=True,
                  update_U=True, update_V=True, update_Z=True,
                  x_link="linear", y_link="linear", hessian_pertubation=0.2,
-                 sg_sample_ratio=1., random_state=None, device=0, stream=None, sg_sampler="numpy"):
+                 sg_sample_ratio=1., random_state=None, device=0, stream=None, sg_sampler="numpy",
+                 cython_variant=False):
         # like the reference, any beta_loss sklearn can parse is accepted and then ignored: only the
         # Frobenius objective is implemented by either solver (cmf_solvers.py:106, :166)
         if isinstance(beta_loss, str) and beta_loss not in ("frobenius", "kullback-leibler", "itakura-saito"):
@@ -63,6 +64,9 @@ class _HipIterativeSolver:
         if sg_sampler not in ("numpy", "device"):
             raise ValueError("sg_sampler must be 'numpy' (reference RNG stream) or 'device', got %r" % (sg_sampler,))
         self.sg_sampler = sg_sampler
+        # True: numerics of the reference's (unused) Cython twin, whose Z sweep shares U's routine and
+        # therefore has no l2 term in its logit Hessian (cmf_newton_solver.pyx:287-290; SURVEY N-cy1)
+        self.cython_variant = bool(cython_variant)
         self._sample_seed = (int(random_state) if isinstance(random_state, (int, np.integer)) else 0) << 20
         self._ctx = None
         self._bound = None
@@ -99,6 +103,8 @@ class _HipIterativeSolver:
             mode = os.environ.get("PYCMF_AMD_SPARSE_MODE")  # "dense" | "native": override the auto choice
             if mode:
                 self._ctx.set_option("sparse_mode", {"auto": 0, "dense": 1, "native": 2}[mode])
+            if self.cython_variant:
+                self._ctx.set_option("z_logit_hessian_l2", 0)
         if self._bound != key:
             self._ctx.set_problem(m, d, p, k)
             if X is not None:

@@ -271,6 +271,47 @@ def g6_mid():
          errs=np.array(errs), normX=np.array(np.linalg.norm(X)), normY=np.array(np.linalg.norm(Y)))
 
 
+
+
+# ---------------------------------------------------------------- G7 Cython twin (dead code upstream)
+def g7_cython():
+    """pycmf/cmf_newton_solver.pyx is never imported by the reference; it is compiled here from its
+    source where it lies (build dir: $CMF_CYTHON_BUILD, default /tmp/cybuild; see the recipe in
+    tests/golden/README.md) only to pin the N-cy rows of SURVEY 8(a)."""
+    build = os.environ.get("CMF_CYTHON_BUILD", "/tmp/cybuild")
+    sys.path.insert(0, build)
+    try:
+        import cmf_newton_solver as cy
+    except ImportError:
+        print("skip g7: compiled Cython twin not found in", build)
+        return
+    out = {}
+    X, Y, U0p, V0p, Z0p = base_problem(7, 9, 8, 5, 3)
+    _, _, U0s, V0s, Z0s = base_problem(7, 9, 8, 5, 3, signed=True)
+    Ylog = 1.0 / (1.0 + np.exp(-np.random.RandomState(21).randn(8, 5)))
+    Xlog = 1.0 / (1.0 + np.exp(-np.random.RandomState(22).randn(9, 8)))
+    alpha, pert = 0.3, 0.2
+    cases = {"lin_log_nn": ("linear", "logit", True, 1.0, None, 0.1, 0.2, False),
+             "log_log_free": ("logit", "logit", False, 1.0, None, 0.1, 0.2, True),
+             "lin_log_free_sg": ("linear", "logit", False, 0.5, 3, 0.1, 0.2, True)}
+    for name, (xl, yl, nn, ratio, seed, l1, l2, signed) in cases.items():
+        Xi = Xlog if xl == "logit" else X
+        Yt = np.ascontiguousarray((Ylog if yl == "logit" else Y).T)      # the Cython path solves Y^T ~ f(Z V^T)
+        if signed:
+            U, V, Z = 0.3 * U0s, 0.3 * V0s, 0.3 * Z0s
+        else:
+            U, V, Z = U0p.copy(), V0p.copy(), Z0p.copy()
+        U, V, Z = np.ascontiguousarray(U), np.ascontiguousarray(V), np.ascontiguousarray(Z)
+        if seed is not None:
+            np.random.seed(seed)
+        # NewtonSolver.update_step of the USE_CYTHON branch, cmf_solvers.py:292-311
+        cy._newton_update_left(U, V, Xi, alpha, l1, l2, xl, nn, ratio, pert)
+        cy._newton_update_left(Z, V, Yt, 1 - alpha, l1, l2, yl, nn, ratio, pert)
+        cy._newton_update_V(V, U, Z, Xi, Yt, alpha, l1, l2, xl, yl, nn, ratio, pert)
+        out[name + "_U1"], out[name + "_V1"], out[name + "_Z1"] = U, V, Z
+    save("g7_cython_steps", **out)
+
+
 if __name__ == "__main__":
     g1_readme()
     g2_mu()
@@ -278,3 +319,4 @@ if __name__ == "__main__":
     g4_fit()
     g5_init()
     g6_mid()
+    g7_cython()

@@ -196,3 +196,23 @@ def test_row_kernel_and_gemm_formulation_agree(lib, row_kernel):
     ctx.close()
     for a, b in zip(got, (Ur, Vr, Zr)):
         np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-3 * np.abs(b).max())
+
+
+@pytest.mark.parametrize("name", ["lin_log_nn", "log_log_free", "lin_log_free_sg"])
+def test_cython_variant_matches_compiled_reference(lib, name):
+    """HipNewtonSolver(cython_variant=True) reproduces the reference's Cython twin (g7 fixture)."""
+    from pycmf_amd.solver_shell import HipNewtonSolver
+    xl, yl, nn, ratio, seed, l1, l2, signed = NEWTON_CASES[name]
+    g, c = load_golden("g3_newton_steps"), load_golden("g7_cython_steps")
+    X = g["Xlog"] if xl == "logit" else g["X"]
+    Y = g["Ylog"] if yl == "logit" else g["Y"]
+    sfx = "s" if signed else "p"
+    U, V, Z = g["U0" + sfx].copy(), g["V0" + sfx].copy(), g["Z0" + sfx].copy()
+    s = HipNewtonSolver(alpha=0.3, l1_reg=l1, l2_reg=l2, x_link=xl, y_link=yl, U_non_negative=nn, V_non_negative=nn,
+                        Z_non_negative=nn, hessian_pertubation=0.2, sg_sample_ratio=ratio, random_state=seed,
+                        cython_variant=True)
+    s.update_step(X, Y, U, V, Z, l1, l2, 0.3)
+    s.release()
+    for n, a in (("U", U), ("V", V), ("Z", Z)):
+        ref = c["%s_%s1" % (name, n)]
+        np.testing.assert_allclose(a, ref, rtol=5e-4, atol=5e-4 * max(1.0, np.abs(ref).max()))

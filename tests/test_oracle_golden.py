@@ -118,3 +118,27 @@ def test_error_metric_sparse_equals_dense():
 def test_readme_case():
     g = load_golden("g1_readme")
     assert int(g["n_iter"]) > 0 and float(g["err"]) < 0.1
+
+
+CYTHON_CASES = {"lin_log_nn": ("linear", "logit", True, 1.0, None, 0.1, 0.2, False),
+                "log_log_free": ("logit", "logit", False, 1.0, None, 0.1, 0.2, True),
+                "lin_log_free_sg": ("linear", "logit", False, 0.5, 3, 0.1, 0.2, True)}
+
+
+@pytest.mark.parametrize("name", sorted(CYTHON_CASES))
+def test_cython_twin_steps_match_compiled_reference(name):
+    """SURVEY N-cy rows: the oracle's ``cython_variant`` flag reproduces the reference's Cython module
+    (compiled out of tree for the fixture): same as the live path except Z's logit Hessian has no l2."""
+    xl, yl, nn, ratio, seed, l1, l2, signed = CYTHON_CASES[name]
+    g, c = load_golden("g3_newton_steps"), load_golden("g7_cython_steps")
+    X = g["Xlog"] if xl == "logit" else g["X"]
+    Y = g["Ylog"] if yl == "logit" else g["Y"]
+    sfx = "s" if signed else "p"
+    U, V, Z = g["U0" + sfx].copy(), g["V0" + sfx].copy(), g["Z0" + sfx].copy()
+    if seed is not None:
+        np.random.seed(seed)
+    O.newton_update_step(X, Y, U, V, Z, 0.3, l1, l2, xl, yl, nn, nn, nn, ratio=ratio, pert=0.2, cython_variant=True)
+    for n, a in (("U", U), ("V", V), ("Z", Z)):
+        np.testing.assert_allclose(a, c["%s_%s1" % (name, n)], rtol=1e-8, atol=1e-10)
+    # and it really differs from the live path where l2 > 0
+    assert np.abs(Z - g["%s_dense_Z1" % name]).max() > 1e-3
