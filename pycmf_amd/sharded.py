@@ -122,3 +122,55 @@ def make_torch_sharded_newton(ctx, world, device, alpha, nn_mask=0, pert=0.2):
     def all_reduce(t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return ShardedNewtonLinear(backend, buf, world, all_reduce if world > 1 else None)
+
+
+def fit_mu_sharded(X_rows, Y_cols, U_rows, V, Z_rows, l1_reg=0.0, l2_reg=0.0, max_iter=200, tol=1e-4,
+                   device=0, verbose=0):
+    """Data-parallel MU fit: call from every rank of an initialised ``torch.distributed`` group.
+
+    Rank g passes its row block of X (and the matching rows of U), the matching column block of Y (and rows
+    of Z) and the full V (identical on every rank).  Runs the reference's outer loop
+    (pycmf/cmf_solvers.py:132-195: step, convergence test every 10th iteration on the *global* error
+    0.5||X-UV^T|| + 0.5||Y-VZ^T||) with one all-reduce per iteration for V and one 2-float all-reduce per
+    convergence check.  U_rows, V, Z_rows are updated in place; returns (U_rows, V, Z_rows, n_iter).
+    """
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    dev = torch.device("cuda", device)
+    torch.cuda.set_device(dev)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx = _lib.Context(device, stream.cuda_stream)
+        ctx.set_problem(X_rows.shape[0], X_rows.shape[1], Y_cols.shape[1], V.shape[1])
+        ctx.set_data(0, X_rows)
+        ctx.set_data(1, Y_cols)
+        for which, F in ((_lib.CMF_U, U_rows), (_lib.CMF_V, V), (_lib.CMF_Z, Z_rows)):
+            ctx.set_factor(which, F)
+        drv = make_torch_sharded_mu(ctx, world, dev)
+
+        def global_error():
+            ex2, ey2 = ctx.residual_sq("linear", "linear")
+            t = torch.tensor([ex2, ey2], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            ex2, ey2 = (float(v) for v in t.tolist())
+            return 0.5 * np.sqrt(ex2) + 0.5 * np.sqrt(ey2)
+
+        previous = at_init = global_error()
+        n_iter = 0
+        for n_iter in range(1, max_iter + 1):
+            drv.step(l1_reg, l2_reg, 7)
+            if tol > 0 and n_iter % 10 == 0:
+                err = global_error()
+                if verbose:
+                    print("Epoch %02d, error: %f" % (n_iter, err))
+                if (previous - err) / at_init < tol:
+                    break
+                previous = err
+        torch.cuda.synchronize(dev)
+        for which, F in ((_lib.CMF_U, U_rows), (_lib.CMF_V, V), (_lib.CMF_Z, Z_rows)):
+            ctx.get_factor_into(which, F)
+        ctx.close()
+    return U_rows, V, Z_rows, n_iter

@@ -1,0 +1,72 @@
+"""Two real processes, one per rank, sharing the single GPU of the test box (gloo for the collectives, since
+RCCL refuses two ranks on one device): the sharded fit must reproduce the single-process fit."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from pycmf_amd.sharded import fit_mu_sharded, shard_bounds
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+d = np.load(%(data)r)
+X, Y, U, V, Z = d["X"], d["Y"], d["U"].copy(), d["V"].copy(), d["Z"].copy()
+r0, r1 = shard_bounds(X.shape[0], world, rank)
+c0, c1 = shard_bounds(Y.shape[1], world, rank)
+Ur, Zr = U[r0:r1].copy(), Z[c0:c1].copy()
+Ur, V, Zr, n_iter = fit_mu_sharded(X[r0:r1], Y[:, c0:c1], Ur, V, Zr, l1_reg=0.01, l2_reg=0.02, max_iter=40, tol=1e-4, device=0)
+np.savez(%(out)r + str(rank) + ".npz", U=Ur, V=V, Z=Zr, n_iter=n_iter, r=np.array([r0, r1, c0, c1]))
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_fit_two_processes(tmp_path, world):
+    from pycmf_amd import _lib
+    from pycmf_amd.solver_shell import HipMUSolver
+    if _lib.device_count() < 1:
+        pytest.fail("no GPU visible")
+    rng = np.random.RandomState(0)
+    m, d, p, k = 530, 300, 410, 12
+    X, Y = np.abs(rng.randn(m, d)), np.abs(rng.randn(d, p))
+    s = np.sqrt(X.mean() / k)
+    U, V, Z = s * np.abs(rng.randn(m, k)), s * np.abs(rng.randn(d, k)), s * np.abs(rng.randn(p, k))
+    data = str(tmp_path / "data.npz")
+    np.savez(data, X=X, Y=Y, U=U, V=V, Z=Z)
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "data": data, "out": str(tmp_path / "out")})
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, str(script)],
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [q.communicate(timeout=600)[0].decode() for q in procs]
+    for r, (q, o) in enumerate(zip(procs, outs)):
+        assert q.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+    # single-process reference through the ordinary solver shell
+    ref = HipMUSolver(l1_reg=0.01, l2_reg=0.02, max_iter=40, tol=1e-4)
+    Ur, Vr, Zr = U.copy(), V.copy(), Z.copy()
+    _, _, _, n_ref = ref.fit_iterative_update(X, Y, Ur, Vr, Zr)
+    ref.release()
+    for r in range(world):
+        o = np.load(str(tmp_path / "out") + "%d.npz" % r)
+        r0, r1, c0, c1 = o["r"]
+        assert int(o["n_iter"]) == n_ref
+        np.testing.assert_allclose(o["V"], Vr, rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(o["U"], Ur[r0:r1], rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(o["Z"], Zr[c0:c1], rtol=2e-4, atol=1e-6)
