@@ -60,10 +60,12 @@ def test_fit_level_parity_with_reference(solver):
     m = CMF(n_components=5, solver=solver, x_init="custom", y_init="custom", random_state=0, max_iter=1000)
     U, V, Z = m.fit_transform(g["fc_X"], g["fc_Y"], U=g["fc_U0"].copy(), V=g["fc_V0"].copy(), Z=g["fc_Z0"].copy())
     ref_iter, ref_err = int(g["fc_%s_n_iter" % solver]), float(g["fc_%s_err" % solver])
-    assert abs(m.n_iter_ - ref_iter) <= 10  # the stopping test runs every 10th iteration
+    # measured (tools/fit_parity.py): mu 210/210 iterations, error 2e-6 rel; newton 730/730, 7e-4 rel
+    assert m.n_iter_ == ref_iter if solver == "mu" else abs(m.n_iter_ - ref_iter) <= 10
     ex = np.linalg.norm(g["fc_X"] - U @ V.T) + np.linalg.norm(g["fc_Y"] - V @ Z.T)
     np.testing.assert_allclose(m.reconstruction_err_, ex, rtol=1e-4)
-    assert abs(m.reconstruction_err_ - ref_err) <= 0.05 * ref_err + 1e-4
+    np.testing.assert_allclose(m.reconstruction_err_, ref_err, rtol=1e-4 if solver == "mu" else 5e-3)
+    np.testing.assert_allclose(U, g["fc_%s_U" % solver], rtol=0, atol=1e-4 if solver == "mu" else 5e-3)
 
 
 def test_readme_smoke():
@@ -72,8 +74,9 @@ def test_readme_smoke():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         U, V, Z = m.fit_transform(g["X"], g["Y"])
-    assert m.reconstruction_err_ < 0.1
-    assert np.linalg.norm(g["X"] - U @ V.T) / np.linalg.norm(g["X"]) < 0.05
+    assert m.n_iter_ == int(g["n_iter"])
+    np.testing.assert_allclose(m.reconstruction_err_, float(g["err"]), rtol=1e-4)   # north_star: 1e-4 rel
+    np.testing.assert_allclose(U, g["U"], rtol=0, atol=1e-4)
 
 
 def test_n_components_greater_n_features():  # :104-109
