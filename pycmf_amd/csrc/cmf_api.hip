@@ -829,8 +829,8 @@ static int run_graphed(cmf_ctx *c, StepGraph &g, const double *key, int nkey, F 
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
         g.failed = true;
-        // capture swallowed the launches: run the step for real
-        return rc != CMF_OK ? rc : eager();
+        // capture swallowed the launches (or hit a host synchronisation): run the step for real
+        return eager();
     }
     hipGraphExec_t exec = nullptr;
     const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);

@@ -129,6 +129,69 @@ __global__ __launch_bounds__(256) void jacobi_safe_inverse_kernel(const float *H
 }
 
 // ---------------------------------------------------------------------------------------
+// One SINGLE matrix (the shared Hessian of the linear-link sweeps) whose spectrum dips under the
+// perturbation: the same Hestenes sweep spread over the whole chip, one launch per round-robin step.
+// A step's n/2 column pairs are independent, so each gets its own one-wave workgroup; the kernel
+// boundary between steps is what makes a step's rotations visible to the next (no in-kernel grid
+// barrier, no cross-XCD coherence protocol).  ~4 us per step: n = 256 -> ~1 ms per sweep instead of
+// ~30 ms for the one-workgroup kernel working out of L2.
+__global__ __launch_bounds__(64) void jacobi_init_kernel(const float *H, float *B, float *Vt, int n, int kp) {
+    for (int idx = blockIdx.x * 64 + threadIdx.x; idx < n * n; idx += gridDim.x * 64) {
+        const int r = idx / n, c = idx % n;
+        B[idx] = H[r * kp + c];
+        Vt[idx] = (r == c) ? 1.0f : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(64) void jacobi_pair_step_kernel(float *B, float *Vt, int n, int N, int s, int *rotated) {
+    const int pi = blockIdx.x, lane = threadIdx.x;
+    int p, q;
+    if (pi == 0) { p = s; q = N - 1; }
+    else { p = (s + pi) % (N - 1); q = (s - pi + (N - 1)) % (N - 1); }
+    if (p >= n || q >= n) return;
+    float *bp = B + p * n, *bq = B + q * n;
+    float a = 0.f, b = 0.f, g = 0.f;
+    for (int e = lane; e < n; e += 64) {
+        const float x = bp[e], y = bq[e];
+        a += x * x; b += y * y; g += x * y;
+    }
+    a = wave_sum(a); b = wave_sum(b); g = wave_sum(g);
+    if (fabsf(g) > 2.0e-7f * sqrtf(a * b) && a > 0.f && b > 0.f) {
+        const float zeta = (b - a) / (2.0f * g);
+        const float tt = copysignf(1.0f, zeta) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
+        const float cs = 1.0f / sqrtf(1.0f + tt * tt), sn = cs * tt;
+        float *vp = Vt + p * n, *vq = Vt + q * n;
+        for (int e = lane; e < n; e += 64) {
+            const float x = bp[e], y = bq[e];
+            bp[e] = cs * x - sn * y; bq[e] = sn * x + cs * y;
+            const float u = vp[e], w = vq[e];
+            vp[e] = cs * u - sn * w; vq[e] = sn * u + cs * w;
+        }
+        if (lane == 0) *rotated = 1;
+    }
+}
+
+// inv[j] = 1 / max(||row j of (HV)^T||, pert)
+__global__ __launch_bounds__(64) void jacobi_sigma_kernel(const float *B, float *inv, int n, float pert) {
+    const int j = blockIdx.x, lane = threadIdx.x;
+    float a = 0.f;
+    for (int e = lane; e < n; e += 64) { const float x = B[j * n + e]; a += x * x; }
+    a = wave_sum(a);
+    if (lane == 0) { float sg = sqrtf(a); if (sg < pert) sg = pert; inv[j] = 1.0f / sg; }
+}
+
+// O = V diag(inv) V^T over the padded kp x kp output (zero on the padding)
+__global__ __launch_bounds__(256) void jacobi_compose_kernel(const float *Vt, const float *inv, float *O, int n, int kp) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= kp * kp) return;
+    const int r = idx / kp, c = idx % kp;
+    float acc = 0.f;
+    if (r < n && c < n)
+        for (int j = 0; j < n; ++j) acc += inv[j] * Vt[j * n + r] * Vt[j * n + c];
+    O[idx] = acc;
+}
+
+// ---------------------------------------------------------------------------------------
 // Cholesky fast path of the safe inverse.  When every eigenvalue of the (symmetric) H is
 // >= pert, the clamp of _safe_invert is the identity and the result is simply H^-1.  That is
 // decided exactly by trying to factor H - pert*I: it is positive definite iff lambda_min > pert.

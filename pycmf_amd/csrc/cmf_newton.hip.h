@@ -47,7 +47,33 @@ static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat,
         else if (n <= 128) hipLaunchKernelGGL((chol_solve_kernel<8>), grid, block, 0, c->stream, Hin, (const float *)c->Eye, Hout, flags, n, kp, (int64_t)0, (float)pert, kp);
         else hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, Hin, (const float *)c->Eye, Hout, flags, n, kp, (int64_t)0, (float)pert, kp);
         HIPCHK(hipGetLastError());
-        need = (const int *)flags; // flags[0]: the single matrix needs the Jacobi path
+        // did the Cholesky test accept it (lambda_min >= pert)?  one 4-byte read-back
+        int flag0 = 0;
+        HIPCHK(hipMemcpyAsync(&flag0, flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!flag0) return CMF_OK;
+        if (n >= 48) { // chip-wide Jacobi: one launch per round-robin step (cmf_eigen.hip.h)
+            const int N = n + (n & 1);
+            CHK(ensure(c, c->eigws, (size_t)(2 * n * n + n) * sizeof(float)));
+            float *Bw = (float *)c->eigws.p, *Vw = Bw + (size_t)n * n, *invw = Vw + (size_t)n * n;
+            hipLaunchKernelGGL(jacobi_init_kernel, dim3(std::min(1024, (n * n + 63) / 64)), dim3(64), 0, c->stream, Hin, Bw, Vw, n, kp);
+            for (int sweep = 0; sweep < 30; ++sweep) {
+                HIPCHK(hipMemsetAsync(flags, 0, sizeof(int), c->stream));
+                for (int st = 0; st < N - 1; ++st)
+                    hipLaunchKernelGGL(jacobi_pair_step_kernel, dim3(N / 2), dim3(64), 0, c->stream, Bw, Vw, n, N, st, flags);
+                int rotated = 0;
+                HIPCHK(hipMemcpyAsync(&rotated, flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if (!rotated) break;
+            }
+            hipLaunchKernelGGL(jacobi_sigma_kernel, dim3(n), dim3(64), 0, c->stream, (const float *)Bw, invw, n, (float)pert);
+            hipLaunchKernelGGL(jacobi_compose_kernel, dim3((kp * kp + 255) / 256), dim3(256), 0, c->stream, (const float *)Vw, (const float *)invw,
+                               Hout, n, kp);
+            HIPCHK(hipGetLastError());
+            return CMF_OK;
+        }
+        HIPCHK(hipMemsetAsync(flags, 0xFF, sizeof(int), c->stream)); // small n: the one-workgroup kernel below
+        need = (const int *)flags;
     } else if (c->opt_chol && tri_bytes <= 150 * 1024 && n <= 512) {
         CHK(ensure(c, c->eigflag, (size_t)nmat * sizeof(int)));
         const float *src = Hin;
