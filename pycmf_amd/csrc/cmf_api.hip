@@ -94,6 +94,7 @@ struct cmf_ctx {
     int opt_split = -1;    // force split-K factor (<=0: heuristic)
     int opt_chol = 1;      // Cholesky fast path of the safe inverse (0: always Jacobi)
     int opt_zlogit_l2 = 1;  // 0: Cython-twin numerics (Z's logit Hessian without l2 I, pyx:287-290)
+    int opt_rowdiag = 0;    // diagnostic builds of row_hess_kernel<256> (1: no staging, 2: stage only, 3: gather only)
     int opt_rowstagger = 1; // row_hess_kernel: waves 4-7 stage half a K-step after waves 0-3
     int opt_rowkernel = 1; // per-row Newton sweeps: fused gather kernel (1) or masked-dense GEMMs (0)
     double flop_scale = 1.0;   // algorithmic/executed flop ratio of the launches being issued (sampled sweeps run masked-dense)
@@ -506,6 +507,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_split = (int)value;
     } else if (!strcmp(name, "z_logit_hessian_l2")) {
         c->opt_zlogit_l2 = value != 0;
+    } else if (!strcmp(name, "row_diag")) {
+        c->opt_rowdiag = (int)value;
     } else if (!strcmp(name, "row_stagger")) {
         c->opt_rowstagger = value != 0;
     } else if (!strcmp(name, "row_kernel")) {

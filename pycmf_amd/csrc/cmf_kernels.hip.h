@@ -69,6 +69,35 @@ struct GemmCfg {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// Sum over aligned groups of GS lanes (8, 16, 32 or 64); every lane of a group receives the sum.
+// Pure VALU: v_add_f32_dpp for the in-row steps, v_permlane16/32_swap for the row exchanges -- the
+// __shfl_xor form goes through ds_bpermute (LDS crossbar, ~64-cycle dependent steps).
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int GS>
+__device__ __forceinline__ float group_sum(float v) {
+    v += dpp_move<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v); // row_half_mirror: the other quad of the 8-lane half row
+    if constexpr (GS >= 16) v += dpp_move<0x140>(v); // row_mirror: the other half of the 16-lane row
+    // v_permlane16/32_swap exchange rows between TWO registers in place.  Written as inline asm: with equal
+    // operand values hipcc (ROCm 7.2) folds the builtin's second result onto the first (emits v + v).  The two
+    // v_nop cover the VALU-write -> permlane-read hazard, which hipcc does not pad inside an asm statement.
+    if constexpr (GS >= 32) { // rows 2r and 2r+1
+        float a = v, b = v;
+        asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        v = a + b;
+    }
+    if constexpr (GS >= 64) { // lower and upper 32 lanes
+        float a = v, b = v;
+        asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        v = a + b;
+    }
+    return v;
+}
+
 template <int N>
 struct VecLoad;
 template <>

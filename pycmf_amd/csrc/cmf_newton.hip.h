@@ -416,7 +416,15 @@ static int sweep_v_rows(cmf_ctx *c, double alpha, double l1, double l2, int x_li
 template <int KP>
 static int launch_row_hess_kp(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
     using Cfg = RowHessCfg<KP>;
-    if (c->opt_rowstagger) {
+    if (KP == 256 && c->opt_rowdiag > 0) { // DIAGNOSTIC builds of the k_pad = 256 kernel (wrong results)
+        const void *fn = c->opt_rowdiag == 1 ? reinterpret_cast<const void *>(&row_hess_kernel<256, 1, 1>)
+                       : c->opt_rowdiag == 2 ? reinterpret_cast<const void *>(&row_hess_kernel<256, 1, 2>)
+                                             : reinterpret_cast<const void *>(&row_hess_kernel<256, 1, 3>);
+        CHK(allow_big_lds(c, fn, (int)Cfg::LDS_BYTES));
+        if (c->opt_rowdiag == 1) hipLaunchKernelGGL((row_hess_kernel<256, 1, 1>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
+        else if (c->opt_rowdiag == 2) hipLaunchKernelGGL((row_hess_kernel<256, 1, 2>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
+        else hipLaunchKernelGGL((row_hess_kernel<256, 1, 3>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
+    } else if (c->opt_rowstagger) {
         CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<KP, 1>), (int)Cfg::LDS_BYTES));
         hipLaunchKernelGGL((row_hess_kernel<KP, 1>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
     } else {

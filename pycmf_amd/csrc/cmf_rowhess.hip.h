@@ -45,7 +45,7 @@ struct RowHessCfg {
     static constexpr size_t LDS_BYTES = (2 * TILE + 2 * 64) * sizeof(float);
 };
 
-template <int KP, int STAGGER = 1>
+template <int KP, int STAGGER = 1, int DIAG = 0>
 __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
     using C = RowHessCfg<KP>;
     const bool late = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >= 4;
@@ -104,8 +104,7 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
 #pragma unroll
         for (int p = 0; p < C::LD; ++p) {
             float z = u4[0] * rr[p][0] + u4[1] * rr[p][1] + u4[2] * rr[p][2] + u4[3] * rr[p][3];
-#pragma unroll
-            for (int off = C::GS / 2; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
+            z = group_sum<C::GS>(z);
             const float f = g.link ? sigmoidf_(z) : z;
             const float valid = vv[p] ? 1.0f : 0.0f;
             const float res = valid * g.scale * (f - tt[p]);
@@ -136,10 +135,10 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
             // SIMD one wave's dot products / sigmoids sit beside its partner's MFMAs (STAGGER = 0: lockstep)
             const int g0 = (STAGGER && late) ? 8 : 0;
             if (sidx == g0) {
-                if (do_stage && loader) stage(nb);
+                if (DIAG != 1 && DIAG != 3 && do_stage && loader) stage(nb);
             } else if (sidx == g0 + 1) {
-                if (do_gather && loader) gather(tl_gather);
-                if (do_idx && loader) load_idx(tl_idx);
+                if (DIAG != 1 && DIAG != 2 && do_gather && loader) gather(tl_gather);
+                if (DIAG != 1 && DIAG != 2 && do_idx && loader) load_idx(tl_idx);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (mfma_wave) {
