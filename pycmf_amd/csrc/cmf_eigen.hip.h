@@ -15,11 +15,7 @@
 
 namespace cmfk {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); } // VALU only (DPP + permlane swaps)
 
 // Hin/Hout: nmat matrices, row-major, leading dimension kp, matrix stride `stride`.
 // n = valid order (<= kp).  Only the leading n x n block is read; Hout's padding is zeroed.
@@ -448,10 +444,7 @@ __global__ __launch_bounds__(256, 2) void chol_solve_kernel(const float *Hin, co
                     const int i = ti + 16 * a;
                     if (i > j && i < n) sacc += R.M[a][jb] * vec[i];
                 }
-                sacc += __shfl_xor(sacc, 8, 16);
-                sacc += __shfl_xor(sacc, 4, 16);
-                sacc += __shfl_xor(sacc, 2, 16);
-                sacc += __shfl_xor(sacc, 1, 16);
+                sacc = group_sum<16>(sacc); // the active lanes are exactly one aligned 16-lane row
                 if (ti == jl) vec[j] = (vec[j] - sacc) / R.M[jb][jb];
             }
             __syncthreads();

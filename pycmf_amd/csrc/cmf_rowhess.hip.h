@@ -7,9 +7,9 @@
 // One 512-thread workgroup per row.  The 32 gathered rows of a K-step are staged through registers
 // into an LDS tile; while they are still in registers the owning lanes take the dot product with
 // f_i (butterfly over the k_pad/4 lanes that share a row), so z, r, w and the gradient cost no LDS
-// traffic.  H_i is a rank-32 MFMA update per step, both operands read from the SAME LDS tile (the A
-// fragment is scaled by w_j as it is read) -- only the sampled rows are ever touched, there is no
-// residual / weight / mask image and no Khatri-Rao matrix.
+// traffic.  The rows are written to LDS twice, raw (B operand) and scaled by w_j (A operand), so that H_i is a
+// rank-32 MFMA update per step with exactly the TN GEMM's inner loop -- only the sampled rows are ever touched,
+// there is no residual / weight / mask image and no Khatri-Rao matrix.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -42,7 +42,7 @@ struct RowHessCfg {
     static constexpr int TM = KP == 256 ? 2 : 1;
     static constexpr int TN = KP == 256 ? 4 : (KP == 128 ? 2 : 1);
     static constexpr int TILE = 32 * KP;
-    static constexpr size_t LDS_BYTES = (2 * TILE + 2 * 64) * sizeof(float);
+    static constexpr size_t LDS_BYTES = (4 * TILE) * sizeof(float); // 2 stages x (raw rows, rows scaled by w_j)
 };
 
 template <int KP, int STAGGER = 1, int DIAG = 0>
@@ -50,8 +50,8 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
     using C = RowHessCfg<KP>;
     const bool late = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >= 4;
     extern __shared__ __attribute__((aligned(16))) float rsm[];
-    auto tile_of = [&](int b) { return rsm + b * C::TILE; };        // two row tiles
-    auto wv_of = [&](int b) { return rsm + 2 * C::TILE + 32 * b; }; // their weights
+    auto tile_of = [&](int b) { return rsm + 2 * b * C::TILE; };             // raw rows o_j      (B operand)
+    auto wtile_of = [&](int b) { return rsm + (2 * b + 1) * C::TILE; };      // rows w_j * o_j    (A operand)
 
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -111,26 +111,24 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
             const float wgt = valid * g.scale * (g.link ? f * (1.0f - f) : 1.0f);
             gacc += res * rr[p];
             const int r = row_of(p);
-            if (c4 == 0) wv_of(nb)[r] = wgt;
             *reinterpret_cast<f32x4 *>(tile_of(nb) + r * KP + 4 * c4) = rr[p];
+            *reinterpret_cast<f32x4 *>(wtile_of(nb) + r * KP + 4 * c4) = wgt * rr[p];
         }
     };
     auto mfma_tile = [&](int cb, bool do_stage, int nb, bool do_gather, int tl_gather, bool do_idx, int tl_idx) {
         const float *Rt = tile_of(cb);
-        const float *Wv = wv_of(cb);
-        float a[2][C::TM], b[2][C::TN], wf[2];
-        // raw fragment + weight reads are prefetched one group ahead; the scaling by w_j happens right before the
-        // MFMAs that consume the fragment (multiplying at load time would expose the LDS latency every group)
-        auto ld_frag = [&](int sidx, float *da, float *db, float *dw) {
+        const float *Wt = wtile_of(cb);
+        float a[2][C::TM], b[2][C::TN];
+        // exactly the TN GEMM's inner loop: A fragments from the pre-scaled image, B fragments from the raw one
+        auto ld_frag = [&](int sidx, float *da, float *db) {
             const int kk = 2 * sidx + lh;
-            *dw = Wv[kk];
-            VecLoad<C::TM>::ld(Rt + kk * KP + wrow0 + C::TM * l31, da);
+            VecLoad<C::TM>::ld(Wt + kk * KP + wrow0 + C::TM * l31, da);
             VecLoad<C::TN>::ld(Rt + kk * KP + wcol0 + C::TN * l31, db);
         };
-        if (mfma_wave) ld_frag(0, a[0], b[0], &wf[0]);
+        if (mfma_wave) ld_frag(0, a[0], b[0]);
 #pragma unroll
         for (int sidx = 0; sidx < 16; ++sidx) {
-            if (mfma_wave && sidx + 1 < 16) ld_frag(sidx + 1, a[(sidx + 1) & 1], b[(sidx + 1) & 1], &wf[(sidx + 1) & 1]);
+            if (mfma_wave && sidx + 1 < 16) ld_frag(sidx + 1, a[(sidx + 1) & 1], b[(sidx + 1) & 1]);
             // the VALU-heavy staging of waves 4-7 runs half a step after that of waves 0-3, so that on every
             // SIMD one wave's dot products / sigmoids sit beside its partner's MFMAs (STAGGER = 0: lockstep)
             const int g0 = (STAGGER && late) ? 8 : 0;
@@ -142,14 +140,11 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
             }
             __builtin_amdgcn_sched_barrier(0);
             if (mfma_wave) {
-                float as[C::TM];
-#pragma unroll
-                for (int x = 0; x < C::TM; ++x) as[x] = a[sidx & 1][x] * wf[sidx & 1];
 #pragma unroll
                 for (int x = 0; x < C::TM; ++x)
 #pragma unroll
                     for (int y = 0; y < C::TN; ++y)
-                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[x], b[sidx & 1][y], acc[x][y], 0, 0, 0);
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sidx & 1][x], b[sidx & 1][y], acc[x][y], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
