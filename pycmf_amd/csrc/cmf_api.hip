@@ -90,6 +90,7 @@ struct cmf_ctx {
     int opt_graph = 0;     // replay MU / linear-Newton steps from a captured hipGraph (opt-in: measured neutral,
                            // the ~4 us per dependent kernel boundary is device-side, not host launch cost)
     StepGraph mu_graph, newton_graph;
+    int opt_pipe_small = 4; // staging schedule of the factor-side products (0 or 4; 4 measured +5..15 %, tools/ab_small.py)
     int opt_pipe = 4;      // GEMM staging schedule (see gemm_kernel PIPE); 4 measured best (tools/ab_gemm.py)
     int opt_split = -1;    // force split-K factor (<=0: heuristic)
     int opt_chol = 1;      // Cholesky fast path of the safe inverse (0: always Jacobi)
@@ -303,6 +304,8 @@ static int launch_gemm_mode(cmf_ctx *c, const GemmArgs &a, const GemmPlan &pl) {
         if (c->opt_pipe == 5) return launch_gemm_pipe<MODE, ROLE, (ROLE == 0 && MODE != MODE_NT) ? 5 : 0>(c, a, pl);
         if (c->opt_pipe == 10) return launch_gemm_pipe<MODE, ROLE, (ROLE == 0 && MODE != MODE_NT) ? 10 : 0>(c, a, pl);
     }
+    if (ROLE == 1 && MODE != MODE_NT && c->opt_pipe_small == 4)
+        return launch_gemm_pipe<MODE, ROLE, (ROLE == 1 && MODE != MODE_NT) ? 4 : 0>(c, a, pl);
     return launch_gemm_pipe<MODE, ROLE, 0>(c, a, pl);
 }
 
@@ -503,6 +506,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "gemm_pipe")) {
         if (value < 0 || (value > 5 && value != 10)) return fail(CMF_EINVAL, "gemm_pipe must be 0..5 or 10");
         c->opt_pipe = (int)value;
+    } else if (!strcmp(name, "gemm_pipe_small")) {
+        c->opt_pipe_small = (int)value;
     } else if (!strcmp(name, "gemm_split")) {
         c->opt_split = (int)value;
     } else if (!strcmp(name, "z_logit_hessian_l2")) {
