@@ -133,7 +133,10 @@ struct VecLoad<4> {
 // the 7 % between schedule 4 and the bare MFMA+fragment loop is the 64 KB/step of LDS fill traffic and the
 // global loads themselves, not where in the step they are issued.
 // (also tried and dropped: piece p written in group p and re-loaded at once: -1..-3 %; one piece in the shadow
-//  of each MFMA: -25 %, hipcc's conservative waitcnts serialise it)
+//  of each MFMA: -25 %, hipcc's conservative waitcnts serialise it; wave specialisation, 12 waves with one
+//  loader wave per SIMD doing all the staging and the 8 MFMA waves only reading fragments: 131/121 TF/s NN/TN
+//  with direct-to-LDS loads, 131/136 with register staging, against 142.5/141.7 for schedule 4 - a third wave
+//  per SIMD costs more than the staging instructions it takes off the MFMA waves)
 template <int MODE, int BN, int ROLE = 0, int PIPE = 0>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
     using C = GemmCfg<MODE, BN>;
