@@ -216,3 +216,73 @@ def test_cython_variant_matches_compiled_reference(lib, name):
     for n, a in (("U", U), ("V", V), ("Z", Z)):
         ref = c["%s_%s1" % (name, n)]
         np.testing.assert_allclose(a, ref, rtol=5e-4, atol=5e-4 * max(1.0, np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("fmt", ["dense", "csr"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_newton_protocol_matches_oracle(lib, world, fmt):
+    """SURVEY 8(e), Newton with linear links: `world` shards as separate contexts on this GPU, the all-reduce
+    emulated by summing their partial buffers; every shard must land on the oracle's unsharded step
+    (cmf_solvers.py:510-522), with dense and with native-CSR row blocks of X."""
+    import torch
+    from oracle import cmf_oracle as O
+    from pycmf_amd.sharded import ShardedNewtonLinear, HipNewtonShardBackend, shard_bounds
+    m, d, p, k = 610, 280, 330, 20
+    rng = np.random.RandomState(31)
+    X = np.abs(rng.randn(m, d)) * (rng.rand(m, d) < 0.15)
+    Y = np.abs(rng.randn(d, p))
+    U0, V0, Z0 = 0.3 * rng.randn(m, k), 0.3 * rng.randn(d, k), 0.3 * rng.randn(p, k)
+    alpha, l1, l2, pert, nn = 0.35, 0.01, 0.05, 0.2, 0b101
+    o = O.OracleSolver("newton", alpha=alpha, l1_reg=l1, l2_reg=l2, x_link="linear", y_link="linear",
+                       U_non_negative=True, V_non_negative=False, Z_non_negative=True,
+                       hessian_pertubation=pert, sg_sample_ratio=1.0)
+    Ur, Vr, Zr = U0.copy(), V0.copy(), Z0.copy()
+    for _ in range(2):
+        o.update_step(X, Y, Ur, Vr, Zr)
+    shards, bounds = [], []
+    for r in range(world):
+        r0, r1 = shard_bounds(m, world, r)
+        c0, c1 = shard_bounds(p, world, r)
+        ctx = lib.Context(0)
+        ctx.set_problem(r1 - r0, d, c1 - c0, k)
+        ctx.set_data(0, sp.csr_matrix(X[r0:r1]) if fmt == "csr" else X[r0:r1])
+        ctx.set_data(1, Y[:, c0:c1])
+        ctx.set_factor(0, U0[r0:r1]); ctx.set_factor(1, V0); ctx.set_factor(2, Z0[c0:c1])
+        backend = HipNewtonShardBackend(ctx, alpha, nn, pert)
+        buf = torch.zeros(backend.buf_elems(), dtype=torch.float32, device="cuda:0")
+        shards.append((ctx, backend, buf)); bounds.append((r0, r1, c0, c1))
+
+    def all_reduce_emulated(_):
+        for ctx, _, _ in shards:
+            ctx.sync()
+        total = torch.stack([b for _, _, b in shards]).sum(0)
+        for _, _, b in shards:
+            b.copy_(total)
+        torch.cuda.synchronize()
+
+    for _ in range(2):
+        # the three phases of ShardedNewtonLinear.step, run phase by phase over the shards
+        for ctx, backend, buf in shards:
+            backend.update_uz(l1, l2, 7)
+            backend.partials(buf)
+        all_reduce_emulated(None)
+        for ctx, backend, buf in shards:
+            backend.apply_v(buf, l1, l2)
+            ctx.sync()
+    for (ctx, _, _), (r0, r1, c0, c1) in zip(shards, bounds):
+        for got, ref in ((ctx.get_factor(1), Vr), (ctx.get_factor(0), Ur[r0:r1]), (ctx.get_factor(2), Zr[c0:c1])):
+            np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+        ctx.close()
+    # and the driver object itself on a single shard equals the fused step
+    ctx = lib.Context(0)
+    ctx.set_problem(m, d, p, k)
+    ctx.set_data(0, sp.csr_matrix(X) if fmt == "csr" else X); ctx.set_data(1, Y)
+    ctx.set_factor(0, U0); ctx.set_factor(1, V0); ctx.set_factor(2, Z0)
+    backend = HipNewtonShardBackend(ctx, alpha, nn, pert)
+    drv = ShardedNewtonLinear(backend, torch.zeros(backend.buf_elems(), dtype=torch.float32, device="cuda:0"))
+    for _ in range(2):
+        drv.step(l1, l2, 7)
+    ctx.sync()
+    for got, ref in ((ctx.get_factor(0), Ur), (ctx.get_factor(1), Vr), (ctx.get_factor(2), Zr)):
+        np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    ctx.close()
