@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="cmf_set_option knob for A/B runs (e.g. row_symmetric=0); recorded in config")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -170,6 +172,9 @@ def main():
     stream = torch.cuda.Stream(device=device)
     with torch.cuda.stream(stream):
         ctx = _lib.Context(local_rank, stream.cuda_stream)
+        for kv in args.option:
+            name, _, val = kv.partition("=")
+            ctx.set_option(name, int(val))
         ctx.set_problem(r1 - r0, d, c1 - c0, k)
         if "nnz_per_row" in w:
             # CSR row block generated on the host (values 1.0: binary bag-of-words like the reference's
@@ -306,6 +311,8 @@ def main():
     for key in ("x_link", "y_link", "ratio"):
         if key in w:
             out["config"][key] = w[key]
+    if args.option:
+        out["config"]["options"] = list(args.option)
     if world == 1 and not args.no_cpu_baseline:
         cits, shp, n_it, el, threads, work_ratio = cpu_baseline(w)
         out["cpu_baseline"] = {

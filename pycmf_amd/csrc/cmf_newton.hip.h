@@ -424,6 +424,12 @@ static int launch_row_hess_kp(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
         if (c->opt_rowdiag == 1) hipLaunchKernelGGL((row_hess_kernel<256, 1, 1>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
         else if (c->opt_rowdiag == 2) hipLaunchKernelGGL((row_hess_kernel<256, 1, 2>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
         else hipLaunchKernelGGL((row_hess_kernel<256, 1, 3>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
+    } else if (KP == 256 && c->opt_rowsym) {
+        constexpr int KS = KP == 256 ? 256 : 0; // only the k_pad = 256 instantiation exists
+        if constexpr (KS == 256) {
+            CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<256, 1, 0, 1>), (int)Cfg::LDS_BYTES));
+            hipLaunchKernelGGL((row_hess_kernel<256, 1, 0, 1>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
+        }
     } else if (c->opt_rowstagger) {
         CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<KP, 1>), (int)Cfg::LDS_BYTES));
         hipLaunchKernelGGL((row_hess_kernel<KP, 1>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);

@@ -45,9 +45,26 @@ struct RowHessCfg {
     static constexpr size_t LDS_BYTES = (4 * TILE) * sizeof(float); // 2 stages x (raw rows, rows scaled by w_j)
 };
 
-template <int KP, int STAGGER = 1, int DIAG = 0>
+// SYM (k_pad = 256 only): H_i is symmetric, so only the 36 blocks (32 x 32) on or above the block diagonal are
+// accumulated -- 9 MFMAs per k-pair and SIMD instead of 16 -- and every off-diagonal block is stored twice.
+// Block columns are contiguous here (block b = columns 32b..32b+31).  Wave -> blocks, balanced 4 + 5 per SIMD:
+//   waves 0-3 (type 0): (w, 4) (w, 5) (w, 6) (w, 7)
+//   waves 4, 6 (type 1, base 0 / 4): (b, b) (b, b+1) (b, b+2) (b, b+3) (b+3, b+3)
+//   waves 5, 7 (type 2, base 0 / 4): (b+1, b+1) (b+1, b+2) (b+1, b+3) (b+2, b+2) (b+2, b+3)
+__host__ __device__ constexpr int sym_np(int ty) { return ty == 0 ? 4 : 5; }   // blocks of the wave
+__host__ __device__ constexpr int sym_na(int ty) { return ty == 0 ? 1 : 2; }   // distinct A fragments
+__host__ __device__ constexpr int sym_nb(int ty) { return ty == 2 ? 3 : 4; }   // distinct B fragments
+__host__ __device__ constexpr int sym_ai(int ty, int n) { return ty == 0 ? 0 : (ty == 1 ? (n == 4 ? 1 : 0) : (n >= 3 ? 1 : 0)); }
+__host__ __device__ constexpr int sym_bi(int ty, int n) { return ty == 0 ? n : (ty == 1 ? (n == 4 ? 3 : n) : (n < 3 ? n : n - 2)); }
+template <int V>
+struct IntC {
+    static constexpr int value = V;
+};
+
+template <int KP, int STAGGER = 1, int DIAG = 0, int SYM = 0>
 __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
     using C = RowHessCfg<KP>;
+    static_assert(!SYM || KP == 256, "the symmetric block map is laid out for k_pad = 256");
     const bool late = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >= 4;
     extern __shared__ __attribute__((aligned(16))) float rsm[];
     auto tile_of = [&](int b) { return rsm + 2 * b * C::TILE; };             // raw rows o_j      (B operand)
@@ -75,6 +92,26 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     f32x4 gacc = {0.f, 0.f, 0.f, 0.f};
+    // SYM: block accumulators and this wave's block rows / columns (all wave-uniform)
+    f32x16 hs[5];
+#pragma unroll
+    for (int n = 0; n < 5; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hs[n][r] = 0.f;
+    const int uw = __builtin_amdgcn_readfirstlane(wid);
+    const int wty = uw < 4 ? 0 : ((uw & 1) ? 2 : 1);
+    const int sbase = uw >= 6 ? 4 : 0;
+    int ablk[2], bblk[4];
+    if (wty == 0) {
+        ablk[0] = ablk[1] = uw;
+        bblk[0] = 4; bblk[1] = 5; bblk[2] = 6; bblk[3] = 7;
+    } else if (wty == 1) {
+        ablk[0] = sbase; ablk[1] = sbase + 3;
+        bblk[0] = sbase; bblk[1] = sbase + 1; bblk[2] = sbase + 2; bblk[3] = sbase + 3;
+    } else {
+        ablk[0] = sbase + 1; ablk[1] = sbase + 2;
+        bblk[0] = sbase + 1; bblk[1] = sbase + 2; bblk[2] = sbase + 3; bblk[3] = sbase + 3;
+    }
 
     int jn[C::LD];      // indices of the tile about to be gathered
     f32x4 rr[C::LD];    // gathered rows of the tile in flight
@@ -150,6 +187,38 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
         }
     };
 
+    auto sym_tile = [&](auto typ, int cb, bool do_stage, int nb, bool do_gather, int tl_gather, bool do_idx, int tl_idx) {
+        constexpr int TY = decltype(typ)::value;
+        constexpr int NP = sym_np(TY), NA = sym_na(TY), NB = sym_nb(TY);
+        const float *Rt = tile_of(cb) + l31;
+        const float *Wt = wtile_of(cb) + l31;
+        float a[2][2], b[2][4];
+        auto ld_frag = [&](int sidx, float *da, float *db) {
+            const int kk = 2 * sidx + lh;
+#pragma unroll
+            for (int x = 0; x < NA; ++x) da[x] = Wt[kk * KP + 32 * ablk[x]];
+#pragma unroll
+            for (int y = 0; y < NB; ++y) db[y] = Rt[kk * KP + 32 * bblk[y]];
+        };
+        ld_frag(0, a[0], b[0]);
+#pragma unroll
+        for (int sidx = 0; sidx < 16; ++sidx) {
+            if (sidx + 1 < 16) ld_frag(sidx + 1, a[(sidx + 1) & 1], b[(sidx + 1) & 1]);
+            const int g0 = (STAGGER && late) ? 8 : 0;
+            if (sidx == g0) {
+                if (do_stage && loader) stage(nb);
+            } else if (sidx == g0 + 1) {
+                if (do_gather && loader) gather(tl_gather);
+                if (do_idx && loader) load_idx(tl_idx);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < NP; ++n)
+                hs[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sidx & 1][sym_ai(TY, n)], b[sidx & 1][sym_bi(TY, n)], hs[n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     if (nt > 0) {
         if (loader) {
             load_idx(0);
@@ -162,16 +231,56 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
             if (nt > 2) load_idx(2);
         }
         __syncthreads();
-        for (int tl = 0; tl < nt; ++tl) {
-            // tile tl is in LDS; tile tl+1 is in registers; jn holds the indices of tile tl+2
-            mfma_tile(tl & 1, tl + 1 < nt, (tl + 1) & 1, tl + 2 < nt, tl + 2, tl + 3 < nt, tl + 3);
-            __syncthreads();
+        if constexpr (SYM) {
+            // the three wave types run their own copy of the loop (same barrier count in each)
+            auto run = [&](auto typ) {
+                for (int tl = 0; tl < nt; ++tl) {
+                    sym_tile(typ, tl & 1, tl + 1 < nt, (tl + 1) & 1, tl + 2 < nt, tl + 2, tl + 3 < nt, tl + 3);
+                    __syncthreads();
+                }
+            };
+            if (wty == 0) run(IntC<0>{});
+            else if (wty == 1) run(IntC<1>{});
+            else run(IntC<2>{});
+        } else {
+            for (int tl = 0; tl < nt; ++tl) {
+                // tile tl is in LDS; tile tl+1 is in registers; jn holds the indices of tile tl+2
+                mfma_tile(tl & 1, tl + 1 < nt, (tl + 1) & 1, tl + 2 < nt, tl + 2, tl + 3 < nt, tl + 3);
+                __syncthreads();
+            }
         }
     }
 
     // ---- H_i tile out (rows interleaved like the TN GEMM form)
     float *Hi = g.H + (int64_t)blockIdx.x * KP * KP;
-    if (mfma_wave) {
+    if constexpr (SYM) {
+        auto emit = [&](auto typ) {
+            constexpr int TY = decltype(typ)::value;
+#pragma unroll
+            for (int n = 0; n < sym_np(TY); ++n) {
+                const int ba = ablk[sym_ai(TY, n)], bb = bblk[sym_bi(TY, n)];
+                float *blk = Hi + (32 * ba + 4 * lh) * KP + 32 * bb + l31; // + (j + 8q) rows: register r = 4q + j
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float *dst = blk + ((r & 3) + 8 * (r >> 2)) * KP;
+                    *dst = hs[n][r] + ((g.accumulate & 1) ? *dst : 0.f);
+                }
+                if (ba != bb) { // mirror image: row = this lane's column, four consecutive columns per register quad
+                    float *tb = Hi + (32 * bb + l31) * KP + 32 * ba + 4 * lh;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v = {hs[n][4 * q], hs[n][4 * q + 1], hs[n][4 * q + 2], hs[n][4 * q + 3]};
+                        f32x4 *dst = reinterpret_cast<f32x4 *>(tb + 8 * q);
+                        if (g.accumulate & 1) v += *dst;
+                        *dst = v;
+                    }
+                }
+            }
+        };
+        if (wty == 0) emit(IntC<0>{});
+        else if (wty == 1) emit(IntC<1>{});
+        else emit(IntC<2>{});
+    } else if (mfma_wave) {
 #pragma unroll
         for (int x = 0; x < C::TM; ++x)
 #pragma unroll
