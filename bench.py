@@ -52,7 +52,8 @@ HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec
 
 def algorithmic_flops(w):
     """SURVEY.md 8(d).  MU: 4kd(m+p) + 4k^2(m+d+p).  Newton: residual/gradient contractions
-    + per-row Hessians 2k^2(m s_d + p s_d + d(s_m+s_p)) on the sweeps that need them."""
+    + per-row Hessians k(k+1)(m s_d + p s_d + d(s_m+s_p)) on the sweeps that need them -- every H_i is
+    symmetric and only its upper half is credited (8(d): "symmetric half may be credited as half")."""
     m, d, p, k = w["m"], w["d"], w["p"], w["k"]
     if "nnz_per_row" in w:  # sparse X: the X contractions cost 2 k nnz each
         nnz = float(m) * w["nnz_per_row"]
@@ -66,13 +67,13 @@ def algorithmic_flops(w):
     s_d, s_m, s_p = int(d * r), int(m * r), int(p * r)
     f = base
     if xl == "logit" or r < 1:  # U rows
-        f += 2.0 * k * k * m * s_d + 2.0 * k * m * s_d
+        f += k * (k + 1.0) * m * s_d + 2.0 * k * m * s_d
     if yl == "logit" or r < 1:  # Z rows
-        f += 2.0 * k * k * p * s_d + 2.0 * k * p * s_d
+        f += k * (k + 1.0) * p * s_d + 2.0 * k * p * s_d
     if xl == "logit" or yl == "logit" or r < 1:  # V rows
         hx = s_m if (xl == "logit" or r < 1) else 0
         hy = s_p if (yl == "logit" or r < 1) else 0
-        f += 2.0 * k * k * d * (hx + hy) + 2.0 * k * d * (s_m + s_p)
+        f += k * (k + 1.0) * d * (hx + hy) + 2.0 * k * d * (s_m + s_p)
     return f
 
 
@@ -273,7 +274,8 @@ def main():
             except Exception:
                 traffic = None
         if dom == "rowhess":
-            kname = "cmfk::row_hess_kernel<%d>  (fused per-row gradient + Hessian over the sampled rows)" % kp
+            kname = ("cmfk::row_hess_kernel<%d>  (fused per-row gradient + Hessian over the sampled rows; flops "
+                     "credited for the symmetric half of each H_i, k(k+1) per sample)" % kp)
         else:
             kname = "cmfk::gemm_kernel<%d, %d, 0, 4>  (%s data pass)" % (
                 0 if dom == "gemm_nn" else 1, 256 if k >= 256 else kp,
@@ -285,6 +287,9 @@ def main():
                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/traffic_%s.json)" % args.workload,
                 "algorithmic_flops_per_launch": dfl / max(dn, 1),
                 "avg_launch_ms": dms / max(dn, 1), "launches": dn}
+    if dom == "rowhess" and kp == 256 and "row_symmetric=0" not in args.option:
+        # the MFMAs cover 36 whole 32x32 blocks (the diagonal blocks are computed in full)
+        roof["mfma_executed_tflops"] = achieved * (36 * 2048.0 + 4 * kp) / (kp * (kp + 1.0) + 4 * kp)
     roof["per_class_ms_per_step"] = {c: v[0] / args.steps for c, v in classes.items() if v[1]}
     out = {
         "metric": "factor-update iterations/s (%s solver: one full update_step per iteration)" % w["solver"],

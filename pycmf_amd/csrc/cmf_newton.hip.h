@@ -417,13 +417,23 @@ template <int KP>
 static int launch_row_hess_kp(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
     using Cfg = RowHessCfg<KP>;
     if (KP == 256 && c->opt_rowdiag > 0) { // DIAGNOSTIC builds of the k_pad = 256 kernel (wrong results)
-        const void *fn = c->opt_rowdiag == 1 ? reinterpret_cast<const void *>(&row_hess_kernel<256, 1, 1>)
-                       : c->opt_rowdiag == 2 ? reinterpret_cast<const void *>(&row_hess_kernel<256, 1, 2>)
-                                             : reinterpret_cast<const void *>(&row_hess_kernel<256, 1, 3>);
-        CHK(allow_big_lds(c, fn, (int)Cfg::LDS_BYTES));
-        if (c->opt_rowdiag == 1) hipLaunchKernelGGL((row_hess_kernel<256, 1, 1>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
-        else if (c->opt_rowdiag == 2) hipLaunchKernelGGL((row_hess_kernel<256, 1, 2>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
-        else hipLaunchKernelGGL((row_hess_kernel<256, 1, 3>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
+#define CMF_ROWDIAG(D_, S_)                                                                                          \
+    do {                                                                                                           \
+        CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<256, 1, D_, S_>), (int)Cfg::LDS_BYTES)); \
+        hipLaunchKernelGGL((row_hess_kernel<256, 1, D_, S_>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a); \
+    } while (0)
+        if (c->opt_rowsym) {
+            if (c->opt_rowdiag == 1) CMF_ROWDIAG(1, 1);
+            else if (c->opt_rowdiag == 2) CMF_ROWDIAG(2, 1);
+            else if (c->opt_rowdiag == 4) CMF_ROWDIAG(4, 1);
+            else if (c->opt_rowdiag == 5) CMF_ROWDIAG(5, 1);
+            else CMF_ROWDIAG(3, 1);
+        } else {
+            if (c->opt_rowdiag == 1) CMF_ROWDIAG(1, 0);
+            else if (c->opt_rowdiag == 2) CMF_ROWDIAG(2, 0);
+            else CMF_ROWDIAG(3, 0);
+        }
+#undef CMF_ROWDIAG
     } else if (KP == 256 && c->opt_rowsym) {
         constexpr int KS = KP == 256 ? 256 : 0; // only the k_pad = 256 instantiation exists
         if constexpr (KS == 256) {
@@ -443,7 +453,9 @@ static int launch_row_hess_kp(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
 
 static int launch_row_hess(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
     if (nrows <= 0) return CMF_OK;
-    Timed tm(c, CMF_K_ROWHESS, 2.0 * (double)nrows * (double)a.s * ((double)c->kp * c->kp + 2.0 * c->kp));
+    // algorithmic credit: H_i is symmetric, so k_pad (k_pad + 1) / 2 multiply-adds per sample ("the
+    // symmetric half may be credited as half"), plus the dot product and the gradient accumulation (2 k_pad each)
+    Timed tm(c, CMF_K_ROWHESS, (double)nrows * (double)a.s * ((double)c->kp * (c->kp + 1.0) + 4.0 * c->kp));
     switch (c->kp) {
     case 32: return launch_row_hess_kp<32>(c, a, nrows);
     case 64: return launch_row_hess_kp<64>(c, a, nrows);

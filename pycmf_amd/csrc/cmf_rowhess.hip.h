@@ -6,8 +6,9 @@
 //     g_i = sum_j r_j o_j        H_i = sum_j w_j o_j o_j^T
 // One 512-thread workgroup per row.  The 32 gathered rows of a K-step are staged through registers
 // into an LDS tile; while they are still in registers the owning lanes take the dot product with
-// f_i (butterfly over the k_pad/4 lanes that share a row), so z, r, w and the gradient cost no LDS
-// traffic.  The rows are written to LDS twice, raw (B operand) and scaled by w_j (A operand), so that H_i is a
+// f_i (each thread holds k_pad/64 16-byte chunks of ONE gathered row, the at most 16 lanes that share
+// the row finish the sum with four DPP adds), so z, r, w and the gradient cost no LDS traffic and one
+// sigmoid / target load per thread and K-step.  The rows are written to LDS twice, raw (B operand) and scaled by w_j (A operand), so that H_i is a
 // rank-32 MFMA update per step with exactly the TN GEMM's inner loop -- only the sampled rows are ever touched,
 // there is no residual / weight / mask image and no Khatri-Rao matrix.
 #pragma once
@@ -35,8 +36,8 @@ struct RowHessArgs {
 
 template <int KP>
 struct RowHessCfg {
-    static constexpr int GS = KP / 4;                      // lanes per gathered row
-    static constexpr int LD = (32 * GS + 511) / 512;       // float4 per thread per tile
+    static constexpr int LPR = KP / 4 < 16 ? KP / 4 : 16;  // lanes per gathered row
+    static constexpr int CPT = (KP / 4) / LPR;             // 16-byte chunks of that row per lane (chunk q*LPR + lane)
     static constexpr int WM = KP >= 128 ? 4 : (KP == 64 ? 2 : 1);
     static constexpr int WN = KP >= 64 ? 2 : 1;
     static constexpr int TM = KP == 256 ? 2 : 1;
@@ -73,9 +74,11 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int64_t i = g.row0 + blockIdx.x;
-    const int c4 = t % C::GS;
-    const bool loader = (C::GS >= 16) || (t < 32 * C::GS);
-    const f32x4 u4 = *reinterpret_cast<const f32x4 *>(g.F + i * KP + 4 * c4);
+    const int trow = t / C::LPR, tl16 = t % C::LPR;          // this thread's tile row and lane within the row
+    const bool loader = t < 32 * C::LPR;                      // k_pad = 32: half of the threads cover the tile
+    f32x4 u4[C::CPT];
+#pragma unroll
+    for (int q = 0; q < C::CPT; ++q) u4[q] = *reinterpret_cast<const f32x4 *>(g.F + i * KP + 4 * (q * C::LPR + tl16));
     const int32_t *list = g.idx ? g.idx + i * g.idx_stride : nullptr;
     const float *Ti = g.T + i * g.t_row;
     const int nt = (g.s + 31) / 32;
@@ -91,7 +94,9 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
         for (int b = 0; b < C::TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    f32x4 gacc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 gacc[C::CPT];
+#pragma unroll
+    for (int q = 0; q < C::CPT; ++q) gacc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     // SYM: block accumulators and this wave's block rows / columns (all wave-uniform)
     f32x16 hs[5];
 #pragma unroll
@@ -113,43 +118,56 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
         bblk[0] = sbase + 1; bblk[1] = sbase + 2; bblk[2] = sbase + 3; bblk[3] = sbase + 3;
     }
 
-    int jn[C::LD];      // indices of the tile about to be gathered
-    f32x4 rr[C::LD];    // gathered rows of the tile in flight
-    float tt[C::LD];    // their targets
-    bool vv[C::LD];     // sample exists (tail of the list)
+    int jn = 0;          // index of the row about to be gathered
+    f32x4 rr[C::CPT];    // this thread's chunks of the gathered row in flight
+    float tt = 0.f;      // its target
+    bool vv = false;     // sample exists (tail of the list)
 
-    auto row_of = [&](int p) { return (t + 512 * p) / C::GS; };
     auto load_idx = [&](int tl) {
-#pragma unroll
-        for (int p = 0; p < C::LD; ++p) {
-            const int q = 32 * tl + row_of(p);
-            const int qc = q < g.s ? q : g.s - 1;
-            jn[p] = list ? list[qc] : qc;
-        }
+        const int q = 32 * tl + trow;
+        const int qc = q < g.s ? q : g.s - 1;
+        jn = list ? list[qc] : qc;
     };
     auto gather = [&](int tl) {
+        vv = 32 * tl + trow < g.s;
+        const float *src = g.O + (int64_t)jn * KP + 4 * tl16;
 #pragma unroll
-        for (int p = 0; p < C::LD; ++p) {
-            const int q = 32 * tl + row_of(p);
-            vv[p] = q < g.s;
-            rr[p] = *reinterpret_cast<const f32x4 *>(g.O + (int64_t)jn[p] * KP + 4 * c4);
-            tt[p] = Ti[(int64_t)jn[p] * g.t_col];
-        }
+        for (int q = 0; q < C::CPT; ++q) rr[q] = *reinterpret_cast<const f32x4 *>(src + 4 * q * C::LPR);
+        tt = Ti[(int64_t)jn * g.t_col];
     };
-    // registers -> (z, r, w, gradient) -> LDS tile
+    // registers -> (z, r, w, gradient) -> LDS tile.  Branch-free in the link:
+    // f = lk sigmoid(z) + (1 - lk) z, w = lk f (1 - f) + (1 - lk), lk = 0 / 1 -- exact, one term is always zero.
+    const float lk = g.link ? 1.0f : 0.0f, nlk = 1.0f - lk;
     auto stage = [&](int nb) {
+        float *rdst = tile_of(nb) + trow * KP + 4 * tl16;
+        float *wdst = wtile_of(nb) + trow * KP + 4 * tl16;
+        if constexpr (DIAG == 4) { // diagnostic: LDS writes only
 #pragma unroll
-        for (int p = 0; p < C::LD; ++p) {
-            float z = u4[0] * rr[p][0] + u4[1] * rr[p][1] + u4[2] * rr[p][2] + u4[3] * rr[p][3];
-            z = group_sum<C::GS>(z);
-            const float f = g.link ? sigmoidf_(z) : z;
-            const float valid = vv[p] ? 1.0f : 0.0f;
-            const float res = valid * g.scale * (f - tt[p]);
-            const float wgt = valid * g.scale * (g.link ? f * (1.0f - f) : 1.0f);
-            gacc += res * rr[p];
-            const int r = row_of(p);
-            *reinterpret_cast<f32x4 *>(tile_of(nb) + r * KP + 4 * c4) = rr[p];
-            *reinterpret_cast<f32x4 *>(wtile_of(nb) + r * KP + 4 * c4) = wgt * rr[p];
+            for (int q = 0; q < C::CPT; ++q) {
+                *reinterpret_cast<f32x4 *>(rdst + 4 * q * C::LPR) = rr[q];
+                *reinterpret_cast<f32x4 *>(wdst + 4 * q * C::LPR) = rr[q];
+            }
+            return;
+        }
+        float z = 0.f;
+#pragma unroll
+        for (int q = 0; q < C::CPT; ++q)
+            z += u4[q][0] * rr[q][0] + u4[q][1] * rr[q][1] + u4[q][2] * rr[q][2] + u4[q][3] * rr[q][3];
+        z = group_sum<C::LPR>(z);
+        const float sg = sigmoidf_(z);
+        const float f = lk * sg + nlk * z;
+        const float valid = vv ? g.scale : 0.0f;
+        const float res = valid * (f - tt);
+        const float wgt = valid * (lk * (f * (1.0f - f)) + nlk);
+#pragma unroll
+        for (int q = 0; q < C::CPT; ++q) {
+            gacc[q] += res * rr[q];
+            if constexpr (DIAG == 5) { // diagnostic: the arithmetic only
+                gacc[q] += wgt * rr[q];
+                continue;
+            }
+            *reinterpret_cast<f32x4 *>(rdst + 4 * q * C::LPR) = rr[q];
+            *reinterpret_cast<f32x4 *>(wdst + 4 * q * C::LPR) = wgt * rr[q];
         }
     };
     auto mfma_tile = [&](int cb, bool do_stage, int nb, bool do_gather, int tl_gather, bool do_idx, int tl_idx) {
@@ -206,10 +224,10 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
             if (sidx + 1 < 16) ld_frag(sidx + 1, a[(sidx + 1) & 1], b[(sidx + 1) & 1]);
             const int g0 = (STAGGER && late) ? 8 : 0;
             if (sidx == g0) {
-                if (do_stage && loader) stage(nb);
+                if (DIAG != 1 && DIAG != 3 && do_stage && loader) stage(nb);
             } else if (sidx == g0 + 1) {
-                if (do_gather && loader) gather(tl_gather);
-                if (do_idx && loader) load_idx(tl_idx);
+                if (DIAG != 1 && DIAG != 2 && do_gather && loader) gather(tl_gather);
+                if (DIAG != 1 && DIAG != 2 && do_idx && loader) load_idx(tl_idx);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -303,9 +321,12 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
     }
     // ---- gradient part: sum the per-thread partials that share a column chunk
     __syncthreads();
-    constexpr int NREP = 512 / C::GS; // threads per column chunk
-    float *gr = rsm;                  // [NREP][KP] staging (the tiles are dead now); 512*4 floats <= 2*TILE
-    *reinterpret_cast<f32x4 *>(gr + (t / C::GS) * KP + 4 * c4) = loader ? gacc : f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int NREP = 32;          // one partial per tile row
+    float *gr = rsm;                  // [NREP][KP] staging (the tiles are dead now)
+    if (loader) {
+#pragma unroll
+        for (int q = 0; q < C::CPT; ++q) *reinterpret_cast<f32x4 *>(gr + trow * KP + 4 * (q * C::LPR + tl16)) = gacc[q];
+    }
     __syncthreads();
     if (t < KP) {
         float sacc = 0.f;

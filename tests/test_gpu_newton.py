@@ -291,8 +291,9 @@ def test_sharded_newton_protocol_matches_oracle(lib, world, fmt):
 def test_symmetric_block_row_kernel_matches_full(lib):
     """k_pad = 256: the row kernel that accumulates only the blocks on or above the diagonal of every H_i and
     mirrors them must give the factors of the full-block kernel (same device-drawn samples), for both accumulate
-    modes (the V sweep adds its Y-side Hessian onto the X-side one) and a ragged sample count."""
-    m, d, p, k = 150, 333, 90, 256
+    modes (the V sweep adds its Y-side Hessian onto the X-side one) and ragged sample counts.  Every row draws
+    more samples than k, so the Hessians are well conditioned and the comparison is not about the eigenvalue clamp."""
+    m, d, p, k = 500, 601, 450, 256
     rng = np.random.RandomState(12)
     X, Y = rng.rand(m, d), rng.rand(d, p)
     U0, V0, Z0 = 0.2 * rng.randn(m, k), 0.2 * rng.randn(d, k), 0.2 * rng.randn(p, k)
@@ -304,9 +305,10 @@ def test_symmetric_block_row_kernel_matches_full(lib):
         ctx.set_data(0, X); ctx.set_data(1, Y)
         for w, F in enumerate((U0, V0, Z0)):
             ctx.set_factor(w, F)
-        for it in range(2):
-            ctx.newton_step_device_sampled(0.4, 0.01, 0.05, "logit", "logit", 0, 7, 0.2, 0.37, 99 + it)
+        # one step: a second one starts from factors of magnitude 2 (saturated sigmoids, near-singular Hessians)
+        # and amplifies the fp32 summation-order difference between the two kernels
+        ctx.newton_step_device_sampled(0.4, 0.01, 0.05, "logit", "logit", 0, 7, 0.2, 0.63, 99)
         out.append([ctx.get_factor(w) for w in range(3)])
         ctx.close()
-    for a, b in zip(*out):  # fp32 Hessians summed in a different order, then solved: same tolerance as vs the oracle
-        np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-3 * np.abs(b).max())
+    for a, b in zip(*out):  # fp32 Hessians summed in a different order, then solved
+        np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4 * np.abs(b).max())
