@@ -335,9 +335,11 @@ __device__ __forceinline__ void chol_load(CholRegs<NB> &R, const float *H, int n
     }
 }
 
-// in-register Cholesky; returns false (uniformly) on a pivot <= floor_
-template <int NB>
-__device__ __forceinline__ bool chol_factor(CholRegs<NB> &R, int n, float floor_, float *col, int t) {
+// in-register Cholesky; returns false (uniformly) on a pivot <= floor_.  With RHS the forward substitution
+// L y = g rides along (vec holds g on entry, y on exit): y_j and the update of vec[i > j] use the scaled column
+// the owners of column j already hold, between the two barriers the column step has anyway.
+template <int NB, bool RHS = false>
+__device__ __forceinline__ bool chol_factor(CholRegs<NB> &R, int n, float floor_, float *col, int t, float *vec = nullptr) {
     const int ti = t & 15, tc = t >> 4;
     bool ok = true;
 #pragma unroll
@@ -366,6 +368,15 @@ __device__ __forceinline__ bool chol_factor(CholRegs<NB> &R, int n, float floor_
                     const int i = ti + 16 * a;
                     if (i > j) R.M[a][jb] = li[a];
                     else if (i == j) R.M[a][jb] = ljj;
+                }
+                if constexpr (RHS) {
+                    const float yj = vec[j] * inv;
+#pragma unroll
+                    for (int a = jb; a < NB; ++a) {
+                        const int i = ti + 16 * a;
+                        if (i > j) vec[i] -= li[a] * yj;
+                    }
+                    if (ti == jl) vec[j] = yj;
                 }
             }
 #pragma unroll
@@ -407,48 +418,40 @@ __global__ __launch_bounds__(256, 2) void chol_solve_kernel(const float *Hin, co
     }
     if (t == 0) need_jacobi[mat] = 0;
     __syncthreads();
-    chol_load<NB>(R, H, n, kp, 0.f, stage, t);
-    (void)chol_factor<NB>(R, n, 0.f, col, t);
-
-    // forward substitution  L y = g
     for (int i = t; i < 16 * NB; i += 256) vec[i] = (i < n) ? grad[(int64_t)mat * kp + i] : 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int jb = 0; jb < NB; ++jb) {
-        for (int jl = 0; jl < 16; ++jl) {
-            const int j = 16 * jb + jl;
-            if (j >= n) break;
-            if (tc == jl && ti == jl) vec[j] = vec[j] / R.M[jb][jb];
-            __syncthreads();
-            if (tc == jl) {
-                const float yj = vec[j];
-#pragma unroll
-                for (int a = jb; a < NB; ++a) {
-                    const int i = ti + 16 * a;
-                    if (i > j && i < n) vec[i] -= R.M[a][jb] * yj;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    // back substitution  L^T x = y
+    chol_load<NB>(R, H, n, kp, 0.f, stage, t); // (its barriers also publish vec)
+    (void)chol_factor<NB, true>(R, n, 0.f, col, t, vec); // H = L L^T and, on the way, L y = g
+
+    // back substitution  L^T x = y, one 16-column block per pair of barriers: (i) every 16-lane group subtracts
+    // the solved blocks from its own column, (ii) wave 0 finishes the 16 x 16 triangle with lane broadcasts
+    float *dblk = stage;           // [16][17] diagonal block
+    float *rblk = stage + 16 * 17; // [16] right-hand side of the block
 #pragma unroll
     for (int jb = NB - 1; jb >= 0; --jb) {
-        for (int jl = 15; jl >= 0; --jl) {
-            const int j = 16 * jb + jl;
-            if (j >= n) continue;
-            if (tc == jl) { // the 16 consecutive lanes that own column j
-                float sacc = 0.f;
+        if (16 * jb >= n) continue;
+        float sacc = 0.f;
 #pragma unroll
-                for (int a = jb; a < NB; ++a) {
-                    const int i = ti + 16 * a;
-                    if (i > j && i < n) sacc += R.M[a][jb] * vec[i];
-                }
-                sacc = group_sum<16>(sacc); // the active lanes are exactly one aligned 16-lane row
-                if (ti == jl) vec[j] = (vec[j] - sacc) / R.M[jb][jb];
+        for (int a = jb + 1; a < NB; ++a) sacc += R.M[a][jb] * vec[ti + 16 * a];
+        sacc = group_sum<16>(sacc); // t = 16 tc + ti: the 16 lanes of a DPP row own one column
+        dblk[ti * 17 + tc] = R.M[jb][jb];
+        if (ti == 0) rblk[tc] = vec[16 * jb + tc] - sacc;
+        __syncthreads();
+        if (t < 64) {
+            const int c = t & 15;
+            float r = rblk[c];
+            const float invd = 1.0f / dblk[c * 17 + c];
+            float drow[16]; // L[j][c], j = 0..15: what x_j contributes to column c
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) drow[jj] = dblk[jj * 17 + c];
+#pragma unroll
+            for (int jj = 15; jj >= 0; --jj) {
+                const float xj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r * invd), jj));
+                if (c == jj) r = xj;
+                else if (c < jj) r -= drow[jj] * xj;
             }
-            __syncthreads();
+            if (t < 16) vec[16 * jb + c] = r;
         }
+        __syncthreads();
     }
     for (int i = t; i < kp; i += 256) step[(int64_t)mat * kp + i] = (i < n) ? vec[i] : 0.f;
 }
