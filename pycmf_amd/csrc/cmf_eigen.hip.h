@@ -335,12 +335,32 @@ __device__ __forceinline__ void chol_load(CholRegs<NB> &R, const float *H, int n
     }
 }
 
-// in-register Cholesky; returns false (uniformly) on a pivot <= floor_.  With RHS the forward substitution
-// L y = g rides along (vec holds g on entry, y on exit): y_j and the update of vec[i > j] use the scaled column
-// the owners of column j already hold, between the two barriers the column step has anyway.
+// in-register Cholesky; returns false (uniformly) on a pivot <= floor_.  A column step: the 16 lanes that own
+// column j take the pivot by readlane, scale their 16 column entries (zero on and above the diagonal) and publish
+// them -- row i = ti + 16 a at col[ti * NB + a], so that afterwards every thread fetches its NB row values and its
+// NB column values with wide LDS reads and goes straight to the rank-1 update of its own registers.
+// With RHS the forward substitution L y = g rides along (vec holds g on entry, y on exit), between the two
+// barriers the column step has anyway.
+template <int NB>
+__device__ __forceinline__ void chol_col_io(float *p, float (&v)[NB], bool write) {
+    if constexpr (NB >= 4) {
+#pragma unroll
+        for (int k = 0; k < NB / 4; ++k) {
+            f32x4 *q = reinterpret_cast<f32x4 *>(p + 4 * k);
+            if (write) *q = f32x4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+            else { const f32x4 x = *q; v[4 * k] = x[0]; v[4 * k + 1] = x[1]; v[4 * k + 2] = x[2]; v[4 * k + 3] = x[3]; }
+        }
+    } else {
+        f32x2 *q = reinterpret_cast<f32x2 *>(p);
+        if (write) *q = f32x2{v[0], v[1]};
+        else { const f32x2 x = *q; v[0] = x[0]; v[1] = x[1]; }
+    }
+}
+
 template <int NB, bool RHS = false>
 __device__ __forceinline__ bool chol_factor(CholRegs<NB> &R, int n, float floor_, float *col, int t, float *vec = nullptr) {
     const int ti = t & 15, tc = t >> 4;
+    float *pivslot = col + 16 * NB;
     bool ok = true;
 #pragma unroll
     for (int jb = 0; jb < NB; ++jb) {
@@ -348,37 +368,37 @@ __device__ __forceinline__ bool chol_factor(CholRegs<NB> &R, int n, float floor_
             const int j = 16 * jb + jl;
             if (j >= n) break;
             if (tc == jl) {
+                // the diagonal element sits in lane ti == jl of this 16-lane row
+                const float piv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, R.M[jb][jb]), 16 * (jl & 3) + jl));
+                const float inv = piv > floor_ ? __builtin_amdgcn_rsqf(piv) : 0.f;
+                const float ljj = piv * inv;
+                float sc[NB];
 #pragma unroll
-                for (int a = jb; a < NB; ++a) col[ti + 16 * a] = R.M[a][jb];
-            }
-            __syncthreads();
-            const float piv = col[j];
-            if (!(piv > floor_)) { ok = false; break; }
-            const float ljj = sqrtf(piv), inv = 1.0f / ljj;
-            float li[NB], lc[NB];
-#pragma unroll
-            for (int a = jb; a < NB; ++a) {
-                const int i = ti + 16 * a, c = tc + 16 * a;
-                li[a] = (i > j) ? col[i] * inv : 0.f;
-                lc[a] = (c > j) ? col[c] * inv : 0.f;
-            }
-            if (tc == jl) {
-#pragma unroll
-                for (int a = jb; a < NB; ++a) {
+                for (int a = 0; a < NB; ++a) {
                     const int i = ti + 16 * a;
-                    if (i > j) R.M[a][jb] = li[a];
-                    else if (i == j) R.M[a][jb] = ljj;
+                    sc[a] = (a >= jb && i > j) ? R.M[a][jb] * inv : 0.f;
+                    if (a >= jb) {
+                        if (i > j) R.M[a][jb] = sc[a];
+                        else if (i == j) R.M[a][jb] = ljj;
+                    }
                 }
+                chol_col_io<NB>(col + ti * NB, sc, true);
+                if (ti == 0) *pivslot = piv;
                 if constexpr (RHS) {
                     const float yj = vec[j] * inv;
 #pragma unroll
                     for (int a = jb; a < NB; ++a) {
                         const int i = ti + 16 * a;
-                        if (i > j) vec[i] -= li[a] * yj;
+                        if (i > j) vec[i] -= sc[a] * yj;
                     }
                     if (ti == jl) vec[j] = yj;
                 }
             }
+            __syncthreads();
+            if (!(*pivslot > floor_)) { ok = false; break; }
+            float li[NB], lc[NB];
+            chol_col_io<NB>(col + ti * NB, li, false);
+            chol_col_io<NB>(col + tc * NB, lc, false);
 #pragma unroll
             for (int a = jb; a < NB; ++a)
 #pragma unroll
@@ -393,7 +413,7 @@ __device__ __forceinline__ bool chol_factor(CholRegs<NB> &R, int n, float floor_
 template <int NB>
 __global__ __launch_bounds__(256, 2) void chol_solve_kernel(const float *Hin, const float *grad, float *step, int *need_jacobi,
                                                             int n, int kp, int64_t stride, float pert, int nmat) {
-    __shared__ float col[16 * NB];
+    __shared__ __attribute__((aligned(16))) float col[16 * NB + 4]; // published column + the pivot slot
     __shared__ float vec[16 * NB];
     __shared__ float stage[16 * 16 * NB];
     __shared__ float red[4];
@@ -541,13 +561,17 @@ __device__ __forceinline__ uint32_t sample_key(uint64_t seed, uint64_t l, uint64
     return (uint32_t)(mix64(mix64(seed ^ (l * 0xD1342543DE82EF95ull)) ^ (j + 0x632BE59BD9B4E019ull)) >> 32);
 }
 
-__global__ __launch_bounds__(256) void sample_mask_kernel(uint8_t *mask, int64_t ld, int by_row, int64_t nlists, int n, int s,
-                                                          uint64_t seed) {
+// Output: the 0/1 byte mask (masked-dense formulation) and / or the ascending list of the s winners (fused row
+// kernel); either pointer may be null.
+__global__ __launch_bounds__(256) void sample_select_kernel(uint8_t *mask, int64_t ld, int by_row, int32_t *lists, int64_t nlists,
+                                                            int n, int s, uint64_t seed) {
     __shared__ unsigned hist[4096];
+    __shared__ unsigned wsum[4];
     __shared__ unsigned sel_prefix, sel_remaining, tie_budget;
+    __shared__ int wave_cnt[4];
     const int64_t l = blockIdx.x;
     if (l >= nlists) return;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     unsigned prefix = 0, remaining = (unsigned)s; // keys < prefix region already counted as winners
     // level 0: bits 31..20, level 1: bits 19..8, level 2: bits 7..0
     const int shifts[3] = {20, 8, 0};
@@ -556,19 +580,37 @@ __global__ __launch_bounds__(256) void sample_mask_kernel(uint8_t *mask, int64_t
     for (int lev = 0; lev < 3; ++lev) {
         const int nb = 1 << widths[lev];
         for (int b = t; b < nb; b += 256) hist[b] = 0;
+        if (t == 0) { // fallback if no bin reaches `remaining` (s > n, never for s = int(n * ratio))
+            sel_prefix = prefix | ((unsigned)(nb - 1) << shifts[lev]);
+            sel_remaining = 0;
+        }
         __syncthreads();
         for (int j = t; j < n; j += 256) {
             const uint32_t k = sample_key(seed, (uint64_t)l, (uint64_t)j);
             if ((k & known_mask) == prefix) atomicAdd(&hist[(k >> shifts[lev]) & (nb - 1)], 1u);
         }
         __syncthreads();
-        if (t == 0) {
-            unsigned acc = 0, b = 0;
-            for (; b < (unsigned)nb; ++b) {
+        // the bin holding the `remaining`-th smallest key: every thread sums its nb/256 consecutive bins, a block
+        // scan places those sums, and the one thread whose range crosses `remaining` walks its own bins
+        const int per_t = nb / 256;
+        unsigned loc = 0;
+        for (int q = 0; q < per_t; ++q) loc += hist[t * per_t + q];
+        unsigned incl = loc;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        unsigned excl = incl - loc;
+        for (int w = 0; w < wid; ++w) excl += wsum[w];
+        if (excl < remaining && remaining <= excl + loc) {
+            unsigned acc = excl, b = (unsigned)(t * per_t);
+            for (int q = 0; q < per_t - 1; ++q) {
                 if (acc + hist[b] >= remaining) break;
                 acc += hist[b];
+                ++b;
             }
-            if (b >= (unsigned)nb) b = nb - 1;
             sel_prefix = prefix | (b << shifts[lev]);
             sel_remaining = remaining - acc; // how many winners still to pick inside the chosen bin
         }
@@ -580,6 +622,7 @@ __global__ __launch_bounds__(256) void sample_mask_kernel(uint8_t *mask, int64_t
     }
     // winners: key < prefix, plus the first `remaining` (by index) of the candidates with key == prefix
     if (t == 0) tie_budget = remaining;
+    int base = 0; // winners emitted so far (uniform)
     __syncthreads();
     for (int j0 = 0; j0 < n; j0 += 256) {
         const int j = j0 + t;
@@ -598,9 +641,20 @@ __global__ __launch_bounds__(256) void sample_mask_kernel(uint8_t *mask, int64_t
                 __syncthreads();
             }
         }
-        if (j < n) {
+        if (mask && j < n) {
             const int64_t off = by_row ? (l * ld + j) : ((int64_t)j * ld + l);
             mask[off] = win ? 1 : 0;
+        }
+        if (lists) { // ordered compaction of this 256-candidate slice
+            const unsigned long long bal = __ballot(win);
+            if (lane == 0) wave_cnt[wid] = __popcll(bal);
+            __syncthreads();
+            int off = base;
+            for (int w = 0; w < wid; ++w) off += wave_cnt[w];
+            off += __popcll(bal & ((1ull << lane) - 1ull));
+            if (win && off < s) lists[l * (int64_t)s + off] = j;
+            base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            __syncthreads();
         }
     }
 }

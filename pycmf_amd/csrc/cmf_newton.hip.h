@@ -252,8 +252,8 @@ static int build_mask(cmf_ctx *c, DevBuf &mb, int64_t rows_pad, int64_t cols_pad
     if (nlists * per == 0) return CMF_OK;
     if (c->dev_sampling) { // draw the samples on the device (counter-based)
         Timed tm(c, CMF_K_ELEMWISE);
-        hipLaunchKernelGGL(sample_mask_kernel, dim3((unsigned)nlists), dim3(256), 0, c->stream, (uint8_t *)mb.p, cols_pad,
-                           by_row ? 1 : 0, nlists, (int)n, (int)per, c->dev_seed * 4 + (uint64_t)salt);
+        hipLaunchKernelGGL(sample_select_kernel, dim3((unsigned)nlists), dim3(256), 0, c->stream, (uint8_t *)mb.p, cols_pad,
+                           by_row ? 1 : 0, (int32_t *)nullptr, nlists, (int)n, (int)per, c->dev_seed * 4 + (uint64_t)salt);
         HIPCHK(hipGetLastError());
         return CMF_OK;
     }
@@ -472,14 +472,11 @@ static int sample_lists(cmf_ctx *c, DevBuf &lb, DevBuf &mb, const int32_t *host_
     if (nlists * per == 0) return CMF_OK;
     CHK(ensure(c, lb, (size_t)nlists * per * sizeof(int32_t)));
     if (c->dev_sampling) {
-        // sample into a transient byte mask [nlists x n_pad], then compact every row into an ascending list
-        const int64_t ldm = rup(n, 256);
-        CHK(ensure(c, mb, (size_t)nlists * ldm));
+        // exactly `per` winners per list, emitted in ascending index order
+        (void)mb;
         Timed tm(c, CMF_K_ELEMWISE);
-        hipLaunchKernelGGL(sample_mask_kernel, dim3((unsigned)nlists), dim3(256), 0, c->stream, (uint8_t *)mb.p, ldm, 1, nlists, (int)n,
-                           (int)per, c->dev_seed * 4 + (uint64_t)salt);
-        hipLaunchKernelGGL(mask_to_list_kernel, dim3((unsigned)nlists), dim3(256), 0, c->stream, (const uint8_t *)mb.p, ldm, 1, nlists,
-                           (int)n, (int)per, (int32_t *)lb.p);
+        hipLaunchKernelGGL(sample_select_kernel, dim3((unsigned)nlists), dim3(256), 0, c->stream, (uint8_t *)nullptr, (int64_t)0, 1,
+                           (int32_t *)lb.p, nlists, (int)n, (int)per, c->dev_seed * 4 + (uint64_t)salt);
         HIPCHK(hipGetLastError());
     } else {
         HIPCHK(hipMemcpyAsync(lb.p, host_idx, (size_t)nlists * per * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
@@ -524,10 +521,11 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
             a.H = Hc; a.G = grad; a.accumulate = 0; a.row0 = r0; a.nrows = nr;
             // H and G accumulate independently: encode as two flags in one int (bit0: H, bit1: G)
             a.accumulate = (have_h ? 1 : 0) | (have_g ? 2 : 0);
+            a.S = S; a.diag = (float)diag; a.kvalid = c->k; // folded into the epilogue of the launch that starts H_i
             CHK(launch_row_hess(c, a, nr));
             have_h = have_g = true;
         }
-        CHK(launch_ew(c, hessian_finalize_kernel, nr * kk, Hc, S, (float)diag, nr, c->kp, c->k, have_h ? 1 : 0));
+        if (!have_h) CHK(launch_ew(c, hessian_finalize_kernel, nr * kk, Hc, S, (float)diag, nr, c->kp, c->k, 0));
         CHK(launch_ew(c, newton_grad_kernel, nr * c->kp, grad + r0 * c->kp, (const float *)(grad + r0 * c->kp), 1.0f, (const float *)nullptr, 0.f,
                       (const float *)(c->F[which] + r0 * c->kp), (float)l1, (float)l2, nr * c->kp));
         CHK(safe_solve_rows(c, Hc, grad + r0 * c->kp, step + r0 * c->kp, nr, c->k, c->kp, pert));

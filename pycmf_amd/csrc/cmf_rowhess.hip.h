@@ -30,6 +30,9 @@ struct RowHessArgs {
     float *H;             // [nrows x KP x KP] out (accumulate ? += : =)
     float *G;             // [nrows x KP] gradient part out (accumulate ? += : =)
     int accumulate;       // bit 0: H += , bit 1: G +=
+    const float *S;       // shared (symmetric) k_pad x k_pad part added to every H_i by the launch that does not accumulate, or null
+    float diag;           // ... together with diag * I on the first kvalid diagonal entries
+    int kvalid;
     int64_t row0;         // first row of this launch (blockIdx.x + row0 = i)
     int64_t nrows;        // rows in this launch; H, G are indexed by blockIdx.x (H) / i (G)
 };
@@ -278,20 +281,25 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
             for (int n = 0; n < sym_np(TY); ++n) {
                 const int ba = ablk[sym_ai(TY, n)], bb = bblk[sym_bi(TY, n)];
                 float *blk = Hi + (32 * ba + 4 * lh) * KP + 32 * bb + l31; // + (j + 8q) rows: register r = 4q + j
+                const int col = 32 * bb + l31;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * ba + 4 * lh + (r & 3) + 8 * (r >> 2);
                     float *dst = blk + ((r & 3) + 8 * (r >> 2)) * KP;
-                    *dst = hs[n][r] + ((g.accumulate & 1) ? *dst : 0.f);
+                    float v = hs[n][r];
+                    if (g.accumulate & 1) v += *dst;
+                    else { // the launch that starts H_i also adds the shared part and the diagonal (S is symmetric)
+                        if (g.S) v += g.S[row * KP + col];
+                        if (row == col && row < g.kvalid) v += g.diag;
+                    }
+                    hs[n][r] = v;
+                    *dst = v;
                 }
                 if (ba != bb) { // mirror image: row = this lane's column, four consecutive columns per register quad
                     float *tb = Hi + (32 * bb + l31) * KP + 32 * ba + 4 * lh;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        f32x4 v = {hs[n][4 * q], hs[n][4 * q + 1], hs[n][4 * q + 2], hs[n][4 * q + 3]};
-                        f32x4 *dst = reinterpret_cast<f32x4 *>(tb + 8 * q);
-                        if (g.accumulate & 1) v += *dst;
-                        *dst = v;
-                    }
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<f32x4 *>(tb + 8 * q) = f32x4{hs[n][4 * q], hs[n][4 * q + 1], hs[n][4 * q + 2], hs[n][4 * q + 3]};
                 }
             }
         };
@@ -305,18 +313,21 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
             for (int r = 0; r < 16; ++r) {
                 const int rrw = (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int row = wrow0 + C::TM * rrw + x;
-                float *dst = Hi + row * KP + wcol0 + C::TN * l31;
-                if constexpr (C::TN == 4) {
-                    f32x4 v = {acc[x][0][r], acc[x][1][r], acc[x][2][r], acc[x][3][r]};
-                    if (g.accumulate & 1) v += *reinterpret_cast<f32x4 *>(dst);
-                    *reinterpret_cast<f32x4 *>(dst) = v;
-                } else if constexpr (C::TN == 2) {
-                    f32x2 v = {acc[x][0][r], acc[x][1][r]};
-                    if (g.accumulate & 1) v += *reinterpret_cast<f32x2 *>(dst);
-                    *reinterpret_cast<f32x2 *>(dst) = v;
-                } else {
-                    dst[0] = acc[x][0][r] + ((g.accumulate & 1) ? dst[0] : 0.f);
+                const int col0 = wcol0 + C::TN * l31;
+                float *dst = Hi + row * KP + col0;
+                float v[C::TN];
+#pragma unroll
+                for (int y = 0; y < C::TN; ++y) {
+                    v[y] = acc[x][y][r];
+                    if (g.accumulate & 1) v[y] += dst[y];
+                    else {
+                        if (g.S) v[y] += g.S[row * KP + col0 + y];
+                        if (row == col0 + y && row < g.kvalid) v[y] += g.diag;
+                    }
                 }
+                if constexpr (C::TN == 4) *reinterpret_cast<f32x4 *>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                else if constexpr (C::TN == 2) *reinterpret_cast<f32x2 *>(dst) = f32x2{v[0], v[1]};
+                else dst[0] = v[0];
             }
     }
     // ---- gradient part: sum the per-thread partials that share a column chunk
@@ -333,32 +344,6 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
         for (int rep = 0; rep < NREP; ++rep) sacc += gr[rep * KP + t];
         float *dst = g.G + i * KP + t;
         *dst = sacc + ((g.accumulate & 2) ? *dst : 0.f);
-    }
-}
-
-// compact a 0/1 byte mask row (or column) into an ascending index list of exactly `per` entries
-__global__ __launch_bounds__(256) void mask_to_list_kernel(const uint8_t *mask, int64_t ld, int by_row, int64_t nlists, int n,
-                                                           int per, int32_t *lists) {
-    __shared__ int wave_cnt[4];
-    __shared__ int base;
-    const int64_t l = blockIdx.x;
-    if (l >= nlists) return;
-    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    if (t == 0) base = 0;
-    __syncthreads();
-    for (int j0 = 0; j0 < n; j0 += 256) {
-        const int j = j0 + t;
-        const bool on = j < n && mask[by_row ? (l * ld + j) : ((int64_t)j * ld + l)] != 0;
-        const unsigned long long bal = __ballot(on);
-        const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_cnt[wid] = __popcll(bal);
-        __syncthreads();
-        int off = base;
-        for (int w = 0; w < wid; ++w) off += wave_cnt[w];
-        if (on && off + before < per) lists[l * per + off + before] = j;
-        __syncthreads();
-        if (t == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        __syncthreads();
     }
 }
 
