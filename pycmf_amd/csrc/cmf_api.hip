@@ -93,6 +93,7 @@ struct cmf_ctx {
     int opt_pipe_small = 4; // staging schedule of the factor-side products (0 or 4; 4 measured +5..15 %, tools/ab_small.py)
     int opt_pipe = 4;      // GEMM staging schedule (see gemm_kernel PIPE); 4 measured best (tools/ab_gemm.py)
     int opt_split = -1;    // force split-K factor (<=0: heuristic)
+    int opt_choldiag = 0;  // timing diagnostics of chol_solve_kernel (wrong results)
     int opt_chol = 1;      // Cholesky fast path of the safe inverse (0: always Jacobi)
     int opt_zlogit_l2 = 1;  // 0: Cython-twin numerics (Z's logit Hessian without l2 I, pyx:287-290)
     int opt_rowdiag = 0;    // diagnostic builds of row_hess_kernel<256> (1: no staging, 2: stage only, 3: gather only)
@@ -521,6 +522,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_rowsym = value != 0;
     } else if (!strcmp(name, "row_kernel")) {
         c->opt_rowkernel = value != 0;
+    } else if (!strcmp(name, "chol_diag")) {
+        c->opt_choldiag = (int)value;
     } else if (!strcmp(name, "safe_inverse_cholesky")) {
         c->opt_chol = value != 0;
     } else if (!strcmp(name, "sparse_mode")) {

@@ -316,23 +316,19 @@ struct CholRegs {
 };
 
 template <int NB>
-__device__ __forceinline__ void chol_load(CholRegs<NB> &R, const float *H, int n, int kp, float shift, float *stage, int t) {
+__device__ __forceinline__ void chol_load(CholRegs<NB> &R, const float *H, int n, int kp, float shift, int t) {
+    // element (i, c) = (16 a + ti, 16 b + tc) is fetched as H[c][i] (H is symmetric): the 16 lanes of a DPP row
+    // then read 64 contiguous bytes, nothing goes through LDS and all loads of a thread are in flight together
     const int ti = t & 15, tc = t >> 4;
 #pragma unroll
-    for (int a = 0; a < NB; ++a) {
-        const int W = 16 * (a + 1);
-        for (int idx = t; idx < 16 * W; idx += 256) {
-            const int r = idx / W, cc = idx % W;
-            const int i = 16 * a + r;
-            float v = (i == cc) ? 1.0f : 0.0f; // identity outside the valid n x n block
-            if (i < n && cc < n) v = H[i * kp + cc] - (i == cc ? shift : 0.f);
-            stage[r * (16 * NB) + cc] = v;
-        }
-        __syncthreads();
+    for (int a = 0; a < NB; ++a)
 #pragma unroll
-        for (int b = 0; b <= a; ++b) R.M[a][b] = stage[ti * (16 * NB) + tc + 16 * b];
-        __syncthreads();
-    }
+        for (int b = 0; b <= a; ++b) {
+            const int i = 16 * a + ti, cc = 16 * b + tc;
+            float v = (i == cc) ? 1.0f : 0.0f; // identity outside the valid n x n block
+            if (i < n && cc < n) v = H[cc * kp + i] - (i == cc ? shift : 0.f);
+            R.M[a][b] = v;
+        }
 }
 
 // in-register Cholesky; returns false (uniformly) on a pivot <= floor_.  A column step: the 16 lanes that own
@@ -359,14 +355,17 @@ __device__ __forceinline__ void chol_col_io(float *p, float (&v)[NB], bool write
 
 template <int NB, bool RHS = false>
 __device__ __forceinline__ bool chol_factor(CholRegs<NB> &R, int n, float floor_, float *col, int t, float *vec = nullptr) {
+    // col = two buffers of (16 NB column entries + pivot slot + pad): column j goes to buffer j & 1, so the owners
+    // of column j + 1 may publish while slower waves still read column j -- one barrier per column step
+    constexpr int CB = 16 * NB + 4;
     const int ti = t & 15, tc = t >> 4;
-    float *pivslot = col + 16 * NB;
     bool ok = true;
 #pragma unroll
     for (int jb = 0; jb < NB; ++jb) {
         for (int jl = 0; jl < 16; ++jl) {
             const int j = 16 * jb + jl;
             if (j >= n) break;
+            float *cb = col + (jl & 1) * CB;
             if (tc == jl) {
                 // the diagonal element sits in lane ti == jl of this 16-lane row
                 const float piv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, R.M[jb][jb]), 16 * (jl & 3) + jl));
@@ -382,8 +381,8 @@ __device__ __forceinline__ bool chol_factor(CholRegs<NB> &R, int n, float floor_
                         else if (i == j) R.M[a][jb] = ljj;
                     }
                 }
-                chol_col_io<NB>(col + ti * NB, sc, true);
-                if (ti == 0) *pivslot = piv;
+                chol_col_io<NB>(cb + ti * NB, sc, true);
+                if (ti == 0) cb[16 * NB] = piv;
                 if constexpr (RHS) {
                     const float yj = vec[j] * inv;
 #pragma unroll
@@ -395,27 +394,27 @@ __device__ __forceinline__ bool chol_factor(CholRegs<NB> &R, int n, float floor_
                 }
             }
             __syncthreads();
-            if (!(*pivslot > floor_)) { ok = false; break; }
+            if (!(cb[16 * NB] > floor_)) { ok = false; break; }
             float li[NB], lc[NB];
-            chol_col_io<NB>(col + ti * NB, li, false);
-            chol_col_io<NB>(col + tc * NB, lc, false);
+            chol_col_io<NB>(cb + ti * NB, li, false);
+            chol_col_io<NB>(cb + tc * NB, lc, false);
 #pragma unroll
             for (int a = jb; a < NB; ++a)
 #pragma unroll
                 for (int b = jb; b <= a; ++b) R.M[a][b] -= li[a] * lc[b];
-            __syncthreads();
         }
         if (!ok) break;
     }
+    __syncthreads(); // vec / col are free again
     return ok;
 }
 
 template <int NB>
 __global__ __launch_bounds__(256, 2) void chol_solve_kernel(const float *Hin, const float *grad, float *step, int *need_jacobi,
-                                                            int n, int kp, int64_t stride, float pert, int nmat) {
-    __shared__ __attribute__((aligned(16))) float col[16 * NB + 4]; // published column + the pivot slot
+                                                            int n, int kp, int64_t stride, float pert, int nmat, int diag = 0) {
+    __shared__ __attribute__((aligned(16))) float col[2 * (16 * NB + 4)]; // two buffers of (published column + pivot slot)
     __shared__ float vec[16 * NB];
-    __shared__ float stage[16 * 16 * NB];
+    __shared__ float stage[16 * 17 + 16]; // diagonal block + block right-hand side of the back substitution
     __shared__ float red[4];
     const int mat = blockIdx.x;
     if (mat >= nmat) return;
@@ -431,17 +430,29 @@ __global__ __launch_bounds__(256, 2) void chol_solve_kernel(const float *Hin, co
     const float floor_ = 4.0e-6f * dmax;
 
     CholRegs<NB> R;
-    chol_load<NB>(R, H, n, kp, pert, stage, t);
+    chol_load<NB>(R, H, n, kp, pert, t);
+    if (diag == 3) { // keep the loaded values alive
+        float sink = 0.f;
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) sink += R.M[a][b];
+        if (sink == 12345.678f) need_jacobi[mat] = 2;
+        return;
+    }
     if (!chol_factor<NB>(R, n, floor_, col, t)) { // lambda_min < pert: the clamp matters -> Jacobi
         if (t == 0) need_jacobi[mat] = 1;
         return;
     }
     if (t == 0) need_jacobi[mat] = 0;
-    __syncthreads();
+    if (diag == 1) return; // timing diagnostics (cmf_set_option "chol_diag"): 1 = PD test only, 2 = no back substitution,
+    __syncthreads();       // 3 = loads only
     for (int i = t; i < 16 * NB; i += 256) vec[i] = (i < n) ? grad[(int64_t)mat * kp + i] : 0.f;
-    chol_load<NB>(R, H, n, kp, 0.f, stage, t); // (its barriers also publish vec)
+    chol_load<NB>(R, H, n, kp, 0.f, t);
+    __syncthreads(); // publish vec
     (void)chol_factor<NB, true>(R, n, 0.f, col, t, vec); // H = L L^T and, on the way, L y = g
 
+    if (diag == 2) return;
     // back substitution  L^T x = y, one 16-column block per pair of barriers: (i) every 16-lane group subtracts
     // the solved blocks from its own column, (ii) wave 0 finishes the 16 x 16 triangle with lane broadcasts
     float *dblk = stage;           // [16][17] diagonal block

@@ -121,10 +121,10 @@ static int safe_solve_rows(cmf_ctx *c, float *Hc, const float *grad, float *step
     {
         Timed tm(c, CMF_K_EIGEN);
         const dim3 grid((unsigned)nr), block(256);
-        if (n <= 32) hipLaunchKernelGGL((chol_solve_kernel<2>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr);
-        else if (n <= 64) hipLaunchKernelGGL((chol_solve_kernel<4>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr);
-        else if (n <= 128) hipLaunchKernelGGL((chol_solve_kernel<8>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr);
-        else hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr);
+        if (n <= 32) hipLaunchKernelGGL((chol_solve_kernel<2>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag);
+        else if (n <= 64) hipLaunchKernelGGL((chol_solve_kernel<4>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag);
+        else if (n <= 128) hipLaunchKernelGGL((chol_solve_kernel<8>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag);
+        else hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag);
         HIPCHK(hipGetLastError());
         // flagged matrices: |lambda| / clamp by Jacobi, in place (the solve kernel does not modify H)
         const size_t lds_need = (size_t)(2 * n * n + n) * sizeof(float);
