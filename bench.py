@@ -145,7 +145,8 @@ def main():
     import torch
     import torch.distributed as dist
     from pycmf_amd import _lib
-    from pycmf_amd.sharded import make_torch_sharded_mu, make_torch_sharded_newton, shard_bounds
+    from pycmf_amd.sharded import (make_torch_sharded_mu, make_torch_sharded_newton, make_torch_sharded_newton_rows,
+                                   shard_bounds)
 
     # Test hooks (not used by the driver): CMF_BENCH_SAME_DEVICE=1 puts every rank on GPU 0 and
     # CMF_BENCH_BACKEND=gloo swaps RCCL for gloo, so the N>1 code path can be exercised on a 1-GPU box.
@@ -165,8 +166,6 @@ def main():
     m, d, p, k = w["m"], w["d"], w["p"], w["k"]
     newton = w["solver"] == "newton"
     sharded_ok = (not newton) or (w["x_link"] == "linear" and w["y_link"] == "linear" and w["ratio"] == 1.0)
-    if world > 1 and not sharded_ok:
-        raise SystemExit("workload %s (per-row Newton sweeps) is single-GPU in this round" % args.workload)
     r0, r1 = shard_bounds(m, world, rank)
     c0, c1 = shard_bounds(p, world, rank)
 
@@ -197,6 +196,7 @@ def main():
         ctx.fill_factor_synthetic(_lib.CMF_U, 101, r0, scale)
         ctx.fill_factor_synthetic(_lib.CMF_V, 102, 0, scale)
         ctx.fill_factor_synthetic(_lib.CMF_Z, 103, c0, scale)
+        ctxs = [ctx]
 
         if not newton:
             drv = make_torch_sharded_mu(ctx, world, device)
@@ -208,6 +208,26 @@ def main():
 
             def do_step(it):
                 drv.step(0.0, 0.1, 7)
+        elif world > 1:
+            # per-row sweeps (logit link and / or sampling): a second context holds the rank's COLUMNS of X and rows
+            # of Y with U and Z whole, and sweeps the rank's rows of V; factor rows are exchanged in between
+            q0, q1 = shard_bounds(d, world, rank)
+            ctx_v = _lib.Context(local_rank, stream.cuda_stream)
+            for kv in args.option:
+                name, _, val = kv.partition("=")
+                ctx_v.set_option(name, int(val))
+            ctx_v.set_problem(m, q1 - q0, p, k)
+            ctx_v.fill_data_synthetic(0, 42, 0, q0)
+            ctx_v.fill_data_synthetic(1, 43, q0, 0)
+            ctx_v.fill_factor_synthetic(_lib.CMF_U, 101, 0, scale)
+            ctx_v.fill_factor_synthetic(_lib.CMF_V, 102, q0, scale)
+            ctx_v.fill_factor_synthetic(_lib.CMF_Z, 103, 0, scale)
+            ctxs.append(ctx_v)
+            drv = make_torch_sharded_newton_rows(ctx, ctx_v, (r0, r1, q0, q1, c0, c1), (m, d, p), world, device, 0.5,
+                                                 w["x_link"], w["y_link"], nn_mask=0, pert=0.2, ratio=w["ratio"])
+
+            def do_step(it):
+                drv.step(0.0, 0.1, 7, 1000 + it)
         else:
             def do_step(it):
                 ctx.newton_step_device_sampled(0.5, 0.0, 0.1, w["x_link"], w["y_link"], 0, 7, 0.2,
@@ -221,8 +241,9 @@ def main():
 
         for it in range(args.warmup):
             do_step(it)
-        ctx.kernel_timing(True)
-        ctx.kernel_timing_reset()
+        for c_ in ctxs:
+            c_.kernel_timing(True)
+            c_.kernel_timing_reset()
         sync_all()
         t0 = time.perf_counter()
         for it in range(args.steps):
@@ -235,8 +256,9 @@ def main():
             elapsed = float(te.item())
 
         names = ("gemm_nn", "gemm_tn", "gemm_small", "gemm_nt", "spmm", "rowhess", "eigen", "elementwise")
-        classes = {c: ctx.kernel_time(c) for c in names}
-        ctx.kernel_timing(False)
+        classes = {c: tuple(sum(v) for v in zip(*(c_.kernel_time(c) for c_ in ctxs))) for c in names}
+        for c_ in ctxs:
+            c_.kernel_timing(False)
         ex2, ey2 = ctx.residual_sq(w.get("x_link", "linear"), w.get("y_link", "linear"))
         x2, y2 = ctx.data_sq()
         kp = ctx.geometry()[3]
@@ -307,8 +329,11 @@ def main():
         "cells_per_s": (float(m) * d + float(d) * p) * its,
         "algorithmic_tflops": algorithmic_flops(w) * its / 1e12,
         "config": {"workload": w["desc"], "m": m, "d": d, "p": p, "n_components": k, "solver": w["solver"],
-                   "parallelism": "X/U row-sharded, Y/Z column-sharded x%d, V replicated, "
-                                  "1 RCCL all-reduce of (d+k)*k f32 per iteration" % world},
+                   "parallelism": ("rows of U, V, Z sharded x%d (every sweep row-parallel; X and Y held by rows and by "
+                                   "columns), factor rows gathered by 3 RCCL all-reduces of (m+p+d)*k f32 per iteration"
+                                   % world) if (newton and not sharded_ok and world > 1) else
+                                  ("X/U row-sharded, Y/Z column-sharded x%d, V replicated, "
+                                   "1 RCCL all-reduce of (d+k)*k f32 per iteration" % world)},
         "roofline": roof,
         "rel_residual": {"x": (ex2 / x2) ** 0.5 if x2 > 0 else None, "y": (ey2 / y2) ** 0.5 if y2 > 0 else None,
                          "note": "rank-0 shard, after warmup+steps iterations"},

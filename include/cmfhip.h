@@ -75,7 +75,10 @@ int cmf_sync(cmf_ctx *ctx);
  * "z_logit_hessian_l2" 1 (live Python path, cmf_solvers.py:505-506) | 0 (Cython twin,
  * cmf_newton_solver.pyx:287-290: Z's logit Hessian without l2 I),
  * "safe_inverse_cholesky" 1 | 0, "graph" 1 | 0 (replay MU / linear-Newton steps from a
- * captured hipGraph; automatically off while cmf_kernel_timing is enabled)              */
+ * captured hipGraph; automatically off while cmf_kernel_timing is enabled),
+ * "row_symmetric" 1 | 0 (k_pad = 256 row kernel: upper block triangle of H_i only),
+ * "sample_row_offset_u|v|z" n = global index of this context's first U / V / Z row in the keys of
+ * the device sampler (a row shard then draws what the unsharded problem draws for its rows)        */
 int cmf_set_option(cmf_ctx *ctx, const char *name, int64_t value);
 
 /* ---- problem ---------------------------------------------------------- */
@@ -176,6 +179,11 @@ int cmf_debug_clock(cmf_ctx *ctx, double *ghz, double *loop_us);
 int cmf_get_geometry(cmf_ctx *ctx, int64_t *m_pad, int64_t *d_pad, int64_t *p_pad, int *k_pad);
 /* device pointers of the factor blocks (float32, row-major, ld = k_pad) */
 int cmf_factor_dev_ptr(cmf_ctx *ctx, int which, float **ptr);
+/* device-to-device copies of all valid rows of a factor, k_pad floats per row, on the context's stream:
+ * what a row-sharded Newton driver exchanges between its U/Z-sweep and V-sweep contexts
+ * (the reference keeps U, V, Z in one address space: cmf_solvers.py:510-522)                      */
+int cmf_export_factor_rows(cmf_ctx *ctx, int which, float *dev_dst);
+int cmf_import_factor_rows(cmf_ctx *ctx, int which, const float *dev_src);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,8 @@ PROTOTYPES = {
     "cmf_kernel_timing_reset": [_vp],
     "cmf_get_geometry": [_vp, _pi64, _pi64, _pi64, C.POINTER(C.c_int)],
     "cmf_factor_dev_ptr": [_vp, _i32, C.POINTER(_pf)],
+    "cmf_export_factor_rows": [_vp, _i32, _vp],
+    "cmf_import_factor_rows": [_vp, _i32, _vp],
 }
 
 _lib = None
@@ -280,6 +282,13 @@ class Context:
         out = np.empty_like(H)
         check(self._lib.cmf_safe_invert_batch(self._h, H.ctypes.data_as(_pd), out.ctypes.data_as(_pd), n, k, pert))
         return out
+
+    def export_factor_rows(self, which, dev_ptr):
+        """Device-to-device copy of all valid rows (k_pad floats each) to `dev_ptr`, on the context's stream."""
+        check(self._lib.cmf_export_factor_rows(self._h, which, _vp(dev_ptr)))
+
+    def import_factor_rows(self, which, dev_ptr):
+        check(self._lib.cmf_import_factor_rows(self._h, which, _vp(dev_ptr)))
 
     def set_option(self, name, value):
         check(self._lib.cmf_set_option(self._h, name.encode(), int(value)))

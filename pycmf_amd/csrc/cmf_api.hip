@@ -103,6 +103,7 @@ struct cmf_ctx {
     double flop_scale = 1.0;   // algorithmic/executed flop ratio of the launches being issued (sampled sweeps run masked-dense)
     bool dev_sampling = false; // armed for one cmf_newton_step by cmf_newton_step_device_sampled
     uint64_t dev_seed = 0;
+    int64_t sample_off[3] = {0, 0, 0}; // global index of local row 0 of U / V / Z for the device sampler's keys
 
     float *X = nullptr, *Y = nullptr; // dense, row-major, ld = dp / pp (null while a sparse input stays native)
     CsrDev sp[2][2];                  // [X|Y][A | A^T] native CSR images
@@ -522,6 +523,12 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_rowsym = value != 0;
     } else if (!strcmp(name, "row_kernel")) {
         c->opt_rowkernel = value != 0;
+    } else if (!strcmp(name, "sample_row_offset_u")) {
+        c->sample_off[CMF_U] = value;
+    } else if (!strcmp(name, "sample_row_offset_v")) {
+        c->sample_off[CMF_V] = value;
+    } else if (!strcmp(name, "sample_row_offset_z")) {
+        c->sample_off[CMF_Z] = value;
     } else if (!strcmp(name, "chol_diag")) {
         c->opt_choldiag = (int)value;
     } else if (!strcmp(name, "safe_inverse_cholesky")) {
@@ -750,6 +757,21 @@ extern "C" int cmf_factor_dev_ptr(cmf_ctx *c, int which, float **ptr) {
     NEED_PROBLEM(c);
     if (which < 0 || which > 2 || !ptr) return fail(CMF_EINVAL, "bad factor argument");
     *ptr = c->F[which];
+    return CMF_OK;
+}
+
+// device-to-device exchange of factor rows (fp32, k_pad floats per row): what a sharded driver all-gathers
+extern "C" int cmf_export_factor_rows(cmf_ctx *c, int which, float *dev_dst) {
+    NEED_PROBLEM(c);
+    if (which < 0 || which > 2 || !dev_dst) return fail(CMF_EINVAL, "bad factor argument");
+    HIPCHK(hipMemcpyAsync(dev_dst, c->F[which], (size_t)c->frows[which] * c->kp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    return CMF_OK;
+}
+
+extern "C" int cmf_import_factor_rows(cmf_ctx *c, int which, const float *dev_src) {
+    NEED_PROBLEM(c);
+    if (which < 0 || which > 2 || !dev_src) return fail(CMF_EINVAL, "bad factor argument");
+    HIPCHK(hipMemcpyAsync(c->F[which], dev_src, (size_t)c->frows[which] * c->kp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     return CMF_OK;
 }
 

@@ -574,8 +574,9 @@ __device__ __forceinline__ uint32_t sample_key(uint64_t seed, uint64_t l, uint64
 
 // Output: the 0/1 byte mask (masked-dense formulation) and / or the ascending list of the s winners (fused row
 // kernel); either pointer may be null.
+// `l0` = global index of list 0 (a shard of the rows draws what the unsharded problem draws for those rows).
 __global__ __launch_bounds__(256) void sample_select_kernel(uint8_t *mask, int64_t ld, int by_row, int32_t *lists, int64_t nlists,
-                                                            int n, int s, uint64_t seed) {
+                                                            int n, int s, uint64_t seed, int64_t l0) {
     __shared__ unsigned hist[4096];
     __shared__ unsigned wsum[4];
     __shared__ unsigned sel_prefix, sel_remaining, tie_budget;
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(256) void sample_select_kernel(uint8_t *mask, int64
         }
         __syncthreads();
         for (int j = t; j < n; j += 256) {
-            const uint32_t k = sample_key(seed, (uint64_t)l, (uint64_t)j);
+            const uint32_t k = sample_key(seed, (uint64_t)(l + l0), (uint64_t)j);
             if ((k & known_mask) == prefix) atomicAdd(&hist[(k >> shifts[lev]) & (nb - 1)], 1u);
         }
         __syncthreads();
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(256) void sample_select_kernel(uint8_t *mask, int64
         const int j = j0 + t;
         bool win = false, tie = false;
         if (j < n) {
-            const uint32_t k = sample_key(seed, (uint64_t)l, (uint64_t)j);
+            const uint32_t k = sample_key(seed, (uint64_t)(l + l0), (uint64_t)j);
             win = k < prefix;
             tie = (k == prefix);
         }

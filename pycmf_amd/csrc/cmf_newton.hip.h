@@ -253,7 +253,8 @@ static int build_mask(cmf_ctx *c, DevBuf &mb, int64_t rows_pad, int64_t cols_pad
     if (c->dev_sampling) { // draw the samples on the device (counter-based)
         Timed tm(c, CMF_K_ELEMWISE);
         hipLaunchKernelGGL(sample_select_kernel, dim3((unsigned)nlists), dim3(256), 0, c->stream, (uint8_t *)mb.p, cols_pad,
-                           by_row ? 1 : 0, (int32_t *)nullptr, nlists, (int)n, (int)per, c->dev_seed * 4 + (uint64_t)salt);
+                           by_row ? 1 : 0, (int32_t *)nullptr, nlists, (int)n, (int)per, c->dev_seed * 4 + (uint64_t)salt,
+                           c->sample_off[salt == 0 ? CMF_U : (salt == 1 ? CMF_Z : CMF_V)]);
         HIPCHK(hipGetLastError());
         return CMF_OK;
     }
@@ -476,7 +477,8 @@ static int sample_lists(cmf_ctx *c, DevBuf &lb, DevBuf &mb, const int32_t *host_
         (void)mb;
         Timed tm(c, CMF_K_ELEMWISE);
         hipLaunchKernelGGL(sample_select_kernel, dim3((unsigned)nlists), dim3(256), 0, c->stream, (uint8_t *)nullptr, (int64_t)0, 1,
-                           (int32_t *)lb.p, nlists, (int)n, (int)per, c->dev_seed * 4 + (uint64_t)salt);
+                           (int32_t *)lb.p, nlists, (int)n, (int)per, c->dev_seed * 4 + (uint64_t)salt,
+                           c->sample_off[salt == 0 ? CMF_U : (salt == 1 ? CMF_Z : CMF_V)]);
         HIPCHK(hipGetLastError());
     } else {
         HIPCHK(hipMemcpyAsync(lb.p, host_idx, (size_t)nlists * per * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));

@@ -101,6 +101,107 @@ class ShardedNewtonLinear:
             self.backend.apply_v(self.buf, l1, l2)
 
 
+class HipNewtonRowsBackend:
+    """Row-sharded Newton for ANY link / sampling combination ("shard V rows instead for that sweep").
+
+    Every rank drives two contexts on its GPU:
+      ctx_uz  problem (m_g, d, p_g):  X rows / Y columns of the rank, V whole      -> sweeps U_g and Z_g
+      ctx_v   problem (m, d_g, p):    X columns / Y rows of the rank, U and Z whole -> sweeps V_g
+    All three sweeps are row-parallel (pycmf/cmf_solvers.py:394-508), so each context runs the unsharded kernels
+    on its rows; what moves between ranks is factor rows only: U, Z before the V sweep, V after it.  The device
+    sampler keys by GLOBAL row index (sample_row_offset_*), so the iteration is bit-identical to the unsharded one.
+    """
+
+    def __init__(self, ctx_uz, ctx_v, bounds, shape, alpha, x_link, y_link, nn_mask=0, pert=0.2, ratio=1.0):
+        self.ctx_uz, self.ctx_v = ctx_uz, ctx_v
+        self.bounds = bounds            # (r0, r1, q0, q1, c0, c1): rows of U, rows of V, rows of Z owned by the rank
+        self.shape = shape              # global (m, d, p)
+        self.alpha, self.x_link, self.y_link = alpha, x_link, y_link
+        self.nn_mask, self.pert, self.ratio = nn_mask, pert, ratio
+        r0, _, q0, _, c0, _ = bounds
+        ctx_uz.set_option("sample_row_offset_u", r0)
+        ctx_uz.set_option("sample_row_offset_z", c0)
+        ctx_v.set_option("sample_row_offset_v", q0)
+        self.k_pad = ctx_uz.geometry()[3]
+
+    def _step(self, ctx, l1, l2, mask, seed):
+        if self.ratio < 1.0:
+            ctx.newton_step_device_sampled(self.alpha, l1, l2, self.x_link, self.y_link, self.nn_mask, mask,
+                                           self.pert, self.ratio, seed)
+        else:
+            ctx.newton_step(self.alpha, l1, l2, self.x_link, self.y_link, self.nn_mask, mask, self.pert, 1.0)
+
+    def sweep_uz(self, l1, l2, mask, seed):
+        if mask & 5:
+            self._step(self.ctx_uz, l1, l2, mask & 5, seed)
+
+    def sweep_v(self, l1, l2, seed):
+        self._step(self.ctx_v, l1, l2, 2, seed)
+
+    def rows(self, which):
+        """(global rows, first owned row, one-past-last owned row) of factor `which` (0 U, 1 V, 2 Z)."""
+        r0, r1, q0, q1, c0, c1 = self.bounds
+        return ((self.shape[0], r0, r1), (self.shape[1], q0, q1), (self.shape[2], c0, c1))[which]
+
+    def export_rows(self, which, full):
+        """Write the rank's rows of factor `which` into its slice of the zeroed staging tensor `full`."""
+        _, lo, hi = self.rows(which)
+        if hi > lo:
+            ctx = self.ctx_v if which == 1 else self.ctx_uz
+            ctx.export_factor_rows(which, full[lo:hi].data_ptr())
+            ctx.sync()  # the two contexts (and the collective) may live on different streams
+
+    def import_rows(self, which, full):
+        """Hand the gathered factor to the context that holds it whole."""
+        ctx = self.ctx_uz if which == 1 else self.ctx_v
+        ctx.import_factor_rows(which, full.data_ptr())
+        ctx.sync()
+
+
+class ShardedNewtonRows:
+    """One Newton iteration (order U -> Z -> V) with every sweep sharded by rows.  The gather of factor rows is an
+    all-reduce(sum) of a staging tensor in which every rank has filled only its own rows (zeros elsewhere): exact,
+    indifferent to uneven shards, (m + p + d) k_pad floats per iteration (58 MB at C3)."""
+
+    def __init__(self, backend, staging, world=1, all_reduce=None, zero=None):
+        self.backend, self.staging, self.world, self.all_reduce = backend, staging, world, all_reduce
+        self.zero = zero if zero is not None else (lambda t: t.zero_())
+
+    def _gather(self, which):
+        full = self.staging[which]
+        if self.world > 1:
+            self.zero(full)  # must have landed before the export below writes the rank's rows
+        self.backend.export_rows(which, full)
+        if self.world > 1:
+            self.all_reduce(full)
+        self.backend.import_rows(which, full)
+
+    def step(self, l1=0.0, l2=0.0, mask=7, seed=0):
+        self.backend.sweep_uz(l1, l2, mask, seed)
+        if mask & 2:
+            self._gather(0)
+            self._gather(2)
+            self.backend.sweep_v(l1, l2, seed)
+            self._gather(1)
+
+
+def make_torch_sharded_newton_rows(ctx_uz, ctx_v, bounds, shape, world, device, alpha, x_link, y_link, nn_mask=0,
+                                   pert=0.2, ratio=1.0):
+    import torch
+    import torch.distributed as dist
+    backend = HipNewtonRowsBackend(ctx_uz, ctx_v, bounds, shape, alpha, x_link, y_link, nn_mask, pert, ratio)
+    staging = [torch.zeros((n, backend.k_pad), dtype=torch.float32, device=device) for n in shape]
+
+    def zero(t):
+        t.zero_()
+        torch.cuda.current_stream(device).synchronize()  # the exporting context may run on its own stream
+
+    def all_reduce(t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        torch.cuda.current_stream(device).synchronize()  # ... and so may the importing one
+    return ShardedNewtonRows(backend, staging, world, all_reduce if world > 1 else None, zero)
+
+
 def make_torch_sharded_mu(ctx, world, device):
     """Wire a HIP context to torch.distributed (backend 'nccl' = RCCL)."""
     import torch

@@ -312,3 +312,96 @@ def test_symmetric_block_row_kernel_matches_full(lib):
         ctx.close()
     for a, b in zip(*out):  # fp32 Hessians summed in a different order, then solved
         np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4 * np.abs(b).max())
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("xl,yl,ratio", [("linear", "logit", 0.5), ("logit", "linear", 1.0), ("linear", "linear", 0.7)])
+def test_row_sharded_newton_is_bit_identical(lib, world, xl, yl, ratio):
+    """per-row Newton sweeps sharded by rows (two contexts per rank: U/Z sweeps on the rank's rows of X
+    and columns of Y, V sweep on its columns of X and rows of Y; factor rows exchanged in between).  `world` ranks
+    emulated on this GPU, the gather emulated by summing the staging tensors: every rank must hold exactly the
+    factors of the unsharded iteration (the device sampler keys by global row)."""
+    import torch
+    from pycmf_amd.sharded import HipNewtonRowsBackend, ShardedNewtonRows, shard_bounds
+    m, d, p, k = 211, 157, 93, 24
+    rng = np.random.RandomState(5)
+    X = rng.rand(m, d) if xl == "logit" else np.abs(rng.randn(m, d))
+    Y = rng.rand(d, p) if yl == "logit" else np.abs(rng.randn(d, p))
+    U0, V0, Z0 = 0.3 * rng.randn(m, k), 0.3 * rng.randn(d, k), 0.3 * rng.randn(p, k)
+    alpha, l1, l2, pert, nn = 0.4, 0.01, 0.05, 0.2, 0b010
+
+    def step(ctx, mask, seed):
+        if ratio < 1:
+            ctx.newton_step_device_sampled(alpha, l1, l2, xl, yl, nn, mask, pert, ratio, seed)
+        else:
+            ctx.newton_step(alpha, l1, l2, xl, yl, nn, mask, pert, 1.0)
+
+    ref = lib.Context(0)
+    ref.set_problem(m, d, p, k)
+    ref.set_data(0, X); ref.set_data(1, Y)
+    for w, F in enumerate((U0, V0, Z0)):
+        ref.set_factor(w, F)
+    for it in range(2):
+        step(ref, 7, 40 + it)
+    want = [ref.get_factor(w) for w in range(3)]
+    ref.close()
+
+    ranks = []
+    for r in range(world):
+        r0, r1 = shard_bounds(m, world, r)
+        q0, q1 = shard_bounds(d, world, r)
+        c0, c1 = shard_bounds(p, world, r)
+        a = lib.Context(0)
+        a.set_problem(r1 - r0, d, c1 - c0, k)
+        a.set_data(0, X[r0:r1]); a.set_data(1, Y[:, c0:c1])
+        a.set_factor(0, U0[r0:r1]); a.set_factor(1, V0); a.set_factor(2, Z0[c0:c1])
+        b = lib.Context(0)
+        b.set_problem(m, q1 - q0, p, k)
+        b.set_data(0, X[:, q0:q1]); b.set_data(1, Y[q0:q1])
+        b.set_factor(0, U0); b.set_factor(1, V0[q0:q1]); b.set_factor(2, Z0)
+        be = HipNewtonRowsBackend(a, b, (r0, r1, q0, q1, c0, c1), (m, d, p), alpha, xl, yl, nn, pert, ratio)
+        staging = [torch.zeros((n, be.k_pad), dtype=torch.float32, device="cuda:0") for n in (m, d, p)]
+        ranks.append((be, staging))
+
+    def gather(which):  # what ShardedNewtonRows._gather does on every rank, with the sum standing in for RCCL
+        for be, st in ranks:
+            st[which].zero_()
+        torch.cuda.synchronize()
+        for be, st in ranks:
+            be.export_rows(which, st[which])
+        total = torch.stack([st[which] for _, st in ranks]).sum(0)
+        torch.cuda.synchronize()
+        for be, st in ranks:
+            st[which].copy_(total)
+        torch.cuda.synchronize()
+        for be, st in ranks:
+            be.import_rows(which, st[which])
+
+    for it in range(2):
+        for be, _ in ranks:
+            be.sweep_uz(l1, l2, 7, 40 + it)
+        gather(0); gather(2)
+        for be, _ in ranks:
+            be.sweep_v(l1, l2, 40 + it)
+        gather(1)
+    for be, _ in ranks:
+        r0, r1, q0, q1, c0, c1 = be.bounds
+        np.testing.assert_array_equal(be.ctx_uz.get_factor(0), want[0][r0:r1])
+        np.testing.assert_array_equal(be.ctx_uz.get_factor(2), want[2][c0:c1])
+        np.testing.assert_array_equal(be.ctx_uz.get_factor(1), want[1])
+        np.testing.assert_array_equal(be.ctx_v.get_factor(1), want[1][q0:q1])
+        np.testing.assert_array_equal(be.ctx_v.get_factor(0), want[0])
+        be.ctx_uz.close(); be.ctx_v.close()
+    # the driver object on a single rank (world 1: gathers degenerate to copies between the two contexts)
+    a = lib.Context(0); a.set_problem(m, d, p, k); a.set_data(0, X); a.set_data(1, Y)
+    b = lib.Context(0); b.set_problem(m, d, p, k); b.set_data(0, X); b.set_data(1, Y)
+    for c in (a, b):
+        for w, F in enumerate((U0, V0, Z0)):
+            c.set_factor(w, F)
+    be = HipNewtonRowsBackend(a, b, (0, m, 0, d, 0, p), (m, d, p), alpha, xl, yl, nn, pert, ratio)
+    drv = ShardedNewtonRows(be, [torch.zeros((n, be.k_pad), dtype=torch.float32, device="cuda:0") for n in (m, d, p)])
+    for it in range(2):
+        drv.step(l1, l2, 7, 40 + it)
+    for w in range(3):
+        np.testing.assert_array_equal(a.get_factor(w), want[w])
+    a.close(); b.close()
