@@ -275,3 +275,80 @@ def fit_mu_sharded(X_rows, Y_cols, U_rows, V, Z_rows, l1_reg=0.0, l2_reg=0.0, ma
             ctx.get_factor_into(which, F)
         ctx.close()
     return U_rows, V, Z_rows, n_iter
+
+
+def fit_newton_sharded(X_rows, X_cols, Y_cols, Y_rows, U_rows, V, Z_rows, alpha=0.5, l1_reg=0.0, l2_reg=0.0,
+                       x_link="linear", y_link="linear", U_non_negative=True, V_non_negative=True, Z_non_negative=True,
+                       hessian_pertubation=0.2, sg_sample_ratio=1.0, random_state=None, max_iter=200, tol=1e-4,
+                       device=0, verbose=0):
+    """Row-sharded Newton fit: call from every rank of an initialised ``torch.distributed`` group.
+
+    Rank g passes its row block of X and the SAME rows of U, the matching column block of Y with its rows of Z, and
+    additionally its column block of X and row block of Y (rows ``shard_bounds(d, world, rank)`` of V: the V sweep
+    reads whole columns of X and rows of Y, pycmf/cmf_solvers.py:432-486); V is passed whole and identical on every
+    rank.  Runs the reference's outer loop (:132-195) with the convergence test on the global error
+    alpha ||X - f(UV^T)|| + (1 - alpha) ||Y - f(VZ^T)||.  ``sg_sample_ratio < 1`` uses the device sampler with the
+    seed schedule of ``HipNewtonSolver(sg_sampler='device')``, so the iterates equal the single-GPU ones.
+    U_rows, V, Z_rows are updated in place; returns (U_rows, V, Z_rows, n_iter).
+    """
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    dev = torch.device("cuda", device)
+    torch.cuda.set_device(dev)
+    m_g, d = X_rows.shape
+    m = X_cols.shape[0]
+    p_g, p = Y_cols.shape[1], Y_rows.shape[1]
+    k = V.shape[1]
+    r0, r1 = shard_bounds(m, world, rank)
+    q0, q1 = shard_bounds(d, world, rank)
+    c0, c1 = shard_bounds(p, world, rank)
+    if (m_g, p_g, X_cols.shape[1], Y_rows.shape[0]) != (r1 - r0, c1 - c0, q1 - q0, q1 - q0):
+        raise ValueError("blocks do not match shard_bounds for rank %d of %d" % (rank, world))
+    nn_mask = (1 if U_non_negative else 0) | (2 if V_non_negative else 0) | (4 if Z_non_negative else 0)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx_uz = _lib.Context(device, stream.cuda_stream)
+        ctx_uz.set_problem(m_g, d, p_g, k)
+        ctx_uz.set_data(0, X_rows)
+        ctx_uz.set_data(1, Y_cols)
+        ctx_uz.set_factor(_lib.CMF_U, U_rows); ctx_uz.set_factor(_lib.CMF_V, V); ctx_uz.set_factor(_lib.CMF_Z, Z_rows)
+        ctx_v = _lib.Context(device, stream.cuda_stream)
+        ctx_v.set_problem(m, q1 - q0, p, k)
+        ctx_v.set_data(0, X_cols)
+        ctx_v.set_data(1, Y_rows)
+        ctx_v.set_factor(_lib.CMF_V, V[q0:q1])
+        drv = make_torch_sharded_newton_rows(ctx_uz, ctx_v, (r0, r1, q0, q1, c0, c1), (m, d, p), world, dev, alpha,
+                                             x_link, y_link, nn_mask, hessian_pertubation, sg_sample_ratio)
+        # the V-sweep context needs U and Z whole before its first sweep: the gathers of the first step provide them
+
+        def global_error():
+            ex2, ey2 = ctx_uz.residual_sq(x_link, y_link)
+            t = torch.tensor([ex2, ey2], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            ex2, ey2 = (float(v) for v in t.tolist())
+            return alpha * np.sqrt(ex2) + (1 - alpha) * np.sqrt(ey2)
+
+        seed = (int(random_state) if isinstance(random_state, (int, np.integer)) else 0) << 20
+        previous = at_init = global_error()
+        n_iter = 0
+        for n_iter in range(1, max_iter + 1):
+            seed += 1
+            drv.step(l1_reg, l2_reg, 7, seed)
+            if tol > 0 and n_iter % 10 == 0:
+                err = global_error()
+                if verbose:
+                    print("Epoch %02d, error: %f" % (n_iter, err))
+                if (previous - err) / at_init < tol:
+                    break
+                previous = err
+        torch.cuda.synchronize(dev)
+        ctx_uz.get_factor_into(_lib.CMF_U, U_rows)
+        ctx_uz.get_factor_into(_lib.CMF_V, V)
+        ctx_uz.get_factor_into(_lib.CMF_Z, Z_rows)
+        ctx_uz.close()
+        ctx_v.close()
+    return U_rows, V, Z_rows, n_iter

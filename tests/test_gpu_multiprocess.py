@@ -70,3 +70,64 @@ def test_sharded_fit_two_processes(tmp_path, world):
         np.testing.assert_allclose(o["V"], Vr, rtol=2e-4, atol=1e-6)
         np.testing.assert_allclose(o["U"], Ur[r0:r1], rtol=2e-4, atol=1e-6)
         np.testing.assert_allclose(o["Z"], Zr[c0:c1], rtol=2e-4, atol=1e-6)
+
+
+NEWTON_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from pycmf_amd.sharded import fit_newton_sharded, shard_bounds
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+d_ = np.load(%(data)r)
+X, Y, U, V, Z = d_["X"], d_["Y"], d_["U"].copy(), d_["V"].copy(), d_["Z"].copy()
+r0, r1 = shard_bounds(X.shape[0], world, rank)
+q0, q1 = shard_bounds(X.shape[1], world, rank)
+c0, c1 = shard_bounds(Y.shape[1], world, rank)
+Ur, Zr = U[r0:r1].copy(), Z[c0:c1].copy()
+Ur, V, Zr, n_iter = fit_newton_sharded(X[r0:r1], X[:, q0:q1], Y[:, c0:c1], Y[q0:q1], Ur, V, Zr, alpha=0.4, l1_reg=0.01,
+                                       l2_reg=0.05, x_link="linear", y_link="logit", U_non_negative=False,
+                                       V_non_negative=False, Z_non_negative=False, hessian_pertubation=0.2,
+                                       sg_sample_ratio=0.6, random_state=3, max_iter=20, tol=1e-4, device=0)
+np.savez(%(out)r + str(rank) + ".npz", U=Ur, V=V, Z=Zr, n_iter=n_iter, r=np.array([r0, r1, c0, c1]))
+dist.destroy_process_group()
+'''
+
+
+def test_row_sharded_newton_fit_two_processes(tmp_path):
+    """fit_newton_sharded on 2 real ranks (gloo, one GPU): y logit, sg_sample_ratio 0.6, device sampler -- the same
+    iterates as the single-process HipNewtonSolver(sg_sampler='device'), including the stopping iteration."""
+    from pycmf_amd import _lib
+    from pycmf_amd.solver_shell import HipNewtonSolver
+    if _lib.device_count() < 1:
+        pytest.fail("no GPU visible")
+    world = 2
+    rng = np.random.RandomState(2)
+    m, d, p, k = 230, 170, 110, 10
+    X, Y = np.abs(rng.randn(m, d)), rng.rand(d, p)
+    U, V, Z = 0.3 * rng.randn(m, k), 0.3 * rng.randn(d, k), 0.3 * rng.randn(p, k)
+    data = str(tmp_path / "data.npz")
+    np.savez(data, X=X, Y=Y, U=U, V=V, Z=Z)
+    script = tmp_path / "worker.py"
+    script.write_text(NEWTON_WORKER % {"root": ROOT, "data": data, "out": str(tmp_path / "out")})
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, str(script)],
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [q.communicate(timeout=600)[0].decode() for q in procs]
+    for r, (q, o) in enumerate(zip(procs, outs)):
+        assert q.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+    ref = HipNewtonSolver(alpha=0.4, l1_reg=0.01, l2_reg=0.05, x_link="linear", y_link="logit", U_non_negative=False,
+                          V_non_negative=False, Z_non_negative=False, hessian_pertubation=0.2, sg_sample_ratio=0.6,
+                          random_state=3, max_iter=20, tol=1e-4, sg_sampler="device")
+    Ur, Vr, Zr = U.copy(), V.copy(), Z.copy()
+    _, _, _, n_ref = ref.fit_iterative_update(X, Y, Ur, Vr, Zr)
+    ref.release()
+    for r in range(world):
+        o = np.load(str(tmp_path / "out") + "%d.npz" % r)
+        r0, r1, c0, c1 = o["r"]
+        assert int(o["n_iter"]) == n_ref
+        np.testing.assert_allclose(o["V"], Vr, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(o["U"], Ur[r0:r1], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(o["Z"], Zr[c0:c1], rtol=1e-5, atol=1e-7)
