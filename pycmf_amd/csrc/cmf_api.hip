@@ -93,6 +93,8 @@ struct cmf_ctx {
     int opt_pipe_small = 4; // staging schedule of the factor-side products (0 or 4; 4 measured +5..15 %, tools/ab_small.py)
     int opt_pipe = 4;      // GEMM staging schedule (see gemm_kernel PIPE); 4 measured best (tools/ab_gemm.py)
     int opt_split = -1;    // force split-K factor (<=0: heuristic)
+    int opt_ns = 1;        // flagged per-row Hessians at k_pad = 256: Newton-Schulz spectral clamp (0: Jacobi)
+    bool hess_psd = true;  // the Hessians of the current step are positive semi-definite by construction (0 <= alpha <= 1)
     int opt_choldiag = 0;  // timing diagnostics of chol_solve_kernel (wrong results)
     int opt_chol = 1;      // Cholesky fast path of the safe inverse (0: always Jacobi)
     int opt_zlogit_l2 = 1;  // 0: Cython-twin numerics (Z's logit Hessian without l2 I, pyx:287-290)
@@ -127,6 +129,7 @@ struct cmf_ctx {
     DevBuf idxbuf;                        // uploaded sample index lists
     DevBuf eigws;                         // Jacobi workspace when k_pad > 128
     DevBuf eigflag, eigcopy;              // Cholesky fast path: per-matrix fallback flags, input copy
+    DevBuf nsidx, nsws;                   // Newton-Schulz clamp: flagged-row list + counters, matrix workspaces
     DevBuf dpart;                         // double partial sums
     double *dscalar = nullptr;            // 4 doubles
     std::vector<void *> owned;
@@ -479,6 +482,7 @@ static void release_problem(cmf_ctx *c) {
     c->kr1 = DevBuf(); c->kr2 = DevBuf(); c->hrows = DevBuf(); c->mask1 = DevBuf(); c->mask2 = DevBuf();
     c->lists1 = DevBuf(); c->lists2 = DevBuf();
     c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf();
+    c->nsidx = DevBuf(); c->nsws = DevBuf();
     c->have_problem = false;
     for (int w = 0; w < 2; ++w) {
         c->sparse[w] = false;
@@ -529,6 +533,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->sample_off[CMF_V] = value;
     } else if (!strcmp(name, "sample_row_offset_z")) {
         c->sample_off[CMF_Z] = value;
+    } else if (!strcmp(name, "newton_schulz")) {
+        c->opt_ns = value != 0;
     } else if (!strcmp(name, "chol_diag")) {
         c->opt_choldiag = (int)value;
     } else if (!strcmp(name, "safe_inverse_cholesky")) {

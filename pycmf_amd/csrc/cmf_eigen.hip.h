@@ -411,7 +411,8 @@ __device__ __forceinline__ bool chol_factor(CholRegs<NB> &R, int n, float floor_
 
 template <int NB>
 __global__ __launch_bounds__(256, 2) void chol_solve_kernel(const float *Hin, const float *grad, float *step, int *need_jacobi,
-                                                            int n, int kp, int64_t stride, float pert, int nmat, int diag = 0) {
+                                                            int n, int kp, int64_t stride, float pert, int nmat, int diag = 0,
+                                                            const int *rowidx = nullptr) {
     __shared__ __attribute__((aligned(16))) float col[2 * (16 * NB + 4)]; // two buffers of (published column + pivot slot)
     __shared__ float vec[16 * NB];
     __shared__ float stage[16 * 17 + 16]; // diagonal block + block right-hand side of the back substitution
@@ -420,6 +421,8 @@ __global__ __launch_bounds__(256, 2) void chol_solve_kernel(const float *Hin, co
     if (mat >= nmat) return;
     const float *H = Hin + (int64_t)mat * stride;
     const int t = threadIdx.x, ti = t & 15, tc = t >> 4;
+    // rowidx: the matrices are a compacted subset; gradient / step / flag live at the original row
+    const int64_t orow = rowidx ? rowidx[mat] : mat;
 
     float dmax = 0.f;
     for (int i = t; i < n; i += 256) dmax = fmaxf(dmax, fabsf(H[i * kp + i]));
@@ -437,17 +440,17 @@ __global__ __launch_bounds__(256, 2) void chol_solve_kernel(const float *Hin, co
         for (int a = 0; a < NB; ++a)
 #pragma unroll
             for (int b = 0; b <= a; ++b) sink += R.M[a][b];
-        if (sink == 12345.678f) need_jacobi[mat] = 2;
+        if (sink == 12345.678f) need_jacobi[orow] = 2;
         return;
     }
     if (!chol_factor<NB>(R, n, floor_, col, t)) { // lambda_min < pert: the clamp matters -> Jacobi
-        if (t == 0) need_jacobi[mat] = 1;
+        if (t == 0) need_jacobi[orow] = 1;
         return;
     }
-    if (t == 0) need_jacobi[mat] = 0;
+    if (t == 0) need_jacobi[orow] = 0;
     if (diag == 1) return; // timing diagnostics (cmf_set_option "chol_diag"): 1 = PD test only, 2 = no back substitution,
     __syncthreads();       // 3 = loads only
-    for (int i = t; i < 16 * NB; i += 256) vec[i] = (i < n) ? grad[(int64_t)mat * kp + i] : 0.f;
+    for (int i = t; i < 16 * NB; i += 256) vec[i] = (i < n) ? grad[orow * kp + i] : 0.f;
     chol_load<NB>(R, H, n, kp, 0.f, t);
     __syncthreads(); // publish vec
     (void)chol_factor<NB, true>(R, n, 0.f, col, t, vec); // H = L L^T and, on the way, L y = g
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(256, 2) void chol_solve_kernel(const float *Hin, co
         }
         __syncthreads();
     }
-    for (int i = t; i < kp; i += 256) step[(int64_t)mat * kp + i] = (i < n) ? vec[i] : 0.f;
+    for (int i = t; i < kp; i += 256) step[orow * kp + i] = (i < n) ? vec[i] : 0.f;
 }
 
 // step_i = g_i * Hinv_i only for the rows flagged for the Jacobi path

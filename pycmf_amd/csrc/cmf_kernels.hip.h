@@ -47,6 +47,10 @@ struct GemmArgs {
     int link;            // 0 linear, 1 logit
     int w_is_slope;      // W = scale_w * sigma'(S) (1) or scale_w (0)
     unsigned long long *dbg; // diagnostic only: per-workgroup {memtime, memrealtime} at start and end (nullable)
+    // ---- ROLE 2 (block-diagonal batch of k_pad = 256 products, NN form): row tile x multiplies its own B ----
+    int64_t b_batch;     // elements between the B operands of consecutive row tiles
+    const float *D;      // C = alpha * A B + beta * D + gamma * I  (D stacked like C, nullable)
+    float alpha, beta, gamma;
 };
 
 template <int MODE, int BN>
@@ -122,6 +126,9 @@ struct VecLoad<4> {
 
 // ROLE only separates the symbols: 0 = pass over a data-sized operand (X, Y, residual or
 // weight image), 1 = factor-side product (Gram, F*G, step); profiles then report them apart.
+// ROLE 2 (NN, BN = 256 only) is the batched 256 x 256 x 256 product of the Newton-Schulz spectral clamp: the
+// matrices of a batch are stacked vertically, row tile x = matrix x reads ITS B operand (B + x * b_batch) and the
+// epilogue forms alpha * A B + beta * D + gamma * I.
 // PIPE selects the staging schedule inside a K-step (A/B-able in one process, cmf_set_option):
 //   0: global loads of tile t+1 at group 0, all LDS writes as a burst after group 15
 //   1: LDS writes of tile t+1 one piece per group in groups 0..7, loads of tile t+2 at group 8
@@ -170,6 +177,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
         g.dbg[4 * wg_linear + 1] = __builtin_amdgcn_s_memrealtime();
     }
 
+    const float *Bbase = (ROLE == 2) ? g.B + (int64_t)blockIdx.x * g.b_batch : g.B;
     f32x4 ra[C::A_LD], rb[C::B_LD];
 
     auto gload = [&](int64_t k0) {
@@ -195,11 +203,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
             if (C::B_F4 >= C::NT || idx < C::B_F4) {
                 if constexpr (C::B_KC) {
                     const int r = idx >> 3, c4 = idx & 7;
-                    rb[p] = *reinterpret_cast<const f32x4 *>(g.B + (n0 + r) * g.ldb + k0 + 4 * c4);
+                    rb[p] = *reinterpret_cast<const f32x4 *>(Bbase + (n0 + r) * g.ldb + k0 + 4 * c4);
                 } else {
                     constexpr int F4R = BN / 4;
                     const int r = idx / F4R, c4 = idx % F4R;
-                    rb[p] = *reinterpret_cast<const f32x4 *>(g.B + (k0 + r) * g.ldb + n0 + 4 * c4);
+                    rb[p] = *reinterpret_cast<const f32x4 *>(Bbase + (k0 + r) * g.ldb + n0 + 4 * c4);
                 }
             }
         }
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
                 const int wave_first = __builtin_amdgcn_readfirstlane(idx & ~63);
                 constexpr int F4R = BN / 4;
                 const int r = idx / F4R, c4 = idx % F4R;
-                const float *src = g.B + (k0 + r) * g.ldb + n0 + 4 * c4;
+                const float *src = Bbase + (k0 + r) * g.ldb + n0 + 4 * c4;
                 __builtin_amdgcn_global_load_lds(src, (lds_f *)(Bs + 4 * wave_first), 16, 0, 0);
             }
         }
@@ -443,7 +451,16 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
                 const int64_t row = row0 + wrow0 + (C::A_KC ? (32 * i + rr) : (C::TM * rr + i));
                 if (row < g.Mout) {
                     float *dst = Cs + row * g.ldc + n0 + wcol0 + C::TN * l31;
-                    if constexpr (C::TN == 4) {
+                    if constexpr (ROLE == 2) {
+                        static_assert(ROLE != 2 || (MODE == MODE_NN && BN == 256), "batched form: NN, 256 x 256 blocks");
+                        const int rin = wrow0 + 32 * i + rr, c0 = wcol0 + 4 * l31; // coordinates inside the 256 x 256 block
+                        f32x4 v = {g.alpha * acc[i][0][r], g.alpha * acc[i][1][r], g.alpha * acc[i][2][r], g.alpha * acc[i][3][r]};
+                        if (g.D) v += g.beta * *reinterpret_cast<const f32x4 *>(g.D + row * g.ldc + c0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (rin == c0 + j) v[j] += g.gamma;
+                        *reinterpret_cast<f32x4 *>(dst) = v;
+                    } else if constexpr (C::TN == 4) {
                         *reinterpret_cast<f32x4 *>(dst) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
                     } else if constexpr (C::TN == 2) {
                         *reinterpret_cast<f32x2 *>(dst) = f32x2{acc[i][0][r], acc[i][1][r]};
@@ -632,6 +649,50 @@ __global__ void fill_absnormal_kernel(float *A, int64_t ld, int64_t rows, int64_
         for (int e = 0; e < 4 && c + e < cols; ++e)
             A[r * ld + c + e] = scale * absnormal_at(seed, (uint64_t)(row0 + r), (uint64_t)(col0 + c + e));
     }
+}
+
+// ---- Newton-Schulz spectral clamp (flagged per-row Hessians, k_pad = 256) -------------------------------------
+// indices of the flagged matrices of a chunk (order irrelevant) and their count
+__global__ __launch_bounds__(256) void compact_flags_kernel(const int *flags, int n, int *idx, int *count) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (flags[i]) idx[atomicAdd(count, 1)] = i;
+}
+
+// B = H - pert I for flagged matrix b (valid n x n block; padding: c on the diagonal, 0 elsewhere),
+// c = min(||B||_F, ||B||_inf) >= rho(B), X0 = B / c.  One workgroup per matrix; thread t owns column t
+// (H is symmetric, so column sums are row sums and the reads are coalesced).  cmax collects max c (float bits).
+__global__ __launch_bounds__(256) void ns_prepare_kernel(const float *H, const int *idx, float *Bm, float *X, int n, int kp,
+                                                         int64_t stride, float pert, unsigned *cmax) {
+    __shared__ float red_f[4], red_m[4];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float *src = H + (int64_t)idx[b] * stride;
+    float *Bb = Bm + (int64_t)b * stride, *Xb = X + (int64_t)b * stride;
+    float fro = 0.f, colsum = 0.f;
+    if (t < n)
+        for (int r = 0; r < n; ++r) {
+            const float v = src[r * kp + t] - (r == t ? pert : 0.f);
+            fro += v * v;
+            colsum += fabsf(v);
+        }
+    for (int off = 32; off > 0; off >>= 1) {
+        fro += __shfl_xor(fro, off, 64);
+        colsum = fmaxf(colsum, __shfl_xor(colsum, off, 64));
+    }
+    if ((t & 63) == 0) { red_f[t >> 6] = fro; red_m[t >> 6] = colsum; }
+    __syncthreads();
+    fro = red_f[0] + red_f[1] + red_f[2] + red_f[3];
+    colsum = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+    float c = fminf(sqrtf(fro), colsum);
+    if (!(c > 1e-30f)) c = 1.0f;
+    const float ci = 1.0f / c;
+    if (t == 0) atomicMax(cmax, __float_as_uint(c));
+    if (t < kp)
+        for (int r = 0; r < kp; ++r) {
+            float v = (r == t) ? c : 0.f;
+            if (r < n && t < n) v = src[r * kp + t] - (r == t ? pert : 0.f);
+            Bb[r * kp + t] = v;
+            Xb[r * kp + t] = v * ci;
+        }
 }
 
 } // namespace cmfk

@@ -103,6 +103,74 @@ static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat,
     return CMF_OK;
 }
 
+// C_b = alpha A_b B_b + beta D_b + gamma I for nb stacked 256 x 256 matrices (gemm_kernel ROLE 2)
+static int gemm_blockdiag(cmf_ctx *c, const float *A, const float *B, float *C, const float *D, float alpha, float beta, float gamma,
+                          int64_t nb) {
+    using Cfg = GemmCfg<MODE_NN, 256>;
+    GemmArgs a;
+    memset(&a, 0, sizeof a);
+    a.A = A; a.lda = 256; a.B = B; a.ldb = 256; a.b_batch = 256 * 256;
+    a.C = C; a.ldc = 256; a.slab_stride = 0;
+    a.Mout = nb * 256; a.Kred = 256; a.klen = 256;
+    a.D = D; a.alpha = alpha; a.beta = beta; a.gamma = gamma;
+    Timed tm(c, CMF_K_EIGEN, 2.0 * 256 * 256 * 256 * (double)nb);
+    CHK(allow_big_lds(c, reinterpret_cast<const void *>(&gemm_kernel<MODE_NN, 256, 2, 4>), (int)Cfg::LDS_BYTES));
+    hipLaunchKernelGGL((gemm_kernel<MODE_NN, 256, 2, 4>), dim3((unsigned)nb, 1, 1), dim3(512), Cfg::LDS_BYTES, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
+// Flagged rows of a chunk (lambda_min(H) < pert), H positive semi-definite, k_pad = 256:
+//   safe_inverse(H) = max(H, pert I)^-1  with the spectral max  M = (H + pert I + |H - pert I|) / 2,
+//   |B| = sign(B) B,  sign(B) by the Newton-Schulz iteration X <- (3 X - X^3) / 2 from X0 = B / c, c >= rho(B)
+// -- nothing but 256^3 products (gemm_kernel ROLE 2, all flagged matrices of the chunk per launch).  An eigenvalue at
+// distance delta from the threshold needs about log_1.5(c / delta) steps; the count below resolves delta = 1e-4 pert
+// (closer ones keep an error <= delta in M, i.e. 1e-4 relative in that eigen-direction: the clamp is continuous).
+// M >= pert I is then solved by the ordinary Cholesky kernel, which also clears the flag.
+static int ns_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, float *step, int *flags, int64_t nr, int n, double pert) {
+    const int kp = 256;
+    const int64_t stride = (int64_t)kp * kp;
+    CHK(ensure(c, c->nsidx, (size_t)(nr + 2) * sizeof(int)));
+    int *idx = (int *)c->nsidx.p, *count = idx + nr;
+    unsigned *cmax = (unsigned *)(idx + nr + 1);
+    HIPCHK(hipMemsetAsync(count, 0, 2 * sizeof(int), c->stream));
+    hipLaunchKernelGGL(compact_flags_kernel, dim3(32), dim3(256), 0, c->stream, (const int *)flags, (int)nr, idx, count);
+    HIPCHK(hipGetLastError());
+    int nf = 0;
+    HIPCHK(hipMemcpyAsync(&nf, count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (nf <= 0) return CMF_OK;
+    // workspaces: B, X, X', Y -- one spare matrix at the end (the A tile of the last block may be read past Mout)
+    CHK(ensure(c, c->nsws, (size_t)(4 * (int64_t)nf + 1) * stride * sizeof(float)));
+    float *Bm = (float *)c->nsws.p, *X = Bm + nf * stride, *X2 = X + nf * stride, *Y = X2 + nf * stride;
+    {
+        Timed tm(c, CMF_K_EIGEN);
+        hipLaunchKernelGGL(ns_prepare_kernel, dim3((unsigned)nf), dim3(256), 0, c->stream, Hc, (const int *)idx, Bm, X, n, kp, stride,
+                           (float)pert, cmax);
+        HIPCHK(hipGetLastError());
+    }
+    unsigned cbits = 0;
+    HIPCHK(hipMemcpyAsync(&cbits, cmax, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float cm;
+    memcpy(&cm, &cbits, sizeof cm);
+    const double delta = 1e-4 * pert;
+    int iters = (int)std::ceil(std::log(std::max((double)cm, pert) / delta) / std::log(1.5)) + 5;
+    iters = std::min(std::max(iters, 12), 80);
+    for (int it = 0; it < iters; ++it) {
+        CHK(gemm_blockdiag(c, X, X, Y, nullptr, 1.0f, 0.f, 0.f, nf));       // Y = X^2
+        CHK(gemm_blockdiag(c, X, Y, X2, X, -0.5f, 1.5f, 0.f, nf));          // X' = 1.5 X - 0.5 X Y
+        std::swap(X, X2);
+    }
+    // M = (S B + B) / 2 + pert I   (H = B + pert I)
+    CHK(gemm_blockdiag(c, X, Bm, Y, Bm, 0.5f, 0.5f, (float)pert, nf));
+    Timed tm(c, CMF_K_EIGEN);
+    hipLaunchKernelGGL((chol_solve_kernel<16>), dim3((unsigned)nf), dim3(256), 0, c->stream, (const float *)Y, grad, step, flags, n, kp, stride,
+                       0.0f, nf, 0, (const int *)idx);
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
 // step_i = grad_i * safe_inverse(H_i) for a chunk of per-row Hessians (H is clobbered):
 // register-resident Cholesky solve for the rows with lambda_min >= pert, Jacobi + row product
 // for the flagged rest.
@@ -126,7 +194,10 @@ static int safe_solve_rows(cmf_ctx *c, float *Hc, const float *grad, float *step
         else if (n <= 128) hipLaunchKernelGGL((chol_solve_kernel<8>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag);
         else hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag);
         HIPCHK(hipGetLastError());
-        // flagged matrices: |lambda| / clamp by Jacobi, in place (the solve kernel does not modify H)
+        // flagged matrices, k_pad = 256, Hessians positive semi-definite by construction (weights >= 0):
+        // spectral clamp by Newton-Schulz (MFMA) + a second Cholesky solve; clears the flags it serves
+        if (kp == 256 && c->opt_ns && c->hess_psd) CHK(ns_clamp_solve_rows(c, Hc, grad, step, flags, nr, n, pert));
+        // whatever is still flagged: |lambda| / clamp by Jacobi, in place (the solve kernel does not modify H)
         const size_t lds_need = (size_t)(2 * n * n + n) * sizeof(float);
         if (lds_need <= 150 * 1024) {
             CHK(allow_big_lds(c, reinterpret_cast<const void *>(&jacobi_safe_inverse_kernel<true>), 150 * 1024));
@@ -626,6 +697,7 @@ static int newton_step_impl(cmf_ctx *c, double alpha, double l1, double l2, int 
         ~SamplingScope() { if (!keep) c->dev_sampling = false; }
     } scope{c, false};
     if (!sampled) c->dev_sampling = false;
+    c->hess_psd = (alpha >= 0.0 && alpha <= 1.0 && l2 >= 0.0); // Gram-like sums with non-negative weights
     const bool fused = c->opt_rowkernel && c->kp <= 256; // fused gather kernel vs masked-dense GEMMs
     const int64_t su = (int64_t)((double)c->d * ratio);  // int(n * ratio), cmf_solvers.py:331
     const int64_t sm = (int64_t)((double)c->m * ratio), sp = (int64_t)((double)c->p * ratio);

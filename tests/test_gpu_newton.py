@@ -405,3 +405,30 @@ def test_row_sharded_newton_is_bit_identical(lib, world, xl, yl, ratio):
     for w in range(3):
         np.testing.assert_array_equal(a.get_factor(w), want[w])
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("ns", [1, 0])
+def test_flagged_hessians_k256_newton_schulz_and_jacobi(lib, ns):
+    """k_pad = 256 with rank-deficient per-row Hessians (fewer samples than k, logit U sweep without l2): every row
+    fails the `lambda_min >= pert` test, so the eigenvalue clamp of _safe_invert (:346-356) really acts.  Both
+    treatments of the flagged rows -- the Newton-Schulz spectral clamp (default) and the Jacobi eigen-solver --
+    must reproduce the fp64 oracle."""
+    from oracle import cmf_oracle as O
+    m, d, p, k = 70, 96, 40, 200
+    rng = np.random.RandomState(21)
+    X, Y = rng.rand(m, d), rng.rand(d, p)
+    U0, V0, Z0 = 0.15 * rng.randn(m, k), 0.15 * rng.randn(d, k), 0.15 * rng.randn(p, k)
+    alpha, l1, l2, pert = 0.4, 0.0, 0.05, 0.2
+    Ur, Vr, Zr = U0.copy(), V0.copy(), Z0.copy()
+    O.newton_update_step(X, Y, Ur, Vr, Zr, alpha, l1, l2, "logit", "logit", False, False, False, 1.0, pert)
+    ctx = lib.Context(0)
+    ctx.set_option("newton_schulz", ns)
+    ctx.set_problem(m, d, p, k)
+    ctx.set_data(0, X); ctx.set_data(1, Y)
+    for w, F in enumerate((U0, V0, Z0)):
+        ctx.set_factor(w, F)
+    ctx.newton_step(alpha, l1, l2, "logit", "logit", 0, 7, pert, 1.0)
+    got = [ctx.get_factor(w) for w in range(3)]
+    ctx.close()
+    for a, b in zip(got, (Ur, Vr, Zr)):
+        np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-3 * np.abs(b).max())
