@@ -122,10 +122,11 @@ static int gemm_blockdiag(cmf_ctx *c, const float *A, const float *B, float *C, 
 
 // Flagged rows of a chunk (lambda_min(H) < pert), H positive semi-definite, k_pad = 256:
 //   safe_inverse(H) = max(H, pert I)^-1  with the spectral max  M = (H + pert I + |H - pert I|) / 2,
-//   |B| = sign(B) B,  sign(B) by the Newton-Schulz iteration X <- (3 X - X^3) / 2 from X0 = B / c, c >= rho(B)
+//   |B| = sign(B) B,  sign(B) by odd matrix polynomials of X0 = B / c, c >= rho(B) (Newton-Schulz family)
 // -- nothing but 256^3 products (gemm_kernel ROLE 2, all flagged matrices of the chunk per launch).  An eigenvalue at
-// distance delta from the threshold needs about log_1.5(c / delta) steps; the count below resolves delta = 1e-4 pert
-// (closer ones keep an error <= delta in M, i.e. 1e-4 relative in that eigen-direction: the clamp is continuous).
+// distance delta from the threshold needs about log_3.44(c / delta) growth steps; the count below resolves
+// delta = 1e-3 pert (closer ones keep an error <= delta in M, i.e. 1e-3 relative in that eigen-direction at worst:
+// the clamp is continuous; measured 1e-6 .. 1e-4 on the solve).
 // M >= pert I is then solved by the ordinary Cholesky kernel, which also clears the flag.
 static int ns_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, float *step, int *flags, int64_t nr, int n, double pert) {
     const int kp = 256;
@@ -140,9 +141,9 @@ static int ns_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, f
     HIPCHK(hipMemcpyAsync(&nf, count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (nf <= 0) return CMF_OK;
-    // workspaces: B, X, X', Y -- one spare matrix at the end (the A tile of the last block may be read past Mout)
-    CHK(ensure(c, c->nsws, (size_t)(4 * (int64_t)nf + 1) * stride * sizeof(float)));
-    float *Bm = (float *)c->nsws.p, *X = Bm + nf * stride, *X2 = X + nf * stride, *Y = X2 + nf * stride;
+    // workspaces: B, X, X', Y, Z (+ one spare matrix)
+    CHK(ensure(c, c->nsws, (size_t)(5 * (int64_t)nf + 1) * stride * sizeof(float)));
+    float *Bm = (float *)c->nsws.p, *X = Bm + nf * stride, *X2 = X + nf * stride, *Y = X2 + nf * stride, *Z = Y + nf * stride;
     {
         Timed tm(c, CMF_K_EIGEN);
         hipLaunchKernelGGL(ns_prepare_kernel, dim3((unsigned)nf), dim3(256), 0, c->stream, Hc, (const int *)idx, Bm, X, n, kp, stride,
@@ -154,12 +155,20 @@ static int ns_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, f
     HIPCHK(hipStreamSynchronize(c->stream));
     float cm;
     memcpy(&cm, &cbits, sizeof cm);
-    const double delta = 1e-4 * pert;
-    int iters = (int)std::ceil(std::log(std::max((double)cm, pert) / delta) / std::log(1.5)) + 5;
-    iters = std::min(std::max(iters, 12), 80);
-    for (int it = 0; it < iters; ++it) {
-        CHK(gemm_blockdiag(c, X, X, Y, nullptr, 1.0f, 0.f, 0.f, nf));       // Y = X^2
-        CHK(gemm_blockdiag(c, X, Y, X2, X, -0.5f, 1.5f, 0.f, nf));          // X' = 1.5 X - 0.5 X Y
+    // growth phase: the odd quintic a x + b x^3 + c x^5 with (3.4445, -4.7750, 2.0315) multiplies small |x| by 3.44 per
+    // step (3 products) and keeps [0, 1] inside about [0.7, 1.2]; six cubic steps then converge quadratically to +-1
+    const double delta = 1e-3 * pert;
+    int nq = (int)std::ceil(std::log(std::max((double)cm, pert) / delta) / std::log(3.4445));
+    nq = std::min(std::max(nq, 4), 24);
+    for (int it = 0; it < nq; ++it) {
+        CHK(gemm_blockdiag(c, X, X, Y, nullptr, 1.0f, 0.f, 0.f, nf));            // Y = X^2
+        CHK(gemm_blockdiag(c, Y, Y, Z, Y, 2.0315f, -4.7750f, 3.4445f, nf));      // Z = c Y^2 + b Y + a I
+        CHK(gemm_blockdiag(c, X, Z, X2, nullptr, 1.0f, 0.f, 0.f, nf));           // X' = X Z
+        std::swap(X, X2);
+    }
+    for (int it = 0; it < 6; ++it) {
+        CHK(gemm_blockdiag(c, X, X, Y, nullptr, 1.0f, 0.f, 0.f, nf));            // Y = X^2
+        CHK(gemm_blockdiag(c, X, Y, X2, X, -0.5f, 1.5f, 0.f, nf));               // X' = 1.5 X - 0.5 X Y
         std::swap(X, X2);
     }
     // M = (S B + B) / 2 + pert I   (H = B + pert I)
