@@ -77,6 +77,8 @@ int cmf_sync(cmf_ctx *ctx);
  * "safe_inverse_cholesky" 1 | 0, "graph" 1 | 0 (replay MU / linear-Newton steps from a
  * captured hipGraph; automatically off while cmf_kernel_timing is enabled),
  * "row_symmetric" 1 | 0 (k_pad = 256 row kernel: upper block triangle of H_i only),
+ * "newton_schulz" 1 | 0 (k_pad = 256: rows whose eigenvalue clamp acts go through the GEMM-only
+ * spectral clamp | through the Jacobi eigen-solver),
  * "sample_row_offset_u|v|z" n = global index of this context's first U / V / Z row in the keys of
  * the device sampler (a row shard then draws what the unsharded problem draws for its rows)        */
 int cmf_set_option(cmf_ctx *ctx, const char *name, int64_t value);
