@@ -316,7 +316,7 @@ struct CholRegs {
 };
 
 template <int NB>
-__device__ __forceinline__ void chol_load(CholRegs<NB> &R, const float *H, int n, int kp, float shift, int t) {
+__device__ __forceinline__ void chol_load(CholRegs<NB> &R, const float *H, int n, int ldh, float shift, int t) {
     // element (i, c) = (16 a + ti, 16 b + tc) is fetched as H[c][i] (H is symmetric): the 16 lanes of a DPP row
     // then read 64 contiguous bytes, nothing goes through LDS and all loads of a thread are in flight together
     const int ti = t & 15, tc = t >> 4;
@@ -326,7 +326,7 @@ __device__ __forceinline__ void chol_load(CholRegs<NB> &R, const float *H, int n
         for (int b = 0; b <= a; ++b) {
             const int i = 16 * a + ti, cc = 16 * b + tc;
             float v = (i == cc) ? 1.0f : 0.0f; // identity outside the valid n x n block
-            if (i < n && cc < n) v = H[cc * kp + i] - (i == cc ? shift : 0.f);
+            if (i < n && cc < n) v = H[cc * ldh + i] - (i == cc ? shift : 0.f);
             R.M[a][b] = v;
         }
 }
@@ -412,20 +412,22 @@ __device__ __forceinline__ bool chol_factor(CholRegs<NB> &R, int n, float floor_
 template <int NB>
 __global__ __launch_bounds__(256, 2) void chol_solve_kernel(const float *Hin, const float *grad, float *step, int *need_jacobi,
                                                             int n, int kp, int64_t stride, float pert, int nmat, int diag = 0,
-                                                            const int *rowidx = nullptr) {
+                                                            const int *rowidx = nullptr, int sub = 1) {
     __shared__ __attribute__((aligned(16))) float col[2 * (16 * NB + 4)]; // two buffers of (published column + pivot slot)
     __shared__ float vec[16 * NB];
     __shared__ float stage[16 * 17 + 16]; // diagonal block + block right-hand side of the back substitution
     __shared__ float red[4];
     const int mat = blockIdx.x;
     if (mat >= nmat) return;
-    const float *H = Hin + (int64_t)mat * stride;
+    // sub > 1: matrix `mat` is diagonal block mat % sub of the (sub k_pad)^2 block-diagonal image mat / sub
+    const int ldh = sub * kp;
+    const float *H = Hin + (int64_t)(mat / sub) * stride + (int64_t)(mat % sub) * kp * (ldh + 1);
     const int t = threadIdx.x, ti = t & 15, tc = t >> 4;
     // rowidx: the matrices are a compacted subset; gradient / step / flag live at the original row
     const int64_t orow = rowidx ? rowidx[mat] : mat;
 
     float dmax = 0.f;
-    for (int i = t; i < n; i += 256) dmax = fmaxf(dmax, fabsf(H[i * kp + i]));
+    for (int i = t; i < n; i += 256) dmax = fmaxf(dmax, fabsf(H[i * ldh + i]));
     for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
     if ((t & 63) == 0) red[t >> 6] = dmax;
     __syncthreads();
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void chol_solve_kernel(const float *Hin, co
     const float floor_ = 4.0e-6f * dmax;
 
     CholRegs<NB> R;
-    chol_load<NB>(R, H, n, kp, pert, t);
+    chol_load<NB>(R, H, n, ldh, pert, t);
     if (diag == 3) { // keep the loaded values alive
         float sink = 0.f;
 #pragma unroll
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void chol_solve_kernel(const float *Hin, co
     if (diag == 1) return; // timing diagnostics (cmf_set_option "chol_diag"): 1 = PD test only, 2 = no back substitution,
     __syncthreads();       // 3 = loads only
     for (int i = t; i < 16 * NB; i += 256) vec[i] = (i < n) ? grad[orow * kp + i] : 0.f;
-    chol_load<NB>(R, H, n, kp, 0.f, t);
+    chol_load<NB>(R, H, n, ldh, 0.f, t);
     __syncthreads(); // publish vec
     (void)chol_factor<NB, true>(R, n, 0.f, col, t, vec); // H = L L^T and, on the way, L y = g
 

@@ -661,12 +661,27 @@ __global__ __launch_bounds__(256) void compact_flags_kernel(const int *flags, in
 // B = H - pert I for flagged matrix b (valid n x n block; padding: c on the diagonal, 0 elsewhere),
 // c = min(||B||_F, ||B||_inf) >= rho(B), X0 = B / c.  One workgroup per matrix; thread t owns column t
 // (H is symmetric, so column sums are row sums and the reads are coalesced).  cmax collects max c (float bits).
+// sub = 256 / k_pad matrices share one 256 x 256 block-diagonal image (matrix b = diagonal block b % sub of image
+// b / sub, zeros off the diagonal blocks): products of block-diagonal matrices stay block-diagonal, so the 256^3
+// batched kernel serves k_pad = 128 too.  Workgroups b >= nf fill the unused diagonal blocks with the identity.
 __global__ __launch_bounds__(256) void ns_prepare_kernel(const float *H, const int *idx, float *Bm, float *X, int n, int kp,
-                                                         int64_t stride, float pert, unsigned *cmax) {
+                                                         int64_t stride, float pert, unsigned *cmax, int sub, int nf) {
     __shared__ float red_f[4], red_m[4];
     const int b = blockIdx.x, t = threadIdx.x;
+    const int ld = sub * kp;                       // = 256
+    const int64_t img = (int64_t)(b / sub) * ld * ld + (int64_t)(b % sub) * kp * ld; // first row of this matrix in its image
+    const int c0 = (b % sub) * kp;                 // first column of its diagonal block
+    float *Bb = Bm + img, *Xb = X + img;
+    if (b >= nf) { // filler block: identity (sign +1), never read back
+        if (t < ld)
+            for (int r = 0; r < kp; ++r) {
+                const float v = (t == c0 + r) ? 1.0f : 0.f;
+                Bb[r * ld + t] = v;
+                Xb[r * ld + t] = v;
+            }
+        return;
+    }
     const float *src = H + (int64_t)idx[b] * stride;
-    float *Bb = Bm + (int64_t)b * stride, *Xb = X + (int64_t)b * stride;
     float fro = 0.f, colsum = 0.f;
     if (t < n)
         for (int r = 0; r < n; ++r) {
@@ -686,12 +701,16 @@ __global__ __launch_bounds__(256) void ns_prepare_kernel(const float *H, const i
     if (!(c > 1e-30f)) c = 1.0f;
     const float ci = 1.0f / c;
     if (t == 0) atomicMax(cmax, __float_as_uint(c));
-    if (t < kp)
+    if (t < ld)
         for (int r = 0; r < kp; ++r) {
-            float v = (r == t) ? c : 0.f;
-            if (r < n && t < n) v = src[r * kp + t] - (r == t ? pert : 0.f);
-            Bb[r * kp + t] = v;
-            Xb[r * kp + t] = v * ci;
+            const int cc = t - c0; // column inside the diagonal block (outside: zero)
+            float v = 0.f;
+            if (cc >= 0 && cc < kp) {
+                v = (r == cc) ? c : 0.f;
+                if (r < n && cc < n) v = src[r * kp + cc] - (r == cc ? pert : 0.f);
+            }
+            Bb[r * ld + t] = v;
+            Xb[r * ld + t] = v * ci;
         }
 }
 

@@ -120,7 +120,7 @@ static int gemm_blockdiag(cmf_ctx *c, const float *A, const float *B, float *C, 
     return CMF_OK;
 }
 
-// Flagged rows of a chunk (lambda_min(H) < pert), H positive semi-definite, k_pad = 256:
+// Flagged rows of a chunk (lambda_min(H) < pert), H positive semi-definite, k_pad = 256 (or 128: two per image):
 //   safe_inverse(H) = max(H, pert I)^-1  with the spectral max  M = (H + pert I + |H - pert I|) / 2,
 //   |B| = sign(B) B,  sign(B) by odd matrix polynomials of X0 = B / c, c >= rho(B) (Newton-Schulz family)
 // -- nothing but 256^3 products (gemm_kernel ROLE 2, all flagged matrices of the chunk per launch).  An eigenvalue at
@@ -128,9 +128,11 @@ static int gemm_blockdiag(cmf_ctx *c, const float *A, const float *B, float *C, 
 // delta = 1e-3 pert (closer ones keep an error <= delta in M, i.e. 1e-3 relative in that eigen-direction at worst:
 // the clamp is continuous; measured 1e-6 .. 1e-4 on the solve).
 // M >= pert I is then solved by the ordinary Cholesky kernel, which also clears the flag.
-static int ns_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, float *step, int *flags, int64_t nr, int n, double pert) {
-    const int kp = 256;
-    const int64_t stride = (int64_t)kp * kp;
+static int ns_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, float *step, int *flags, int64_t nr, int n, int kp,
+                               double pert) {
+    const int sub = 256 / kp;                       // matrices per 256 x 256 block-diagonal image (k_pad = 256: 1, 128: 2)
+    const int64_t stride = (int64_t)kp * kp;        // of the per-row Hessians
+    const int64_t istride = 256 * 256;              // of the images
     CHK(ensure(c, c->nsidx, (size_t)(nr + 2) * sizeof(int)));
     int *idx = (int *)c->nsidx.p, *count = idx + nr;
     unsigned *cmax = (unsigned *)(idx + nr + 1);
@@ -141,13 +143,14 @@ static int ns_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, f
     HIPCHK(hipMemcpyAsync(&nf, count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (nf <= 0) return CMF_OK;
-    // workspaces: B, X, X', Y, Z (+ one spare matrix)
-    CHK(ensure(c, c->nsws, (size_t)(5 * (int64_t)nf + 1) * stride * sizeof(float)));
-    float *Bm = (float *)c->nsws.p, *X = Bm + nf * stride, *X2 = X + nf * stride, *Y = X2 + nf * stride, *Z = Y + nf * stride;
+    const int64_t ni = (nf + sub - 1) / sub;        // images
+    // workspaces: B, X, X', Y, Z (+ one spare image)
+    CHK(ensure(c, c->nsws, (size_t)(5 * ni + 1) * istride * sizeof(float)));
+    float *Bm = (float *)c->nsws.p, *X = Bm + ni * istride, *X2 = X + ni * istride, *Y = X2 + ni * istride, *Z = Y + ni * istride;
     {
         Timed tm(c, CMF_K_EIGEN);
-        hipLaunchKernelGGL(ns_prepare_kernel, dim3((unsigned)nf), dim3(256), 0, c->stream, Hc, (const int *)idx, Bm, X, n, kp, stride,
-                           (float)pert, cmax);
+        hipLaunchKernelGGL(ns_prepare_kernel, dim3((unsigned)(ni * sub)), dim3(256), 0, c->stream, Hc, (const int *)idx, Bm, X, n, kp, stride,
+                           (float)pert, cmax, sub, nf);
         HIPCHK(hipGetLastError());
     }
     unsigned cbits = 0;
@@ -161,21 +164,26 @@ static int ns_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, f
     int nq = (int)std::ceil(std::log(std::max((double)cm, pert) / delta) / std::log(3.4445));
     nq = std::min(std::max(nq, 4), 24);
     for (int it = 0; it < nq; ++it) {
-        CHK(gemm_blockdiag(c, X, X, Y, nullptr, 1.0f, 0.f, 0.f, nf));            // Y = X^2
-        CHK(gemm_blockdiag(c, Y, Y, Z, Y, 2.0315f, -4.7750f, 3.4445f, nf));      // Z = c Y^2 + b Y + a I
-        CHK(gemm_blockdiag(c, X, Z, X2, nullptr, 1.0f, 0.f, 0.f, nf));           // X' = X Z
+        CHK(gemm_blockdiag(c, X, X, Y, nullptr, 1.0f, 0.f, 0.f, ni));            // Y = X^2
+        CHK(gemm_blockdiag(c, Y, Y, Z, Y, 2.0315f, -4.7750f, 3.4445f, ni));      // Z = c Y^2 + b Y + a I
+        CHK(gemm_blockdiag(c, X, Z, X2, nullptr, 1.0f, 0.f, 0.f, ni));           // X' = X Z
         std::swap(X, X2);
     }
     for (int it = 0; it < 6; ++it) {
-        CHK(gemm_blockdiag(c, X, X, Y, nullptr, 1.0f, 0.f, 0.f, nf));            // Y = X^2
-        CHK(gemm_blockdiag(c, X, Y, X2, X, -0.5f, 1.5f, 0.f, nf));               // X' = 1.5 X - 0.5 X Y
+        CHK(gemm_blockdiag(c, X, X, Y, nullptr, 1.0f, 0.f, 0.f, ni));            // Y = X^2
+        CHK(gemm_blockdiag(c, X, Y, X2, X, -0.5f, 1.5f, 0.f, ni));               // X' = 1.5 X - 0.5 X Y
         std::swap(X, X2);
     }
     // M = (S B + B) / 2 + pert I   (H = B + pert I)
-    CHK(gemm_blockdiag(c, X, Bm, Y, Bm, 0.5f, 0.5f, (float)pert, nf));
+    CHK(gemm_blockdiag(c, X, Bm, Y, Bm, 0.5f, 0.5f, (float)pert, ni));
     Timed tm(c, CMF_K_EIGEN);
-    hipLaunchKernelGGL((chol_solve_kernel<16>), dim3((unsigned)nf), dim3(256), 0, c->stream, (const float *)Y, grad, step, flags, n, kp, stride,
-                       0.0f, nf, 0, (const int *)idx);
+    const dim3 grid((unsigned)nf), block(256);
+    if (kp == 256)
+        hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, (const float *)Y, grad, step, flags, n, kp, istride, 0.0f, nf, 0,
+                           (const int *)idx, 1);
+    else
+        hipLaunchKernelGGL((chol_solve_kernel<8>), grid, block, 0, c->stream, (const float *)Y, grad, step, flags, n, kp, istride, 0.0f, nf, 0,
+                           (const int *)idx, 2);
     HIPCHK(hipGetLastError());
     return CMF_OK;
 }
@@ -203,9 +211,9 @@ static int safe_solve_rows(cmf_ctx *c, float *Hc, const float *grad, float *step
         else if (n <= 128) hipLaunchKernelGGL((chol_solve_kernel<8>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag);
         else hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag);
         HIPCHK(hipGetLastError());
-        // flagged matrices, k_pad = 256, Hessians positive semi-definite by construction (weights >= 0):
+        // flagged matrices, k_pad = 128 / 256, Hessians positive semi-definite by construction (weights >= 0):
         // spectral clamp by Newton-Schulz (MFMA) + a second Cholesky solve; clears the flags it serves
-        if (kp == 256 && c->opt_ns && c->hess_psd) CHK(ns_clamp_solve_rows(c, Hc, grad, step, flags, nr, n, pert));
+        if ((kp == 256 || kp == 128) && c->opt_ns && c->hess_psd) CHK(ns_clamp_solve_rows(c, Hc, grad, step, flags, nr, n, kp, pert));
         // whatever is still flagged: |lambda| / clamp by Jacobi, in place (the solve kernel does not modify H)
         const size_t lds_need = (size_t)(2 * n * n + n) * sizeof(float);
         if (lds_need <= 150 * 1024) {

@@ -1,12 +1,13 @@
 """Cost of the flagged-row treatment at k_pad = 256: Newton-Schulz spectral clamp vs Jacobi.
-usage: python tools/probe_flagged.py [rows] [samples]"""
+usage: python tools/probe_flagged.py [rows] [samples] [k]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pycmf_amd import _lib
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 128      # samples per U row < k: every U Hessian is rank-deficient
-p, k = 64, 256
+p = 64
+k = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 rng = np.random.RandomState(0)
 X, Y = rng.rand(m, d), rng.rand(d, p)
 U0, V0, Z0 = 0.1 * rng.randn(m, k), 0.1 * rng.randn(d, k), 0.1 * rng.randn(p, k)
