@@ -27,7 +27,9 @@ static int launch_ew(cmf_ctx *c, void (*kern)(Args...), int64_t n, Args... args)
 
 // Hout_i = safe_inverse(Hin_i) for nmat k_pad x k_pad matrices (valid order n).
 // Cholesky fast path first (exact when lambda_min >= pert), Jacobi for the flagged rest.
-static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat, int n, int kp, double pert) {
+static int ns_clamp_images(cmf_ctx *c, const float *Hc, const int *idx, int nf, int n, int kp, double pert, float **M_out);
+
+static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat, int n, int kp, double pert, bool psd = false) {
     if (nmat <= 0) return CMF_OK;
     const int64_t stride = (int64_t)kp * kp;
     Timed tm(c, CMF_K_EIGEN);
@@ -52,6 +54,25 @@ static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat,
         HIPCHK(hipMemcpyAsync(&flag0, flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (!flag0) return CMF_OK;
+        if (psd && c->opt_ns && (kp == 256 || kp == 128)) {
+            // positive semi-definite and clamped: spectral max M = max(H, pert I) by matrix polynomials (below), then the
+            // same k_pad unit-vector solves on M
+            CHK(ensure(c, c->nsidx, 4 * sizeof(int)));
+            HIPCHK(hipMemsetAsync(c->nsidx.p, 0, 4 * sizeof(int), c->stream));
+            float *M = nullptr;
+            CHK(ns_clamp_images(c, Hin, (const int *)c->nsidx.p, 1, n, kp, pert, &M));
+            const float *Mc = M;
+            if (kp == 128) { // the matrix is the first diagonal block of a 256 x 256 image: compact it
+                CHK(ensure(c, c->eigcopy, (size_t)kp * kp * sizeof(float)));
+                HIPCHK(hipMemcpy2DAsync(c->eigcopy.p, kp * sizeof(float), M, 256 * sizeof(float), kp * sizeof(float), kp,
+                                        hipMemcpyDeviceToDevice, c->stream));
+                Mc = (const float *)c->eigcopy.p;
+            }
+            if (kp == 128) hipLaunchKernelGGL((chol_solve_kernel<8>), grid, block, 0, c->stream, Mc, (const float *)c->Eye, Hout, flags, n, kp, (int64_t)0, 0.0f, kp);
+            else hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, Mc, (const float *)c->Eye, Hout, flags, n, kp, (int64_t)0, 0.0f, kp);
+            HIPCHK(hipGetLastError());
+            return CMF_OK;
+        }
         if (n >= 48) { // chip-wide Jacobi: one launch per round-robin step (cmf_eigen.hip.h)
             const int N = n + (n & 1);
             CHK(ensure(c, c->eigws, (size_t)(2 * n * n + n) * sizeof(float)));
@@ -128,28 +149,20 @@ static int gemm_blockdiag(cmf_ctx *c, const float *A, const float *B, float *C, 
 // delta = 1e-3 pert (closer ones keep an error <= delta in M, i.e. 1e-3 relative in that eigen-direction at worst:
 // the clamp is continuous; measured 1e-6 .. 1e-4 on the solve).
 // M >= pert I is then solved by the ordinary Cholesky kernel, which also clears the flag.
-static int ns_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, float *step, int *flags, int64_t nr, int n, int kp,
-                               double pert) {
+// M images of the nf matrices Hc[idx[b]] (see above); *M_out = nf / sub images of 256 x 256 floats
+static int ns_clamp_images(cmf_ctx *c, const float *Hc, const int *idx, int nf, int n, int kp, double pert, float **M_out) {
     const int sub = 256 / kp;                       // matrices per 256 x 256 block-diagonal image (k_pad = 256: 1, 128: 2)
-    const int64_t stride = (int64_t)kp * kp;        // of the per-row Hessians
+    const int64_t stride = (int64_t)kp * kp;        // of the input matrices
     const int64_t istride = 256 * 256;              // of the images
-    CHK(ensure(c, c->nsidx, (size_t)(nr + 2) * sizeof(int)));
-    int *idx = (int *)c->nsidx.p, *count = idx + nr;
-    unsigned *cmax = (unsigned *)(idx + nr + 1);
-    HIPCHK(hipMemsetAsync(count, 0, 2 * sizeof(int), c->stream));
-    hipLaunchKernelGGL(compact_flags_kernel, dim3(32), dim3(256), 0, c->stream, (const int *)flags, (int)nr, idx, count);
-    HIPCHK(hipGetLastError());
-    int nf = 0;
-    HIPCHK(hipMemcpyAsync(&nf, count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (nf <= 0) return CMF_OK;
     const int64_t ni = (nf + sub - 1) / sub;        // images
-    // workspaces: B, X, X', Y, Z (+ one spare image)
-    CHK(ensure(c, c->nsws, (size_t)(5 * ni + 1) * istride * sizeof(float)));
+    // workspaces: B, X, X', Y, Z (+ one spare image), then one word for max c
+    CHK(ensure(c, c->nsws, (size_t)(5 * ni + 1) * istride * sizeof(float) + 16));
     float *Bm = (float *)c->nsws.p, *X = Bm + ni * istride, *X2 = X + ni * istride, *Y = X2 + ni * istride, *Z = Y + ni * istride;
+    unsigned *cmax = (unsigned *)(Z + (ni + 1) * istride);
+    HIPCHK(hipMemsetAsync(cmax, 0, sizeof(unsigned), c->stream));
     {
         Timed tm(c, CMF_K_EIGEN);
-        hipLaunchKernelGGL(ns_prepare_kernel, dim3((unsigned)(ni * sub)), dim3(256), 0, c->stream, Hc, (const int *)idx, Bm, X, n, kp, stride,
+        hipLaunchKernelGGL(ns_prepare_kernel, dim3((unsigned)(ni * sub)), dim3(256), 0, c->stream, Hc, idx, Bm, X, n, kp, stride,
                            (float)pert, cmax, sub, nf);
         HIPCHK(hipGetLastError());
     }
@@ -176,13 +189,31 @@ static int ns_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, f
     }
     // M = (S B + B) / 2 + pert I   (H = B + pert I)
     CHK(gemm_blockdiag(c, X, Bm, Y, Bm, 0.5f, 0.5f, (float)pert, ni));
+    *M_out = Y;
+    return CMF_OK;
+}
+
+static int ns_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, float *step, int *flags, int64_t nr, int n, int kp,
+                               double pert) {
+    CHK(ensure(c, c->nsidx, (size_t)(nr + 1) * sizeof(int)));
+    int *idx = (int *)c->nsidx.p, *count = idx + nr;
+    HIPCHK(hipMemsetAsync(count, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(compact_flags_kernel, dim3(32), dim3(256), 0, c->stream, (const int *)flags, (int)nr, idx, count);
+    HIPCHK(hipGetLastError());
+    int nf = 0;
+    HIPCHK(hipMemcpyAsync(&nf, count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (nf <= 0) return CMF_OK;
+    float *M = nullptr;
+    CHK(ns_clamp_images(c, Hc, (const int *)idx, nf, n, kp, pert, &M));
     Timed tm(c, CMF_K_EIGEN);
     const dim3 grid((unsigned)nf), block(256);
+    const int64_t istride = 256 * 256;
     if (kp == 256)
-        hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, (const float *)Y, grad, step, flags, n, kp, istride, 0.0f, nf, 0,
+        hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, (const float *)M, grad, step, flags, n, kp, istride, 0.0f, nf, 0,
                            (const int *)idx, 1);
     else
-        hipLaunchKernelGGL((chol_solve_kernel<8>), grid, block, 0, c->stream, (const float *)Y, grad, step, flags, n, kp, istride, 0.0f, nf, 0,
+        hipLaunchKernelGGL((chol_solve_kernel<8>), grid, block, 0, c->stream, (const float *)M, grad, step, flags, n, kp, istride, 0.0f, nf, 0,
                            (const int *)idx, 2);
     HIPCHK(hipGetLastError());
     return CMF_OK;
@@ -265,7 +296,7 @@ extern "C" int cmf_safe_invert_batch(cmf_ctx *c, const double *H, double *out, i
 // F <- clamp(F - grad * safe_inverse(Hm)); grad lives in c->den, scratch in c->num
 static int shared_step(cmf_ctx *c, int which, double pert, bool non_negative) {
     const int64_t rows = c->frows_pad[which];
-    CHK(safe_inverse_dev(c, c->Hm, c->Hinv, 1, c->k, c->kp, pert));
+    CHK(safe_inverse_dev(c, c->Hm, c->Hinv, 1, c->k, c->kp, pert, c->hess_psd));
     CHK(gemm(c, MODE_NN, c->den, c->kp, c->Hinv, c->kp, c->num, rows, c->kp, c->kp));
     return launch_ew(c, newton_apply_kernel, rows * c->kp, c->F[which], (const float *)c->num, c->frows[which], c->kp, c->k,
                      rows * c->kp, non_negative ? 1 : 0);

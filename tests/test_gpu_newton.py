@@ -433,3 +433,27 @@ def test_flagged_hessians_newton_schulz_and_jacobi(lib, ns, k):
     ctx.close()
     for a, b in zip(got, (Ur, Vr, Zr)):
         np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-3 * np.abs(b).max())
+
+
+@pytest.mark.parametrize("k", [256, 120])
+@pytest.mark.parametrize("ns", [1, 0])
+def test_clamped_shared_hessian(lib, ns, k):
+    """Linear links, no sampling, d < k: the ONE shared Hessian alpha V^T V + l2 I of the U sweep is rank deficient
+    plus l2 < pert, so its eigenvalue clamp acts.  Spectral-clamp route and chip-wide Jacobi route vs the oracle."""
+    from oracle import cmf_oracle as O
+    m, d, p = 300, k // 2, 40
+    rng = np.random.RandomState(k)
+    X, Y = np.abs(rng.randn(m, d)), np.abs(rng.randn(d, p))
+    U0, V0, Z0 = 0.1 * rng.randn(m, k), 0.1 * rng.randn(d, k), 0.1 * rng.randn(p, k)
+    Ur = U0.copy()
+    O.newton_sweep_U(Ur, V0, X, 0.5, 0.0, 0.05, "linear", False, 1.0, 0.2)
+    ctx = lib.Context(0)
+    ctx.set_option("newton_schulz", ns)
+    ctx.set_problem(m, d, p, k)
+    ctx.set_data(0, X); ctx.set_data(1, Y)
+    for w, F in enumerate((U0, V0, Z0)):
+        ctx.set_factor(w, F)
+    ctx.newton_step(0.5, 0.0, 0.05, "linear", "linear", 0, 1, 0.2, 1.0)   # U sweep only
+    got = ctx.get_factor(0)
+    ctx.close()
+    np.testing.assert_allclose(got, Ur, rtol=2e-3, atol=2e-3 * np.abs(Ur).max())
