@@ -6,7 +6,7 @@ n_components=256, 65536^2 dense.  One "step" = one full ``update_step`` of the
 reference (MU: V,U,Z, pycmf/cmf_solvers.py:248-263; Newton: U,Z,V, :510-522)
 over synthetic X (m x d), Y (d x p) already resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c2|c3|c5|tiny]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c2|c3|c5|tiny] [--option name=value ...]
 
 Default workload = C4 (the configuration the metric is quoted on; it fits one
 GPU: 34.4 GB).  c2 / c3 / c5 are the other BASELINE configs (parity-test
@@ -15,7 +15,8 @@ shapes; same JSON contract, for the record in DESIGN.md).
 N > 1 is launched by torch.distributed.run (one rank per GPU).  The problem is
 FIXED (strong scaling): rank g owns rows [g*m/N, (g+1)*m/N) of X/U and the same
 fraction of Y's columns / Z's rows; V is replicated and reassembled by one RCCL
-all-reduce per iteration (pycmf_amd/sharded.py).
+all-reduce per iteration (pycmf_amd/sharded.py).  The per-row Newton workload (c3) shards the rows of all three
+factors instead (two contexts per rank, factor rows exchanged; ShardedNewtonRows).
 
 Prints ONE JSON line on rank 0 with ``roofline`` (dominant kernel class, HIP
 events on the launch stream over the timed region) and ``cpu_baseline`` (CPU
