@@ -95,6 +95,7 @@ struct cmf_ctx {
     int opt_split = -1;    // force split-K factor (<=0: heuristic)
     int opt_ns = 1;        // flagged per-row Hessians at k_pad = 256: Newton-Schulz spectral clamp (0: Jacobi)
     bool hess_psd = true;  // the Hessians of the current step are positive semi-definite by construction (0 <= alpha <= 1)
+    int opt_pipe_nt = 4;   // staging schedule of the NT (residual / error) GEMMs: 0 | 4
     int opt_choldiag = 0;  // timing diagnostics of chol_solve_kernel (wrong results)
     int opt_chol = 1;      // Cholesky fast path of the safe inverse (0: always Jacobi)
     int opt_zlogit_l2 = 1;  // 0: Cython-twin numerics (Z's logit Hessian without l2 I, pyx:287-290)
@@ -312,6 +313,7 @@ static int launch_gemm_mode(cmf_ctx *c, const GemmArgs &a, const GemmPlan &pl) {
     }
     if (ROLE == 1 && MODE != MODE_NT && c->opt_pipe_small == 4)
         return launch_gemm_pipe<MODE, ROLE, (ROLE == 1 && MODE != MODE_NT) ? 4 : 0>(c, a, pl);
+    if (MODE == MODE_NT && c->opt_pipe_nt == 4) return launch_gemm_pipe<MODE, ROLE, (MODE == MODE_NT) ? 4 : 0>(c, a, pl);
     return launch_gemm_pipe<MODE, ROLE, 0>(c, a, pl);
 }
 
@@ -513,6 +515,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
     if (!strcmp(name, "gemm_pipe")) {
         if (value < 0 || (value > 5 && value != 10)) return fail(CMF_EINVAL, "gemm_pipe must be 0..5 or 10");
         c->opt_pipe = (int)value;
+    } else if (!strcmp(name, "gemm_pipe_nt")) {
+        c->opt_pipe_nt = (int)value;
     } else if (!strcmp(name, "gemm_pipe_small")) {
         c->opt_pipe_small = (int)value;
     } else if (!strcmp(name, "gemm_split")) {

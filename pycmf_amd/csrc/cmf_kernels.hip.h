@@ -482,6 +482,44 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
         const int ldt = (int)g.ldt, ldr = (int)g.ldr, ldm = (int)g.ldm;
         const int rlim = (int)min((int64_t)1 << 20, g.Mvalid - rbase); // valid iff rr < rlim
         const int clim = (int)min((int64_t)1 << 20, g.Nvalid - cbase);
+        if (!Mp) {
+            // no byte mask (everything but the masked-dense Newton formulation): fetch ALL targets of the wave tile
+            // first -- one latency for 64 loads in flight instead of 64 dependent load -> wait -> use rounds, which
+            // made this epilogue longer than the 8 K-steps in front of it -- then the arithmetic
+            float tv[C::TM][16][C::TN];
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int j = 0; j < C::TN; ++j) tv[i][r][j] = 0.0f;
+            if (Tp) {
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+#pragma unroll
+                        for (int j = 0; j < C::TN; ++j) tv[i][r][j] = Tp[(32 * i + (r & 3) + 8 * (r >> 2)) * ldt + 32 * j];
+            }
+            const float lkf = g.link ? 1.0f : 0.0f, nlk = 1.0f - lkf;
+            const float slope = g.w_is_slope ? 1.0f : 0.0f, nslope = 1.0f - slope;
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = 32 * i + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                    for (int j = 0; j < C::TN; ++j) {
+                        const float s = acc[i][j][r];
+                        const float f = lkf * sigmoidf_(s) + nlk * s; // exact: one of the two terms is zero
+                        const float mk = (rr < rlim && 32 * j < clim) ? 1.0f : 0.0f;
+                        const float res = f - tv[i][r][j];
+                        sq += mk * res * res;
+                        if (Rp) Rp[rr * ldr + 32 * j] = g.scale_r * mk * res;
+                        if (Wp) Wp[rr * ldr + 32 * j] = g.scale_w * mk * (slope * (f * (1.0f - f)) + nslope);
+                    }
+                }
+        } else
 #pragma unroll
         for (int i = 0; i < C::TM; ++i)
 #pragma unroll
