@@ -281,8 +281,17 @@ def main():
         nnz = float(r1 - r0) * w["nnz_per_row"]
         comp = nnz * 8.0 + ((r1 - r0) + d) * kp * 4.0
         achieved = comp / (dms / max(dn, 1) * 1e-3) / 1e9
+        spmm_traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        if world == 1 and os.path.exists(tpath):
+            try:
+                spmm_traffic = json.load(open(tpath)).get("spmm")
+            except Exception:
+                spmm_traffic = None
         roof = {"bound": "hbm", "kernel": "cmfk::spmm_csr_kernel<64, 1>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": spmm_traffic,
+                "traffic_unit": "bytes per launch past L2 (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic_c5.json): "
+                                "Infinity-Cache hits of the factor-row gathers included",
                 "gathered_GBps": nnz * (kp * 4.0 + 8.0) / (dms / max(dn, 1) * 1e-3) / 1e9,
                 "note": "achieved = compulsory HBM bytes (CSR + dense operand + output) / launch time; the "
                         "per-nonzero factor-row gathers (gathered_GBps) are served by L2 / Infinity Cache",
