@@ -1,0 +1,42 @@
+"""End-to-end `fit_transform` wall time on the six workloads the reference's own benchmark prints
+(benchmarks/benchmark_cmf.py:42-82 upstream: 2000 x 150 / 150 x 10, n_components=10, max_iter=10), here through
+pycmf_amd.CMF.  BASELINE.md section 2 holds the reference's times on 8 vCPU (0.23 .. 0.50 s; 28.1 s at ratio 0.2).
+usage: python tools/reference_cases.py [repeats]"""
+import os, sys, time
+import numpy as np
+from scipy.sparse import csr_matrix
+from scipy.special import expit
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pycmf_amd import CMF
+
+repeats = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+
+
+def data(sparse, logits):
+    rng = np.random.mtrand.RandomState(42)
+    X = np.abs(rng.randn(2000, 150))
+    if sparse:
+        X[:1000, 2 * np.arange(10) + 100] = 0
+        X[1000:, 2 * np.arange(10)] = 0
+        X = csr_matrix(X)
+    Y = rng.randn(150, 10)
+    return X, (expit(Y) if logits else np.abs(Y))
+
+
+cases = [("dense, mu", False, False, dict(solver="mu")),
+         ("dense, newton", False, False, dict(solver="newton")),
+         ("sparse, mu", True, False, dict(solver="mu")),
+         ("sparse, newton", True, False, dict(solver="newton")),
+         ("sparse, Y logits, newton, ratio 1.0", True, True, dict(solver="newton", sg_sample_ratio=1.0)),
+         ("sparse, Y logits, newton, ratio 0.2", True, True, dict(solver="newton", sg_sample_ratio=0.2)),
+         ("sparse, Y logits, newton, ratio 0.2, device sampler", True, True,
+          dict(solver="newton", sg_sample_ratio=0.2, sg_sampler="device"))]
+for name, sparse, logits, kw in cases:
+    X, Y = data(sparse, logits)
+    best = 1e9
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        model = CMF(n_components=10, random_state=42, max_iter=10, **kw)
+        U, V, Z = model.fit_transform(X, Y)
+        best = min(best, time.perf_counter() - t0)
+    print("%-55s best of %d: %.3f s   (n_iter_ %d, err %.4f)" % (name, repeats, best, model.n_iter_, model.reconstruction_err_))
