@@ -48,6 +48,7 @@ WORKLOADS = {
     "tiny": dict(m=2048, d=1024, p=512, k=64, solver="mu", desc="debug shape"),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 (v_mfma_f32_32x32x16_bf16)
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec
 
 
@@ -165,6 +166,7 @@ def main():
 
     w = WORKLOADS[args.workload]
     m, d, p, k = w["m"], w["d"], w["p"], w["k"]
+    bf16x6 = "gemm_arith=1" in args.option
     newton = w["solver"] == "newton"
     sharded_ok = (not newton) or (w["x_link"] == "linear" and w["y_link"] == "linear" and w["ratio"] == 1.0)
     r0, r1 = shard_bounds(m, world, rank)
@@ -312,10 +314,17 @@ def main():
             kname = "cmfk::gemm_kernel<%d, %d, 0, 4>  (%s data pass)" % (
                 0 if dom == "gemm_nn" else 1, 256 if k >= 256 else kp,
                 "NN: X V / Y Z / W KR" if dom == "gemm_nn" else "TN: X^T U / Y^T V / W^T KR")
+        peak = FP32_MFMA_PEAK_TFLOPS
+        if bf16x6 and dom in ("gemm_nn", "gemm_tn"):
+            # optional arithmetic: 6 bf16 MFMA products per fp32-equivalent product -> the bound is the bf16 matrix peak / 6
+            peak = BF16_MFMA_PEAK_TFLOPS / 6.0
+            kname = ("cmfk::bf16x6_gemm_kernel  (data pass on v_mfma_f32_32x32x16_bf16, three bf16 planes per fp32 operand, "
+                     "six cross products, f32 accumulation; peak = bf16 dense peak / 6)")
+            traffic = None
         roof = {"bound": "mfma",
                 "kernel": kname,
-                "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak, "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/traffic_%s.json)" % args.workload,
                 "algorithmic_flops_per_launch": dfl / max(dn, 1),
                 "avg_launch_ms": dms / max(dn, 1), "launches": dn}
@@ -334,7 +343,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "bf16x6 (fp32 operands split exactly into three bf16 planes, f32 accumulation)" if bf16x6 else "f32",
         "data": "synthetic",
         "cells_per_s": (float(m) * d + float(d) * p) * its,
         "algorithmic_tflops": algorithmic_flops(w) * its / 1e12,

@@ -6,6 +6,7 @@
 #include "cmf_eigen.hip.h"
 #include "cmf_sparse.hip.h"
 #include "cmf_rowhess.hip.h"
+#include "cmf_bf16x6.hip.h"
 
 #include <hip/hip_runtime.h>
 
@@ -93,6 +94,8 @@ struct cmf_ctx {
     int opt_pipe_small = 4; // staging schedule of the factor-side products (0 or 4; 4 measured +5..15 %, tools/ab_small.py)
     int opt_pipe = 4;      // GEMM staging schedule (see gemm_kernel PIPE); 4 measured best (tools/ab_gemm.py)
     int opt_split = -1;    // force split-K factor (<=0: heuristic)
+    int opt_arith_min_tiles = 128; // ... only for operands of at least this many 256-row tiles (no split-K in that kernel)
+    int opt_arith = 0;     // data passes at k_pad = 256: 0 fp32 MFMA | 1 bf16x6 (three bf16 planes per operand, fp32-equivalent)
     int opt_ns = 1;        // flagged per-row Hessians at k_pad = 256: Newton-Schulz spectral clamp (0: Jacobi)
     bool hess_psd = true;  // the Hessians of the current step are positive semi-definite by construction (0 <= alpha <= 1)
     int opt_pipe_nt = 4;   // staging schedule of the NT (residual / error) GEMMs: 0 | 4
@@ -130,6 +133,8 @@ struct cmf_ctx {
     DevBuf idxbuf;                        // uploaded sample index lists
     DevBuf eigws;                         // Jacobi workspace when k_pad > 128
     DevBuf eigflag, eigcopy;              // Cholesky fast path: per-matrix fallback flags, input copy
+    DevBuf bfp[2][2], bff;                // gemm_arith = 1: bf16 planes of X / Y (normal, transposed) and of the factor operand
+    bool bfp_valid[2][2] = {{false, false}, {false, false}};
     DevBuf nsidx, nsws;                   // Newton-Schulz clamp: flagged-row list + counters, matrix workspaces
     DevBuf dpart;                         // double partial sums
     double *dscalar = nullptr;            // 4 doubles
@@ -485,6 +490,9 @@ static void release_problem(cmf_ctx *c) {
     c->lists1 = DevBuf(); c->lists2 = DevBuf();
     c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf();
     c->nsidx = DevBuf(); c->nsws = DevBuf();
+    for (int w = 0; w < 2; ++w)
+        for (int o = 0; o < 2; ++o) { c->bfp[w][o] = DevBuf(); c->bfp_valid[w][o] = false; }
+    c->bff = DevBuf();
     c->have_problem = false;
     for (int w = 0; w < 2; ++w) {
         c->sparse[w] = false;
@@ -537,6 +545,11 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->sample_off[CMF_V] = value;
     } else if (!strcmp(name, "sample_row_offset_z")) {
         c->sample_off[CMF_Z] = value;
+    } else if (!strcmp(name, "gemm_arith")) {
+        if (value != 0 && value != 1) return fail(CMF_EINVAL, "gemm_arith must be 0 (fp32 MFMA) or 1 (bf16x6)");
+        c->opt_arith = (int)value;
+    } else if (!strcmp(name, "gemm_arith_min_tiles")) {
+        c->opt_arith_min_tiles = (int)std::max<int64_t>(1, value);
     } else if (!strcmp(name, "newton_schulz")) {
         c->opt_ns = value != 0;
     } else if (!strcmp(name, "chol_diag")) {
@@ -611,6 +624,7 @@ static int data_dims(cmf_ctx *c, int which, int64_t *rows, int64_t *cols, int64_
 
 static int ensure_dense(cmf_ctx *c, int which) {
     invalidate_graphs(c);
+    c->bfp_valid[which][0] = c->bfp_valid[which][1] = false; // the dense image is about to be (re)written
     int64_t r, cc, rp, cp; float **slot;
     CHK(data_dims(c, which, &r, &cc, &rp, &cp, &slot));
     if (!*slot) CHK(dev_alloc(c, (void **)slot, (size_t)rp * cp * sizeof(float)));

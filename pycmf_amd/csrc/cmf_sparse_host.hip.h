@@ -96,11 +96,50 @@ static int need_dense(cmf_ctx *c, int which) {
 // data-times-factor products of the update steps:
 //   which = 0: X (m x d)   trans = false: X B (B has d rows) -> m rows ; true: X^T B (B has m rows) -> d rows
 //   which = 1: Y (d x p)   trans = false: Y B (B has p rows) -> d rows ; true: Y^T B (B has d rows) -> p rows
+// gemm_arith = 1 (cmf_bf16x6.hip.h): out[R x 256] (+)= op(A)[R x K] * B[K x 256] on the bf16 matrix pipe with three planes
+// per operand.  The planes of op(A) are built on first use and stay resident (6 bytes per element and orientation).
+static int data_times_bf16x6(cmf_ctx *c, int which, bool trans, const float *A, const float *B, float *out, bool accumulate) {
+    const int64_t rp = which == 0 ? c->mp : c->dp, cp = which == 0 ? c->dp : c->pp;
+    const int64_t R = trans ? cp : rp, K = trans ? rp : cp;   // rows of op(A), reduction length
+    const int o = trans ? 1 : 0;
+    const size_t plane = (size_t)R * K * sizeof(unsigned short);
+    if (!c->bfp_valid[which][o]) {
+        CHK(ensure(c, c->bfp[which][o], 3 * plane));
+        Timed tm(c, CMF_K_ELEMWISE);
+        unsigned short *P = (unsigned short *)c->bfp[which][o].p;
+        hipLaunchKernelGGL(bf16x3_split_kernel, dim3(8192), dim3(256), 0, c->stream, A, cp, trans ? 1 : 0, R, K, P, P + (size_t)R * K,
+                           P + 2 * (size_t)R * K);
+        HIPCHK(hipGetLastError());
+        c->bfp_valid[which][o] = true;
+    }
+    // factor operand: B^T planes [256 x K]
+    const size_t fplane = (size_t)256 * K * sizeof(unsigned short);
+    CHK(ensure(c, c->bff, 3 * fplane));
+    unsigned short *F = (unsigned short *)c->bff.p;
+    {
+        Timed tm(c, CMF_K_ELEMWISE);
+        hipLaunchKernelGGL(bf16x3_split_kernel, dim3(1024), dim3(256), 0, c->stream, B, (int64_t)c->kp, 1, (int64_t)256, K, F, F + (size_t)256 * K,
+                           F + 2 * (size_t)256 * K);
+        HIPCHK(hipGetLastError());
+    }
+    Bf16x6Args g;
+    const unsigned short *P = (const unsigned short *)c->bfp[which][o].p;
+    for (int p = 0; p < 3; ++p) { g.A[p] = P + (size_t)p * R * K; g.B[p] = F + (size_t)p * 256 * K; }
+    g.C = out; g.KT = K / 16; g.accumulate = accumulate ? 1 : 0;
+    Timed tm(c, trans ? CMF_K_GEMM_TN : CMF_K_GEMM_NN, 2.0 * (double)R * 256.0 * (double)K);
+    CHK(allow_big_lds(c, reinterpret_cast<const void *>(&bf16x6_gemm_kernel), BX_LDS_BYTES));
+    hipLaunchKernelGGL(bf16x6_gemm_kernel, dim3((unsigned)(R / 256)), dim3(512), BX_LDS_BYTES, c->stream, g);
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
 static int data_times(cmf_ctx *c, int which, bool trans, const float *B, float *out, bool accumulate = false) {
     const int64_t rp = which == 0 ? c->mp : c->dp, cp = which == 0 ? c->dp : c->pp;
     if (c->sparse[which] && !(which == 0 ? c->X : c->Y)) return spmm(c, c->sp[which][trans ? 1 : 0], B, out, trans ? cp : rp, accumulate);
     const float *A = which == 0 ? c->X : c->Y;
     if (!A) return fail(CMF_EINVAL, "%s has not been set", which == 0 ? "X" : "Y");
+    // optional arithmetic: only where one 256-row tile per CU keeps the chip busy without split-K
+    if (c->opt_arith == 1 && c->kp == 256 && (trans ? cp : rp) >= (int64_t)c->opt_arith_min_tiles * 256) return data_times_bf16x6(c, which, trans, A, B, out, accumulate);
     if (!trans) return gemm(c, MODE_NN, A, cp, B, c->kp, out, rp, c->kp, cp, accumulate);
     return gemm(c, MODE_TN, A, cp, B, c->kp, out, cp, c->kp, rp, accumulate);
 }
