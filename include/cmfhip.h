@@ -76,6 +76,8 @@ int cmf_sync(cmf_ctx *ctx);
  * cmf_newton_solver.pyx:287-290: Z's logit Hessian without l2 I),
  * "safe_inverse_cholesky" 1 | 0, "graph" 1 | 0 (replay MU / linear-Newton steps from a
  * captured hipGraph; automatically off while cmf_kernel_timing is enabled),
+ * "gemm_arith" 0 (fp32 MFMA, default) | 1 (k_pad = 256 data passes on the bf16 matrix pipe: every fp32 operand
+ * split exactly into three bf16 planes, six cross products, fp32 accumulation; planes stay resident),
  * "row_symmetric" 1 | 0 (k_pad = 256 row kernel: upper block triangle of H_i only),
  * "newton_schulz" 1 | 0 (k_pad = 256: rows whose eigenvalue clamp acts go through the GEMM-only
  * spectral clamp | through the Jacobi eigen-solver),

@@ -197,3 +197,30 @@ def test_c5_full_size_sparse_shard_independence(lib):
         for w, sl in ((1, slice(None)), (0, slice(r0, r1)), (2, slice(c0, c1))):
             np.testing.assert_allclose(ctx.get_factor(w), ref[w][sl], rtol=1e-3, atol=1e-5 * np.abs(ref[w]).max())
         ctx.close()
+
+
+def test_c4_full_size_bf16x6_matches_fp32_path(lib):
+    """BASELINE configs[3] with the optional arithmetic (gemm_arith = 1: three bf16 planes per fp32 operand, six cross
+    products on the bf16 matrix pipe): one full-size MU iteration gives the factors of the fp32-MFMA path to fp32
+    round-off, the objective decreases identically, and the power-of-two gauge stays bit-exact."""
+    m = d = p = 65536
+    k = 256
+    out = {}
+    for arith in (0, 1):
+        ctx = _synthetic(lib, m, d, p, k)
+        ctx.set_option("gemm_arith", arith)
+        e0 = _err(ctx)
+        ctx.mu_step(0.0, 0.0, 7)
+        out[arith] = ([ctx.get_factor(w) for w in range(3)], e0, _err(ctx))
+        if arith == 1:
+            scale = (0.7979 / k) ** 0.5
+            ctx.fill_factor_synthetic(lib.CMF_U, 101, 0, scale * 2.0)
+            ctx.fill_factor_synthetic(lib.CMF_V, 102, 0, scale / 2.0)
+            ctx.fill_factor_synthetic(lib.CMF_Z, 103, 0, scale * 2.0)
+            ctx.mu_step(0.0, 0.0, 7)
+            for w, g in ((0, 2.0), (1, 0.5), (2, 2.0)):
+                np.testing.assert_array_equal(ctx.get_factor(w), g * out[1][0][w])
+        ctx.close()
+    for a, b in zip(out[0][0], out[1][0]):  # 65536-term fp32 sums accumulated in a different order
+        np.testing.assert_allclose(b, a, rtol=1e-4, atol=0)
+    assert out[1][2] < out[1][1] and abs(out[1][2] - out[0][2]) <= 1e-6 * out[0][2]
