@@ -94,7 +94,7 @@ struct cmf_ctx {
     int opt_pipe_small = 4; // staging schedule of the factor-side products (0 or 4; 4 measured +5..15 %, tools/ab_small.py)
     int opt_pipe = 4;      // GEMM staging schedule (see gemm_kernel PIPE); 4 measured best (tools/ab_gemm.py)
     int opt_split = -1;    // force split-K factor (<=0: heuristic)
-    int opt_arith_min_tiles = 128; // ... only for operands of at least this many 256-row tiles (no split-K in that kernel)
+    int opt_arith_min_tiles = 8;   // ... only for operands of at least this many 256-row tiles
     int opt_arith = 0;     // data passes at k_pad = 256: 0 fp32 MFMA | 1 bf16x6 (three bf16 planes per operand, fp32-equivalent)
     int opt_ns = 1;        // flagged per-row Hessians at k_pad = 256: Newton-Schulz spectral clamp (0: Jacobi)
     bool hess_psd = true;  // the Hessians of the current step are positive semi-definite by construction (0 <= alpha <= 1)

@@ -70,8 +70,10 @@ constexpr int BX_LDS_BYTES = 2 * BX_STAGE;  // 147456
 struct Bf16x6Args {
     const unsigned short *A[3];   // planes of the data operand, rows R
     const unsigned short *B[3];   // planes of the transposed factor operand, 256 rows
-    float *C;                     // [R x 256] row-major
+    float *C;                     // [R x 256] row-major; split-K: slab blockIdx.y at C + blockIdx.y * slab_stride
     int64_t KT;                   // K / 16
+    int64_t kt_per_split;         // k tiles per blockIdx.y (multiple of 2 unless it is the whole range)
+    int64_t slab_stride;
     int accumulate;
 };
 
@@ -81,7 +83,10 @@ __global__ __launch_bounds__(512, 2) void bf16x6_gemm_kernel(Bf16x6Args g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bxl[];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6, l31 = lane & 31, lh = lane >> 5;
     const int wrow0 = (wid >> 1) * 64, wcol0 = (wid & 1) * 128;
-    const int64_t KT = g.KT, atile0 = (int64_t)blockIdx.x * KT;
+    // this workgroup reduces k tiles [kt0, kt0 + KT) of the g.KT in a row tile
+    const int64_t kt0 = (int64_t)blockIdx.y * g.kt_per_split;
+    const int64_t KT = (g.KT - kt0 < g.kt_per_split) ? g.KT - kt0 : g.kt_per_split;
+    const int64_t atile0 = (int64_t)blockIdx.x * g.KT + kt0;
     f32x16 acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(512, 2) void bf16x6_gemm_kernel(Bf16x6Args g) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             st[set][p] = *reinterpret_cast<const f32x4 *>(g.A[p] + ((atile0 + kt) * 4096 + 8 * t));
-            st[set][3 + p] = *reinterpret_cast<const f32x4 *>(g.B[p] + (kt * 4096 + 8 * t));
+            st[set][3 + p] = *reinterpret_cast<const f32x4 *>(g.B[p] + ((kt0 + kt) * 4096 + 8 * t));
         }
     };
     const int srow = t >> 1, shalf = t & 1;
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void bf16x6_gemm_kernel(Bf16x6Args g) {
         }
     }
     // lane = column l31, register r = row (r & 3) + 8 (r >> 2) + 4 lh
-    float *Cw = g.C + ((int64_t)blockIdx.x * 256 + wrow0 + 4 * lh) * 256 + wcol0 + l31;
+    float *Cw = g.C + (int64_t)blockIdx.y * g.slab_stride + ((int64_t)blockIdx.x * 256 + wrow0 + 4 * lh) * 256 + wcol0 + l31;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll

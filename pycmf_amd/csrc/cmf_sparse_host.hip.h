@@ -125,11 +125,26 @@ static int data_times_bf16x6(cmf_ctx *c, int which, bool trans, const float *A, 
     Bf16x6Args g;
     const unsigned short *P = (const unsigned short *)c->bfp[which][o].p;
     for (int p = 0; p < 3; ++p) { g.A[p] = P + (size_t)p * R * K; g.B[p] = F + (size_t)p * 256 * K; }
-    g.C = out; g.KT = K / 16; g.accumulate = accumulate ? 1 : 0;
-    Timed tm(c, trans ? CMF_K_GEMM_TN : CMF_K_GEMM_NN, 2.0 * (double)R * 256.0 * (double)K);
-    CHK(allow_big_lds(c, reinterpret_cast<const void *>(&bf16x6_gemm_kernel), BX_LDS_BYTES));
-    hipLaunchKernelGGL(bf16x6_gemm_kernel, dim3((unsigned)(R / 256)), dim3(512), BX_LDS_BYTES, c->stream, g);
-    HIPCHK(hipGetLastError());
+    // fewer row tiles than CUs: split the reduction over blockIdx.y into slabs (deterministic, summed afterwards)
+    const int64_t tiles = R / 256, KT = K / 16;
+    int64_t nsplit = 1;
+    if (tiles < 192) nsplit = std::min<int64_t>(std::max<int64_t>(1, 256 / tiles), std::max<int64_t>(1, KT / 64));
+    int64_t per = (KT + nsplit - 1) / nsplit;
+    per += per & 1;                              // whole pairs of k tiles per split
+    nsplit = (KT + per - 1) / per;
+    g.KT = KT; g.kt_per_split = per; g.accumulate = (accumulate && nsplit == 1) ? 1 : 0;
+    g.C = out; g.slab_stride = 0;
+    if (nsplit > 1) {
+        CHK(ensure(c, c->slabs, (size_t)nsplit * R * 256 * sizeof(float)));
+        g.C = (float *)c->slabs.p; g.slab_stride = R * 256;
+    }
+    {
+        Timed tm(c, trans ? CMF_K_GEMM_TN : CMF_K_GEMM_NN, 2.0 * (double)R * 256.0 * (double)K);
+        CHK(allow_big_lds(c, reinterpret_cast<const void *>(&bf16x6_gemm_kernel), BX_LDS_BYTES));
+        hipLaunchKernelGGL(bf16x6_gemm_kernel, dim3((unsigned)tiles, (unsigned)nsplit), dim3(512), BX_LDS_BYTES, c->stream, g);
+        HIPCHK(hipGetLastError());
+    }
+    if (nsplit > 1) CHK(sum_slabs(c, out, (const float *)c->slabs.p, R * 256, (int)nsplit, g.slab_stride, accumulate));
     return CMF_OK;
 }
 
@@ -138,7 +153,7 @@ static int data_times(cmf_ctx *c, int which, bool trans, const float *B, float *
     if (c->sparse[which] && !(which == 0 ? c->X : c->Y)) return spmm(c, c->sp[which][trans ? 1 : 0], B, out, trans ? cp : rp, accumulate);
     const float *A = which == 0 ? c->X : c->Y;
     if (!A) return fail(CMF_EINVAL, "%s has not been set", which == 0 ? "X" : "Y");
-    // optional arithmetic: only where one 256-row tile per CU keeps the chip busy without split-K
+    // optional arithmetic (k_pad = 256; tiny operands stay on the fp32 kernels)
     if (c->opt_arith == 1 && c->kp == 256 && (trans ? cp : rp) >= (int64_t)c->opt_arith_min_tiles * 256) return data_times_bf16x6(c, which, trans, A, B, out, accumulate);
     if (!trans) return gemm(c, MODE_NN, A, cp, B, c->kp, out, rp, c->kp, cp, accumulate);
     return gemm(c, MODE_TN, A, cp, B, c->kp, out, cp, c->kp, rp, accumulate);

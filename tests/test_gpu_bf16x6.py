@@ -33,10 +33,10 @@ def _run(lib, arith, X, Y, U, V, Z, steps, l1=0.0, l2=0.0):
     return out, err
 
 
-@pytest.mark.parametrize("k", [256, 200])
-def test_bf16x6_mu_matches_fp32_path_and_oracle(lib, k):
+@pytest.mark.parametrize("k,shape", [(256, (700, 530, 300)), (200, (700, 530, 300)), (256, (300, 4300, 260))])
+def test_bf16x6_mu_matches_fp32_path_and_oracle(lib, k, shape):
     from oracle import cmf_oracle as O
-    m, d, p = 700, 530, 300          # ragged: 3 / 3 / 2 row tiles after padding, k = 200 pads to 256
+    m, d, p = shape                  # ragged; k = 200 pads to 256; d = 4300 makes X V / Y^T V split their reduction into slabs
     rng = np.random.RandomState(9)
     X, Y = np.abs(rng.randn(m, d)), np.abs(rng.randn(d, p))
     s = np.sqrt(X.mean() / k)
