@@ -105,6 +105,8 @@ class _HipIterativeSolver:
                 self._ctx.set_option("sparse_mode", {"auto": 0, "dense": 1, "native": 2}[mode])
             if self.cython_variant:
                 self._ctx.set_option("z_logit_hessian_l2", 0)
+            if os.environ.get("PYCMF_AMD_GEMM_ARITH") == "bf16x6":  # opt-in arithmetic of the k_pad = 256 data passes
+                self._ctx.set_option("gemm_arith", 1)
         if self._bound != key:
             self._ctx.set_problem(m, d, p, k)
             if X is not None:
