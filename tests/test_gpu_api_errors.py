@@ -36,6 +36,8 @@ def test_call_order_and_arguments(lib):
         ctx.set_option("no_such_knob", 1)
     with pytest.raises(ValueError, match="gemm_pipe must be"):
         ctx.set_option("gemm_pipe", 99)
+    with pytest.raises(ValueError, match="gemm_arith must be"):
+        ctx.set_option("gemm_arith", 2)
     with pytest.raises(ValueError, match="operand has 5 rows, expected 3"):
         ctx.data_matmul(0, False, np.ones((5, 2)))
     ctx.close()
