@@ -55,7 +55,7 @@ def test_sharded_fit_two_processes(tmp_path, world):
     procs = [subprocess.Popen([sys.executable, str(script)],
                               env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
-    outs = [q.communicate(timeout=600)[0].decode() for q in procs]
+    outs = [q.communicate(timeout=1800)[0].decode() for q in procs]
     for r, (q, o) in enumerate(zip(procs, outs)):
         assert q.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
     # single-process reference through the ordinary solver shell
@@ -115,7 +115,7 @@ def test_row_sharded_newton_fit_two_processes(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script)],
                               env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
-    outs = [q.communicate(timeout=600)[0].decode() for q in procs]
+    outs = [q.communicate(timeout=1800)[0].decode() for q in procs]
     for r, (q, o) in enumerate(zip(procs, outs)):
         assert q.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
     ref = HipNewtonSolver(alpha=0.4, l1_reg=0.01, l2_reg=0.05, x_link="linear", y_link="logit", U_non_negative=False,
