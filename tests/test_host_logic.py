@@ -210,7 +210,7 @@ def test_sharded_mu_world2_gloo(tmp_path):
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
         assert "rank %d ok" % r in o
@@ -287,7 +287,7 @@ def test_row_sharded_newton_world2_gloo(tmp_path):
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
         assert "rank %d ok" % r in o
