@@ -16,8 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcmfhip.so")
 SOURCES = ["cmf_api.hip"]
-DEPS = ["cmf_api.hip", "cmf_kernels.hip.h", "cmf_newton.hip.h", "cmf_eigen.hip.h",
-        os.path.join(ROOT, "include", "cmfhip.h")]
+DEPS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [os.path.join(ROOT, "include", "cmfhip.h")]
 
 
 def _hipcc():

@@ -108,23 +108,24 @@ static int data_times_bf16x6(cmf_ctx *c, int which, bool trans, const float *A, 
         Timed tm(c, CMF_K_ELEMWISE);
         unsigned short *P = (unsigned short *)c->bfp[which][o].p;
         hipLaunchKernelGGL(bf16x3_split_kernel, dim3(8192), dim3(256), 0, c->stream, A, cp, trans ? 1 : 0, R, K, P, P + (size_t)R * K,
-                           P + 2 * (size_t)R * K);
+                           P + 2 * (size_t)R * K, 256);
         HIPCHK(hipGetLastError());
         c->bfp_valid[which][o] = true;
     }
-    // factor operand: B^T planes [256 x K]
-    const size_t fplane = (size_t)256 * K * sizeof(unsigned short);
+    // factor operand: B^T planes [k_pad x K]; their tiles hold k_pad rows (k_pad * 16 entries per k tile)
+    const int64_t bn = c->kp;
+    const size_t fplane = (size_t)bn * K * sizeof(unsigned short);
     CHK(ensure(c, c->bff, 3 * fplane));
     unsigned short *F = (unsigned short *)c->bff.p;
     {
         Timed tm(c, CMF_K_ELEMWISE);
-        hipLaunchKernelGGL(bf16x3_split_kernel, dim3(1024), dim3(256), 0, c->stream, B, (int64_t)c->kp, 1, (int64_t)256, K, F, F + (size_t)256 * K,
-                           F + 2 * (size_t)256 * K);
+        hipLaunchKernelGGL(bf16x3_split_kernel, dim3(1024), dim3(256), 0, c->stream, B, (int64_t)c->kp, 1, bn, K, F, F + (size_t)bn * K,
+                           F + 2 * (size_t)bn * K, (int)bn);
         HIPCHK(hipGetLastError());
     }
     Bf16x6Args g;
     const unsigned short *P = (const unsigned short *)c->bfp[which][o].p;
-    for (int p = 0; p < 3; ++p) { g.A[p] = P + (size_t)p * R * K; g.B[p] = F + (size_t)p * 256 * K; }
+    for (int p = 0; p < 3; ++p) { g.A[p] = P + (size_t)p * R * K; g.B[p] = F + (size_t)p * bn * K; }
     // fewer row tiles than CUs: split the reduction over blockIdx.y into slabs (deterministic, summed afterwards)
     const int64_t tiles = R / 256, KT = K / 16;
     int64_t nsplit = 1;
@@ -135,16 +136,22 @@ static int data_times_bf16x6(cmf_ctx *c, int which, bool trans, const float *A, 
     g.KT = KT; g.kt_per_split = per; g.accumulate = (accumulate && nsplit == 1) ? 1 : 0;
     g.C = out; g.slab_stride = 0;
     if (nsplit > 1) {
-        CHK(ensure(c, c->slabs, (size_t)nsplit * R * 256 * sizeof(float)));
-        g.C = (float *)c->slabs.p; g.slab_stride = R * 256;
+        CHK(ensure(c, c->slabs, (size_t)nsplit * R * bn * sizeof(float)));
+        g.C = (float *)c->slabs.p; g.slab_stride = R * bn;
     }
     {
-        Timed tm(c, trans ? CMF_K_GEMM_TN : CMF_K_GEMM_NN, 2.0 * (double)R * 256.0 * (double)K);
-        CHK(allow_big_lds(c, reinterpret_cast<const void *>(&bf16x6_gemm_kernel), BX_LDS_BYTES));
-        hipLaunchKernelGGL(bf16x6_gemm_kernel, dim3((unsigned)tiles, (unsigned)nsplit), dim3(512), BX_LDS_BYTES, c->stream, g);
+        Timed tm(c, trans ? CMF_K_GEMM_TN : CMF_K_GEMM_NN, 2.0 * (double)R * (double)bn * (double)K);
+        const dim3 grid((unsigned)tiles, (unsigned)nsplit);
+        if (bn == 256) {
+            CHK(allow_big_lds(c, reinterpret_cast<const void *>(&bf16x6_gemm_kernel<4>), BxCfg<4>::LDS_BYTES));
+            hipLaunchKernelGGL((bf16x6_gemm_kernel<4>), grid, dim3(512), BxCfg<4>::LDS_BYTES, c->stream, g);
+        } else {
+            CHK(allow_big_lds(c, reinterpret_cast<const void *>(&bf16x6_gemm_kernel<2>), BxCfg<2>::LDS_BYTES));
+            hipLaunchKernelGGL((bf16x6_gemm_kernel<2>), grid, dim3(512), BxCfg<2>::LDS_BYTES, c->stream, g);
+        }
         HIPCHK(hipGetLastError());
     }
-    if (nsplit > 1) CHK(sum_slabs(c, out, (const float *)c->slabs.p, R * 256, (int)nsplit, g.slab_stride, accumulate));
+    if (nsplit > 1) CHK(sum_slabs(c, out, (const float *)c->slabs.p, R * bn, (int)nsplit, g.slab_stride, accumulate));
     return CMF_OK;
 }
 
@@ -153,8 +160,8 @@ static int data_times(cmf_ctx *c, int which, bool trans, const float *B, float *
     if (c->sparse[which] && !(which == 0 ? c->X : c->Y)) return spmm(c, c->sp[which][trans ? 1 : 0], B, out, trans ? cp : rp, accumulate);
     const float *A = which == 0 ? c->X : c->Y;
     if (!A) return fail(CMF_EINVAL, "%s has not been set", which == 0 ? "X" : "Y");
-    // optional arithmetic (k_pad = 256; tiny operands stay on the fp32 kernels)
-    if (c->opt_arith == 1 && c->kp == 256 && (trans ? cp : rp) >= (int64_t)c->opt_arith_min_tiles * 256) return data_times_bf16x6(c, which, trans, A, B, out, accumulate);
+    // optional arithmetic (k_pad = 256 or 128; tiny operands stay on the fp32 kernels)
+    if (c->opt_arith == 1 && (c->kp == 256 || c->kp == 128) && (trans ? cp : rp) >= (int64_t)c->opt_arith_min_tiles * 256) return data_times_bf16x6(c, which, trans, A, B, out, accumulate);
     if (!trans) return gemm(c, MODE_NN, A, cp, B, c->kp, out, rp, c->kp, cp, accumulate);
     return gemm(c, MODE_TN, A, cp, B, c->kp, out, cp, c->kp, rp, accumulate);
 }

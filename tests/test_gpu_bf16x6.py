@@ -1,4 +1,4 @@
-"""Optional arithmetic of the data passes at k_pad = 256 (cmf_set_option "gemm_arith" = 1): three bf16 planes per fp32
+"""Optional arithmetic of the data passes at k_pad = 256 / 128 (cmf_set_option "gemm_arith" = 1): three bf16 planes per fp32
 operand, six cross products on the bf16 matrix pipe -- must be indistinguishable from the fp32 MFMA path at fp32
 tolerance, and match the fp64 oracle like it."""
 import numpy as np
@@ -33,7 +33,8 @@ def _run(lib, arith, X, Y, U, V, Z, steps, l1=0.0, l2=0.0):
     return out, err
 
 
-@pytest.mark.parametrize("k,shape", [(256, (700, 530, 300)), (200, (700, 530, 300)), (256, (300, 4300, 260))])
+@pytest.mark.parametrize("k,shape", [(256, (700, 530, 300)), (200, (700, 530, 300)), (256, (300, 4300, 260)),
+                                     (128, (700, 530, 300)), (100, (300, 4300, 260))])
 def test_bf16x6_mu_matches_fp32_path_and_oracle(lib, k, shape):
     from oracle import cmf_oracle as O
     m, d, p = shape                  # ragged; k = 200 pads to 256; d = 4300 makes X V / Y^T V split their reduction into slabs
