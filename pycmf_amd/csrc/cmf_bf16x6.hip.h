@@ -93,7 +93,8 @@ __global__ __launch_bounds__(512, 2) void bf16x6_gemm_kernel(Bf16x6Args g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bxl[];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6, l31 = lane & 31, lh = lane >> 5;
     const int wrow0 = (wid >> 1) * 64, wcol0 = (wid & 1) * (32 * NJ);
-    const bool bload = t < 2 * BN; // the B tile has 2 BN 16-byte chunks
+    const bool bload = (2 * BN >= 512) || t < 2 * BN; // the B tile has 2 BN 16-byte chunks (compile-time true at BN = 256:
+                                                      // a predicated load would make hipcc wait right behind it)
     // this workgroup reduces k tiles [kt0, kt0 + KT) of the g.KT in a row tile
     const int64_t kt0 = (int64_t)blockIdx.y * g.kt_per_split;
     const int64_t KT = (g.KT - kt0 < g.kt_per_split) ? g.KT - kt0 : g.kt_per_split;
