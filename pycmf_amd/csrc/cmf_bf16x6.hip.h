@@ -21,10 +21,12 @@ namespace cmfk {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned short bf16_rn_bits(float f) { // round to nearest even (inputs are finite)
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+__device__ __forceinline__ unsigned short bf16_rn_bits(float f) { // round to nearest even
+    const unsigned u = __float_as_uint(f);
+    unsigned r = u + 0x7FFFu + ((u >> 16) & 1u);
+    // a finite value just under FLT_MAX must not round up to infinity (the remainder would be -inf): truncate it instead
+    if ((r & 0x7F800000u) == 0x7F800000u && (u & 0x7F800000u) != 0x7F800000u) r = u;
+    return (unsigned short)(r >> 16);
 }
 __device__ __forceinline__ float bf16_bits_f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
