@@ -2,6 +2,10 @@
 // exactly into three bf16 planes and the six leading cross products formed on v_mfma_f32_32x32x16_bf16 with fp32
 // accumulation ("bf16x6": fp32-equivalent products at 1/6 of the bf16 matrix rate = 2.6x the fp32 MFMA rate).
 // Planes are stored tile-major ([row tile 256][k tile 16][256 rows][16 k] bf16 = 8 KB contiguous per tile).
+// Tried on top of this and dropped (same-run A/B at the C4 shape, six products 9.9-10.0 ms): staging two groups later
+// (-3 %, within noise), first-use order of the fragment loads (+8 %), conflict-free [k half][row] tile layout (+-0),
+// mid-step barrier with the next step's fragments prefetched in groups 2 / 3 (10.35 ms).  PMC of the library kernel: the
+// matrix pipe is busy 70 % of the cycles at an effective clock of 1.66 GHz -- the chip throttles under this load.
 // build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 tools/spike/bf16x6.hip -o /tmp/bf16x6 && /tmp/bf16x6
 #include <hip/hip_runtime.h>
 #include <cmath>
