@@ -103,7 +103,7 @@ struct cmf_ctx {
     int opt_chol = 1;      // Cholesky fast path of the safe inverse (0: always Jacobi)
     int opt_zlogit_l2 = 1;  // 0: Cython-twin numerics (Z's logit Hessian without l2 I, pyx:287-290)
     int opt_rowdiag = 0;    // diagnostic builds of row_hess_kernel<256> (1: no staging, 2: stage only, 3: gather only)
-    int opt_rowsym = 1;     // row_hess_kernel<256>: accumulate only the blocks on or above the diagonal of H_i
+    int opt_rowsym = 3;     // row_hess_kernel<256>: 0 full blocks | 1 upper block triangle, raw + weighted images | 3 ... one sqrt-weighted image
     int opt_rowstagger = 1; // row_hess_kernel: waves 4-7 stage half a K-step after waves 0-3
     int opt_rowkernel = 1; // per-row Newton sweeps: fused gather kernel (1) or masked-dense GEMMs (0)
     double flop_scale = 1.0;   // algorithmic/executed flop ratio of the launches being issued (sampled sweeps run masked-dense)
@@ -536,7 +536,7 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "row_stagger")) {
         c->opt_rowstagger = value != 0;
     } else if (!strcmp(name, "row_symmetric")) {
-        c->opt_rowsym = value != 0;
+        c->opt_rowsym = (int)value;
     } else if (!strcmp(name, "row_kernel")) {
         c->opt_rowkernel = value != 0;
     } else if (!strcmp(name, "sample_row_offset_u")) {

@@ -554,6 +554,12 @@ static int launch_row_hess_kp(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
             else CMF_ROWDIAG(3, 0);
         }
 #undef CMF_ROWDIAG
+    } else if (KP == 256 && c->opt_rowsym == 3 && a.scale >= 0.f) { // non-negative weights: single sqrt-weighted image
+        constexpr int KS = KP == 256 ? 256 : 0;
+        if constexpr (KS == 256) {
+            CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<256, 1, 0, 3>), (int)Cfg::LDS_BYTES));
+            hipLaunchKernelGGL((row_hess_kernel<256, 1, 0, 3>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
+        }
     } else if (KP == 256 && c->opt_rowsym) {
         constexpr int KS = KP == 256 ? 256 : 0; // only the k_pad = 256 instantiation exists
         if constexpr (KS == 256) {

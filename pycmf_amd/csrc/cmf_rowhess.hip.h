@@ -61,6 +61,13 @@ __host__ __device__ constexpr int sym_na(int ty) { return ty == 0 ? 1 : 2; }   /
 __host__ __device__ constexpr int sym_nb(int ty) { return ty == 2 ? 3 : 4; }   // distinct B fragments
 __host__ __device__ constexpr int sym_ai(int ty, int n) { return ty == 0 ? 0 : (ty == 1 ? (n == 4 ? 1 : 0) : (n >= 3 ? 1 : 0)); }
 __host__ __device__ constexpr int sym_bi(int ty, int n) { return ty == 0 ? n : (ty == 1 ? (n == 4 ? 3 : n) : (n < 3 ? n : n - 2)); }
+// SYM = 3 (weights >= 0): ONE staged image sqrt(w_j) o_j feeds both MFMA operands, H_i = sum_j (sqrt(w_j) o_j)(sqrt(w_j) o_j)^T:
+// half the LDS fill of the raw + weighted pair, and a wave reads each block fragment once (5 / 4 / 3 per k-pair for the
+// three wave types instead of 5 / 6 / 5).  Measured at C3: 385.6 ms against 388.2 ms -- the LDS fill was not the cost.  Fragment f of a wave: type 0 -> block row w, then block columns 4..7;
+// types 1, 2 -> its block columns.
+__host__ __device__ constexpr int s3_nf(int ty) { return ty == 0 ? 5 : (ty == 1 ? 4 : 3); }
+__host__ __device__ constexpr int s3_ai(int ty, int n) { return ty == 0 ? 0 : (ty == 1 ? (n == 4 ? 3 : 0) : (n >= 3 ? 1 : 0)); }
+__host__ __device__ constexpr int s3_bi(int ty, int n) { return ty == 0 ? n + 1 : (ty == 1 ? (n == 4 ? 3 : n) : (n < 3 ? n : n - 2)); }
 template <int V>
 struct IntC {
     static constexpr int value = V;
@@ -163,6 +170,7 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
         const float valid = vv ? g.scale : 0.0f;
         const float res = valid * (f - tt);
         const float wgt = valid * (lk * (f * (1.0f - f)) + nlk);
+        const float sqw = __builtin_amdgcn_sqrtf(fmaxf(wgt, 0.0f)); // SYM == 3 only (launched when the weights are non-negative)
 #pragma unroll
         for (int q = 0; q < C::CPT; ++q) {
             gacc[q] += res * rr[q];
@@ -170,8 +178,12 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
                 gacc[q] += wgt * rr[q];
                 continue;
             }
-            *reinterpret_cast<f32x4 *>(rdst + 4 * q * C::LPR) = rr[q];
-            *reinterpret_cast<f32x4 *>(wdst + 4 * q * C::LPR) = wgt * rr[q];
+            if constexpr (SYM == 3) {
+                *reinterpret_cast<f32x4 *>(rdst + 4 * q * C::LPR) = sqw * rr[q];
+            } else {
+                *reinterpret_cast<f32x4 *>(rdst + 4 * q * C::LPR) = rr[q];
+                *reinterpret_cast<f32x4 *>(wdst + 4 * q * C::LPR) = wgt * rr[q];
+            }
         }
     };
     auto mfma_tile = [&](int cb, bool do_stage, int nb, bool do_gather, int tl_gather, bool do_idx, int tl_idx) {
@@ -214,13 +226,18 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
         constexpr int NP = sym_np(TY), NA = sym_na(TY), NB = sym_nb(TY);
         const float *Rt = tile_of(cb) + l31;
         const float *Wt = wtile_of(cb) + l31;
-        float a[2][2], b[2][4];
+        float a[2][2], b[2][5];
         auto ld_frag = [&](int sidx, float *da, float *db) {
             const int kk = 2 * sidx + lh;
+            if constexpr (SYM == 3) { // one image: db[f] = fragment f of this wave (da unused)
 #pragma unroll
-            for (int x = 0; x < NA; ++x) da[x] = Wt[kk * KP + 32 * ablk[x]];
+                for (int f = 0; f < s3_nf(TY); ++f) db[f] = Rt[kk * KP + 32 * (TY == 0 ? (f == 0 ? ablk[0] : bblk[f - 1]) : bblk[f])];
+            } else {
 #pragma unroll
-            for (int y = 0; y < NB; ++y) db[y] = Rt[kk * KP + 32 * bblk[y]];
+                for (int x = 0; x < NA; ++x) da[x] = Wt[kk * KP + 32 * ablk[x]];
+#pragma unroll
+                for (int y = 0; y < NB; ++y) db[y] = Rt[kk * KP + 32 * bblk[y]];
+            }
         };
         ld_frag(0, a[0], b[0]);
 #pragma unroll
@@ -235,8 +252,12 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int n = 0; n < NP; ++n)
-                hs[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sidx & 1][sym_ai(TY, n)], b[sidx & 1][sym_bi(TY, n)], hs[n], 0, 0, 0);
+            for (int n = 0; n < NP; ++n) {
+                if constexpr (SYM == 3)
+                    hs[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[sidx & 1][s3_ai(TY, n)], b[sidx & 1][s3_bi(TY, n)], hs[n], 0, 0, 0);
+                else
+                    hs[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sidx & 1][sym_ai(TY, n)], b[sidx & 1][sym_bi(TY, n)], hs[n], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
