@@ -144,8 +144,6 @@ def main():
         args.gpus = world
 
     import numpy as np
-    import torch
-    import torch.distributed as dist
     from pycmf_amd import _lib
     from pycmf_amd.sharded import (make_torch_sharded_mu, make_torch_sharded_newton, make_torch_sharded_newton_rows,
                                    shard_bounds)
@@ -155,9 +153,14 @@ def main():
     if os.environ.get("CMF_BENCH_SAME_DEVICE") == "1":
         local_rank = 0
     backend = os.environ.get("CMF_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # PyTorch is plumbing for the collectives only: a single-rank run never imports it (on a cold box that import
+    # alone can take minutes, which has no place in or around a timed run)
+    torch = dist = device = None
     if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -172,9 +175,14 @@ def main():
     r0, r1 = shard_bounds(m, world, rank)
     c0, c1 = shard_bounds(p, world, rank)
 
-    stream = torch.cuda.Stream(device=device)
-    with torch.cuda.stream(stream):
-        ctx = _lib.Context(local_rank, stream.cuda_stream)
+    import contextlib
+    if world > 1:  # the contexts launch on a torch stream, which is also the stream the collectives synchronise with
+        stream = torch.cuda.Stream(device=device)
+        stream_ctx, stream_handle = torch.cuda.stream(stream), stream.cuda_stream
+    else:          # single rank: a context-private stream, no PyTorch
+        stream_ctx, stream_handle = contextlib.nullcontext(), None
+    with stream_ctx:
+        ctx = _lib.Context(local_rank, stream_handle)
         for kv in args.option:
             name, _, val = kv.partition("=")
             ctx.set_option(name, int(val))
@@ -215,7 +223,7 @@ def main():
             # per-row sweeps (logit link and / or sampling): a second context holds the rank's COLUMNS of X and rows
             # of Y with U and Z whole, and sweeps the rank's rows of V; factor rows are exchanged in between
             q0, q1 = shard_bounds(d, world, rank)
-            ctx_v = _lib.Context(local_rank, stream.cuda_stream)
+            ctx_v = _lib.Context(local_rank, stream_handle)
             for kv in args.option:
                 name, _, val = kv.partition("=")
                 ctx_v.set_option(name, int(val))
@@ -237,10 +245,13 @@ def main():
                                                w["ratio"], 1000 + it)
 
         def sync_all():
+            if world == 1:
+                for c_ in ctxs:
+                    c_.sync()          # hipStreamSynchronize of the launch stream
+                return
             torch.cuda.synchronize(device)
-            if world > 1:
-                dist.barrier()
-                torch.cuda.synchronize(device)
+            dist.barrier()
+            torch.cuda.synchronize(device)
 
         for it in range(args.warmup):
             do_step(it)

@@ -183,6 +183,11 @@ int cmf_debug_clock(cmf_ctx *ctx, double *ghz, double *loop_us);
 int cmf_get_geometry(cmf_ctx *ctx, int64_t *m_pad, int64_t *d_pad, int64_t *p_pad, int *k_pad);
 /* device pointers of the factor blocks (float32, row-major, ld = k_pad) */
 int cmf_factor_dev_ptr(cmf_ctx *ctx, int which, float **ptr);
+/* zero-filled device scratch owned by the context: the partial / staging buffer of the sharded entry points when the
+ * caller brings no device allocator (bench.py at N = 1 runs without PyTorch); freed by cmf_scratch_free, by the next
+ * cmf_set_problem or by cmf_ctx_destroy                                                                             */
+int cmf_scratch_alloc(cmf_ctx *ctx, int64_t bytes, void **dev_ptr);
+int cmf_scratch_free(cmf_ctx *ctx, void *dev_ptr);
 /* device-to-device copies of all valid rows of a factor, k_pad floats per row, on the context's stream:
  * what a row-sharded Newton driver exchanges between its U/Z-sweep and V-sweep contexts
  * (the reference keeps U, V, Z in one address space: cmf_solvers.py:510-522)                      */

@@ -62,6 +62,8 @@ PROTOTYPES = {
     "cmf_kernel_timing_reset": [_vp],
     "cmf_get_geometry": [_vp, _pi64, _pi64, _pi64, C.POINTER(C.c_int)],
     "cmf_factor_dev_ptr": [_vp, _i32, C.POINTER(_pf)],
+    "cmf_scratch_alloc": [_vp, _i64, C.POINTER(_vp)],
+    "cmf_scratch_free": [_vp, _vp],
     "cmf_export_factor_rows": [_vp, _i32, _vp],
     "cmf_import_factor_rows": [_vp, _i32, _vp],
 }
@@ -128,6 +130,21 @@ def device_count():
 
 def _strides(a):
     return a.strides[0] // a.itemsize, a.strides[1] // a.itemsize
+
+
+class _Scratch:
+    """Device scratch handed out by Context.scratch (freed with the context or by release())."""
+
+    def __init__(self, ctx, ptr, nbytes):
+        self._ctx, self._ptr, self.nbytes = ctx, ptr, nbytes
+
+    def data_ptr(self):
+        return self._ptr
+
+    def release(self):
+        if self._ptr and self._ctx._h:
+            check(self._ctx._lib.cmf_scratch_free(self._ctx._h, _vp(self._ptr)))
+        self._ptr = None
 
 
 class Context:
@@ -282,6 +299,12 @@ class Context:
         out = np.empty_like(H)
         check(self._lib.cmf_safe_invert_batch(self._h, H.ctypes.data_as(_pd), out.ctypes.data_as(_pd), n, k, pert))
         return out
+
+    def scratch(self, nbytes):
+        """Zero-filled device buffer owned by the context; the returned object has ``data_ptr()`` like a torch tensor."""
+        p = _vp()
+        check(self._lib.cmf_scratch_alloc(self._h, int(nbytes), C.byref(p)))
+        return _Scratch(self, p.value, int(nbytes))
 
     def export_factor_rows(self, which, dev_ptr):
         """Device-to-device copy of all valid rows (k_pad floats each) to `dev_ptr`, on the context's stream."""

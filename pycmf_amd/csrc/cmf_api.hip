@@ -784,6 +784,25 @@ extern "C" int cmf_factor_dev_ptr(cmf_ctx *c, int which, float **ptr) {
     return CMF_OK;
 }
 
+// zero-filled device scratch owned by the context (the partial / staging buffers of the sharded drivers when the caller
+// has no allocator of its own at hand); released by cmf_scratch_free, the next cmf_set_problem or cmf_ctx_destroy
+extern "C" int cmf_scratch_alloc(cmf_ctx *c, int64_t bytes, void **dev_ptr) {
+    if (!c || !dev_ptr || bytes < 0) return fail(CMF_EINVAL, "bad scratch request");
+    DeviceGuard dg(c->device);
+    CHK(dev_alloc(c, dev_ptr, (size_t)bytes, true));
+    return CMF_OK;
+}
+
+extern "C" int cmf_scratch_free(cmf_ctx *c, void *dev_ptr) {
+    if (!c) return fail(CMF_EINVAL, "null context");
+    if (!dev_ptr) return CMF_OK;
+    DeviceGuard dg(c->device);
+    if (std::find(c->owned.begin(), c->owned.end(), dev_ptr) == c->owned.end()) return fail(CMF_EINVAL, "not a scratch buffer of this context");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_free(c, dev_ptr);
+    return CMF_OK;
+}
+
 // device-to-device exchange of factor rows (fp32, k_pad floats per row): what a sharded driver all-gathers
 extern "C" int cmf_export_factor_rows(cmf_ctx *c, int which, float *dev_dst) {
     NEED_PROBLEM(c);

@@ -203,10 +203,13 @@ def make_torch_sharded_newton_rows(ctx_uz, ctx_v, bounds, shape, world, device, 
 
 
 def make_torch_sharded_mu(ctx, world, device):
-    """Wire a HIP context to torch.distributed (backend 'nccl' = RCCL)."""
+    """Wire a HIP context to torch.distributed (backend 'nccl' = RCCL).  With world == 1 nothing of PyTorch is touched:
+    the partial buffer is context scratch."""
+    backend = HipShardBackend(ctx)
+    if world == 1:
+        return ShardedMU(backend, ctx.scratch(4 * backend.buf_elems()), 1, None)
     import torch
     import torch.distributed as dist
-    backend = HipShardBackend(ctx)
     buf = torch.zeros(backend.buf_elems(), dtype=torch.float32, device=device)
 
     def all_reduce(t):
@@ -215,9 +218,11 @@ def make_torch_sharded_mu(ctx, world, device):
 
 
 def make_torch_sharded_newton(ctx, world, device, alpha, nn_mask=0, pert=0.2):
+    backend = HipNewtonShardBackend(ctx, alpha, nn_mask, pert)
+    if world == 1:
+        return ShardedNewtonLinear(backend, ctx.scratch(4 * backend.buf_elems()), 1, None)
     import torch
     import torch.distributed as dist
-    backend = HipNewtonShardBackend(ctx, alpha, nn_mask, pert)
     buf = torch.zeros(backend.buf_elems(), dtype=torch.float32, device=device)
 
     def all_reduce(t):
