@@ -82,3 +82,16 @@ def test_empty_and_degenerate_shapes(lib):
     ctx.mu_step(0.0, 0.0, 7)
     assert np.isfinite(ctx.get_factor(0)).all() and (ctx.get_factor(0) == 0).all()   # X = 0 -> U numerator 0
     ctx.close()
+
+
+def test_single_rank_bench_never_imports_torch():
+    """bench.py at N = 1 (the driver's headline run) must not pull PyTorch in: its cold import was seen to take many
+    minutes on some boxes, inside the driver's own clock around the run."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_no_torch_check.py"), "--workload", "tiny", "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "torch imported: False" in out.stdout, out.stdout
