@@ -373,6 +373,10 @@ def main():
             out["config"][key] = w[key]
     if args.option:
         out["config"]["options"] = list(args.option)
+    if args.workload == "c4" and not bf16x6:
+        out["note"] = ("fp32 MFMA arithmetic (the default).  Opt-in --option gemm_arith=1 (fp32 operands split exactly into three "
+                       "bf16 planes, six products on the bf16 matrix pipe, fp32-equivalent to 4e-7): 23.3-24.0 it/s, "
+                       "profiles/r01_c4_n1_bench_bf16x6.json, DESIGN.md section 4")
     if world == 1 and not args.no_cpu_baseline:
         cits, shp, n_it, el, threads, work_ratio = cpu_baseline(w)
         out["cpu_baseline"] = {
