@@ -7,6 +7,7 @@
 #include "cmf_sparse.hip.h"
 #include "cmf_rowhess.hip.h"
 #include "cmf_bf16x6.hip.h"
+#include "cmf_rowhess6.hip.h"
 
 #include <hip/hip_runtime.h>
 

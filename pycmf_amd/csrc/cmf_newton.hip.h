@@ -554,6 +554,9 @@ static int launch_row_hess_kp(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
             else CMF_ROWDIAG(3, 0);
         }
 #undef CMF_ROWDIAG
+    } else if (KP == 256 && c->opt_arith == 1 && c->opt_rowsym && a.scale >= 0.f) { // optional arithmetic: bf16 planes, six products
+        CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess6_kernel), R6_LDS_BYTES));
+        hipLaunchKernelGGL(row_hess6_kernel, dim3((unsigned)nrows), dim3(512), R6_LDS_BYTES, c->stream, a);
     } else if (KP == 256 && c->opt_rowsym == 3 && a.scale >= 0.f) { // non-negative weights: single sqrt-weighted image
         constexpr int KS = KP == 256 ? 256 : 0;
         if constexpr (KS == 256) {

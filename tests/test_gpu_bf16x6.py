@@ -69,3 +69,53 @@ def test_bf16x6_signed_data_and_wide_dynamic_range(lib):
         # signed sums cancel: compare against the oracle with the error scale of the fp32 path itself
         scale = np.abs(ref).max()
         assert np.abs(a - ref).max() <= 4.0 * max(np.abs(b - ref).max(), 1e-6 * scale)
+
+
+@pytest.mark.parametrize("k", [256, 200])
+def test_bf16x6_row_kernel_matches_fp32_row_kernel(lib, k):
+    """Per-row Newton sweeps at k_pad = 256 with gemm_arith = 1: the Hessians accumulate on the bf16 matrix pipe from
+    three-plane splits of sqrt(w_j) o_j fetched with transposing LDS reads (row_hess6_kernel).  Same device-drawn samples
+    -> the factors of the fp32 row kernel; ragged sample counts and both accumulate modes (the V sweep) included."""
+    m, d, p = 500, 601, 450
+    rng = np.random.RandomState(12)
+    X, Y = rng.rand(m, d), rng.rand(d, p)
+    U0, V0, Z0 = 0.2 * rng.randn(m, k), 0.2 * rng.randn(d, k), 0.2 * rng.randn(p, k)
+    out = []
+    for arith in (0, 1):
+        ctx = lib.Context(0)
+        ctx.set_option("gemm_arith", arith)
+        ctx.set_problem(m, d, p, k)
+        ctx.set_data(0, X); ctx.set_data(1, Y)
+        for w, F in enumerate((U0, V0, Z0)):
+            ctx.set_factor(w, F)
+        ctx.newton_step_device_sampled(0.4, 0.01, 0.05, "logit", "logit", 0, 7, 0.2, 0.63, 99)
+        out.append([ctx.get_factor(w) for w in range(3)])
+        ctx.close()
+    for a, b in zip(*out):
+        np.testing.assert_allclose(b, a, rtol=1e-3, atol=1e-4 * np.abs(a).max())
+
+
+def test_bf16x6_newton_matches_oracle(lib):
+    """The same arithmetic against the fp64 oracle with host-drawn samples (linear x, logit y, ratio 0.5, k = 256)."""
+    from oracle import cmf_oracle as O
+    m, d, p, k = 270, 90, 40, 256
+    rng = np.random.RandomState(k)
+    X, Y = np.abs(rng.randn(m, d)), rng.rand(d, p)
+    U0, V0, Z0 = 0.3 * rng.randn(m, k), 0.3 * rng.randn(d, k), 0.3 * rng.randn(p, k)
+    np.random.seed(4)
+    masks = {"U": [], "Z": [], "V": []}
+    Ur, Vr, Zr = U0.copy(), V0.copy(), Z0.copy()
+    O.newton_update_step(X, Y, Ur, Vr, Zr, 0.4, 0.01, 0.05, "linear", "logit", False, False, False, ratio=0.5, pert=0.2, masks=masks)
+    ctx = lib.Context(0)
+    ctx.set_option("gemm_arith", 1)
+    ctx.set_option("gemm_arith_min_tiles", 1)
+    ctx.set_problem(m, d, p, k)
+    ctx.set_data(0, X); ctx.set_data(1, Y)
+    for w, F in enumerate((U0, V0, Z0)):
+        ctx.set_factor(w, F)
+    ctx.newton_step(0.4, 0.01, 0.05, "linear", "logit", 0, 7, 0.2, 0.5, np.array(masks["U"]), np.array(masks["Z"]),
+                    np.array([a for a, _ in masks["V"]]), np.array([b for _, b in masks["V"]]))
+    got = [ctx.get_factor(w) for w in range(3)]
+    ctx.close()
+    for a, b in zip(got, (Ur, Vr, Zr)):
+        np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-3 * np.abs(b).max())
