@@ -339,7 +339,12 @@ def main():
                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/traffic_%s.json)" % args.workload,
                 "algorithmic_flops_per_launch": dfl / max(dn, 1),
                 "avg_launch_ms": dms / max(dn, 1), "launches": dn}
-    if dom == "rowhess" and kp == 256 and "row_symmetric=0" not in args.option:
+    if dom == "rowhess" and bf16x6 and kp == 256:
+        roof["kernel"] = ("cmfk::row_hess6_kernel  (fused per-row gradient + Hessian; Hessian on v_mfma_f32_32x32x16_bf16 from three "
+                          "bf16 planes of sqrt(w) o, six products per block; flops credited for the symmetric half, k(k+1) per sample)")
+        roof["peak"] = BF16_MFMA_PEAK_TFLOPS / 6.0
+        roof["frac"] = roof["achieved"] / roof["peak"]
+    elif dom == "rowhess" and kp == 256 and "row_symmetric=0" not in args.option:
         # the MFMAs cover 36 whole 32x32 blocks (the diagonal blocks are computed in full)
         roof["mfma_executed_tflops"] = achieved * (36 * 2048.0 + 4 * kp) / (kp * (kp + 1.0) + 4 * kp)
     roof["per_class_ms_per_step"] = {c: v[0] / args.steps for c, v in classes.items() if v[1]}
