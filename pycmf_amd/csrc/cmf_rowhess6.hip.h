@@ -14,10 +14,11 @@
 
 namespace cmfk {
 
-constexpr int R6_PITCH = 256 + 8;               // bf16 elements per LDS row (a multiple of 8 bytes, not a power of two)
+constexpr int R6_PITCH = 256 + 32;              // bf16 elements per LDS row: 576 bytes = 16 banks mod 64, so the four rows a
+                                                // 16-lane group addresses in one transposing read fall on disjoint bank quarters
 constexpr int R6_PLANE = 32 * R6_PITCH;         // elements per plane of a 32-row tile
 constexpr int R6_STAGE = 3 * R6_PLANE;
-constexpr int R6_LDS_BYTES = 2 * R6_STAGE * 2;  // 101376
+constexpr int R6_LDS_BYTES = 2 * R6_STAGE * 2;  // 110592
 
 __device__ __forceinline__ uint64_t r6_tr_read(unsigned addr) {
     uint64_t v;

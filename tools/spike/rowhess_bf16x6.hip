@@ -27,10 +27,11 @@ __global__ void fill(float *U, int64_t n, int64_t cols) {
 __device__ __forceinline__ u16 bf16_rn(float f) { unsigned u = __float_as_uint(f); u += 0x7FFFu + ((u >> 16) & 1u); return (u16)(u >> 16); }
 __device__ __forceinline__ float bf16_f(u16 h) { return __uint_as_float((unsigned)h << 16); }
 
-constexpr int KP = 256, PITCH = KP + 8;          // bf16 elements per LDS row (8-byte multiple, not a power of two)
+constexpr int KP = 256, PITCH = KP + 32;         // bf16 elements per LDS row: 576 B = 16 banks mod 64, so the four rows of a
+                                                 // transposing read land on disjoint bank quarters (conflict-free)
 constexpr int PLANE = 32 * PITCH;                // elements per plane of a 32-row tile
 constexpr int STAGE = 3 * PLANE;                 // three planes
-constexpr int LDS_BYTES = 2 * STAGE * 2;         // double buffered: 101376 bytes
+constexpr int LDS_BYTES = 2 * STAGE * 2;         // double buffered: 110592 bytes
 
 __device__ __forceinline__ uint64_t tr_read(unsigned addr) {
     uint64_t v;
