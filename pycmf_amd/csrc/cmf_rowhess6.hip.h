@@ -126,18 +126,37 @@ __global__ __launch_bounds__(512, 2) void row_hess6_kernel(RowHessArgs g) {
                 if (do_gather) gather(tl_gather);
                 if (do_idx) load_idx(tl_idx);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)"); // the transposing reads are invisible to the compiler's counters
+            // The transposing reads are invisible to the compiler's counters: wait by hand, plane by plane (the reads were
+            // issued plane 0, 1, 2 and LDS operations complete in order; at most 2 NF <= 10 reads per plane, so
+            // "<= 2 NF (2 - p) outstanding" means plane p has landed -- later staging stores only make that conservative).
+            // Largest terms first here, so that the first MFMAs need plane 0 only.
+            if constexpr (NF == 5) asm volatile("s_waitcnt lgkmcnt(15)"); // 4-bit counter: 20 is not expressible
+            else if constexpr (NF == 4) asm volatile("s_waitcnt lgkmcnt(15)");
+            else asm volatile("s_waitcnt lgkmcnt(12)");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < NP; ++n)
+                hs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[0][s3_ai(TY, n)], fr[0][s3_bi(TY, n)], hs[n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NF == 5) asm volatile("s_waitcnt lgkmcnt(10)");
+            else if constexpr (NF == 4) asm volatile("s_waitcnt lgkmcnt(8)");
+            else asm volatile("s_waitcnt lgkmcnt(6)");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int n = 0; n < NP; ++n) {
                 const int ai = s3_ai(TY, n), bi = s3_bi(TY, n);
-                // smallest terms first
-                hs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2][ai], fr[0][bi], hs[n], 0, 0, 0);
-                hs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[1][ai], fr[1][bi], hs[n], 0, 0, 0);
-                hs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[0][ai], fr[2][bi], hs[n], 0, 0, 0);
-                hs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[1][ai], fr[0][bi], hs[n], 0, 0, 0);
                 hs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[0][ai], fr[1][bi], hs[n], 0, 0, 0);
-                hs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[0][ai], fr[0][bi], hs[n], 0, 0, 0);
+                hs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[1][ai], fr[0][bi], hs[n], 0, 0, 0);
+                hs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[1][ai], fr[1][bi], hs[n], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < NP; ++n) {
+                const int ai = s3_ai(TY, n), bi = s3_bi(TY, n);
+                hs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[0][ai], fr[2][bi], hs[n], 0, 0, 0);
+                hs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2][ai], fr[0][bi], hs[n], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
