@@ -12,7 +12,9 @@ Default workload = C4 (the configuration the metric is quoted on; it fits one
 GPU: 34.4 GB).  c2 / c3 / c5 are the other BASELINE configs (parity-test
 shapes; same JSON contract, for the record in DESIGN.md).
 
-N > 1 is launched by torch.distributed.run (one rank per GPU).  The problem is
+N > 1: either under torch.distributed.run (one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
+environment) or plain ``python bench.py --gpus N``, which starts the N rank processes itself before any GPU call
+in the parent and forwards rank 0's JSON line.  The problem is
 FIXED (strong scaling): rank g owns rows [g*m/N, (g+1)*m/N) of X/U and the same
 fraction of Y's columns / Z's rows; V is replicated and reassembled by one RCCL
 all-reduce per iteration (pycmf_amd/sharded.py).  The per-row Newton workload (c3) shards the rows of all three
@@ -45,7 +47,11 @@ WORKLOADS = {
                nnz_per_row=100,
                desc="BASELINE configs[4]: CSR X 1e6 x 1e5 at 0.1% nnz (100 per row, values 1.0, native CSR), "
                     "dense Y 1e5 x 64, n_components=256, newton solver, linear links"),
-    "tiny": dict(m=2048, d=1024, p=512, k=64, solver="mu", desc="debug shape"),
+    "tiny": dict(m=2048, d=1024, p=512, k=64, solver="mu", desc="debug shape (mu)"),
+    "tiny3": dict(m=1536, d=1024, p=512, k=64, solver="newton", x_link="linear", y_link="logit", ratio=0.5,
+                  desc="debug shape (per-row newton, y logit, sg_sample_ratio 0.5, device sampler)"),
+    "tiny5": dict(m=20000, d=3000, p=64, k=64, solver="newton", x_link="linear", y_link="linear", ratio=1.0,
+                  nnz_per_row=30, desc="debug shape (native CSR X, linear newton)"),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 (v_mfma_f32_32x32x16_bf16)
@@ -124,6 +130,45 @@ def cpu_baseline(w, budget_s=20.0):
     return iters / el, (ms, ds, ps), iters, el, threads, ratio
 
 
+def launch_ranks(n, argv):
+    """``python bench.py --gpus N`` without a launcher: start N fresh rank processes (one per GPU) BEFORE anything in
+    this process touches the GPU, wait for them, forward rank 0's JSON line.  Never exec: the parent only supervises."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    failed = None
+    while failed is None and any(q.poll() is None for q in procs):
+        for r, q in enumerate(procs):
+            if q.poll() not in (None, 0):
+                failed = r
+        time.sleep(0.2)
+    if failed is None:
+        failed = next((r for r, q in enumerate(procs) if q.returncode != 0), None)
+    if failed is not None:  # a dead rank leaves the others waiting in a collective: end exactly the processes started here
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+        for q in procs:
+            q.wait()
+        raise SystemExit("bench.py: rank %d exited with code %s" % (failed, procs[failed].returncode))
+    out = procs[0].stdout.read().decode()
+    line = next((ln for ln in reversed(out.splitlines()) if ln.startswith("{")), None)
+    if line is None:
+        raise SystemExit("bench.py: rank 0 printed no JSON line")
+    print(line)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,33 +180,35 @@ def main():
                     help="cmf_set_option knob for A/B runs (e.g. row_symmetric=0); recorded in config")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
 
     import numpy as np
     from pycmf_amd import _lib
-    from pycmf_amd.sharded import (make_torch_sharded_mu, make_torch_sharded_newton, make_torch_sharded_newton_rows,
-                                   shard_bounds)
+    from pycmf_amd.sharded import (block_bounds, make_torch_sharded_mu, make_torch_sharded_newton,
+                                   make_torch_sharded_newton_rows, shard_bounds)
 
-    # Test hooks (not used by the driver): CMF_BENCH_SAME_DEVICE=1 puts every rank on GPU 0 and
-    # CMF_BENCH_BACKEND=gloo swaps RCCL for gloo, so the N>1 code path can be exercised on a 1-GPU box.
+    # Test hooks (not used by the driver): CMF_BENCH_SAME_DEVICE=1 puts every rank on GPU 0, CMF_BENCH_BACKEND=gloo
+    # swaps RCCL for gloo (RCCL refuses two ranks on one device), so the N>1 code path runs on a 1-GPU box;
+    # CMF_BENCH_FORCE_DIST=1 takes the torch.distributed path at N = 1 too (RCCL with a single rank).
     if os.environ.get("CMF_BENCH_SAME_DEVICE") == "1":
         local_rank = 0
     backend = os.environ.get("CMF_BENCH_BACKEND", "nccl")
+    use_dist = world > 1 or os.environ.get("CMF_BENCH_FORCE_DIST") == "1"
     # PyTorch is plumbing for the collectives only: a single-rank run never imports it (on a cold box that import
     # alone can take minutes, which has no place in or around a timed run)
     torch = dist = device = None
-    if world > 1:
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -172,113 +219,123 @@ def main():
     bf16x6 = "gemm_arith=1" in args.option
     newton = w["solver"] == "newton"
     sharded_ok = (not newton) or (w["x_link"] == "linear" and w["y_link"] == "linear" and w["ratio"] == 1.0)
-    r0, r1 = shard_bounds(m, world, rank)
-    c0, c1 = shard_bounds(p, world, rank)
+    rows_mode = newton and not sharded_ok and use_dist
+    bounds_fn = block_bounds if rows_mode else shard_bounds   # the row-sharded Newton all-gathers equal blocks
+    r0, r1 = bounds_fn(m, world, rank)
+    c0, c1 = bounds_fn(p, world, rank)
 
-    import contextlib
-    if world > 1:  # the contexts launch on a torch stream, which is also the stream the collectives synchronise with
-        stream = torch.cuda.Stream(device=device)
-        stream_ctx, stream_handle = torch.cuda.stream(stream), stream.cuda_stream
-    else:          # single rank: a context-private stream, no PyTorch
-        stream_ctx, stream_handle = contextlib.nullcontext(), None
-    with stream_ctx:
-        ctx = _lib.Context(local_rank, stream_handle)
+    # every context of a rank launches on ONE stream; the collectives are ordered on it explicitly (TorchCollectives)
+    stream = torch.cuda.Stream(device=device) if use_dist else None
+    stream_handle = stream.cuda_stream if use_dist else None
+    force = world if world > 1 else (2 if use_dist else 1)  # FORCE_DIST: drivers built as if sharded, collectives of 1 rank
+    ctx = _lib.Context(local_rank, stream_handle)
+    for kv in args.option:
+        name, _, val = kv.partition("=")
+        ctx.set_option(name, int(val))
+    ctx.set_problem(r1 - r0, d, c1 - c0, k)
+    if "nnz_per_row" in w:
+        # CSR row block generated on the host (values 1.0: binary bag-of-words like the reference's
+        # notebook) and kept native on the device
+        import scipy.sparse as sp
+        npr = w["nnz_per_row"]
+        rng = np.random.default_rng(42 + rank)
+        rows = r1 - r0
+        X = sp.csr_matrix((np.ones(rows * npr), rng.integers(0, d, size=rows * npr, dtype=np.int32),
+                           np.arange(0, rows * npr + 1, npr, dtype=np.int64)), shape=(rows, d))
+        ctx.set_option("sparse_mode", 2)
+        ctx.set_data(0, X)
+        del X
+        scale = (npr / d / k) ** 0.5
+    else:
+        ctx.fill_data_synthetic(0, 42, r0, 0)   # X rows [r0,r1): values depend only on global coordinates
+        scale = (0.7979 / k) ** 0.5             # 'random' init rule sqrt(mean / k), pycmf/cmf.py:111
+    ctx.fill_data_synthetic(1, 43, 0, c0)       # Y columns [c0,c1)
+    ctx.fill_factor_synthetic(_lib.CMF_U, 101, r0, scale)
+    ctx.fill_factor_synthetic(_lib.CMF_V, 102, 0, scale)
+    ctx.fill_factor_synthetic(_lib.CMF_Z, 103, c0, scale)
+    ctxs = [ctx]
+    drv = None
+
+    if not newton:
+        drv = make_torch_sharded_mu(ctx, force, device, timed=True)
+
+        def do_step(it):
+            drv.step(0.0, 0.0, 7)
+    elif sharded_ok:
+        drv = make_torch_sharded_newton(ctx, force, device, alpha=0.5, nn_mask=0, pert=0.2, timed=True)
+
+        def do_step(it):
+            drv.step(0.0, 0.1, 7)
+    elif use_dist:
+        # per-row sweeps (logit link and / or sampling): a second context holds the rank's COLUMNS of X and rows
+        # of Y with U and Z whole, and sweeps the rank's rows of V; factor rows are all-gathered in between
+        q0, q1 = block_bounds(d, world, rank)
+        ctx_v = _lib.Context(local_rank, stream_handle)
         for kv in args.option:
             name, _, val = kv.partition("=")
-            ctx.set_option(name, int(val))
-        ctx.set_problem(r1 - r0, d, c1 - c0, k)
-        if "nnz_per_row" in w:
-            # CSR row block generated on the host (values 1.0: binary bag-of-words like the reference's
-            # notebook) and kept native on the device
-            import scipy.sparse as sp
-            npr = w["nnz_per_row"]
-            rng = np.random.default_rng(42 + rank)
-            rows = r1 - r0
-            X = sp.csr_matrix((np.ones(rows * npr), rng.integers(0, d, size=rows * npr, dtype=np.int32),
-                               np.arange(0, rows * npr + 1, npr, dtype=np.int64)), shape=(rows, d))
-            ctx.set_option("sparse_mode", 2)
-            ctx.set_data(0, X)
-            del X
-            scale = (npr / d / k) ** 0.5
-        else:
-            ctx.fill_data_synthetic(0, 42, r0, 0)   # X rows [r0,r1): values depend only on global coordinates
-            scale = (0.7979 / k) ** 0.5             # 'random' init rule sqrt(mean / k), pycmf/cmf.py:111
-        ctx.fill_data_synthetic(1, 43, 0, c0)       # Y columns [c0,c1)
-        ctx.fill_factor_synthetic(_lib.CMF_U, 101, r0, scale)
-        ctx.fill_factor_synthetic(_lib.CMF_V, 102, 0, scale)
-        ctx.fill_factor_synthetic(_lib.CMF_Z, 103, c0, scale)
-        ctxs = [ctx]
+            ctx_v.set_option(name, int(val))
+        ctx_v.set_problem(m, q1 - q0, p, k)
+        ctx_v.fill_data_synthetic(0, 42, 0, q0)
+        ctx_v.fill_data_synthetic(1, 43, q0, 0)
+        ctx_v.fill_factor_synthetic(_lib.CMF_U, 101, 0, scale)
+        ctx_v.fill_factor_synthetic(_lib.CMF_V, 102, q0, scale)
+        ctx_v.fill_factor_synthetic(_lib.CMF_Z, 103, 0, scale)
+        ctxs.append(ctx_v)
+        drv = make_torch_sharded_newton_rows(ctx, ctx_v, (r0, r1, q0, q1, c0, c1), (m, d, p), world, device, 0.5,
+                                             w["x_link"], w["y_link"], nn_mask=0, pert=0.2, ratio=w["ratio"],
+                                             rank=rank, timed=True)
 
-        if not newton:
-            drv = make_torch_sharded_mu(ctx, world, device)
+        def do_step(it):
+            drv.step(0.0, 0.1, 7, 1000 + it)
+    else:
+        def do_step(it):
+            ctx.newton_step_device_sampled(0.5, 0.0, 0.1, w["x_link"], w["y_link"], 0, 7, 0.2,
+                                           w["ratio"], 1000 + it)
+    coll = getattr(drv, "collectives", None)
 
-            def do_step(it):
-                drv.step(0.0, 0.0, 7)
-        elif sharded_ok:
-            drv = make_torch_sharded_newton(ctx, world, device, alpha=0.5, nn_mask=0, pert=0.2)
+    def sync_all():
+        if not use_dist:
+            for c_ in ctxs:
+                c_.sync()          # hipStreamSynchronize of the launch stream
+            return
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        torch.cuda.synchronize(device)
 
-            def do_step(it):
-                drv.step(0.0, 0.1, 7)
-        elif world > 1:
-            # per-row sweeps (logit link and / or sampling): a second context holds the rank's COLUMNS of X and rows
-            # of Y with U and Z whole, and sweeps the rank's rows of V; factor rows are exchanged in between
-            q0, q1 = shard_bounds(d, world, rank)
-            ctx_v = _lib.Context(local_rank, stream_handle)
-            for kv in args.option:
-                name, _, val = kv.partition("=")
-                ctx_v.set_option(name, int(val))
-            ctx_v.set_problem(m, q1 - q0, p, k)
-            ctx_v.fill_data_synthetic(0, 42, 0, q0)
-            ctx_v.fill_data_synthetic(1, 43, q0, 0)
-            ctx_v.fill_factor_synthetic(_lib.CMF_U, 101, 0, scale)
-            ctx_v.fill_factor_synthetic(_lib.CMF_V, 102, q0, scale)
-            ctx_v.fill_factor_synthetic(_lib.CMF_Z, 103, 0, scale)
-            ctxs.append(ctx_v)
-            drv = make_torch_sharded_newton_rows(ctx, ctx_v, (r0, r1, q0, q1, c0, c1), (m, d, p), world, device, 0.5,
-                                                 w["x_link"], w["y_link"], nn_mask=0, pert=0.2, ratio=w["ratio"])
+    for it in range(args.warmup):
+        do_step(it)
+    for c_ in ctxs:
+        c_.kernel_timing(True)
+        c_.kernel_timing_reset()
+    if coll:
+        coll.stream.synchronize()
+        coll.reset()
+    sync_all()
+    t0 = time.perf_counter()
+    ctx.marker()
+    for it in range(args.steps):
+        do_step(args.warmup + it)
+        ctx.marker()               # one event per iteration on the launch stream: the auditable time series
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    marks = ctx.marker_times()
+    series_ms = [b_ - a_ for a_, b_ in zip(marks, marks[1:])]
+    coll_stats = coll.stats() if coll else None
 
-            def do_step(it):
-                drv.step(0.0, 0.1, 7, 1000 + it)
-        else:
-            def do_step(it):
-                ctx.newton_step_device_sampled(0.5, 0.0, 0.1, w["x_link"], w["y_link"], 0, 7, 0.2,
-                                               w["ratio"], 1000 + it)
-
-        def sync_all():
-            if world == 1:
-                for c_ in ctxs:
-                    c_.sync()          # hipStreamSynchronize of the launch stream
-                return
-            torch.cuda.synchronize(device)
-            dist.barrier()
-            torch.cuda.synchronize(device)
-
-        for it in range(args.warmup):
-            do_step(it)
-        for c_ in ctxs:
-            c_.kernel_timing(True)
-            c_.kernel_timing_reset()
-        sync_all()
-        t0 = time.perf_counter()
-        for it in range(args.steps):
-            do_step(args.warmup + it)
-        sync_all()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            te = torch.tensor([elapsed], dtype=torch.float64, device=device)
-            dist.all_reduce(te, op=dist.ReduceOp.MAX)
-            elapsed = float(te.item())
-
-        names = ("gemm_nn", "gemm_tn", "gemm_small", "gemm_nt", "spmm", "rowhess", "eigen", "elementwise")
-        classes = {c: tuple(sum(v) for v in zip(*(c_.kernel_time(c) for c_ in ctxs))) for c in names}
-        for c_ in ctxs:
-            c_.kernel_timing(False)
-        ex2, ey2 = ctx.residual_sq(w.get("x_link", "linear"), w.get("y_link", "linear"))
-        x2, y2 = ctx.data_sq()
-        kp = ctx.geometry()[3]
+    names = ("gemm_nn", "gemm_tn", "gemm_small", "gemm_nt", "spmm", "rowhess", "eigen", "elementwise")
+    classes = {c: tuple(sum(v) for v in zip(*(c_.kernel_time(c) for c_ in ctxs))) for c in names}
+    for c_ in ctxs:
+        c_.kernel_timing(False)
+    ex2, ey2 = ctx.residual_sq(w.get("x_link", "linear"), w.get("y_link", "linear"))
+    x2, y2 = ctx.data_sq()
+    kp = ctx.geometry()[3]
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -365,14 +422,23 @@ def main():
         "algorithmic_tflops": algorithmic_flops(w) * its / 1e12,
         "config": {"workload": w["desc"], "m": m, "d": d, "p": p, "n_components": k, "solver": w["solver"],
                    "parallelism": ("rows of U, V, Z sharded x%d (every sweep row-parallel; X and Y held by rows and by "
-                                   "columns), factor rows gathered by 3 RCCL all-reduces of (m+p+d)*k f32 per iteration"
-                                   % world) if (newton and not sharded_ok and world > 1) else
+                                   "columns), factor rows reassembled by 3 in-place RCCL all-gathers, (m+p+d)*k f32 in all "
+                                   "per iteration" % world) if rows_mode else
                                   ("X/U row-sharded, Y/Z column-sharded x%d, V replicated, "
                                    "1 RCCL all-reduce of (d+k)*k f32 per iteration" % world)},
         "roofline": roof,
         "rel_residual": {"x": (ex2 / x2) ** 0.5 if x2 > 0 else None, "y": (ey2 / y2) ** 0.5 if y2 > 0 else None,
                          "note": "rank-0 shard, after warmup+steps iterations"},
     }
+    out["series_ms"] = {"per_iteration": [round(v, 4) for v in series_ms],
+                        "note": "HIP events on the launch stream of rank 0, one per iteration inside the timed region"}
+    if use_dist:
+        calls, nbytes, cms = coll_stats if coll_stats else (0, 0, 0.0)
+        out["collective"] = {"backend": "rccl" if backend == "nccl" else backend, "ranks": world,
+                             "calls_per_iteration": calls / args.steps, "payload_bytes_per_iteration": nbytes / args.steps,
+                             "ms_per_iteration": cms / args.steps,
+                             "note": "rank 0; ms = events on the launch stream around every collective (waiting for the "
+                                     "slowest rank included)"}
     for key in ("x_link", "y_link", "ratio"):
         if key in w:
             out["config"][key] = w[key]
@@ -394,7 +460,7 @@ def main():
                       "%.3g" % (w["solver"], shp, k, n_it, el, cits, work_ratio),
         }
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

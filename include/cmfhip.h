@@ -176,6 +176,14 @@ int cmf_safe_invert_batch(cmf_ctx *ctx, const double *H, double *out, int n, int
 int cmf_kernel_timing(cmf_ctx *ctx, int enable);
 int cmf_kernel_time(cmf_ctx *ctx, int kernel_class, double *ms, int64_t *launches, double *flops);
 int cmf_kernel_timing_reset(cmf_ctx *ctx);
+/* stream markers (bench.py's per-iteration time series, auditable beside the whole-region clock): cmf_marker records an
+ * event on the launch stream; cmf_marker_times waits for the stream, writes the elapsed ms of every marker since the
+ * first one (at most cap entries), stores the marker count in *n and clears the list                                */
+int cmf_marker(cmf_ctx *ctx);
+int cmf_marker_times(cmf_ctx *ctx, double *ms, int64_t cap, int64_t *n);
+/* the hipStream_t the context launches on (its own, or the one given to cmf_ctx_create): a caller that enqueues
+ * collectives between the *_partials / *_apply calls orders them on this stream                                      */
+int cmf_get_stream(cmf_ctx *ctx, void **stream);
 /* diagnostic: one X*V data pass with s_memtime / s_memrealtime stamps around the main loop;
  * median in-kernel shader clock (GHz) and main-loop duration (us) over the workgroups        */
 int cmf_debug_clock(cmf_ctx *ctx, double *ghz, double *loop_us);

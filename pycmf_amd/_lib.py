@@ -60,6 +60,9 @@ PROTOTYPES = {
     "cmf_kernel_timing": [_vp, _i32],
     "cmf_kernel_time": [_vp, _i32, _pd, _pi64, _pd],
     "cmf_kernel_timing_reset": [_vp],
+    "cmf_marker": [_vp],
+    "cmf_marker_times": [_vp, _pd, _i64, _pi64],
+    "cmf_get_stream": [_vp, C.POINTER(_vp)],
     "cmf_get_geometry": [_vp, _pi64, _pi64, _pi64, C.POINTER(C.c_int)],
     "cmf_factor_dev_ptr": [_vp, _i32, C.POINTER(_pf)],
     "cmf_scratch_alloc": [_vp, _i64, C.POINTER(_vp)],
@@ -177,8 +180,10 @@ class Context:
         """Upload X (which=0) or Y (which=1): ndarray (any strides) or scipy CSR/CSC."""
         import scipy.sparse as sp
         if sp.issparse(A):
-            A = A.tocsr()
-            A.sum_duplicates()
+            A = A.tocsr()  # a copy unless A already is CSR
+            if not A.has_canonical_format:
+                A = A.copy()           # never canonicalise the caller's matrix in place
+                A.sum_duplicates()
             indptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
             indices = np.ascontiguousarray(A.indices, dtype=np.int32)
             data = np.ascontiguousarray(A.data, dtype=np.float64)
@@ -335,6 +340,21 @@ class Context:
         ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
         check(self._lib.cmf_kernel_time(self._h, KERNEL_CLASSES.get(cls, cls), C.byref(ms), C.byref(n), C.byref(fl)))
         return ms.value, n.value, fl.value
+
+    def marker(self):
+        check(self._lib.cmf_marker(self._h))
+
+    def marker_times(self, cap=4096):
+        """Elapsed ms of every marker since the first one (waits for the stream; clears the markers)."""
+        buf = (C.c_double * cap)()
+        n = C.c_int64(0)
+        check(self._lib.cmf_marker_times(self._h, buf, cap, C.byref(n)))
+        return [buf[i] for i in range(min(n.value, cap))]
+
+    def stream_handle(self):
+        p = _vp()
+        check(self._lib.cmf_get_stream(self._h, C.byref(p)))
+        return p.value or 0
 
     def geometry(self):
         a, b, c_, k = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int(0)

@@ -89,6 +89,7 @@ struct cmf_ctx {
     int kp = 0;
     bool have_problem = false;
     unsigned long long *dbg_stamps = nullptr; // set by cmf_debug_clock for its own launches only
+    bool diag_ok = false;  // CMF_DIAG=1 in the environment: the timing-only knobs (wrong results) may be set
     int opt_graph = 0;     // replay MU / linear-Newton steps from a captured hipGraph (opt-in: measured neutral,
                            // the ~4 us per dependent kernel boundary is device-side, not host launch cost)
     StepGraph mu_graph, newton_graph;
@@ -139,7 +140,8 @@ struct cmf_ctx {
     DevBuf nsidx, nsws;                   // Newton-Schulz clamp: flagged-row list + counters, matrix workspaces
     DevBuf dpart;                         // double partial sums
     double *dscalar = nullptr;            // 4 doubles
-    std::vector<void *> owned;
+    std::vector<void *> owned;            // problem-scoped allocations (released by the next cmf_set_problem)
+    std::vector<void *> scratch;          // cmf_scratch_alloc buffers: live until cmf_scratch_free / cmf_ctx_destroy
     std::set<const void *> lds_opt_in;    // kernels whose >64 KB dynamic-LDS attribute is set on THIS device
 
     // timing
@@ -149,6 +151,7 @@ struct cmf_ctx {
     double ms[CMF_K_COUNT] = {0};
     int64_t launches[CMF_K_COUNT] = {0};
     double flops[CMF_K_COUNT] = {0};
+    std::vector<hipEvent_t> markers;      // cmf_marker: per-iteration time series of a bench run
 };
 
 struct DeviceGuard {
@@ -443,7 +446,7 @@ extern "C" int cmf_ctx_create(cmf_ctx **out, int device, void *stream) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return fail(CMF_ENODEV, "no HIP device visible: libcmfhip needs an MI355X (gfx950); there is no CPU fallback");
     if (device < 0 || device >= n) return fail(CMF_EINVAL, "device %d out of range (have %d)", device, n);
-    HIPCHK(hipSetDevice(device));
+    DeviceGuard dg(device); // leaves the calling thread's current device as it was
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -461,6 +464,7 @@ extern "C" int cmf_ctx_create(cmf_ctx **out, int device, void *stream) {
         }
         c->own_stream = true;
     }
+    c->diag_ok = getenv("CMF_DIAG") != nullptr && atoi(getenv("CMF_DIAG")) != 0;
     if (const char *e = getenv("CMF_GEMM_PIPE")) { // A/B hook for the test-suite: staging schedule of the data-pass GEMMs
         const int v = atoi(e);
         if ((v >= 0 && v <= 5) || v == 10) c->opt_pipe = v;
@@ -506,9 +510,12 @@ extern "C" int cmf_ctx_destroy(cmf_ctx *c) {
     if (!c) return CMF_OK;
     DeviceGuard dg(c->device);
     release_problem(c);
+    for (void *p : c->scratch) (void)hipFree(p);
+    c->scratch.clear();
     (void)hipFree(c->dscalar);
     for (auto &e : c->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto e : c->evpool) (void)hipEventDestroy(e);
+    for (auto e : c->markers) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return CMF_OK;
@@ -533,6 +540,7 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "z_logit_hessian_l2")) {
         c->opt_zlogit_l2 = value != 0;
     } else if (!strcmp(name, "row_diag")) {
+        if (value != 0 && !c->diag_ok) return fail(CMF_EINVAL, "row_diag is a timing-only diagnostic (wrong results): set CMF_DIAG=1 in the environment to allow it");
         c->opt_rowdiag = (int)value;
     } else if (!strcmp(name, "row_stagger")) {
         c->opt_rowstagger = value != 0;
@@ -554,6 +562,7 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "newton_schulz")) {
         c->opt_ns = value != 0;
     } else if (!strcmp(name, "chol_diag")) {
+        if (value != 0 && !c->diag_ok) return fail(CMF_EINVAL, "chol_diag is a timing-only diagnostic (wrong results): set CMF_DIAG=1 in the environment to allow it");
         c->opt_choldiag = (int)value;
     } else if (!strcmp(name, "safe_inverse_cholesky")) {
         c->opt_chol = value != 0;
@@ -679,8 +688,22 @@ extern "C" int cmf_set_data_csr(cmf_ctx *c, int which, const int64_t *indptr, co
     const double dense_bytes = (double)rp * (double)cp * 4.0;
     const double density = (r > 0 && cc > 0) ? (double)nnz / ((double)r * (double)cc) : 1.0;
     const bool native = c->opt_sparse == 2 || (c->opt_sparse == 0 && density < 0.02 && dense_bytes > 1e9);
-    if (*slot) { HIPCHK(hipStreamSynchronize(c->stream)); dev_free(c, *slot); *slot = nullptr; }
+    // validate the row pointer before anything reads through it
+    if (indptr[0] != 0) return fail(CMF_EINVAL, "CSR indptr[0] must be 0");
+    for (int64_t i = 0; i < r; ++i)
+        if (indptr[i + 1] < indptr[i]) return fail(CMF_EINVAL, "CSR indptr is not monotonic at row %lld", (long long)i);
+    if (indptr[r] != nnz) return fail(CMF_EINVAL, "CSR indptr[rows] = %lld does not match nnz = %lld", (long long)indptr[r], (long long)nnz);
+    invalidate_graphs(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (*slot) { dev_free(c, *slot); *slot = nullptr; }
+    c->bfp_valid[which][0] = c->bfp_valid[which][1] = false; // bf16 planes of a previous matrix are stale
+    for (int t = 0; t < 2; ++t) {                              // so are its native CSR images
+        CsrDev &old = c->sp[which][t];
+        dev_free(c, old.indptr); dev_free(c, old.idx); dev_free(c, old.val);
+        old = CsrDev();
+    }
     c->sparse[which] = false;
+    c->sp_sq[which] = 0.0;
     if (native) return set_data_csr_native(c, which, indptr, indices, data, nnz, r, cc);
     if (dense_bytes > 200e9) return fail(CMF_EUNSUPPORTED, "CSR input too large to expand densely (%lld x %lld)", (long long)r, (long long)cc);
     CHK(ensure_dense(c, which));
@@ -786,11 +809,14 @@ extern "C" int cmf_factor_dev_ptr(cmf_ctx *c, int which, float **ptr) {
 }
 
 // zero-filled device scratch owned by the context (the partial / staging buffers of the sharded drivers when the caller
-// has no allocator of its own at hand); released by cmf_scratch_free, the next cmf_set_problem or cmf_ctx_destroy
+// has no allocator of its own at hand); released by cmf_scratch_free or cmf_ctx_destroy -- it SURVIVES cmf_set_problem
 extern "C" int cmf_scratch_alloc(cmf_ctx *c, int64_t bytes, void **dev_ptr) {
     if (!c || !dev_ptr || bytes < 0) return fail(CMF_EINVAL, "bad scratch request");
     DeviceGuard dg(c->device);
-    CHK(dev_alloc(c, dev_ptr, (size_t)bytes, true));
+    const size_t n = bytes ? (size_t)bytes : 16;
+    HIPCHK(hipMalloc(dev_ptr, n));
+    c->scratch.push_back(*dev_ptr);
+    HIPCHK(hipMemsetAsync(*dev_ptr, 0, n, c->stream));
     return CMF_OK;
 }
 
@@ -798,9 +824,11 @@ extern "C" int cmf_scratch_free(cmf_ctx *c, void *dev_ptr) {
     if (!c) return fail(CMF_EINVAL, "null context");
     if (!dev_ptr) return CMF_OK;
     DeviceGuard dg(c->device);
-    if (std::find(c->owned.begin(), c->owned.end(), dev_ptr) == c->owned.end()) return fail(CMF_EINVAL, "not a scratch buffer of this context");
+    auto it = std::find(c->scratch.begin(), c->scratch.end(), dev_ptr);
+    if (it == c->scratch.end()) return fail(CMF_EINVAL, "not a scratch buffer of this context");
     HIPCHK(hipStreamSynchronize(c->stream));
-    dev_free(c, dev_ptr);
+    c->scratch.erase(it);
+    (void)hipFree(dev_ptr);
     return CMF_OK;
 }
 
@@ -808,6 +836,7 @@ extern "C" int cmf_scratch_free(cmf_ctx *c, void *dev_ptr) {
 extern "C" int cmf_export_factor_rows(cmf_ctx *c, int which, float *dev_dst) {
     NEED_PROBLEM(c);
     if (which < 0 || which > 2 || !dev_dst) return fail(CMF_EINVAL, "bad factor argument");
+    DeviceGuard dg(c->device);
     HIPCHK(hipMemcpyAsync(dev_dst, c->F[which], (size_t)c->frows[which] * c->kp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     return CMF_OK;
 }
@@ -815,6 +844,7 @@ extern "C" int cmf_export_factor_rows(cmf_ctx *c, int which, float *dev_dst) {
 extern "C" int cmf_import_factor_rows(cmf_ctx *c, int which, const float *dev_src) {
     NEED_PROBLEM(c);
     if (which < 0 || which > 2 || !dev_src) return fail(CMF_EINVAL, "bad factor argument");
+    DeviceGuard dg(c->device);
     HIPCHK(hipMemcpyAsync(c->F[which], dev_src, (size_t)c->frows[which] * c->kp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     return CMF_OK;
 }
@@ -1031,6 +1061,37 @@ extern "C" int cmf_debug_clock(cmf_ctx *c, double *ghz, double *loop_us) {
     std::sort(f.begin(), f.end()); std::sort(us.begin(), us.end());
     if (ghz) *ghz = f[f.size() / 2];
     if (loop_us) *loop_us = us[us.size() / 2];
+    return CMF_OK;
+}
+
+// stream markers: one event per call on the launch stream; cmf_marker_times returns the elapsed ms of every marker
+// since the first one and clears the list (bench.py's per-iteration time series)
+extern "C" int cmf_marker(cmf_ctx *c) {
+    if (!c) return fail(CMF_EINVAL, "null context");
+    DeviceGuard dg(c->device);
+    hipEvent_t e;
+    CHK(ev_get(c, &e));
+    HIPCHK(hipEventRecord(e, c->stream));
+    c->markers.push_back(e);
+    return CMF_OK;
+}
+extern "C" int cmf_marker_times(cmf_ctx *c, double *ms, int64_t cap, int64_t *n) {
+    if (!c || !n || (cap > 0 && !ms)) return fail(CMF_EINVAL, "bad argument");
+    DeviceGuard dg(c->device);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *n = (int64_t)c->markers.size();
+    for (int64_t i = 0; i < *n && i < cap; ++i) {
+        float t = 0.f;
+        if (i > 0) HIPCHK(hipEventElapsedTime(&t, c->markers[0], c->markers[i]));
+        ms[i] = (double)t;
+    }
+    for (auto e : c->markers) c->evpool.push_back(e);
+    c->markers.clear();
+    return CMF_OK;
+}
+extern "C" int cmf_get_stream(cmf_ctx *c, void **stream) {
+    if (!c || !stream) return fail(CMF_EINVAL, "null argument");
+    *stream = (void *)c->stream;
     return CMF_OK;
 }
 

@@ -622,14 +622,14 @@ __global__ void newton_apply_kernel(float *F, const float *step, int64_t rows_va
 
 __global__ void axpby_diag_kernel(float *H, const float *A, float a, const float *B, float b, float diag,
                                   int kp, int kvalid) {
-    // H = a*A + b*B + diag*I on the valid k x k block; identity on the padding
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= kp * kp) return;
-    const int r = i / kp, c = i % kp;
-    float v = a * A[i] + (B ? b * B[i] : 0.f);
-    if (r == c) v += diag;
-    if (r >= kvalid || c >= kvalid) v = (r == c) ? 1.0f : 0.0f;
-    H[i] = v;
+    // H = a*A + b*B + diag*I on the valid k x k block; identity on the padding (grid-stride: any k_pad, any grid)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)kp * kp; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / kp), c = (int)(i % kp);
+        float v = a * A[i] + (B ? b * B[i] : 0.f);
+        if (r == c) v += diag;
+        if (r >= kvalid || c >= kvalid) v = (r == c) ? 1.0f : 0.0f;
+        H[i] = v;
+    }
 }
 
 __global__ void sum_doubles_kernel(const double *in, int64_t n, double *out) {

@@ -1,0 +1,515 @@
+// cmf_shared64.hip.h -- float64 treatment of the ONE shared k x k Hessian of a linear-link Newton sweep (gfx950).
+//
+// Reference: NewtonSolver._newton_update_U / _newton_update_V with sg_sample_ratio == 1 and linear links form a single
+// Hessian  H = s F^T F (+ s' F'^T F') + l2 I  for all rows of the sweep and invert it once with _safe_invert
+// (pycmf/cmf_solvers.py:407-410, :448-450, :346-356), everything in float64.  The factor data on the device is
+// float32, but a step is  grad H^-1, so an error dH in H comes back multiplied by cond(H): Grams accumulated and
+// inverted in float32 carry about cond(H) 1e-6 into the step.  H is one matrix per sweep, so it is cheap to do right:
+//   * gram64_partial_kernel / gram64_reduce_kernel: F^T F with float64 products and float64 accumulation on the
+//     float64 matrix pipe (v_mfma_f64_16x16x4_f64; the f32 inputs convert exactly), upper 64 x 64 tiles only, the
+//     rows split over workgroups into slabs that are summed in a fixed order (deterministic, no atomics);
+//   * safe_inverse64_small_kernel (n <= 64): one workgroup, everything in LDS: Cholesky test of H - pert I, then
+//     H^-1 = L^-T L^-1, or -- when an eigenvalue lies under the perturbation -- the reference's own formula
+//     Q diag(1 / max(|lambda|, pert)) Q^T by a float64 Hestenes-Jacobi sweep.  One launch, no host round trip;
+//   * n > 64: chol64_kernel (blocked right-looking Cholesky of H - pert I and of H by two workgroups, matrix in L2),
+//     tri_inverse64_kernel (X = L^-1, 16 columns per workgroup) and gemm64_kernel (H^-1 = X^T X); when the test
+//     fails and H is positive semi-definite, the spectral clamp M = max(H, pert I) by float64 matrix polynomials of
+//     sign(H - pert I) (the same Newton-Schulz construction as the float32 per-row path in cmf_newton.hip.h, here on
+//     gemm64_kernel), then the same Cholesky inverse of M.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cmfk {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// sum over aligned groups of 16 lanes
+__device__ __forceinline__ double group16_sum_f64(double v) {
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------ Gram
+// slab[split][tile][TS x TS] = sum over this split's rows of F[r, tile_i cols]^T F[r, tile_j cols]   (tile_j >= tile_i)
+// F: float32, row-major, ld = kp, rows_pad rows (padding rows are zero).  Workgroup = (TS/32)^2 waves, wave tile 32 x 32
+// = 2 x 2 MFMA blocks of 16 x 16; the rows pass through LDS 32 at a time (row pitch TS + 16 floats: the two 16-lane
+// halves of a ds_read_b32 group read rows k and k + 1, 16 banks apart).
+template <int TS>
+__global__ __launch_bounds__((TS / 32) * (TS / 32) * 64) void gram64_partial_kernel(const float *F, int kp, int64_t rows_pad, int64_t chunk,
+                                                                                   double *slab) {
+    constexpr int WPS = TS / 32, NT = WPS * WPS * 64, LD = TS + 16;
+    __shared__ __attribute__((aligned(16))) float sA[32 * LD];
+    __shared__ __attribute__((aligned(16))) float sB[32 * LD];
+    const int T = kp / TS;
+    int b = blockIdx.x, ti = 0;
+    while (b >= T - ti) { b -= T - ti; ++ti; }
+    const int tj = ti + b;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wi = w / WPS, wj = w % WPS;
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.y * chunk;
+    const int64_t r1 = r0 + chunk < rows_pad ? r0 + chunk : rows_pad;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int64_t r = r0; r < r1; r += 32) {
+        __syncthreads();
+        for (int idx = t; idx < 8 * TS; idx += NT) {
+            const int row = idx / (TS / 4), c4 = idx % (TS / 4);
+            const float *src = F + (r + row) * kp + 4 * c4;
+            *reinterpret_cast<f32x4 *>(sA + row * LD + 4 * c4) = *reinterpret_cast<const f32x4 *>(src + ti * TS);
+            *reinterpret_cast<f32x4 *>(sB + row * LD + 4 * c4) = *reinterpret_cast<const f32x4 *>(src + tj * TS);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            double a[2], bb[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                a[q] = (double)sA[(4 * s + lk) * LD + wi * 32 + 16 * q + l15];
+                bb[q] = (double)sB[(4 * s + lk) * LD + wj * 32 + 16 * q + l15];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    double *out = slab + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (TS * TS);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                out[(wi * 32 + 16 * i + lk + 4 * reg) * TS + wj * 32 + 16 * j + l15] = acc[i][j][reg];
+}
+
+// G64[r][c] (kp x kp, symmetric) = sum over the splits, in split order; optional float32 copy
+__global__ __launch_bounds__(256) void gram64_reduce_kernel(const double *slab, int ts, int kp, int nsplit, double *G64, float *G32) {
+    const int T = kp / ts, ntile = T * (T + 1) / 2;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < kp * kp; idx += gridDim.x * 256) {
+        int r = idx / kp, c = idx % kp;
+        const int rr = r < c ? r : c, cc = r < c ? c : r; // upper-triangle representative (tile row <= tile column)
+        int ti = rr / ts, tj = cc / ts;
+        int ir = rr % ts, ic = cc % ts;
+        if (ti == tj) { ir = r % ts; ic = c % ts; } // diagonal tiles are stored whole
+        const int tile = ti * T - ti * (ti - 1) / 2 + (tj - ti);
+        const double *p = slab + (int64_t)tile * ts * ts + ir * ts + ic;
+        double s = 0.0;
+        for (int q = 0; q < nsplit; ++q) s += p[(int64_t)q * ntile * ts * ts];
+        G64[idx] = s;
+        if (G32) G32[idx] = (float)s;
+    }
+}
+
+// H64 = a A + b B + diag I on the valid n x n block, identity on the padding; A, B float64 (B nullable)
+__global__ __launch_bounds__(256) void hess64_build_kernel(double *H, const double *A, double a, const double *B, double b, double diag,
+                                                           int kp, int n) {
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < kp * kp; idx += gridDim.x * 256) {
+        const int r = idx / kp, c = idx % kp;
+        double v = a * A[idx] + (B ? b * B[idx] : 0.0);
+        if (r == c) v += diag;
+        if (r >= n || c >= n) v = (r == c) ? 1.0 : 0.0;
+        H[idx] = v;
+    }
+}
+// the same from a float32 matrix (the all-reduced Gram of the sharded step)
+__global__ __launch_bounds__(256) void hess64_from_f32_kernel(double *H, const float *A, double a, double diag, int kp, int n) {
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < kp * kp; idx += gridDim.x * 256) {
+        const int r = idx / kp, c = idx % kp;
+        double v = a * (double)A[idx];
+        if (r == c) v += diag;
+        if (r >= n || c >= n) v = (r == c) ? 1.0 : 0.0;
+        H[idx] = v;
+    }
+}
+__global__ __launch_bounds__(256) void axpby64_to_f32_kernel(float *out, const double *A, double a, const double *B, double b, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = (float)(a * A[i] + (B ? b * B[i] : 0.0));
+}
+
+// ------------------------------------------------------------------------------------------ n <= 64: one workgroup, LDS
+// right-looking Cholesky of the n x n matrix A (LDS, pitch n), L written to Lm (LDS, pitch n, lower incl. diagonal);
+// A is consumed.  One barrier per column: the trailing update divides by the pivot itself, so it reads only the
+// UNscaled column j of A, which no thread writes in step j.  Returns false (uniformly) on a pivot <= floor.
+__device__ __forceinline__ bool chol64_lds(double *A, double *Lm, int n, double floor_, int t, int nt) {
+    for (int j = 0; j < n; ++j) {
+        __syncthreads();
+        const double d = A[j * n + j];
+        if (!(d > floor_)) return false;
+        const double inv = 1.0 / d, is = 1.0 / sqrt(d);
+        const int rem = n - j; // rows j .. n-1
+        for (int i = j + t; i < n; i += nt) Lm[i * n + j] = A[i * n + j] * is;
+        // trailing (i, c), j < c <= i < n: flat index over the (rem-1) x (rem-1) lower triangle
+        const int m1 = rem - 1, cnt = m1 * (m1 + 1) / 2;
+        for (int e = t; e < cnt; e += nt) {
+            int ii = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+            while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
+            while (ii * (ii + 1) / 2 > e) --ii;
+            const int cc = e - ii * (ii + 1) / 2;
+            const int i = j + 1 + ii, c = j + 1 + cc;
+            A[i * n + c] -= A[i * n + j] * A[c * n + j] * inv;
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
+// Hinv32 (kp x kp float, zero on the padding) = safe_inverse(H64) for ONE matrix of valid order n <= 64.
+// dynamic LDS: 2 n^2 + n doubles.
+__global__ __launch_bounds__(256) void safe_inverse64_small_kernel(const double *H, float *Hinv, int n, int kp, double pert) {
+    extern __shared__ __attribute__((aligned(16))) double dsm[];
+    double *A = dsm, *W = dsm + n * n, *inv = dsm + 2 * n * n;
+    const int t = threadIdx.x, nt = 256, lane = t & 63, wid = t >> 6;
+    __shared__ double red[4];
+    double dmax = 0.0;
+    for (int i = t; i < n; i += nt) dmax = fmax(dmax, fabs(H[i * kp + i]));
+    for (int off = 32; off > 0; off >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
+    if (lane == 0) red[wid] = dmax;
+    __syncthreads();
+    dmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    const double floor_ = 1.0e-13 * dmax;
+    // 1) lambda_min(H) >= pert  <=>  H - pert I factors
+    for (int idx = t; idx < n * n; idx += nt) {
+        const int r = idx / n, c = idx % n;
+        A[idx] = H[r * kp + c] - (r == c ? pert : 0.0);
+    }
+    const bool pd = chol64_lds(A, W, n, floor_, t, nt);
+    __syncthreads();
+    if (pd) {
+        // 2) H = L L^T, X = L^-1 (column c by thread c), H^-1 = X^T X
+        for (int idx = t; idx < n * n; idx += nt) A[idx] = H[(idx / n) * kp + idx % n];
+        (void)chol64_lds(A, W, n, 0.0, t, nt);
+        __syncthreads();
+        // X into A (lower): four lanes share a column's dot products
+        for (int idx = t; idx < n * n; idx += nt) A[idx] = 0.0;
+        __syncthreads();
+        if (t < n) {
+            const int c = t;
+            A[c * n + c] = 1.0 / W[c * n + c];
+            for (int i = c + 1; i < n; ++i) {
+                double s = 0.0;
+                for (int q = c; q < i; ++q) s += W[i * n + q] * A[q * n + c];
+                A[i * n + c] = -s / W[i * n + i];
+            }
+        }
+        __syncthreads();
+        for (int idx = t; idx < kp * kp; idx += nt) {
+            const int r = idx / kp, c = idx % kp;
+            double acc = 0.0;
+            if (r < n && c < n)
+                for (int q = (r > c ? r : c); q < n; ++q) acc += A[q * n + r] * A[q * n + c];
+            Hinv[idx] = (float)acc;
+        }
+        return;
+    }
+    // 3) the clamp acts: Q diag(1 / max(|lambda|, pert)) Q^T by one-sided Jacobi on B = H (rows of B = columns of H V)
+    double *B = A, *Vt = W;
+    for (int idx = t; idx < n * n; idx += nt) {
+        const int r = idx / n, c = idx % n;
+        B[idx] = H[r * kp + c];
+        Vt[idx] = (r == c) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const int N = n + (n & 1);
+    const double tol = 1.0e-15;
+    for (int sweep = 0; sweep < 40 && N >= 2; ++sweep) {
+        int rotated = 0;
+        for (int s = 0; s < N - 1; ++s) {
+            for (int pi = wid; pi < N / 2; pi += 4) {
+                int p, q;
+                if (pi == 0) { p = s; q = N - 1; }
+                else { p = (s + pi) % (N - 1); q = (s - pi + (N - 1)) % (N - 1); }
+                if (p >= n || q >= n) continue;
+                double *bp = B + p * n, *bq = B + q * n;
+                const double x = lane < n ? bp[lane] : 0.0, y = lane < n ? bq[lane] : 0.0; // n <= 64: one element per lane
+                const double a = wave_sum_f64(x * x), b = wave_sum_f64(y * y), g = wave_sum_f64(x * y);
+                if (fabs(g) > tol * sqrt(a * b) && a > 0.0 && b > 0.0) {
+                    const double zeta = (b - a) / (2.0 * g);
+                    const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
+                    if (lane < n) {
+                        bp[lane] = cs * x - sn * y;
+                        bq[lane] = sn * x + cs * y;
+                        const double u = Vt[p * n + lane], v = Vt[q * n + lane];
+                        Vt[p * n + lane] = cs * u - sn * v;
+                        Vt[q * n + lane] = sn * u + cs * v;
+                    }
+                    rotated = 1;
+                }
+            }
+            __syncthreads();
+        }
+        if (!__syncthreads_or(rotated)) break;
+    }
+    for (int j = wid; j < n; j += 4) {
+        const double x = lane < n ? B[j * n + lane] : 0.0;
+        const double a = wave_sum_f64(x * x);
+        if (lane == 0) {
+            double sg = sqrt(a);
+            if (sg < pert) sg = pert;
+            inv[j] = 1.0 / sg;
+        }
+    }
+    __syncthreads();
+    for (int idx = t; idx < kp * kp; idx += nt) {
+        const int r = idx / kp, c = idx % kp;
+        double acc = 0.0;
+        if (r < n && c < n)
+            for (int j = 0; j < n; ++j) acc += inv[j] * Vt[j * n + r] * Vt[j * n + c];
+        Hinv[idx] = (float)acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ n > 64: matrix in L2
+// Blocked right-looking Cholesky, ONE 1024-thread workgroup per matrix: workgroup b factors  H - shift[b] I  in its own
+// workspace W_b (n x n doubles, pitch ld; lower triangle + diagonal hold L on exit).  flag[b] = 1 on a pivot <= floor.
+// Panel width 32: (a) the diagonal block is factored in LDS (thread (i, c) of a 32 x 32 grid, one barrier per column),
+// (b) the rows under it are solved against it one row per thread, and kept TRANSPOSED in LDS (Pt[t][row]) so that
+// (c) the trailing update  W22 -= L21 L21^T  reads 4 x 4 register tiles with conflict-free 16-byte LDS reads.
+// LDS: D 8.25 KB + Lb 8.25 KB + Pt 32 x PR doubles, PR = rows under the first panel (<= 992 -> 254 KB would not fit):
+// up to n = 512 + 32 the panel lives in LDS (PT_ROWS = 512); larger n take the panel from global memory.
+#define CMF_CHOL64_PT_ROWS 512
+__global__ __launch_bounds__(1024) void chol64_kernel(const double *H, int n, int ldh, double *Wbase, int64_t wstride, int ld,
+                                                      double shift0, double shift1, int *flag) {
+    __shared__ double D[32 * 33];
+    __shared__ double Lb[32 * 33];
+    __shared__ __attribute__((aligned(16))) double Pt[32 * CMF_CHOL64_PT_ROWS];
+    __shared__ double red[16];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    double *W = Wbase + (int64_t)blockIdx.x * wstride;
+    const double shift = blockIdx.x == 0 ? shift0 : shift1;
+    double dmax = 0.0;
+    for (int i = t; i < n; i += 1024) dmax = fmax(dmax, fabs(H[(int64_t)i * ldh + i]));
+    for (int off = 32; off > 0; off >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
+    if (lane == 0) red[wid] = dmax;
+    __syncthreads();
+    dmax = 0.0;
+    for (int q = 0; q < 16; ++q) dmax = fmax(dmax, red[q]);
+    const double floor_ = shift != 0.0 ? 1.0e-13 * dmax : 0.0;
+    for (int idx = t; idx < n * n; idx += 1024) {
+        const int r = idx / n, c = idx % n;
+        if (c <= r) W[(int64_t)r * ld + c] = H[(int64_t)r * ldh + c] - (r == c ? shift : 0.0);
+    }
+    if (t == 0) flag[blockIdx.x] = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += 32) {
+        const int nb = n - j0 < 32 ? n - j0 : 32;
+        // (a) diagonal block
+        {
+            const int i = t >> 5, c = t & 31;
+            D[i * 33 + c] = (i < nb && c < nb && c <= i) ? W[(int64_t)(j0 + i) * ld + j0 + c] : (i == c ? 1.0 : 0.0);
+            Lb[i * 33 + c] = 0.0;
+            for (int j = 0; j < nb; ++j) {
+                __syncthreads();
+                const double d = D[j * 33 + j];
+                if (!(d > floor_)) { // uniform: every thread reads the same pivot
+                    if (t == 0) flag[blockIdx.x] = 1;
+                    return;
+                }
+                if (c == j && i >= j) Lb[i * 33 + j] = D[i * 33 + j] / sqrt(d);
+                if (c > j && i >= c) D[i * 33 + c] -= D[i * 33 + j] * D[c * 33 + j] / d;
+            }
+            __syncthreads();
+            if (i < nb && c < nb && c <= i) W[(int64_t)(j0 + i) * ld + j0 + c] = Lb[i * 33 + c];
+        }
+        const int rbeg = j0 + nb, nrem = n - rbeg; // rows under the panel
+        if (nrem <= 0) break;
+        const bool in_lds = nrem <= CMF_CHOL64_PT_ROWS;
+        // (b) L21 = A21 L11^-T : row per thread
+        for (int r = t; r < nrem; r += 1024) {
+            double x[32];
+            double *row = W + (int64_t)(rbeg + r) * ld + j0;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) x[c] = c < nb ? row[c] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                if (c < nb) {
+                    double s = x[c];
+#pragma unroll
+                    for (int q = 0; q < c; ++q) s -= x[q] * Lb[c * 33 + q];
+                    x[c] = s / Lb[c * 33 + c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                if (c < nb) row[c] = x[c];
+                if (in_lds) Pt[c * CMF_CHOL64_PT_ROWS + r] = x[c];
+            }
+        }
+        __syncthreads();
+        // (c) trailing update, 4 x 4 tiles over the lower triangle (tile row >= tile column)
+        const int nt4 = (nrem + 3) / 4;
+        const int ntile = nt4 * (nt4 + 1) / 2;
+        for (int e = t; e < ntile; e += 1024) {
+            int ti = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+            while ((ti + 1) * (ti + 2) / 2 <= e) ++ti;
+            while (ti * (ti + 1) / 2 > e) --ti;
+            const int tc = e - ti * (ti + 1) / 2;
+            double acc[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+            for (int q = 0; q < nb; ++q) {
+                double ri[4], rc[4];
+                if (in_lds) {
+                    const f64x2 a0 = *reinterpret_cast<const f64x2 *>(Pt + q * CMF_CHOL64_PT_ROWS + 4 * ti);
+                    const f64x2 a1 = *reinterpret_cast<const f64x2 *>(Pt + q * CMF_CHOL64_PT_ROWS + 4 * ti + 2);
+                    const f64x2 b0 = *reinterpret_cast<const f64x2 *>(Pt + q * CMF_CHOL64_PT_ROWS + 4 * tc);
+                    const f64x2 b1 = *reinterpret_cast<const f64x2 *>(Pt + q * CMF_CHOL64_PT_ROWS + 4 * tc + 2);
+                    ri[0] = a0[0]; ri[1] = a0[1]; ri[2] = a1[0]; ri[3] = a1[1];
+                    rc[0] = b0[0]; rc[1] = b0[1]; rc[2] = b1[0]; rc[3] = b1[1];
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        ri[a] = 4 * ti + a < nrem ? W[(int64_t)(rbeg + 4 * ti + a) * ld + j0 + q] : 0.0;
+                        rc[a] = 4 * tc + a < nrem ? W[(int64_t)(rbeg + 4 * tc + a) * ld + j0 + q] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] += ri[a] * rc[b];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int i = 4 * ti + a, c = 4 * tc + b;
+                    if (i < nrem && c <= i) W[(int64_t)(rbeg + i) * ld + rbeg + c] -= acc[a][b];
+                }
+        }
+        __syncthreads();
+    }
+}
+
+// Xt[c][i] = (L^-1)[i][c]  (row c of Xt = column c of the inverse of the lower-triangular L; zero for i < c).
+// Workgroup = 16 columns x 16 lanes; rows of L pass through LDS 32 at a time; y lives in LDS ([n][16]).
+// Pt rows beyond n are zero.  Only runs when *skip == 0.
+__global__ __launch_bounds__(256) void tri_inverse64_kernel(const double *L, int n, int ld, double *Xt, int ldx, int kp, const int *skip) {
+    extern __shared__ __attribute__((aligned(16))) double tsm[];
+    if (skip && *skip) return;
+    double *Y = tsm;               // [n][16]
+    double *Ls = tsm + (size_t)n * 16; // [32][n + 2]
+    const int lp = n + 2;
+    const int t = threadIdx.x, q = t & 15, cl = t >> 4;
+    const int c0 = blockIdx.x * 16, c = c0 + cl;
+    for (int i = t; i < n * 16; i += 256) Y[i] = 0.0;
+    for (int i0 = (c0 / 32) * 32; i0 < n; i0 += 32) {
+        const int nr = n - i0 < 32 ? n - i0 : 32;
+        __syncthreads();
+        for (int idx = t; idx < nr * n; idx += 256) {
+            const int r = idx / n, col = idx % n;
+            Ls[r * lp + col] = col <= i0 + r ? L[(int64_t)(i0 + r) * ld + col] : 0.0;
+        }
+        __syncthreads();
+        for (int r = 0; r < nr; ++r) {
+            const int i = i0 + r;
+            if (i >= c0) {
+                double s = 0.0;
+                for (int u = c0 + q; u < i; u += 16) s += Ls[r * lp + u] * Y[u * 16 + cl];
+                s = group16_sum_f64(s);
+                if (q == 0 && c < n && i >= c) Y[i * 16 + cl] = ((i == c ? 1.0 : 0.0) - s) / Ls[r * lp + i];
+            }
+            __syncthreads();
+        }
+    }
+    for (int idx = t; idx < 16 * kp; idx += 256) {
+        const int cc = idx / kp, i = idx % kp;
+        if (c0 + cc < kp) Xt[(int64_t)(c0 + cc) * ldx + i] = (i < n && c0 + cc < n) ? Y[i * 16 + cc] : 0.0;
+    }
+}
+
+// C = alpha op(A) op(B) + beta D + gamma I, all kp x kp float64 (pitch kp), kp a multiple of 32.
+//   TRANS_B = false: C = A B;  true: C = A B^T.   Optional float32 copy of C (C32, zeroing rows / columns >= nvalid).
+// Runs only while  iter < *limit  when limit is given (device-side predicate of the Newton-Schulz chain).
+// Workgroup = 4 waves, 32 x 32 output tile (one 16 x 16 MFMA block per wave), 32-deep K steps through LDS.
+// LDS pitches: k-contiguous tiles 34 doubles, n-contiguous B tile 48 doubles (conflict-free ds_read_b64 fragments).
+template <bool TRANS_B>
+__global__ __launch_bounds__(256) void gemm64_kernel(const double *A, const double *B, double *C, const double *D, double alpha, double beta,
+                                                     double gamma, int kp, float *C32, int nvalid, const int *limit, int iter) {
+    if (limit && iter >= *limit) return;
+    constexpr int LA = 34, LBN = 48;
+    __shared__ __attribute__((aligned(16))) double As[32 * LA];
+    __shared__ __attribute__((aligned(16))) double Bs[32 * LBN];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wi = w >> 1, wj = w & 1;
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < kp; k0 += 32) {
+        __syncthreads();
+        for (int idx = t; idx < 512; idx += 256) { // 32 rows x 16 double2
+            const int r = idx >> 4, c2 = idx & 15;
+            *reinterpret_cast<f64x2 *>(As + r * LA + 2 * c2) = *reinterpret_cast<const f64x2 *>(A + (int64_t)(m0 + r) * kp + k0 + 2 * c2);
+            if (TRANS_B) *reinterpret_cast<f64x2 *>(Bs + r * LA + 2 * c2) = *reinterpret_cast<const f64x2 *>(B + (int64_t)(n0 + r) * kp + k0 + 2 * c2);
+            else *reinterpret_cast<f64x2 *>(Bs + r * LBN + 2 * c2) = *reinterpret_cast<const f64x2 *>(B + (int64_t)(k0 + r) * kp + n0 + 2 * c2);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const double a = As[(wi * 16 + l15) * LA + 4 * s + lk];
+            const double b = TRANS_B ? Bs[(wj * 16 + l15) * LA + 4 * s + lk] : Bs[(4 * s + lk) * LBN + wj * 16 + l15];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int r = m0 + wi * 16 + lk + 4 * reg, c = n0 + wj * 16 + l15;
+        double v = alpha * acc[reg];
+        if (D) v += beta * D[(int64_t)r * kp + c];
+        if (r == c) v += gamma;
+        if (C) C[(int64_t)r * kp + c] = v;
+        if (C32) C32[(int64_t)r * kp + c] = (r < nvalid && c < nvalid) ? (float)v : 0.f;
+    }
+}
+
+// Newton-Schulz start: Bm = H - pert I on the valid block (padding: c on the diagonal), c = min(||B||_F, ||B||_inf),
+// X = Bm / c;  out[0] = c.  One 1024-thread workgroup (H is symmetric: column sums = row sums).
+__global__ __launch_bounds__(1024) void ns64_prepare_kernel(const double *H, double *Bm, double *X, int n, int kp, double pert, double *out) {
+    __shared__ double red_f[16], red_m[16];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    double fro = 0.0, cmaxv = 0.0;
+    for (int col = t; col < n; col += 1024) {
+        double cs = 0.0;
+        for (int r = 0; r < n; ++r) {
+            const double v = H[(int64_t)r * kp + col] - (r == col ? pert : 0.0);
+            fro += v * v;
+            cs += fabs(v);
+        }
+        cmaxv = fmax(cmaxv, cs);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        fro += __shfl_xor(fro, off, 64);
+        cmaxv = fmax(cmaxv, __shfl_xor(cmaxv, off, 64));
+    }
+    if (lane == 0) { red_f[wid] = fro; red_m[wid] = cmaxv; }
+    __syncthreads();
+    fro = 0.0; cmaxv = 0.0;
+    for (int q = 0; q < 16; ++q) { fro += red_f[q]; cmaxv = fmax(cmaxv, red_m[q]); }
+    double c = fmin(sqrt(fro), cmaxv);
+    if (!(c > 1e-300)) c = 1.0;
+    const double ci = 1.0 / c;
+    if (t == 0) out[0] = c;
+    for (int idx = t; idx < kp * kp; idx += 1024) {
+        const int r = idx / kp, col = idx % kp;
+        double v = (r == col) ? c : 0.0;
+        if (r < n && col < n) v = H[idx] - (r == col ? pert : 0.0);
+        Bm[idx] = v;
+        X[idx] = v * ci;
+    }
+}
+
+} // namespace cmfk

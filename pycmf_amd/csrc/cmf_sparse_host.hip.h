@@ -18,10 +18,36 @@ static int csr_upload(cmf_ctx *c, CsrDev &dst, const int64_t *indptr, const int3
 // keep A as CSR and as CSR of A^T (counting sort on the host, O(nnz))
 static int set_data_csr_native(cmf_ctx *c, int which, const int64_t *indptr, const int32_t *indices, const double *data, int64_t nnz,
                                int64_t rows, int64_t cols) {
+    for (int64_t q = 0; q < nnz; ++q)
+        if (indices[q] < 0 || indices[q] >= cols) return fail(CMF_EINVAL, "CSR column index out of range");
+    // canonical form (column indices strictly increasing inside a row, duplicates summed -- what scipy's
+    // sum_duplicates produces): ||A||^2 of the sparse error expansion is a sum over MERGED entries
+    bool canonical = true;
+    for (int64_t r = 0; r < rows && canonical; ++r)
+        for (int64_t q = indptr[r] + 1; q < indptr[r + 1]; ++q)
+            if (indices[q] <= indices[q - 1]) { canonical = false; break; }
+    std::vector<int64_t> cptr;
+    std::vector<int32_t> cidx;
+    std::vector<double> cval;
+    if (!canonical) {
+        cptr.assign((size_t)rows + 1, 0);
+        cidx.reserve((size_t)nnz); cval.reserve((size_t)nnz);
+        std::vector<std::pair<int32_t, double>> row;
+        for (int64_t r = 0; r < rows; ++r) {
+            row.clear();
+            for (int64_t q = indptr[r]; q < indptr[r + 1]; ++q) row.emplace_back(indices[q], data[q]);
+            std::stable_sort(row.begin(), row.end(), [](const std::pair<int32_t, double> &a, const std::pair<int32_t, double> &b) { return a.first < b.first; });
+            for (size_t i = 0; i < row.size(); ++i) {
+                if (!cidx.empty() && (int64_t)cidx.size() > cptr[r] && cidx.back() == row[i].first) cval.back() += row[i].second;
+                else { cidx.push_back(row[i].first); cval.push_back(row[i].second); }
+            }
+            cptr[r + 1] = (int64_t)cidx.size();
+        }
+        indptr = cptr.data(); indices = cidx.data(); data = cval.data(); nnz = (int64_t)cidx.size();
+    }
     std::vector<float> vals((size_t)std::max<int64_t>(nnz, 1));
     double sq = 0.0;
     for (int64_t q = 0; q < nnz; ++q) {
-        if (indices[q] < 0 || indices[q] >= cols) return fail(CMF_EINVAL, "CSR column index out of range");
         vals[q] = (float)data[q];
         sq += (double)vals[q] * (double)vals[q];
     }

@@ -28,6 +28,35 @@ def shard_bounds(n, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def block_bounds(n, world, rank):
+    """Equal blocks of ceil(n / world) rows (the last non-empty one may be shorter, later ones empty): the
+    layout an all-gather of equal chunks reassembles in place -- rank r's rows start at r * ceil(n / world)."""
+    c = -(-n // world) if world > 0 else n
+    lo = min(rank * c, n)
+    return lo, min(lo + c, n)
+
+
+def nnz_balanced_bounds(indptr, world):
+    """Contiguous row blocks of a CSR matrix with (nearly) equal numbers of stored values per block
+    ("row-shard CSR X by nnz-balanced row blocks"): block g ends at the first row whose
+    cumulative count reaches (g + 1) * nnz / world.  Returns world + 1 row offsets."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    rows = len(indptr) - 1
+    nnz = int(indptr[-1] - indptr[0]) if rows > 0 else 0
+    if nnz == 0:
+        return np.array([shard_bounds(rows, world, r)[0] for r in range(world)] + [rows], dtype=np.int64)
+    targets = indptr[0] + (np.arange(1, world, dtype=np.float64) * nnz / world)
+    cuts = np.searchsorted(indptr, targets, side="left")
+    # nearest row boundary to the target: the row that straddles it goes to the side that leaves the smaller error
+    for i, (c, t) in enumerate(zip(cuts, targets)):
+        c = int(min(max(c, 0), rows))
+        if c > 0 and abs(indptr[c - 1] - t) <= abs(indptr[c] - t):
+            c -= 1
+        cuts[i] = c
+    off = np.concatenate([[0], np.maximum.accumulate(cuts), [rows]]).astype(np.int64)
+    return off
+
+
 class HipShardBackend:
     """Local shard on one MI355X through libcmfhip (no CPU fallback)."""
 
@@ -144,37 +173,36 @@ class HipNewtonRowsBackend:
         return ((self.shape[0], r0, r1), (self.shape[1], q0, q1), (self.shape[2], c0, c1))[which]
 
     def export_rows(self, which, full):
-        """Write the rank's rows of factor `which` into its slice of the zeroed staging tensor `full`."""
+        """Write the rank's rows of factor `which` into rows [lo, hi) of the staging tensor `full` (a device-to-device
+        copy on the contexts' common stream: ordered behind the sweep and in front of the collective by the stream)."""
         _, lo, hi = self.rows(which)
         if hi > lo:
             ctx = self.ctx_v if which == 1 else self.ctx_uz
             ctx.export_factor_rows(which, full[lo:hi].data_ptr())
-            ctx.sync()  # the two contexts (and the collective) may live on different streams
 
     def import_rows(self, which, full):
-        """Hand the gathered factor to the context that holds it whole."""
+        """Hand the gathered factor (the first n rows of `full`) to the context that holds it whole."""
         ctx = self.ctx_uz if which == 1 else self.ctx_v
         ctx.import_factor_rows(which, full.data_ptr())
-        ctx.sync()
 
 
 class ShardedNewtonRows:
-    """One Newton iteration (order U -> Z -> V) with every sweep sharded by rows.  The gather of factor rows is an
-    all-reduce(sum) of a staging tensor in which every rank has filled only its own rows (zeros elsewhere): exact,
-    indifferent to uneven shards, (m + p + d) k_pad floats per iteration (58 MB at C3)."""
+    """One Newton iteration (order U -> Z -> V) with every sweep sharded by rows.  Rows are partitioned by
+    ``block_bounds`` (equal blocks of c = ceil(n / world) rows), so a factor is reassembled by ONE in-place
+    all-gather of equal chunks: rank r writes its rows at r * c of the staging tensor (world * c rows) and the first
+    n rows of the gathered tensor are the factor.  (m + p + d) k_pad floats move per iteration (58 MB at C3) -- half
+    of what an all-reduce of zero-padded full tensors moves."""
 
-    def __init__(self, backend, staging, world=1, all_reduce=None, zero=None):
-        self.backend, self.staging, self.world, self.all_reduce = backend, staging, world, all_reduce
-        self.zero = zero if zero is not None else (lambda t: t.zero_())
+    def __init__(self, backend, staging, world=1, rank=0, all_gather=None):
+        self.backend, self.staging, self.world, self.rank, self.all_gather = backend, staging, world, rank, all_gather
 
     def _gather(self, which):
         full = self.staging[which]
+        self.backend.export_rows(which, full)      # the rank's rows land at rows [lo, hi) = [rank * c, ...)
         if self.world > 1:
-            self.zero(full)  # must have landed before the export below writes the rank's rows
-        self.backend.export_rows(which, full)
-        if self.world > 1:
-            self.all_reduce(full)
-        self.backend.import_rows(which, full)
+            c = full.shape[0] // self.world
+            self.all_gather(full, full[self.rank * c:(self.rank + 1) * c])
+        self.backend.import_rows(which, full)      # reads the first n rows
 
     def step(self, l1=0.0, l2=0.0, mask=7, seed=0):
         self.backend.sweep_uz(l1, l2, mask, seed)
@@ -185,49 +213,91 @@ class ShardedNewtonRows:
             self._gather(1)
 
 
+class TorchCollectives:
+    """torch.distributed collectives (backend 'nccl' = RCCL over xGMI) ordered EXPLICITLY on the stream the context
+    launches on: every call runs under ``torch.cuda.stream(ExternalStream(ctx stream))``, so a driver's ``step()``
+    is correct whatever PyTorch's current stream is at the call site.  Optionally brackets every collective with
+    events on that stream (bench.py reports bytes and ms per iteration)."""
+
+    def __init__(self, ctx, device, timed=False):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=device)
+        self.timed, self.events, self.bytes, self.calls = timed, [], 0, 0
+
+    def _run(self, fn, nbytes):
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            if self.timed:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+            fn()
+            if self.timed:
+                b.record()
+                self.events.append((a, b))
+        self.bytes += nbytes
+        self.calls += 1
+
+    def all_reduce(self, t):
+        self._run(lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM), t.numel() * t.element_size())
+
+    def all_gather(self, full, chunk):
+        self._run(lambda: self.dist.all_gather_into_tensor(full, chunk), full.numel() * full.element_size())
+
+    def reset(self):
+        self.events, self.bytes, self.calls = [], 0, 0
+
+    def stats(self):
+        """(calls, payload bytes, ms on the stream) since the last reset; waits for the stream."""
+        self.stream.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self.events)
+        return self.calls, self.bytes, ms
+
+
 def make_torch_sharded_newton_rows(ctx_uz, ctx_v, bounds, shape, world, device, alpha, x_link, y_link, nn_mask=0,
-                                   pert=0.2, ratio=1.0):
+                                   pert=0.2, ratio=1.0, rank=0, timed=False):
+    """bounds = block_bounds of (m, d, p) for this rank.  Both contexts must launch on ONE stream (pass the same handle
+    to both constructors): sweeps, row copies and collectives are then ordered by the stream alone, no host syncs."""
     import torch
-    import torch.distributed as dist
+    if ctx_uz.stream_handle() != ctx_v.stream_handle():
+        raise ValueError("the U/Z-sweep and V-sweep contexts must share one stream")
     backend = HipNewtonRowsBackend(ctx_uz, ctx_v, bounds, shape, alpha, x_link, y_link, nn_mask, pert, ratio)
-    staging = [torch.zeros((n, backend.k_pad), dtype=torch.float32, device=device) for n in shape]
+    for n, (lo, hi) in zip(shape, (bounds[0:2], bounds[2:4], bounds[4:6])):
+        if (lo, hi) != block_bounds(n, world, rank):
+            raise ValueError("row-sharded Newton needs block_bounds partitions (got rows [%d, %d) of %d)" % (lo, hi, n))
+    staging = [torch.zeros((max(world * -(-n // world), 1), backend.k_pad), dtype=torch.float32, device=device)
+               for n in shape]
+    coll = TorchCollectives(ctx_uz, device, timed) if world > 1 else None
+    drv = ShardedNewtonRows(backend, staging, world, rank, coll.all_gather if coll else None)
+    drv.collectives = coll
+    return drv
 
-    def zero(t):
-        t.zero_()
-        torch.cuda.current_stream(device).synchronize()  # the exporting context may run on its own stream
 
-    def all_reduce(t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        torch.cuda.current_stream(device).synchronize()  # ... and so may the importing one
-    return ShardedNewtonRows(backend, staging, world, all_reduce if world > 1 else None, zero)
-
-
-def make_torch_sharded_mu(ctx, world, device):
+def make_torch_sharded_mu(ctx, world, device, timed=False):
     """Wire a HIP context to torch.distributed (backend 'nccl' = RCCL).  With world == 1 nothing of PyTorch is touched:
     the partial buffer is context scratch."""
     backend = HipShardBackend(ctx)
     if world == 1:
         return ShardedMU(backend, ctx.scratch(4 * backend.buf_elems()), 1, None)
     import torch
-    import torch.distributed as dist
     buf = torch.zeros(backend.buf_elems(), dtype=torch.float32, device=device)
+    coll = TorchCollectives(ctx, device, timed)
+    drv = ShardedMU(backend, buf, world, coll.all_reduce)
+    drv.collectives = coll
+    return drv
 
-    def all_reduce(t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return ShardedMU(backend, buf, world, all_reduce if world > 1 else None)
 
-
-def make_torch_sharded_newton(ctx, world, device, alpha, nn_mask=0, pert=0.2):
+def make_torch_sharded_newton(ctx, world, device, alpha, nn_mask=0, pert=0.2, timed=False):
     backend = HipNewtonShardBackend(ctx, alpha, nn_mask, pert)
     if world == 1:
         return ShardedNewtonLinear(backend, ctx.scratch(4 * backend.buf_elems()), 1, None)
     import torch
-    import torch.distributed as dist
     buf = torch.zeros(backend.buf_elems(), dtype=torch.float32, device=device)
-
-    def all_reduce(t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return ShardedNewtonLinear(backend, buf, world, all_reduce if world > 1 else None)
+    coll = TorchCollectives(ctx, device, timed)
+    drv = ShardedNewtonLinear(backend, buf, world, coll.all_reduce)
+    drv.collectives = coll
+    return drv
 
 
 def fit_mu_sharded(X_rows, Y_cols, U_rows, V, Z_rows, l1_reg=0.0, l2_reg=0.0, max_iter=200, tol=1e-4,
@@ -289,7 +359,8 @@ def fit_newton_sharded(X_rows, X_cols, Y_cols, Y_rows, U_rows, V, Z_rows, alpha=
     """Row-sharded Newton fit: call from every rank of an initialised ``torch.distributed`` group.
 
     Rank g passes its row block of X and the SAME rows of U, the matching column block of Y with its rows of Z, and
-    additionally its column block of X and row block of Y (rows ``shard_bounds(d, world, rank)`` of V: the V sweep
+    additionally its column block of X and row block of Y (rows ``block_bounds(d, world, rank)`` of V; all three
+    partitions are ``block_bounds``, the layout the in-place all-gathers reassemble: the V sweep
     reads whole columns of X and rows of Y, pycmf/cmf_solvers.py:432-486); V is passed whole and identical on every
     rank.  Runs the reference's outer loop (:132-195) with the convergence test on the global error
     alpha ||X - f(UV^T)|| + (1 - alpha) ||Y - f(VZ^T)||.  ``sg_sample_ratio < 1`` uses the device sampler with the
@@ -307,11 +378,11 @@ def fit_newton_sharded(X_rows, X_cols, Y_cols, Y_rows, U_rows, V, Z_rows, alpha=
     m = X_cols.shape[0]
     p_g, p = Y_cols.shape[1], Y_rows.shape[1]
     k = V.shape[1]
-    r0, r1 = shard_bounds(m, world, rank)
-    q0, q1 = shard_bounds(d, world, rank)
-    c0, c1 = shard_bounds(p, world, rank)
+    r0, r1 = block_bounds(m, world, rank)
+    q0, q1 = block_bounds(d, world, rank)
+    c0, c1 = block_bounds(p, world, rank)
     if (m_g, p_g, X_cols.shape[1], Y_rows.shape[0]) != (r1 - r0, c1 - c0, q1 - q0, q1 - q0):
-        raise ValueError("blocks do not match shard_bounds for rank %d of %d" % (rank, world))
+        raise ValueError("blocks do not match block_bounds for rank %d of %d" % (rank, world))
     nn_mask = (1 if U_non_negative else 0) | (2 if V_non_negative else 0) | (4 if Z_non_negative else 0)
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
@@ -326,7 +397,7 @@ def fit_newton_sharded(X_rows, X_cols, Y_cols, Y_rows, U_rows, V, Z_rows, alpha=
         ctx_v.set_data(1, Y_rows)
         ctx_v.set_factor(_lib.CMF_V, V[q0:q1])
         drv = make_torch_sharded_newton_rows(ctx_uz, ctx_v, (r0, r1, q0, q1, c0, c1), (m, d, p), world, dev, alpha,
-                                             x_link, y_link, nn_mask, hessian_pertubation, sg_sample_ratio)
+                                             x_link, y_link, nn_mask, hessian_pertubation, sg_sample_ratio, rank=rank)
         # the V-sweep context needs U and Z whole before its first sweep: the gathers of the first step provide them
 
         def global_error():

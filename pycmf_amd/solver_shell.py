@@ -96,6 +96,13 @@ class _HipIterativeSolver:
         m, k = U.shape
         return self._bind_dims(X, Y, m, V.shape[0], Z.shape[0], k)
 
+    def rebind(self):
+        """Forget the uploaded X / Y: the next call uploads them again.  The device copies are cached by the
+        IDENTITY of the arrays (``id(X), id(Y)`` and the shapes), which is what lets a loop of ``update_step`` /
+        ``compute_error`` calls on the same matrices (tests/test_cmf.py:126-162 upstream) pay one upload; a caller
+        who edits X or Y IN PLACE between calls must call this (the reference re-reads X on every call)."""
+        self._bound = None
+
     def _bind_dims(self, X, Y, m, d, p, k):
         key = (id(X), id(Y), m, d, p, k)
         if self._ctx is None:

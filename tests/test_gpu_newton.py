@@ -319,10 +319,11 @@ def test_symmetric_block_row_kernel_matches_full(lib):
 def test_row_sharded_newton_is_bit_identical(lib, world, xl, yl, ratio):
     """per-row Newton sweeps sharded by rows (two contexts per rank: U/Z sweeps on the rank's rows of X
     and columns of Y, V sweep on its columns of X and rows of Y; factor rows exchanged in between).  `world` ranks
-    emulated on this GPU, the gather emulated by summing the staging tensors: every rank must hold exactly the
-    factors of the unsharded iteration (the device sampler keys by global row)."""
+    emulated on this GPU (all contexts on one stream), the in-place all-gather of equal blocks emulated by copying
+    every rank's block into every staging tensor: every rank must hold exactly the factors of the unsharded
+    iteration (the device sampler keys by global row)."""
     import torch
-    from pycmf_amd.sharded import HipNewtonRowsBackend, ShardedNewtonRows, shard_bounds
+    from pycmf_amd.sharded import HipNewtonRowsBackend, ShardedNewtonRows, block_bounds
     m, d, p, k = 211, 157, 93, 24
     rng = np.random.RandomState(5)
     X = rng.rand(m, d) if xl == "logit" else np.abs(rng.randn(m, d))
@@ -347,35 +348,37 @@ def test_row_sharded_newton_is_bit_identical(lib, world, xl, yl, ratio):
     ref.close()
 
     ranks = []
+    stream = torch.cuda.Stream(device="cuda:0")
+    sh = stream.cuda_stream
     for r in range(world):
-        r0, r1 = shard_bounds(m, world, r)
-        q0, q1 = shard_bounds(d, world, r)
-        c0, c1 = shard_bounds(p, world, r)
-        a = lib.Context(0)
+        r0, r1 = block_bounds(m, world, r)
+        q0, q1 = block_bounds(d, world, r)
+        c0, c1 = block_bounds(p, world, r)
+        a = lib.Context(0, sh)
         a.set_problem(r1 - r0, d, c1 - c0, k)
         a.set_data(0, X[r0:r1]); a.set_data(1, Y[:, c0:c1])
         a.set_factor(0, U0[r0:r1]); a.set_factor(1, V0); a.set_factor(2, Z0[c0:c1])
-        b = lib.Context(0)
+        b = lib.Context(0, sh)
         b.set_problem(m, q1 - q0, p, k)
         b.set_data(0, X[:, q0:q1]); b.set_data(1, Y[q0:q1])
         b.set_factor(0, U0); b.set_factor(1, V0[q0:q1]); b.set_factor(2, Z0)
         be = HipNewtonRowsBackend(a, b, (r0, r1, q0, q1, c0, c1), (m, d, p), alpha, xl, yl, nn, pert, ratio)
-        staging = [torch.zeros((n, be.k_pad), dtype=torch.float32, device="cuda:0") for n in (m, d, p)]
+        staging = [torch.full((world * -(-n // world), be.k_pad), float("nan"), dtype=torch.float32, device="cuda:0")
+                   for n in (m, d, p)]
         ranks.append((be, staging))
+    torch.cuda.synchronize()
 
-    def gather(which):  # what ShardedNewtonRows._gather does on every rank, with the sum standing in for RCCL
-        for be, st in ranks:
-            st[which].zero_()
-        torch.cuda.synchronize()
-        for be, st in ranks:
-            be.export_rows(which, st[which])
-        total = torch.stack([st[which] for _, st in ranks]).sum(0)
-        torch.cuda.synchronize()
-        for be, st in ranks:
-            st[which].copy_(total)
-        torch.cuda.synchronize()
-        for be, st in ranks:
-            be.import_rows(which, st[which])
+    def gather(which):  # what ShardedNewtonRows._gather does on every rank, block copies standing in for RCCL
+        with torch.cuda.stream(stream):
+            for be, st in ranks:
+                be.export_rows(which, st[which])
+            c = ranks[0][1][which].shape[0] // world
+            for r, (_, src) in enumerate(ranks):           # all_gather_into_tensor(full, full[r*c:(r+1)*c]) on every rank
+                for q, (_, dst) in enumerate(ranks):
+                    if q != r:
+                        dst[which][r * c:(r + 1) * c].copy_(src[which][r * c:(r + 1) * c])
+            for be, st in ranks:
+                be.import_rows(which, st[which])
 
     for it in range(2):
         for be, _ in ranks:
@@ -393,8 +396,8 @@ def test_row_sharded_newton_is_bit_identical(lib, world, xl, yl, ratio):
         np.testing.assert_array_equal(be.ctx_v.get_factor(0), want[0])
         be.ctx_uz.close(); be.ctx_v.close()
     # the driver object on a single rank (world 1: gathers degenerate to copies between the two contexts)
-    a = lib.Context(0); a.set_problem(m, d, p, k); a.set_data(0, X); a.set_data(1, Y)
-    b = lib.Context(0); b.set_problem(m, d, p, k); b.set_data(0, X); b.set_data(1, Y)
+    a = lib.Context(0, sh); a.set_problem(m, d, p, k); a.set_data(0, X); a.set_data(1, Y)
+    b = lib.Context(0, sh); b.set_problem(m, d, p, k); b.set_data(0, X); b.set_data(1, Y)
     for c in (a, b):
         for w, F in enumerate((U0, V0, Z0)):
             c.set_factor(w, F)

@@ -124,7 +124,7 @@ def test_product_never_imports_oracle():
 
 # ------------------------------------------------------------------ sharding
 def test_shard_bounds_cover_and_balance():
-    from pycmf_amd.sharded import shard_bounds
+    from pycmf_amd.sharded import shard_bounds, block_bounds
     for n in (0, 1, 7, 8, 65536, 100003):
         for w in (1, 2, 3, 8):
             parts = [shard_bounds(n, w, r) for r in range(w)]
@@ -132,6 +132,33 @@ def test_shard_bounds_cover_and_balance():
             assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
+            # equal blocks: rank r starts at r * ceil(n / w) (the layout an all-gather of equal chunks reassembles)
+            blocks = [block_bounds(n, w, r) for r in range(w)]
+            c = -(-n // w)
+            assert blocks[-1][1] == n and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            assert all(lo == min(r * c, n) and hi - lo <= c for r, (lo, hi) in enumerate(blocks))
+
+
+def test_nnz_balanced_bounds_on_skewed_rows():
+    """CSR row blocks balanced by stored values, not by rows (real bag-of-words rows are skewed)."""
+    import scipy.sparse as sp
+    from pycmf_amd.sharded import nnz_balanced_bounds, shard_bounds
+    rng = np.random.RandomState(0)
+    rows, cols = 4000, 500
+    per_row = np.minimum(cols, (rng.pareto(1.2, rows) * 3 + 1).astype(int))   # heavy tail: a few very long rows
+    per_row[:50] = cols                                                         # and a dense head
+    indptr = np.concatenate([[0], np.cumsum(per_row)])
+    A = sp.csr_matrix((np.ones(indptr[-1]), np.concatenate([rng.choice(cols, n, replace=False) for n in per_row]), indptr),
+                      shape=(rows, cols))
+    for w in (2, 3, 8):
+        off = nnz_balanced_bounds(A.indptr, w)
+        assert off[0] == 0 and off[-1] == rows and np.all(np.diff(off) >= 0) and len(off) == w + 1
+        nnz = np.diff(A.indptr[off])
+        by_rows = np.array([A.indptr[shard_bounds(rows, w, r)[1]] - A.indptr[shard_bounds(rows, w, r)[0]] for r in range(w)])
+        # within one longest row of the ideal share, and far better than a split by row count
+        assert nnz.max() - A.nnz / w <= per_row.max()
+        assert nnz.max() < by_rows.max()
+    assert list(nnz_balanced_bounds(np.zeros(6, dtype=np.int64), 2)) == [0, 3, 5]   # empty matrix: fall back to rows
 
 
 WORKER = r'''
@@ -221,7 +248,7 @@ import os, sys
 sys.path.insert(0, %(root)r)
 import numpy as np, torch, torch.distributed as dist
 from oracle import cmf_oracle as O
-from pycmf_amd.sharded import ShardedNewtonRows, shard_bounds
+from pycmf_amd.sharded import ShardedNewtonRows, block_bounds
 
 ALPHA, L1, L2, PERT, XL, YL = 0.4, 0.01, 0.05, 0.2, "logit", "linear"
 
@@ -246,7 +273,8 @@ class OracleRows:
         F, lo, hi = self._own(which)
         full[lo:hi] = torch.from_numpy(F)
     def import_rows(self, which, full):
-        (self.U, self.V, self.Z)[which][...] = full.numpy()
+        n = self.shape[which]
+        (self.U, self.V, self.Z)[which][...] = full.numpy()[:n]
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -254,16 +282,19 @@ rng = np.random.RandomState(1)
 m, d, p, k = 17, 13, 7, 3
 X, Y = rng.rand(m, d), np.abs(rng.randn(d, p))
 U, V, Z = 0.3 * rng.randn(m, k), 0.3 * rng.randn(d, k), np.abs(0.3 * rng.randn(p, k))
-bounds = shard_bounds(m, world, rank) + shard_bounds(d, world, rank) + shard_bounds(p, world, rank)
+bounds = block_bounds(m, world, rank) + block_bounds(d, world, rank) + block_bounds(p, world, rank)
 be = OracleRows(X, Y, U, V, Z, bounds)
 calls = []
-def allreduce(t):
-    calls.append(tuple(t.shape))
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-drv = ShardedNewtonRows(be, [torch.zeros((n, k), dtype=torch.float64) for n in (m, d, p)], world, allreduce)
+def allgather(full, chunk):
+    calls.append((tuple(full.shape), tuple(chunk.shape)))
+    dist.all_gather_into_tensor(full, chunk)               # in place: chunk is rank's block of full
+cm, cd, cp = (-(-n // world) for n in (m, d, p))
+staging = [torch.full((world * c, k), float("nan"), dtype=torch.float64) for c in (cm, cd, cp)]
+drv = ShardedNewtonRows(be, staging, world, rank, allgather)
 for it in range(3):
     drv.step(L1, L2, 7, it)
-assert calls == [(m, k), (p, k), (d, k)] * 3, calls      # U and Z before the V sweep, V after it
+# U and Z before the V sweep, V after it: one all-gather of equal blocks each
+assert calls == [((world * cm, k), (cm, k)), ((world * cp, k), (cp, k)), ((world * cd, k), (cd, k))] * 3, calls
 Ur, Vr, Zr = U.copy(), V.copy(), Z.copy()
 for it in range(3):
     O.newton_update_step(X, Y, Ur, Vr, Zr, ALPHA, L1, L2, XL, YL, False, False, True, 1.0, PERT)
@@ -278,8 +309,9 @@ print("rank", rank, "ok")
 
 
 def test_row_sharded_newton_world2_gloo(tmp_path):
-    """Two ranks, gloo on CPU: ShardedNewtonRows (U/Z sweeps on the rank's rows, gather, V sweep on the rank's V rows,
-    gather) with an oracle-backed test double reproduces the unsharded Newton iteration with a logit link."""
+    """Two ranks, gloo on CPU: ShardedNewtonRows (U/Z sweeps on the rank's rows, in-place all-gather of equal blocks,
+    V sweep on the rank's V rows, all-gather) with an oracle-backed test double reproduces the unsharded Newton
+    iteration with a logit link (odd row counts: the last block is shorter than the others)."""
     script = tmp_path / "rows_worker.py"
     script.write_text(ROWS_WORKER % {"root": ROOT})
     port = _free_port()
