@@ -79,6 +79,8 @@ int cmf_sync(cmf_ctx *ctx);
  * "gemm_arith" 0 (fp32 MFMA, default) | 1 (k_pad = 256 data passes on the bf16 matrix pipe: every fp32 operand
  * split exactly into three bf16 planes, six cross products, fp32 accumulation; planes stay resident),
  * "row_symmetric" 1 | 0 (k_pad = 256 row kernel: upper block triangle of H_i only),
+ * "shared_hessian_f64" 1 (default) | 0: the single Hessian of a linear-link sweep is accumulated (float64 Grams on
+ * the float64 matrix pipe) and inverted in float64 | float32 Grams and float32 inverse,
  * "newton_schulz" 1 | 0 (k_pad = 256: rows whose eigenvalue clamp acts go through the GEMM-only
  * spectral clamp | through the Jacobi eigen-solver),
  * "sample_row_offset_u|v|z" n = global index of this context's first U / V / Z row in the keys of
@@ -168,6 +170,11 @@ int cmf_data_sq(cmf_ctx *ctx, double *x2, double *y2);  /* ||X||^2, ||Y||^2 */
 /* ---- batched safe inverse (exposed for tests): _safe_invert :346-356 --- */
 /* H: n symmetric k x k float64 matrices (host), out: Q diag(1/max(|l|,pert)) Q^T */
 int cmf_safe_invert_batch(cmf_ctx *ctx, const double *H, double *out, int n, int k, double pert);
+
+/* float64 path of the ONE shared Hessian of a linear-link sweep (cmf_solvers.py:407-410, :448-450): H is k x k
+ * float64 on the host, k = the problem's n_components; out = Q diag(1/max(|l|,pert)) Q^T computed in float64 on
+ * the device (positive semi-definite H), returned after its rounding to float32 (the form the step product uses) */
+int cmf_safe_invert_f64(cmf_ctx *ctx, const double *H, double *out, int k, double pert);
 
 /* ---- measurement ------------------------------------------------------ */
 /* when enabled every kernel launch is bracketed by hipEvents on the context's

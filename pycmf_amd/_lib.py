@@ -56,6 +56,7 @@ PROTOTYPES = {
     "cmf_residual_sq": [_vp, _i32, _i32, _pd, _pd],
     "cmf_data_sq": [_vp, _pd, _pd],
     "cmf_safe_invert_batch": [_vp, _pd, _pd, _i32, _i32, _dbl],
+    "cmf_safe_invert_f64": [_vp, _pd, _pd, _i32, _dbl],
     "cmf_debug_clock": [_vp, _pd, _pd],
     "cmf_kernel_timing": [_vp, _i32],
     "cmf_kernel_time": [_vp, _i32, _pd, _pi64, _pd],
@@ -303,6 +304,13 @@ class Context:
         n, k, _ = H.shape
         out = np.empty_like(H)
         check(self._lib.cmf_safe_invert_batch(self._h, H.ctypes.data_as(_pd), out.ctypes.data_as(_pd), n, k, pert))
+        return out
+
+    def safe_invert_f64(self, H, pert):
+        """float64 path of the shared Hessian: H is k x k with k = this context's n_components."""
+        H = np.ascontiguousarray(H, dtype=np.float64)
+        out = np.empty_like(H)
+        check(self._lib.cmf_safe_invert_f64(self._h, H.ctypes.data_as(_pd), out.ctypes.data_as(_pd), H.shape[0], pert))
         return out
 
     def scratch(self, nbytes):

@@ -8,6 +8,7 @@
 #include "cmf_rowhess.hip.h"
 #include "cmf_bf16x6.hip.h"
 #include "cmf_rowhess6.hip.h"
+#include "cmf_shared64.hip.h"
 
 #include <hip/hip_runtime.h>
 
@@ -138,6 +139,10 @@ struct cmf_ctx {
     DevBuf bfp[2][2], bff;                // gemm_arith = 1: bf16 planes of X / Y (normal, transposed) and of the factor operand
     bool bfp_valid[2][2] = {{false, false}, {false, false}};
     DevBuf nsidx, nsws;                   // Newton-Schulz clamp: flagged-row list + counters, matrix workspaces
+    DevBuf g64a, g64b, gmix64, h64;       // float64 Grams / shared Hessian of the linear-link Newton sweeps (cmf_shared64.hip.h)
+    DevBuf gslab64, w64, ns64;            // their split slabs, Cholesky workspaces + L^-1 image, Newton-Schulz images
+    bool gmix64_valid = false;            // gmix64 = alpha U^T U + (1 - alpha) Z^T Z of the partials just formed (single-GPU step)
+    int opt_shared64 = 1;                 // 1: shared Hessian in float64 (default) | 0: float32 Grams + float32 inverse (round-1 path)
     DevBuf dpart;                         // double partial sums
     double *dscalar = nullptr;            // 4 doubles
     std::vector<void *> owned;            // problem-scoped allocations (released by the next cmf_set_problem)
@@ -495,6 +500,9 @@ static void release_problem(cmf_ctx *c) {
     c->lists1 = DevBuf(); c->lists2 = DevBuf();
     c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf();
     c->nsidx = DevBuf(); c->nsws = DevBuf();
+    c->g64a = DevBuf(); c->g64b = DevBuf(); c->gmix64 = DevBuf(); c->h64 = DevBuf();
+    c->gslab64 = DevBuf(); c->w64 = DevBuf(); c->ns64 = DevBuf();
+    c->gmix64_valid = false;
     for (int w = 0; w < 2; ++w)
         for (int o = 0; o < 2; ++o) { c->bfp[w][o] = DevBuf(); c->bfp_valid[w][o] = false; }
     c->bff = DevBuf();
@@ -566,6 +574,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_choldiag = (int)value;
     } else if (!strcmp(name, "safe_inverse_cholesky")) {
         c->opt_chol = value != 0;
+    } else if (!strcmp(name, "shared_hessian_f64")) {
+        c->opt_shared64 = value != 0;
     } else if (!strcmp(name, "sparse_mode")) {
         if (value < 0 || value > 2) return fail(CMF_EINVAL, "sparse_mode must be 0 (auto), 1 (dense) or 2 (native CSR)");
         c->opt_sparse = (int)value;

@@ -29,6 +29,29 @@ static int launch_ew(cmf_ctx *c, void (*kern)(Args...), int64_t n, Args... args)
 // Cholesky fast path first (exact when lambda_min >= pert), Jacobi for the flagged rest.
 static int ns_clamp_images(cmf_ctx *c, const float *Hc, const int *idx, int nf, int n, int kp, double pert, float **M_out);
 
+// ONE matrix, |lambda| / clamp by the Hestenes-Jacobi sweep spread over the chip: one launch per round-robin step
+// (cmf_eigen.hip.h), one 4-byte read-back per sweep
+static int jacobi_chipwide(cmf_ctx *c, const float *Hin, float *Hout, int *flags, int n, int kp, double pert) {
+    const int N = n + (n & 1);
+    CHK(ensure(c, c->eigws, (size_t)(2 * (size_t)n * n + n) * sizeof(float)));
+    float *Bw = (float *)c->eigws.p, *Vw = Bw + (size_t)n * n, *invw = Vw + (size_t)n * n;
+    hipLaunchKernelGGL(jacobi_init_kernel, dim3(std::min(1024, (n * n + 63) / 64)), dim3(64), 0, c->stream, Hin, Bw, Vw, n, kp);
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        HIPCHK(hipMemsetAsync(flags, 0, sizeof(int), c->stream));
+        for (int st = 0; st < N - 1; ++st)
+            hipLaunchKernelGGL(jacobi_pair_step_kernel, dim3(N / 2), dim3(64), 0, c->stream, Bw, Vw, n, N, st, flags);
+        int rotated = 0;
+        HIPCHK(hipMemcpyAsync(&rotated, flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!rotated) break;
+    }
+    hipLaunchKernelGGL(jacobi_sigma_kernel, dim3(n), dim3(64), 0, c->stream, (const float *)Bw, invw, n, (float)pert);
+    hipLaunchKernelGGL(jacobi_compose_kernel, dim3((unsigned)(((size_t)kp * kp + 255) / 256)), dim3(256), 0, c->stream, (const float *)Vw,
+                       (const float *)invw, Hout, n, kp);
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
 static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat, int n, int kp, double pert, bool psd = false) {
     if (nmat <= 0) return CMF_OK;
     const int64_t stride = (int64_t)kp * kp;
@@ -73,28 +96,14 @@ static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat,
             HIPCHK(hipGetLastError());
             return CMF_OK;
         }
-        if (n >= 48) { // chip-wide Jacobi: one launch per round-robin step (cmf_eigen.hip.h)
-            const int N = n + (n & 1);
-            CHK(ensure(c, c->eigws, (size_t)(2 * n * n + n) * sizeof(float)));
-            float *Bw = (float *)c->eigws.p, *Vw = Bw + (size_t)n * n, *invw = Vw + (size_t)n * n;
-            hipLaunchKernelGGL(jacobi_init_kernel, dim3(std::min(1024, (n * n + 63) / 64)), dim3(64), 0, c->stream, Hin, Bw, Vw, n, kp);
-            for (int sweep = 0; sweep < 30; ++sweep) {
-                HIPCHK(hipMemsetAsync(flags, 0, sizeof(int), c->stream));
-                for (int st = 0; st < N - 1; ++st)
-                    hipLaunchKernelGGL(jacobi_pair_step_kernel, dim3(N / 2), dim3(64), 0, c->stream, Bw, Vw, n, N, st, flags);
-                int rotated = 0;
-                HIPCHK(hipMemcpyAsync(&rotated, flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(hipStreamSynchronize(c->stream));
-                if (!rotated) break;
-            }
-            hipLaunchKernelGGL(jacobi_sigma_kernel, dim3(n), dim3(64), 0, c->stream, (const float *)Bw, invw, n, (float)pert);
-            hipLaunchKernelGGL(jacobi_compose_kernel, dim3((kp * kp + 255) / 256), dim3(256), 0, c->stream, (const float *)Vw, (const float *)invw,
-                               Hout, n, kp);
-            HIPCHK(hipGetLastError());
-            return CMF_OK;
-        }
+        if (n >= 48) return jacobi_chipwide(c, Hin, Hout, flags, n, kp, pert);
         HIPCHK(hipMemsetAsync(flags, 0xFF, sizeof(int), c->stream)); // small n: the one-workgroup kernel below
         need = (const int *)flags;
+    } else if (nmat == 1 && n > 256 && !inplace) {
+        // a single large matrix (n_components > 256 with the float64 treatment off or out of its range): the
+        // one-workgroup kernels below would walk it out of L2 for seconds -- spread the sweep over the chip
+        CHK(ensure(c, c->eigflag, sizeof(int)));
+        return jacobi_chipwide(c, Hin, Hout, (int *)c->eigflag.p, n, kp, pert);
     } else if (c->opt_chol && tri_bytes <= 150 * 1024 && n <= 512) {
         CHK(ensure(c, c->eigflag, (size_t)nmat * sizeof(int)));
         const float *src = Hin;
@@ -293,28 +302,163 @@ extern "C" int cmf_safe_invert_batch(cmf_ctx *c, const double *H, double *out, i
 }
 
 // ---- shared-Hessian building blocks ------------------------------------------------------
-// F <- clamp(F - grad * safe_inverse(Hm)); grad lives in c->den, scratch in c->num
+// float64 Gram of a factor (cmf_shared64.hip.h): G64 = F^T F, optional float32 copy for the F G product
+static int gram64(cmf_ctx *c, const float *F, int64_t rows_pad, double *G64, float *G32) {
+    const int kp = c->kp;
+    const int ts = kp >= 64 ? 64 : 32, T = kp / ts, ntile = T * (T + 1) / 2;
+    int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>((4 * c->num_cu + ntile - 1) / ntile, rows_pad / 32));
+    const int64_t chunk = rup((rows_pad + nsplit - 1) / nsplit, 32);
+    nsplit = (rows_pad + chunk - 1) / chunk;
+    CHK(ensure(c, c->gslab64, (size_t)nsplit * ntile * ts * ts * sizeof(double)));
+    Timed tm(c, CMF_K_GEMM_SMALL, 2.0 * (double)rows_pad * kp * kp);
+    const dim3 grid((unsigned)ntile, (unsigned)nsplit);
+    if (ts == 64) hipLaunchKernelGGL((gram64_partial_kernel<64>), grid, dim3(256), 0, c->stream, F, kp, rows_pad, chunk, (double *)c->gslab64.p);
+    else hipLaunchKernelGGL((gram64_partial_kernel<32>), grid, dim3(64), 0, c->stream, F, kp, rows_pad, chunk, (double *)c->gslab64.p);
+    hipLaunchKernelGGL(gram64_reduce_kernel, dim3((unsigned)std::min(256, (kp * kp + 255) / 256)), dim3(256), 0, c->stream,
+                       (const double *)c->gslab64.p, ts, kp, (int)nsplit, G64, G32);
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
+static int gemm64(cmf_ctx *c, bool trans_b, const double *A, const double *B, double *C, const double *D, double alpha, double beta,
+                  double gamma, float *C32 = nullptr, int nvalid = 0) {
+    const dim3 grid((unsigned)(c->kp / 32), (unsigned)(c->kp / 32));
+    if (trans_b) hipLaunchKernelGGL((gemm64_kernel<true>), grid, dim3(256), 0, c->stream, A, B, C, D, alpha, beta, gamma, c->kp, C32, nvalid, (const int *)nullptr, 0);
+    else hipLaunchKernelGGL((gemm64_kernel<false>), grid, dim3(256), 0, c->stream, A, B, C, D, alpha, beta, gamma, c->kp, C32, nvalid, (const int *)nullptr, 0);
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
+// c->Hinv (float32, zero on the padding) = safe_inverse(H64) for the one shared Hessian, formed and inverted in float64
+// (reference: _safe_invert, cmf_solvers.py:346-356, on a float64 matrix)
+static int shared_inverse64(cmf_ctx *c, const double *H64, int n, double pert, bool psd) {
+    const int kp = c->kp;
+    Timed tm(c, CMF_K_EIGEN);
+    if (n <= 64) { // one launch, the branch on lambda_min is taken on the device
+        const size_t lds = (size_t)(2 * n * n + n) * sizeof(double);
+        CHK(allow_big_lds(c, reinterpret_cast<const void *>(&safe_inverse64_small_kernel), 80 * 1024));
+        hipLaunchKernelGGL(safe_inverse64_small_kernel, dim3(1), dim3(256), lds, c->stream, H64, c->Hinv, n, kp, pert);
+        HIPCHK(hipGetLastError());
+        return CMF_OK;
+    }
+    const size_t kk = (size_t)kp * kp;
+    // workspaces: W0, W1 (Cholesky of H - pert I and of H), Xt (L^-1 transposed), then 2 flags
+    CHK(ensure(c, c->w64, 3 * kk * sizeof(double) + 16));
+    double *W0 = (double *)c->w64.p, *W1 = W0 + kk, *Xt = W1 + kk;
+    int *flags = (int *)(Xt + kk);
+    // rows of L per LDS panel of the triangular inverse: Y is n x 16, the panel rp x (n + 2) doubles, 150 KB in all
+    const int rp = (int)std::max<int64_t>(1, std::min<int64_t>(32, ((int64_t)150 * 1024 - 128 * (int64_t)n) / (8 * ((int64_t)n + 2))));
+    const size_t tri_lds = ((size_t)16 * n + (size_t)rp * (n + 2)) * sizeof(double);
+    auto inverse_from = [&](const double *L) -> int { // Hinv = L^-T L^-1
+        CHK(allow_big_lds(c, reinterpret_cast<const void *>(&tri_inverse64_kernel), 152 * 1024));
+        hipLaunchKernelGGL(tri_inverse64_kernel, dim3((unsigned)(kp / 16)), dim3(256), tri_lds, c->stream, L, n, kp, Xt, kp, kp, rp);
+        HIPCHK(hipGetLastError());
+        return gemm64(c, true, Xt, Xt, nullptr, nullptr, 1.0, 0.0, 0.0, c->Hinv, n);
+    };
+    hipLaunchKernelGGL(chol64_kernel, dim3(2), dim3(1024), 0, c->stream, H64, n, kp, W0, (int64_t)kk, kp, pert, 0.0, flags);
+    HIPCHK(hipGetLastError());
+    // the spectral clamp needs c = min(||B||_F, ||B||_inf) of B = H - pert I on the host (iteration count): form it now so
+    // that ONE read-back serves both decisions
+    CHK(ensure(c, c->ns64, 6 * kk * sizeof(double) + 16));
+    double *Bm = (double *)c->ns64.p, *X = Bm + kk, *X2 = X + kk, *Y = X2 + kk, *Z = Y + kk, *M = Z + kk;
+    double *cnorm = M + kk;
+    if (psd) {
+        hipLaunchKernelGGL(ns64_prepare_kernel, dim3(1), dim3(1024), 0, c->stream, H64, Bm, X, n, kp, pert, cnorm);
+        HIPCHK(hipGetLastError());
+    }
+    int hflags[2] = {0, 0};
+    double hc = 1.0;
+    HIPCHK(hipMemcpyAsync(hflags, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (psd) HIPCHK(hipMemcpyAsync(&hc, cnorm, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (!hflags[0] && !hflags[1]) return inverse_from(W1); // lambda_min >= pert: the clamp is the identity
+    if (psd) {
+        // M = max(H, pert I) = (sign(B) B + B) / 2 + pert I, sign(B) by odd polynomials of X0 = B / c (see ns_clamp_images);
+        // float64 resolves eigenvalues down to 1e-6 pert from the threshold
+        const double delta = 1e-6 * pert;
+        int nq = (int)std::ceil(std::log(std::max(hc, pert) / delta) / std::log(3.4445));
+        nq = std::min(std::max(nq, 4), 48);
+        for (int it = 0; it < nq; ++it) {
+            CHK(gemm64(c, false, X, X, Y, nullptr, 1.0, 0.0, 0.0));
+            CHK(gemm64(c, false, Y, Y, Z, Y, 2.0315, -4.7750, 3.4445));
+            CHK(gemm64(c, false, X, Z, X2, nullptr, 1.0, 0.0, 0.0));
+            std::swap(X, X2);
+        }
+        for (int it = 0; it < 8; ++it) {
+            CHK(gemm64(c, false, X, X, Y, nullptr, 1.0, 0.0, 0.0));
+            CHK(gemm64(c, false, X, Y, X2, X, -0.5, 1.5, 0.0));
+            std::swap(X, X2);
+        }
+        CHK(gemm64(c, false, X, Bm, M, Bm, 0.5, 0.5, pert));
+        hipLaunchKernelGGL(chol64_kernel, dim3(1), dim3(1024), 0, c->stream, (const double *)M, n, kp, W0, (int64_t)kk, kp, 0.0, 0.0, flags);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(hflags, flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!hflags[0]) return inverse_from(W0);
+    }
+    return CMF_EUNSUPPORTED; // caller falls back to the float32 eigen-solver
+}
+
+// F <- clamp(F - grad * safe_inverse(H)); grad lives in c->den, scratch in c->num.  H: c->h64 (float64) when the
+// float64 treatment is on, else c->Hm (float32).
 static int shared_step(cmf_ctx *c, int which, double pert, bool non_negative) {
     const int64_t rows = c->frows_pad[which];
-    CHK(safe_inverse_dev(c, c->Hm, c->Hinv, 1, c->k, c->kp, pert, c->hess_psd));
+    bool done = false;
+    if (c->opt_shared64 && c->kp <= 1024) {
+        const int rc = shared_inverse64(c, (const double *)c->h64.p, c->k, pert, c->hess_psd);
+        if (rc == CMF_OK) done = true;
+        else if (rc != CMF_EUNSUPPORTED) return rc;
+        else { // not positive semi-definite by construction (alpha outside [0, 1]): |lambda| route of the float32 eigen-solver
+            Timed tm(c, CMF_K_ELEMWISE);
+            hipLaunchKernelGGL(axpby64_to_f32_kernel, dim3(256), dim3(256), 0, c->stream, c->Hm, (const double *)c->h64.p, 1.0,
+                               (const double *)nullptr, 0.0, (int64_t)c->kp * c->kp);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    if (!done) CHK(safe_inverse_dev(c, c->Hm, c->Hinv, 1, c->k, c->kp, pert, c->hess_psd));
     CHK(gemm(c, MODE_NN, c->den, c->kp, c->Hinv, c->kp, c->num, rows, c->kp, c->kp));
     return launch_ew(c, newton_apply_kernel, rows * c->kp, c->F[which], (const float *)c->num, c->frows[which], c->kp, c->k,
                      rows * c->kp, non_negative ? 1 : 0);
 }
 
-// U (left=true: T = X, rows m) or Z (left=false: T = Y^T, rows p) with a shared Hessian
-static int sweep_side_shared(cmf_ctx *c, bool is_u, double scale, double l1, double l2, double pert, bool nn) {
+static bool use_shared64(const cmf_ctx *c) { return c->opt_shared64 && c->kp <= 1024; }
+static int ensure_shared64(cmf_ctx *c) {
+    const size_t kk = (size_t)c->kp * c->kp * sizeof(double);
+    CHK(ensure(c, c->g64a, kk));
+    CHK(ensure(c, c->g64b, kk));
+    CHK(ensure(c, c->gmix64, kk));
+    CHK(ensure(c, c->h64, kk));
+    return CMF_OK;
+}
+static int launch_hess64(cmf_ctx *c, const double *A, double a, const double *B, double b, double diag) {
+    Timed tm(c, CMF_K_ELEMWISE);
+    hipLaunchKernelGGL(hess64_build_kernel, dim3((unsigned)std::min(256, (c->kp * c->kp + 255) / 256)), dim3(256), 0, c->stream,
+                       (double *)c->h64.p, A, a, B, b, diag, c->kp, c->k);
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
+// U (left=true: T = X, rows m) or Z (left=false: T = Y^T, rows p) with a shared Hessian.
+// `vgram_ready`: c->g64a / c->G2 already hold V^T V (the caller's previous sweep used the same V).
+static int sweep_side_shared(cmf_ctx *c, bool is_u, double scale, double l1, double l2, double pert, bool nn, bool vgram_ready = false) {
     const int which = is_u ? CMF_U : CMF_Z;
     const int64_t rows = c->frows_pad[which];
     float *F = c->F[which], *V = c->F[CMF_V];
-    CHK(gemm(c, MODE_TN, V, c->kp, V, c->kp, c->G2, c->kp, c->kp, c->dp)); // V^T V
+    const bool f64 = use_shared64(c);
+    if (f64) {
+        CHK(ensure_shared64(c));
+        if (!vgram_ready) CHK(gram64(c, V, c->dp, (double *)c->g64a.p, c->G2)); // V^T V, float64 + float32 copy
+    } else {
+        CHK(gemm(c, MODE_TN, V, c->kp, V, c->kp, c->G2, c->kp, c->kp, c->dp)); // V^T V
+    }
     if (is_u) CHK(data_times(c, 0, false, V, c->num)); // X V
     else CHK(data_times(c, 1, true, V, c->num));       // Y^T V
     CHK(gemm(c, MODE_NN, F, c->kp, c->G2, c->kp, c->den, rows, c->kp, c->kp));           // F (V^T V)
     CHK(launch_ew(c, newton_grad_kernel, rows * c->kp, c->den, (const float *)c->den, (float)scale, (const float *)c->num,
                   (float)-scale, (const float *)F, (float)l1, (float)l2, rows * c->kp));
-    CHK(launch_ew(c, axpby_diag_kernel, (int64_t)c->kp * c->kp, c->Hm, (const float *)c->G2, (float)scale,
-                  (const float *)nullptr, 0.f, (float)l2, c->kp, c->k));
+    if (f64) CHK(launch_hess64(c, (const double *)c->g64a.p, scale, nullptr, 0.0, l2));
+    else CHK(launch_ew(c, axpby_diag_kernel, (int64_t)c->kp * c->kp, c->Hm, (const float *)c->G2, (float)scale,
+                       (const float *)nullptr, 0.f, (float)l2, c->kp, c->k));
     return shared_step(c, which, pert, nn);
 }
 
@@ -328,6 +472,22 @@ extern "C" int cmf_newton_v_partials(cmf_ctx *c, double alpha, float *buf) {
     CHK(data_times(c, 1, false, c->F[CMF_Z], c->den)); // Y Z
     CHK(launch_ew(c, axpby_kernel, c->dp * c->kp, P, (const float *)c->num, (float)alpha, (const float *)c->den,
                   (float)(1.0 - alpha), c->dp * c->kp));
+    c->gmix64_valid = false;
+    if (use_shared64(c)) {
+        // Grams in float64; the (all-reducible) buffer carries their float32 rounding, the float64 mix stays behind for a
+        // cmf_newton_v_apply that follows directly inside cmf_newton_step (single GPU: no collective in between)
+        CHK(ensure_shared64(c));
+        CHK(gram64(c, c->F[CMF_U], c->mp, (double *)c->g64a.p, nullptr));
+        CHK(gram64(c, c->F[CMF_Z], c->pp, (double *)c->g64b.p, nullptr));
+        Timed tm(c, CMF_K_ELEMWISE);
+        const unsigned nb = (unsigned)std::min(256, (c->kp * c->kp + 255) / 256);
+        hipLaunchKernelGGL(hess64_build_kernel, dim3(nb), dim3(256), 0, c->stream, (double *)c->gmix64.p, (const double *)c->g64a.p, alpha,
+                           (const double *)c->g64b.p, 1.0 - alpha, 0.0, c->kp, c->kp);
+        hipLaunchKernelGGL(axpby64_to_f32_kernel, dim3(nb), dim3(256), 0, c->stream, Gs, (const double *)c->gmix64.p, 1.0,
+                           (const double *)nullptr, 0.0, (int64_t)c->kp * c->kp);
+        HIPCHK(hipGetLastError());
+        return CMF_OK;
+    }
     CHK(gemm(c, MODE_TN, c->F[CMF_U], c->kp, c->F[CMF_U], c->kp, c->G, c->kp, c->kp, c->mp));
     CHK(gemm(c, MODE_TN, c->F[CMF_Z], c->kp, c->F[CMF_Z], c->kp, c->G2, c->kp, c->kp, c->pp));
     return launch_ew(c, axpby_kernel, (int64_t)c->kp * c->kp, Gs, (const float *)c->G, (float)alpha, (const float *)c->G2,
@@ -340,25 +500,64 @@ extern "C" int cmf_newton_v_apply(cmf_ctx *c, const float *buf, double l1, doubl
     DeviceGuard dg(c->device);
     const float *P = buf, *Gs = buf + c->dp * c->kp;
     float *V = c->F[CMF_V];
+    const bool mix64 = c->gmix64_valid; // armed by cmf_newton_step only
+    c->gmix64_valid = false;
     CHK(gemm(c, MODE_NN, V, c->kp, Gs, c->kp, c->den, c->dp, c->kp, c->kp)); // V Gmix
     CHK(launch_ew(c, newton_grad_kernel, c->dp * c->kp, c->den, (const float *)c->den, 1.0f, P, -1.0f, (const float *)V,
                   (float)l1, (float)l2, c->dp * c->kp));
-    CHK(launch_ew(c, axpby_diag_kernel, (int64_t)c->kp * c->kp, c->Hm, Gs, 1.0f, (const float *)nullptr, 0.f, (float)l2,
-                  c->kp, c->k));
+    if (use_shared64(c)) {
+        CHK(ensure_shared64(c));
+        if (mix64) {
+            CHK(launch_hess64(c, (const double *)c->gmix64.p, 1.0, nullptr, 0.0, l2));
+        } else { // the Gram arrives in float32 (summed over ranks by the caller's all-reduce): promote, factor in float64
+            Timed tm(c, CMF_K_ELEMWISE);
+            hipLaunchKernelGGL(hess64_from_f32_kernel, dim3((unsigned)std::min(256, (c->kp * c->kp + 255) / 256)), dim3(256), 0, c->stream,
+                               (double *)c->h64.p, Gs, 1.0, l2, c->kp, c->k);
+            HIPCHK(hipGetLastError());
+        }
+    } else {
+        CHK(launch_ew(c, axpby_diag_kernel, (int64_t)c->kp * c->kp, c->Hm, Gs, 1.0f, (const float *)nullptr, 0.f, (float)l2,
+                      c->kp, c->k));
+    }
     return shared_step(c, CMF_V, pert, (nn_mask & CMF_NN_V) != 0);
 }
 
 extern "C" int cmf_newton_uz_update(cmf_ctx *c, double alpha, double l1, double l2, int nn_mask, int upd, double pert) {
     NEED_PROBLEM(c);
     DeviceGuard dg(c->device);
+    c->hess_psd = (alpha >= 0.0 && alpha <= 1.0 && l2 >= 0.0);
+    bool vgram = false;
     if (upd & CMF_UPD_U) {
         if (!have_data(c, 0)) return fail(CMF_EINVAL, "X must be set before a U update");
         CHK(sweep_side_shared(c, true, alpha, l1, l2, pert, (nn_mask & CMF_NN_U) != 0));
+        vgram = use_shared64(c); // V has not moved: the Z sweep reuses V^T V
     }
     if (upd & CMF_UPD_Z) {
         if (!have_data(c, 1)) return fail(CMF_EINVAL, "Y must be set before a Z update");
-        CHK(sweep_side_shared(c, false, 1.0 - alpha, l1, l2, pert, (nn_mask & CMF_NN_Z) != 0));
+        CHK(sweep_side_shared(c, false, 1.0 - alpha, l1, l2, pert, (nn_mask & CMF_NN_Z) != 0, vgram));
     }
+    return CMF_OK;
+}
+
+// float64 path of the single shared inverse, exposed for tests: H (host, k x k float64, symmetric) -> safe_inverse(H)
+extern "C" int cmf_safe_invert_f64(cmf_ctx *c, const double *H, double *out, int k, double pert) {
+    NEED_PROBLEM(c);
+    if (!H || !out || k != c->k) return fail(CMF_EINVAL, "cmf_safe_invert_f64: k must equal the problem's n_components");
+    DeviceGuard dg(c->device);
+    CHK(ensure_shared64(c));
+    const int kp = c->kp;
+    std::vector<double> host((size_t)kp * kp, 0.0);
+    for (int r = 0; r < kp; ++r)
+        for (int q = 0; q < kp; ++q) host[(size_t)r * kp + q] = (r < k && q < k) ? H[(size_t)r * k + q] : (r == q ? 1.0 : 0.0);
+    HIPCHK(hipMemcpyAsync(c->h64.p, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const int rc = shared_inverse64(c, (const double *)c->h64.p, k, pert, true);
+    if (rc != CMF_OK) return rc == CMF_EUNSUPPORTED ? fail(CMF_EUNSUPPORTED, "float64 shared inverse did not converge (matrix not positive semi-definite?)") : rc;
+    std::vector<float> res((size_t)kp * kp);
+    HIPCHK(hipMemcpyAsync(res.data(), c->Hinv, res.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < k; ++r)
+        for (int q = 0; q < k; ++q) out[(size_t)r * k + q] = (double)res[(size_t)r * kp + q];
     return CMF_OK;
 }
 
@@ -762,11 +961,14 @@ static int newton_step_impl(cmf_ctx *c, double alpha, double l1, double l2, int 
         if (((upd & CMF_UPD_U) && !u_idx) || ((upd & CMF_UPD_Z) && !z_idx) || ((upd & CMF_UPD_V) && (!vx_idx || !vy_idx)))
             return fail(CMF_EINVAL, "sg_sample_ratio < 1 needs the sample index lists of every updated factor");
     }
+    bool vgram = false; // V^T V (float64) left behind by a shared U sweep for the Z sweep that follows (V unchanged)
     if (upd & CMF_UPD_U) {
         if (!have_data(c, 0)) return fail(CMF_EINVAL, "X must be set before a U update");
         if (!(x_link == CMF_LINK_LINEAR && !sampled)) CHK(need_dense(c, 0));
-        if (x_link == CMF_LINK_LINEAR && !sampled)
+        if (x_link == CMF_LINK_LINEAR && !sampled) {
             CHK(sweep_side_shared(c, true, alpha, l1, l2, pert, (nn_mask & CMF_NN_U) != 0));
+            vgram = use_shared64(c);
+        }
         else if (fused) {
             CHK(sweep_side_fused(c, true, x_link, alpha, l1, l2, pert, (nn_mask & CMF_NN_U) != 0, u_idx, su, sampled));
         } else {
@@ -779,7 +981,7 @@ static int newton_step_impl(cmf_ctx *c, double alpha, double l1, double l2, int 
         if (!have_data(c, 1)) return fail(CMF_EINVAL, "Y must be set before a Z update");
         if (!(y_link == CMF_LINK_LINEAR && !sampled)) CHK(need_dense(c, 1));
         if (y_link == CMF_LINK_LINEAR && !sampled)
-            CHK(sweep_side_shared(c, false, 1.0 - alpha, l1, l2, pert, (nn_mask & CMF_NN_Z) != 0));
+            CHK(sweep_side_shared(c, false, 1.0 - alpha, l1, l2, pert, (nn_mask & CMF_NN_Z) != 0, vgram));
         else if (fused) {
             CHK(sweep_side_fused(c, false, y_link, 1.0 - alpha, l1, l2, pert, (nn_mask & CMF_NN_Z) != 0, z_idx, su, sampled));
         } else {
@@ -797,6 +999,7 @@ static int newton_step_impl(cmf_ctx *c, double alpha, double l1, double l2, int 
         }
         if (x_link == CMF_LINK_LINEAR && y_link == CMF_LINK_LINEAR && !sampled) {
             CHK(cmf_newton_v_partials(c, alpha, c->vbuf));
+            c->gmix64_valid = use_shared64(c); // no collective between the two halves: keep the float64 Gram mix
             CHK(cmf_newton_v_apply(c, c->vbuf, l1, l2, nn_mask, pert));
         } else if (fused) {
             CHK(sweep_v_fused(c, alpha, l1, l2, x_link, y_link, pert, (nn_mask & CMF_NN_V) != 0, vx_idx, sm, vy_idx, sp, sampled));

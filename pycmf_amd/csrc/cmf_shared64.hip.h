@@ -396,19 +396,18 @@ __global__ __launch_bounds__(1024) void chol64_kernel(const double *H, int n, in
 }
 
 // Xt[c][i] = (L^-1)[i][c]  (row c of Xt = column c of the inverse of the lower-triangular L; zero for i < c).
-// Workgroup = 16 columns x 16 lanes; rows of L pass through LDS 32 at a time; y lives in LDS ([n][16]).
-// Pt rows beyond n are zero.  Only runs when *skip == 0.
-__global__ __launch_bounds__(256) void tri_inverse64_kernel(const double *L, int n, int ld, double *Xt, int ldx, int kp, const int *skip) {
+// Workgroup = 16 columns x 16 lanes; rows of L pass through LDS rp at a time; y lives in LDS ([n][16]).
+// Rows of Xt beyond n are zero.
+__global__ __launch_bounds__(256) void tri_inverse64_kernel(const double *L, int n, int ld, double *Xt, int ldx, int kp, int rp) {
     extern __shared__ __attribute__((aligned(16))) double tsm[];
-    if (skip && *skip) return;
     double *Y = tsm;               // [n][16]
-    double *Ls = tsm + (size_t)n * 16; // [32][n + 2]
+    double *Ls = tsm + (size_t)n * 16; // [rp][n + 2]
     const int lp = n + 2;
     const int t = threadIdx.x, q = t & 15, cl = t >> 4;
     const int c0 = blockIdx.x * 16, c = c0 + cl;
     for (int i = t; i < n * 16; i += 256) Y[i] = 0.0;
-    for (int i0 = (c0 / 32) * 32; i0 < n; i0 += 32) {
-        const int nr = n - i0 < 32 ? n - i0 : 32;
+    for (int i0 = (c0 / rp) * rp; i0 < n; i0 += rp) {
+        const int nr = n - i0 < rp ? n - i0 : rp;
         __syncthreads();
         for (int idx = t; idx < nr * n; idx += 256) {
             const int r = idx / n, col = idx % n;
