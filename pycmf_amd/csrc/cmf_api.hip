@@ -61,6 +61,12 @@ struct CsrDev {
     int32_t *idx = nullptr;
     float *val = nullptr;
     int64_t rows = 0, cols = 0, nnz = 0;
+    // column-blocked regrouping for the output-stationary SpMM (cmf_sparse.hip.h), built when the gathered operand
+    // exceeds the L2: entries sorted by (row group, column block, owner wave, row)
+    cmfk::BcsrEntry *b_ent = nullptr;
+    int64_t *b_seg = nullptr;
+    int32_t *b_grow = nullptr;
+    int b_ngroups = 0, b_nblocks = 0, b_rows_per_group = 0, b_nsync = 1;
 };
 
 // A captured update step: replayed with hipGraphLaunch while the key (hyper-parameters baked into
@@ -119,6 +125,10 @@ struct cmf_ctx {
     bool sparse[2] = {false, false};
     double sp_sq[2] = {0.0, 0.0};     // sum of squares of the stored values
     int opt_sparse = 0;               // 0 auto, 1 always expand to dense, 2 always native CSR
+    int opt_spmm_blocked = 1;         // column-blocked output-stationary SpMM: 0 never | 1 when the gathered operand exceeds L2 | 2 always
+    int64_t opt_spmm_block_cols = 0;  // gathered rows per column block (0: 2 MB worth)
+    int64_t opt_spmm_stretch = 0;     // entries of a group between two re-alignments of its XCD class (0: 16384)
+    DevBuf spmm_bar;                  // rendezvous counters of the blocked SpMM (8 x 16 bytes)
     float *F[3] = {nullptr, nullptr, nullptr};
     int64_t frows[3] = {0, 0, 0}, frows_pad[3] = {0, 0, 0};
 
@@ -127,6 +137,10 @@ struct cmf_ctx {
     float *G = nullptr, *G2 = nullptr, *Hm = nullptr, *Hinv = nullptr, *Eye = nullptr; // kp x kp
     float *vbuf = nullptr;                // dp*kp + kp*kp
     DevBuf slabs;                         // split-K partial tiles (grow-only)
+    DevBuf tickets;                       // one arrival counter per output tile of a split-K GEMM (zero between launches)
+    int opt_inred = 0;                    // 0: split-K partials summed by a chip-wide kernel | 1: by the last-arriving workgroup of each tile
+                                          // inside the GEMM kernel (A/B option; measured slower)
+    int opt_fused_mu = 1;                 // 1: F <- F num / reg(F G) in the epilogue of the F G product | 0: separate kernel
     DevBuf resid;                         // Newton residual / weights scratch (grow-only)
     DevBuf resid2, resid3;                // sigma' / sample weights (X side, Y side)
     DevBuf kr1, kr2;                      // Khatri-Rao squares of factors
@@ -342,15 +356,24 @@ static int sum_slabs(cmf_ctx *c, float *dst, const float *src, int64_t n, int ns
     return CMF_OK;
 }
 
+static int mu_apply(cmf_ctx *c, float *F, const float *num, const float *den, int64_t n, double l1, double l2);
+
+struct MuEpilogue { // fused multiplicative update of the factor-side product F G (gemm_kernel, mu_num != null)
+    const float *num = nullptr;
+    float *F = nullptr;
+    double l1 = 0.0, l2 = 0.0;
+};
+
 // C[mout x n] (+)= op(A) * B.  mode NN: A is [mout_pad x kred]; TN: A is [kred x >=mout].
-// Result lands in `out` (ld = n); split-K partials go through the slab workspace.
+// Result lands in `out` (ld = n); split-K partials go through the slab workspace and are summed in slab order -- by the
+// last-arriving workgroup of each output tile inside the GEMM kernel (default) or by a separate kernel.
 // `A` is a factor-sized operand when lda == k_pad (Grams, F*G, step products): those launches
 // use the ROLE=1 symbol and the CMF_K_GEMM_SMALL timing class.
 static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *B, int64_t ldb, float *out,
-                int64_t mout, int64_t n, int64_t kred, bool accumulate = false) {
+                int64_t mout, int64_t n, int64_t kred, bool accumulate = false, const MuEpilogue *mu = nullptr) {
     const bool data_pass = (lda != c->kp);
     if (kred % 32 || n % 32) return fail(CMF_EINVAL, "gemm: unpadded extent (k=%lld n=%lld)", (long long)kred, (long long)n);
-    GemmPlan pl = plan_gemm(c, mout, n, kred, true);
+    GemmPlan pl = plan_gemm(c, mout, n, kred, mu == nullptr);
     GemmArgs a;
     memset(&a, 0, sizeof a);
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb;
@@ -359,15 +382,32 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
     a.Kred = kred; a.klen = pl.klen;
     a.dbg = data_pass ? c->dbg_stamps : nullptr;
     const int64_t rows_store = (mode == MODE_TN) ? mout : rup(mout, 256);
+    // in-kernel forms: fused update epilogue; out += acc of an unsplit accumulate; (option) last-arriver reduction of splits
+    const bool in_kernel = mu != nullptr || pl.nsplit == 1 || (c->opt_inred != 0 && (int64_t)pl.tiles_m * pl.ntiles_n >= 16 && pl.nsplit <= 16);
     const bool direct = (pl.nsplit == 1 && !accumulate);
-    if (direct) {
+    if (mu) {
+        if (mode != MODE_NN || pl.ntiles_n != 1 || pl.nsplit != 1) return fail(CMF_EINVAL, "fused update needs one N tile and no split");
+        a.mu_num = mu->num; a.mu_out = mu->F; a.mu_l1 = (float)mu->l1; a.mu_l2 = (float)mu->l2; a.mu_eps = 1.1920928955078125e-07f;
+        a.C = out; // unused
+    } else if (direct) {
         a.C = out;
         a.slab_stride = 0;
+    } else if (in_kernel && pl.nsplit == 1) {
+        a.red_out = out; a.red_acc = 1; // out += acc in the epilogue
+        a.C = out;
     } else {
         const size_t need = (size_t)pl.nsplit * rows_store * n * sizeof(float);
         CHK(ensure(c, c->slabs, need));
         a.C = (float *)c->slabs.p;
         a.slab_stride = rows_store * n;
+        if (in_kernel) {
+            const size_t ntile = (size_t)pl.tiles_m * pl.ntiles_n;
+            if (c->tickets.bytes < ntile * sizeof(unsigned)) {
+                CHK(ensure(c, c->tickets, std::max<size_t>(4096, 2 * ntile) * sizeof(unsigned)));
+                HIPCHK(hipMemsetAsync(c->tickets.p, 0, c->tickets.bytes, c->stream));
+            }
+            a.red_out = out; a.red_acc = accumulate ? 1 : 0; a.ticket = (unsigned *)c->tickets.p;
+        }
     }
     {
         Timed tm(c, !data_pass ? CMF_K_GEMM_SMALL : (mode == MODE_NN ? CMF_K_GEMM_NN : CMF_K_GEMM_TN),
@@ -380,8 +420,20 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
             else CHK((launch_gemm_mode<MODE_TN, 1>(c, a, pl)));
         }
     }
-    if (!direct) CHK(sum_slabs(c, out, (const float *)c->slabs.p, rows_store * n, pl.nsplit, a.slab_stride, accumulate));
+    if (!direct && !in_kernel) CHK(sum_slabs(c, out, (const float *)c->slabs.p, rows_store * n, pl.nsplit, a.slab_stride, accumulate));
     return CMF_OK;
+}
+
+// F <- F * num / reg(F G)   (MUSolver._regularized_delta, cmf_solvers.py:212-228): one launch when the factor-side
+// product has a single N tile (k_pad <= 256), else product + elementwise kernel
+static int mu_update(cmf_ctx *c, float *F, const float *G, const float *num, int64_t rows_pad, double l1, double l2) {
+    if (c->opt_fused_mu && c->kp <= 256) {
+        MuEpilogue mu;
+        mu.num = num; mu.F = F; mu.l1 = l1; mu.l2 = l2;
+        return gemm(c, MODE_NN, F, c->kp, G, c->kp, c->den, rows_pad, c->kp, c->kp, false, &mu);
+    }
+    CHK(gemm(c, MODE_NN, F, c->kp, G, c->kp, c->den, rows_pad, c->kp, c->kp));
+    return mu_apply(c, F, num, c->den, rows_pad * c->kp, l1, l2);
 }
 
 struct NtOut {
@@ -495,11 +547,12 @@ static void release_problem(cmf_ctx *c) {
     c->X = c->Y = nullptr;
     c->F[0] = c->F[1] = c->F[2] = nullptr;
     c->num = c->den = c->G = c->G2 = c->Hm = c->Hinv = c->Eye = c->vbuf = nullptr;
-    c->slabs = DevBuf(); c->resid = DevBuf(); c->resid2 = DevBuf(); c->resid3 = DevBuf(); c->dpart = DevBuf();
+    c->slabs = DevBuf(); c->tickets = DevBuf(); c->resid = DevBuf(); c->resid2 = DevBuf(); c->resid3 = DevBuf(); c->dpart = DevBuf();
     c->kr1 = DevBuf(); c->kr2 = DevBuf(); c->hrows = DevBuf(); c->mask1 = DevBuf(); c->mask2 = DevBuf();
     c->lists1 = DevBuf(); c->lists2 = DevBuf();
     c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf();
     c->nsidx = DevBuf(); c->nsws = DevBuf();
+    c->spmm_bar = DevBuf();
     c->g64a = DevBuf(); c->g64b = DevBuf(); c->gmix64 = DevBuf(); c->h64 = DevBuf();
     c->gslab64 = DevBuf(); c->w64 = DevBuf(); c->ns64 = DevBuf();
     c->gmix64_valid = false;
@@ -574,8 +627,19 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_choldiag = (int)value;
     } else if (!strcmp(name, "safe_inverse_cholesky")) {
         c->opt_chol = value != 0;
+    } else if (!strcmp(name, "split_reduce_in_kernel")) {
+        c->opt_inred = value != 0;
+    } else if (!strcmp(name, "fused_mu_update")) {
+        c->opt_fused_mu = value != 0;
     } else if (!strcmp(name, "shared_hessian_f64")) {
         c->opt_shared64 = value != 0;
+    } else if (!strcmp(name, "spmm_blocked")) {
+        if (value < 0 || value > 2) return fail(CMF_EINVAL, "spmm_blocked must be 0 (never), 1 (auto) or 2 (always); set before cmf_set_data_csr");
+        c->opt_spmm_blocked = (int)value;
+    } else if (!strcmp(name, "spmm_stretch")) {
+        c->opt_spmm_stretch = std::max<int64_t>(0, value);
+    } else if (!strcmp(name, "spmm_block_cols")) {
+        c->opt_spmm_block_cols = std::max<int64_t>(0, value);
     } else if (!strcmp(name, "sparse_mode")) {
         if (value < 0 || value > 2) return fail(CMF_EINVAL, "sparse_mode must be 0 (auto), 1 (dense) or 2 (native CSR)");
         c->opt_sparse = (int)value;
@@ -613,8 +677,12 @@ extern "C" int cmf_set_problem(cmf_ctx *c, int64_t m, int64_t d, int64_t p, int 
     for (int f = 0; f < 3; ++f) {
         c->frows[f] = rows[f];
         c->frows_pad[f] = rowsp[f];
-        CHK(dev_alloc(c, (void **)&c->F[f], (size_t)rowsp[f] * c->kp * sizeof(float)));
     }
+    // U and Z share one allocation, Z right behind U: U^T U + Z^T Z (cmf_solvers.py:245) is then the Gram of the stacked
+    // (m_pad + p_pad) x k_pad matrix -- one launch (padding rows are zero)
+    CHK(dev_alloc(c, (void **)&c->F[CMF_U], (size_t)(c->mp + c->pp) * c->kp * sizeof(float)));
+    c->F[CMF_Z] = c->F[CMF_U] + c->mp * c->kp;
+    CHK(dev_alloc(c, (void **)&c->F[CMF_V], (size_t)c->dp * c->kp * sizeof(float)));
     const int64_t rmax = std::max(c->mp, std::max(c->dp, c->pp));
     CHK(dev_alloc(c, (void **)&c->num, (size_t)rmax * c->kp * sizeof(float)));
     CHK(dev_alloc(c, (void **)&c->den, (size_t)rmax * c->kp * sizeof(float)));
@@ -710,6 +778,7 @@ extern "C" int cmf_set_data_csr(cmf_ctx *c, int which, const int64_t *indptr, co
     for (int t = 0; t < 2; ++t) {                              // so are its native CSR images
         CsrDev &old = c->sp[which][t];
         dev_free(c, old.indptr); dev_free(c, old.idx); dev_free(c, old.val);
+        dev_free(c, old.b_ent); dev_free(c, old.b_seg); dev_free(c, old.b_grow);
         old = CsrDev();
     }
     c->sparse[which] = false;
@@ -877,9 +946,8 @@ extern "C" int cmf_mu_v_partials(cmf_ctx *c, float *buf) {
     // P = X^T U + Y Z
     CHK(data_times(c, 0, true, c->F[CMF_U], P));
     CHK(data_times(c, 1, false, c->F[CMF_Z], P, true));
-    // G = U^T U + Z^T Z
-    CHK(gemm(c, MODE_TN, c->F[CMF_U], c->kp, c->F[CMF_U], c->kp, Gs, c->kp, c->kp, c->mp));
-    CHK(gemm(c, MODE_TN, c->F[CMF_Z], c->kp, c->F[CMF_Z], c->kp, Gs, c->kp, c->kp, c->pp, true));
+    // G = U^T U + Z^T Z: Gram of the stacked [U; Z]
+    CHK(gemm(c, MODE_TN, c->F[CMF_U], c->kp, c->F[CMF_U], c->kp, Gs, c->kp, c->kp, c->mp + c->pp));
     return CMF_OK;
 }
 
@@ -889,9 +957,7 @@ extern "C" int cmf_mu_v_apply(cmf_ctx *c, const float *buf, double l1, double l2
     if (!buf) return fail(CMF_EINVAL, "null buffer");
     DeviceGuard dg(c->device);
     const float *P = buf, *Gs = buf + c->dp * c->kp;
-    CHK(gemm(c, MODE_NN, c->F[CMF_V], c->kp, Gs, c->kp, c->den, c->dp, c->kp, c->kp));
-    CHK(mu_apply(c, c->F[CMF_V], P, c->den, c->dp * c->kp, l1, l2));
-    return CMF_OK;
+    return mu_update(c, c->F[CMF_V], Gs, P, c->dp, l1, l2);
 }
 
 // U *= X V / reg(U V^T V), Z *= Y^T V / reg(Z V^T V): cmf_solvers.py:230-240, :257-263.
@@ -904,14 +970,12 @@ extern "C" int cmf_mu_uz_update(cmf_ctx *c, double l1, double l2, int mask) {
     if (mask & CMF_UPD_U) {
         if (!have_data(c, 0)) return fail(CMF_EINVAL, "X must be set before a U update");
         CHK(data_times(c, 0, false, c->F[CMF_V], c->num));
-        CHK(gemm(c, MODE_NN, c->F[CMF_U], c->kp, c->G2, c->kp, c->den, c->mp, c->kp, c->kp));
-        CHK(mu_apply(c, c->F[CMF_U], c->num, c->den, c->mp * c->kp, l1, l2));
+        CHK(mu_update(c, c->F[CMF_U], c->G2, c->num, c->mp, l1, l2));
     }
     if (mask & CMF_UPD_Z) {
         if (!have_data(c, 1)) return fail(CMF_EINVAL, "Y must be set before a Z update");
         CHK(data_times(c, 1, true, c->F[CMF_V], c->num));
-        CHK(gemm(c, MODE_NN, c->F[CMF_Z], c->kp, c->G2, c->kp, c->den, c->pp, c->kp, c->kp));
-        CHK(mu_apply(c, c->F[CMF_Z], c->num, c->den, c->pp * c->kp, l1, l2));
+        CHK(mu_update(c, c->F[CMF_Z], c->G2, c->num, c->pp, l1, l2));
     }
     return CMF_OK;
 }

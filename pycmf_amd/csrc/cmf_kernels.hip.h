@@ -51,7 +51,27 @@ struct GemmArgs {
     int64_t b_batch;     // elements between the B operands of consecutive row tiles
     const float *D;      // C = alpha * A B + beta * D + gamma * I  (D stacked like C, nullable)
     float alpha, beta, gamma;
+    // ---- in-kernel split-K reduction (NN / TN): red_out != null ----
+    // every split writes its partial tile to slab z of C (write-through stores) and takes a ticket of its output tile; the
+    // workgroup that arrives last sums the slabs IN SLAB ORDER (deterministic) into red_out (+= when red_acc).
+    // A single split writes (or adds) straight into red_out.
+    float *red_out;
+    unsigned *ticket;    // one zero-initialised word per output tile; reset by the last arriver
+    int red_acc;
+    // ---- fused multiplicative update (NN, factor-side, one N tile): mu_num != null ----
+    // acc = F G is the MU denominator: F <- F * num / reg(acc)   (cmf_solvers.py:212-228), written to mu_out (= A, in place)
+    const float *mu_num;
+    float *mu_out;
+    float mu_l1, mu_l2, mu_eps;
 };
+
+// write-through (sc1) stores: the bytes leave the XCD's L2 at once, so a workgroup on another XCD can read them after
+// the storing wave's s_waitcnt vmcnt(0) and a ticket, with no release fence (MI355X_MICROARCH.md, publish-large)
+__device__ __forceinline__ void store_wt(float *p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_wt(float *p, f32x2 v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+typedef float f32x1 __attribute__((ext_vector_type(1)));
+__device__ __forceinline__ void store_wt(float *p, f32x1 v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v[0]) : "memory"); }
+__device__ __forceinline__ void store_wt(float *p, float v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
 
 template <int MODE, int BN>
 struct GemmCfg {
@@ -442,33 +462,130 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
     }
     // ---------------------------------------------------------------- epilogue
     if constexpr (MODE != MODE_NT) {
-        float *Cs = g.C + (int64_t)blockIdx.z * g.slab_stride;
+        typedef float vecN __attribute__((ext_vector_type(C::TN)));
+        const int nsplit = (int)gridDim.z;
+        const bool in_red = g.red_out != nullptr;
+        if (ROLE == 1 && MODE == MODE_NN && g.mu_num) {
+            // fused multiplicative update: acc is the denominator F G of this row segment (cmf_solvers.py:212-228).
+            // F and the numerator of EIGHT rows are fetched before any arithmetic: one latency per batch instead of one per row
 #pragma unroll
-        for (int i = 0; i < C::TM; ++i)
+            for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int64_t row = row0 + wrow0 + (C::A_KC ? (32 * i + rr) : (C::TM * rr + i));
-                if (row < g.Mout) {
-                    float *dst = Cs + row * g.ldc + n0 + wcol0 + C::TN * l31;
-                    if constexpr (ROLE == 2) {
-                        static_assert(ROLE != 2 || (MODE == MODE_NN && BN == 256), "batched form: NN, 256 x 256 blocks");
-                        const int rin = wrow0 + 32 * i + rr, c0 = wcol0 + 4 * l31; // coordinates inside the 256 x 256 block
-                        f32x4 v = {g.alpha * acc[i][0][r], g.alpha * acc[i][1][r], g.alpha * acc[i][2][r], g.alpha * acc[i][3][r]};
-                        if (g.D) v += g.beta * *reinterpret_cast<const f32x4 *>(g.D + row * g.ldc + c0);
+                for (int r0 = 0; r0 < 16; r0 += 8) {
+                    vecN f[8], nu[8];
+                    int64_t off[8];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (rin == c0 + j) v[j] += g.gamma;
-                        *reinterpret_cast<f32x4 *>(dst) = v;
-                    } else if constexpr (C::TN == 4) {
-                        *reinterpret_cast<f32x4 *>(dst) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
-                    } else if constexpr (C::TN == 2) {
-                        *reinterpret_cast<f32x2 *>(dst) = f32x2{acc[i][0][r], acc[i][1][r]};
-                    } else {
-                        dst[0] = acc[i][0][r];
+                    for (int q = 0; q < 8; ++q) {
+                        const int r = r0 + q;
+                        const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        off[q] = (row0 + wrow0 + 32 * i + rr) * g.ldc + n0 + wcol0 + C::TN * l31;
+                        f[q] = *reinterpret_cast<const vecN *>(g.A + off[q]);
+                        nu[q] = *reinterpret_cast<const vecN *>(g.mu_num + off[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        vecN o;
+#pragma unroll
+                        for (int j = 0; j < C::TN; ++j) {
+                            float d = acc[i][j][r0 + q];
+                            if (g.mu_l1 > 0.f) d += g.mu_l1;
+                            if (g.mu_l2 > 0.f) d = d + g.mu_l2 * f[q][j];
+                            if (d == 0.f) d = g.mu_eps;
+                            o[j] = f[q][j] * (nu[q][j] / d);
+                        }
+                        *reinterpret_cast<vecN *>(g.mu_out + off[q]) = o;
+                    }
+                }
+        } else {
+            float *Cs = (in_red && nsplit == 1) ? g.red_out : g.C + (int64_t)blockIdx.z * g.slab_stride;
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int64_t row = row0 + wrow0 + (C::A_KC ? (32 * i + rr) : (C::TM * rr + i));
+                    if (row < g.Mout) {
+                        const int64_t off = row * g.ldc + n0 + wcol0 + C::TN * l31;
+                        float *dst = Cs + off;
+                        if constexpr (ROLE == 2) {
+                            static_assert(ROLE != 2 || (MODE == MODE_NN && BN == 256), "batched form: NN, 256 x 256 blocks");
+                            const int rin = wrow0 + 32 * i + rr, c0 = wcol0 + 4 * l31; // coordinates inside the 256 x 256 block
+                            f32x4 v = {g.alpha * acc[i][0][r], g.alpha * acc[i][1][r], g.alpha * acc[i][2][r], g.alpha * acc[i][3][r]};
+                            if (g.D) v += g.beta * *reinterpret_cast<const f32x4 *>(g.D + row * g.ldc + c0);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (rin == c0 + j) v[j] += g.gamma;
+                            *reinterpret_cast<f32x4 *>(dst) = v;
+                        } else {
+                            vecN v;
+#pragma unroll
+                            for (int j = 0; j < C::TN; ++j) v[j] = acc[i][j][r];
+                            if (in_red && nsplit == 1) {
+                                if (g.red_acc) v += *reinterpret_cast<const vecN *>(dst);
+                                *reinterpret_cast<vecN *>(dst) = v;
+                            } else if (in_red) {
+                                store_wt(dst, v);
+                            } else {
+                                *reinterpret_cast<vecN *>(dst) = v;
+                            }
+                        }
+                    }
+                }
+        }
+        if (ROLE != 2 && in_red && nsplit > 1) {
+            // ticket: the last of the nsplit workgroups of this output tile reduces (Guideline 16: every storing wave drains
+            // its write-through stores, workgroup barrier, ONE agent-scope atomic add; the last arriver acquires once)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unsigned *tk = g.ticket + (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+            int *flag = reinterpret_cast<int *>(smem);
+            if (t == 0) {
+                const unsigned old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = (old == (unsigned)(nsplit - 1)) ? 1 : 0;
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
+                }
+                *flag = last;
+            }
+            __syncthreads();
+            if (*flag) {
+                // 16 independent row segments in flight per thread and slab (a dependent chain of single loads made
+                // this reduction latency-bound: 100 us for 1 MB)
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i) {
+                    vecN sum[16];
+                    int64_t offs[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        int64_t row = row0 + wrow0 + (C::A_KC ? (32 * i + rr) : (C::TM * rr + i));
+                        if (row >= g.Mout) row = g.Mout - 1; // clamped: loaded, never stored
+                        offs[r] = row * g.ldc + n0 + wcol0 + C::TN * l31;
+                        if (g.red_acc) sum[r] = *reinterpret_cast<const vecN *>(g.red_out + offs[r]);
+                        else {
+#pragma unroll
+                            for (int j = 0; j < C::TN; ++j) sum[r][j] = 0.f;
+                        }
+                    }
+                    for (int sidx = 0; sidx < nsplit; ++sidx) {
+                        const float *slab = g.C + (int64_t)sidx * g.slab_stride;
+                        vecN part[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) part[r] = *reinterpret_cast<const vecN *>(slab + offs[r]);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sum[r] += part[r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int64_t row = row0 + wrow0 + (C::A_KC ? (32 * i + rr) : (C::TM * rr + i));
+                        if (row < g.Mout) *reinterpret_cast<vecN *>(g.red_out + offs[r]) = sum[r];
                     }
                 }
             }
+        }
     } else {
         float sq = 0.0f;
         // per-lane origin (row of register 0, this lane's column); every element is then a

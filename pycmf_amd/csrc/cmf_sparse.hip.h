@@ -61,6 +61,135 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(CsrView A, const float *F
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Output-stationary, column-blocked SpMM for matrices whose gathered operand does not fit the XCD's 4 MB L2
+// (C5: X V gathers 1 KB rows of a 102 MB V, X^T U of a 1 GB U; one gather per non-zero served by the Infinity Cache /
+// HBM ran at 7.4 TB/s, 52x the compulsory bytes).  Here the non-zeros are regrouped on the host into
+//   row GROUPS  (<= G consecutive rows, G k_pad floats = 128 KB of LDS accumulators, closed early when a group gets
+//                more than its share of non-zeros: nnz-balanced work items), and
+//   column BLOCKS (B gathered rows = 2 MB of the factor),
+// entries sorted by (group, owner wave, block, row).  A persistent 512-thread workgroup per CU takes one group at a time,
+// keeps its G output rows in LDS for the whole pass and sweeps the column blocks IN ORDER; the workgroups that share an
+// XCD (blockIdx % 8, the dispatcher's observed round-robin: a speed assumption only) start every group together
+// (bounded, timing-only counter barrier), so at any moment they gather from the same 2 MB slab, which stays in their
+// L2: every factor row is fetched from the fabric once per XCD and round instead of once per non-zero
+// (reuse = rows in flight per XCD x density = 4096 x 1e-3 = 4.1 at C5).
+// Wave w owns the rows with row % 8 == w: no two waves touch one accumulator, the sum order inside a row is the order
+// of the entry list -- deterministic, no atomics.  Entry metadata is wave-uniform and comes through the scalar cache.
+struct BcsrEntry {
+    int32_t col;   // gathered row of the factor
+    int32_t rowl;  // output row inside the group
+    float val;
+    int32_t pad;
+};
+struct BcsrView {
+    const BcsrEntry *ent;
+    const int64_t *seg;     // [(g * 8 + w) * nsync + i] -> first entry of stretch i of wave w's list for group g; one extra at the end
+    const int32_t *grow;    // first row of group g; ngroups + 1 entries
+    int ngroups;
+    int nsync;              // stretches per list: the class re-aligns between stretches (every few column blocks)
+};
+
+template <int VEC> // floats per lane; k_pad = 64 * VEC
+__global__ __launch_bounds__(512) void spmm_blocked_kernel(BcsrView A, const float *F, float *out, int accumulate, unsigned *bar) {
+    typedef float vec __attribute__((ext_vector_type(VEC)));
+    constexpr int KP = 64 * VEC;
+    constexpr int CH = 16; // gathers issued together; two chunks are in flight (32 KB per wave at k_pad = 256)
+    extern __shared__ __attribute__((aligned(16))) float lacc[]; // [rows of the group][KP]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = blockIdx.x & 7, j = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const int groups_q = (A.ngroups - q + 7) / 8; // groups of this XCD class: q, q + 8, ...
+    unsigned target = 0;
+    for (int round = 0;; ++round) {
+        const int gi = j + per * round; // index inside the class
+        if (gi >= groups_q) break;
+        const int g = q + 8 * gi;
+        const int r0 = A.grow[g], nrows = A.grow[g + 1] - r0;
+        for (int r = w; r < nrows; r += 8) {
+            vec z;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) z[e] = 0.f;
+            *reinterpret_cast<vec *>(lacc + r * KP + lane * VEC) = z;
+        }
+        const int left = groups_q - per * round;
+        const unsigned active = (unsigned)(left < per ? left : per); // workgroups of the class that work in this round
+        // this wave's entry list for the group: sorted by (column block, row, column), cut into nsync stretches of a few
+        // column blocks.  The metadata of 64 entries arrives by ONE coalesced vector load (lane u holds entry u) and is
+        // broadcast with v_readlane; gathers go out 16 at a time, the next chunk's before the current chunk is consumed.
+        const int64_t *segw = A.seg + ((int64_t)g * 8 + w) * A.nsync;
+        int cur = -1;
+        vec racc;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) racc[e] = 0.f;
+        auto flush = [&]() {
+            if (cur >= 0) {
+                vec *p = reinterpret_cast<vec *>(lacc + cur * KP + lane * VEC);
+                *p = *p + racc;
+            }
+        };
+        for (int st = 0; st < A.nsync; ++st) {
+        // timing-only rendezvous of the class in front of every stretch: the workgroups that share an L2 gather from the
+        // same few column blocks at the same time (a long sweep drifts apart by many blocks otherwise: X^T U at C5 walks
+        // 489 blocks in 4.5 ms).  No data passes through it; on a timeout (GPU shared with another process, placement
+        // not as assumed) only L2 locality is lost.
+        target += active;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(bar + 4 * q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int spin = 0; spin < 4000; ++spin) {
+                if (__hip_atomic_load(bar + 4 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        __syncthreads();
+        const int64_t s0 = segw[st], s1 = segw[st + 1];
+        for (int64_t e0 = s0; e0 < s1; e0 += 64) {
+            const int n = (int)(s1 - e0 < 64 ? s1 - e0 : 64);
+            BcsrEntry me;
+            me.col = 0; me.rowl = 0; me.val = 0.f; me.pad = 0;
+            if (lane < n) me = A.ent[e0 + lane];
+            vec x[2][CH];
+            auto issue = [&](int c0, vec *dst) {
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+                    if (c0 + u < n) {
+                        const int col = __builtin_amdgcn_readlane(me.col, c0 + u);
+                        dst[u] = *reinterpret_cast<const vec *>(F + (int64_t)col * KP + lane * VEC);
+                    }
+            };
+            issue(0, x[0]);
+#pragma unroll
+            for (int c = 0; c < 64 / CH; ++c) {
+                const int c0 = c * CH;
+                if (c0 >= n) break;
+                if (c + 1 < 64 / CH) issue(c0 + CH, x[(c + 1) & 1]);
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+                    if (c0 + u < n) {
+                        const int rl = __builtin_amdgcn_readlane(me.rowl, c0 + u);
+                        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, me.val), c0 + u));
+                        if (rl != cur) {
+                            flush();
+                            cur = rl;
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) racc[e] = 0.f;
+                        }
+                        racc += v * x[c & 1][u];
+                    }
+            }
+        }
+        }
+        flush();
+        for (int r = w; r < nrows; r += 8) {
+            vec v = *reinterpret_cast<const vec *>(lacc + r * KP + lane * VEC);
+            vec *dst = reinterpret_cast<vec *>(out + (int64_t)(r0 + r) * KP + lane * VEC);
+            if (accumulate) v += *dst;
+            *dst = v;
+        }
+    }
+}
+
 // cross[wg] = sum over the nonzeros of this workgroup's rows of  a_ij * (L_i . R_j)
 // (the 2 tr((A R)^T L) term of the expanded Frobenius error, sklearn _beta_divergence
 // sparse branch used at pycmf/cmf_solvers.py:40)

@@ -15,6 +15,81 @@ static int csr_upload(cmf_ctx *c, CsrDev &dst, const int64_t *indptr, const int3
     return CMF_OK;
 }
 
+// Regroup a host CSR matrix for spmm_blocked_kernel (see cmf_sparse.hip.h): row groups of at most G rows, closed early
+// once a group holds twice the average share of non-zeros (nnz-balanced work items: a few very long rows do not make
+// one workgroup the straggler of its round); column blocks of B gathered rows; counting sort by (group, block, wave).
+static int bcsr_build_upload(cmf_ctx *c, CsrDev &dst, const int64_t *indptr, const int32_t *indices, const float *vals, int64_t rows,
+                             int64_t cols, int64_t nnz, int G, int64_t B) {
+    std::vector<int32_t> grow;
+    grow.push_back(0);
+    const double cap = std::max(64.0, 2.0 * (double)nnz / (double)std::max<int64_t>(rows, 1) * G);
+    int64_t gn = 0;
+    int cnt = 0;
+    for (int64_t r = 0; r < rows; ++r) {
+        const int64_t rn = indptr[r + 1] - indptr[r];
+        if (cnt > 0 && (cnt == G || (double)(gn + rn) > cap)) { grow.push_back((int32_t)r); gn = 0; cnt = 0; }
+        gn += rn; ++cnt;
+    }
+    grow.push_back((int32_t)rows);
+    const int64_t ngroups = (int64_t)grow.size() - 1;
+    const int64_t nblocks = std::max<int64_t>(1, (cols + B - 1) / B);
+    if (ngroups * nblocks * 8 > ((int64_t)1 << 31)) return CMF_EUNSUPPORTED; // sort table too large: keep the plain CSR kernel
+    // counting sort by key (group, wave, block); inside a key the CSR order (row, column) is kept
+    const int64_t nkey = ngroups * 8 * nblocks;
+    std::vector<int64_t> kcnt((size_t)nkey + 1, 0);
+    for (int64_t g = 0; g < ngroups; ++g)
+        for (int64_t r = grow[g]; r < grow[g + 1]; ++r) {
+            const int64_t base = (g * 8 + ((r - grow[g]) & 7)) * nblocks;
+            for (int64_t q = indptr[r]; q < indptr[r + 1]; ++q) kcnt[(size_t)(base + indices[q] / B) + 1]++;
+        }
+    for (int64_t i = 0; i < nkey; ++i) kcnt[i + 1] += kcnt[i];
+    // stretches between two re-alignments of an XCD class: about 16k entries of a 128-row group (~150 us), whole blocks
+    const double per_block = (double)nnz / (double)std::max<int64_t>(ngroups * nblocks, 1);
+    const double stretch = c->opt_spmm_stretch > 0 ? (double)c->opt_spmm_stretch : 16384.0;
+    const int64_t kblk = std::max<int64_t>(1, (int64_t)(stretch / std::max(per_block, 1.0)));
+    const int64_t nsync = (nblocks + kblk - 1) / kblk;
+    std::vector<int64_t> seg((size_t)(ngroups * 8 * nsync) + 1);
+    for (int64_t i = 0; i < ngroups * 8; ++i)
+        for (int64_t st = 0; st < nsync; ++st) seg[(size_t)(i * nsync + st)] = kcnt[(size_t)(i * nblocks + std::min(st * kblk, nblocks))];
+    seg[(size_t)(ngroups * 8 * nsync)] = nnz;
+    std::vector<cmfk::BcsrEntry> ent((size_t)std::max<int64_t>(nnz, 1));
+    for (int64_t g = 0; g < ngroups; ++g)
+        for (int64_t r = grow[g]; r < grow[g + 1]; ++r) {
+            const int32_t rl = (int32_t)(r - grow[g]);
+            const int64_t base = (g * 8 + (rl & 7)) * nblocks;
+            for (int64_t q = indptr[r]; q < indptr[r + 1]; ++q) {
+                const int64_t pos = kcnt[(size_t)(base + indices[q] / B)]++;
+                ent[pos] = cmfk::BcsrEntry{indices[q], rl, vals[q], 0};
+            }
+        }
+    CHK(dev_alloc(c, (void **)&dst.b_ent, ent.size() * sizeof(cmfk::BcsrEntry), false));
+    CHK(dev_alloc(c, (void **)&dst.b_seg, seg.size() * sizeof(int64_t), false));
+    CHK(dev_alloc(c, (void **)&dst.b_grow, grow.size() * sizeof(int32_t), false));
+    HIPCHK(hipMemcpyAsync(dst.b_ent, ent.data(), ent.size() * sizeof(cmfk::BcsrEntry), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dst.b_seg, seg.data(), seg.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dst.b_grow, grow.data(), grow.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dst.b_ngroups = (int)ngroups; dst.b_nblocks = (int)nblocks; dst.b_rows_per_group = G; dst.b_nsync = (int)nsync;
+    return CMF_OK;
+}
+
+// rows per group: as many as the LDS holds (150 KB of accumulators), then shrunk so that the groups fill whole rounds of the
+// persistent grid (782 groups on 256 workgroups would leave a fourth round with 14 of them busy)
+static int bcsr_group_rows(const cmf_ctx *c, int64_t rows) {
+    const int64_t gmax = std::max<int64_t>(8, std::min<int64_t>(256, (150 * 1024) / (c->kp * 4)));
+    const int64_t grid = std::max(8, (c->num_cu / 8) * 8);
+    const int64_t rounds = std::max<int64_t>(1, (rows + gmax * grid - 1) / (gmax * grid));
+    int64_t g = (rows + rounds * grid - 1) / (rounds * grid);
+    g = std::min(gmax, std::max<int64_t>(8, (g + 7) / 8 * 8)); // whole octets: wave w owns the rows with row % 8 == w
+    return (int)g;
+}
+
+// should this orientation get the blocked regrouping?  (k_pad 64 / 128 / 256; gathered operand = cols x k_pad floats)
+static bool want_blocked(const cmf_ctx *c, int64_t cols) {
+    if (c->opt_spmm_blocked == 0 || !(c->kp == 64 || c->kp == 128 || c->kp == 256)) return false;
+    return c->opt_spmm_blocked == 2 || (double)cols * c->kp * 4.0 > 16.0 * 1024 * 1024;
+}
+
 // keep A as CSR and as CSR of A^T (counting sort on the host, O(nnz))
 static int set_data_csr_native(cmf_ctx *c, int which, const int64_t *indptr, const int32_t *indices, const double *data, int64_t nnz,
                                int64_t rows, int64_t cols) {
@@ -52,6 +127,11 @@ static int set_data_csr_native(cmf_ctx *c, int which, const int64_t *indptr, con
         sq += (double)vals[q] * (double)vals[q];
     }
     CHK(csr_upload(c, c->sp[which][0], indptr, indices, vals.data(), rows, cols, nnz));
+    const int64_t B = c->opt_spmm_block_cols > 0 ? c->opt_spmm_block_cols : std::max<int64_t>(256, (2 * 1024 * 1024) / (c->kp * 4));
+    if (want_blocked(c, cols)) {
+        const int rc = bcsr_build_upload(c, c->sp[which][0], indptr, indices, vals.data(), rows, cols, nnz, bcsr_group_rows(c, rows), B);
+        if (rc != CMF_OK && rc != CMF_EUNSUPPORTED) return rc;
+    }
     // transpose
     std::vector<int64_t> tptr((size_t)cols + 1, 0);
     for (int64_t q = 0; q < nnz; ++q) tptr[indices[q] + 1]++;
@@ -66,6 +146,10 @@ static int set_data_csr_native(cmf_ctx *c, int which, const int64_t *indptr, con
             tval[pos] = vals[q];
         }
     CHK(csr_upload(c, c->sp[which][1], tptr.data(), tidx.data(), tval.data(), cols, rows, nnz));
+    if (want_blocked(c, rows)) {
+        const int rc = bcsr_build_upload(c, c->sp[which][1], tptr.data(), tidx.data(), tval.data(), cols, rows, nnz, bcsr_group_rows(c, cols), B);
+        if (rc != CMF_OK && rc != CMF_EUNSUPPORTED) return rc;
+    }
     c->sparse[which] = true;
     c->sp_sq[which] = sq;
     return CMF_OK;
@@ -86,6 +170,25 @@ static int spmm(cmf_ctx *c, const CsrDev &A, const float *F, float *out, int64_t
         HIPCHK(hipMemsetAsync(out + A.rows * width, 0, (size_t)(rows_pad - A.rows) * width * sizeof(float), c->stream));
     CsrView v{A.indptr, A.idx, A.val, A.rows};
     Timed tm(c, CMF_K_SPMM, 2.0 * (double)A.nnz * (double)width);
+    if (A.b_ent && width == c->kp) { // column-blocked, output-stationary form
+        CHK(ensure(c, c->spmm_bar, 8 * 16));
+        HIPCHK(hipMemsetAsync(c->spmm_bar.p, 0, 8 * 16, c->stream));
+        BcsrView bv{A.b_ent, A.b_seg, A.b_grow, A.b_ngroups, A.b_nsync};
+        const unsigned grid = (unsigned)std::max(8, (c->num_cu / 8) * 8);
+        const size_t lds = (size_t)A.b_rows_per_group * width * sizeof(float);
+#define CMF_SPMMB(V_)                                                                                                     \
+    do {                                                                                                                  \
+        CHK(allow_big_lds(c, reinterpret_cast<const void *>(&spmm_blocked_kernel<V_>), 156 * 1024));                      \
+        hipLaunchKernelGGL((spmm_blocked_kernel<V_>), dim3(grid), dim3(512), lds, c->stream, bv, F, out, accumulate ? 1 : 0, \
+                           (unsigned *)c->spmm_bar.p);                                                                   \
+    } while (0)
+        if (width == 256) CMF_SPMMB(4);
+        else if (width == 128) CMF_SPMMB(2);
+        else CMF_SPMMB(1);
+#undef CMF_SPMMB
+        HIPCHK(hipGetLastError());
+        return CMF_OK;
+    }
     switch (width) {
     case 32: launch_spmm<8, 1>(c, v, F, out, accumulate, width); break;
     case 64: launch_spmm<16, 1>(c, v, F, out, accumulate, width); break;

@@ -102,3 +102,56 @@ def test_native_csr_newton_golden(lib, name, monkeypatch):
         ref = g["%s_csr_%s1" % (name, n)]
         np.testing.assert_allclose(a, ref, rtol=5e-4, atol=5e-4 * max(1.0, np.abs(ref).max()))
     s.release()
+
+
+@pytest.mark.parametrize("k", [40, 100, 256])
+@pytest.mark.parametrize("skew", [False, True])
+def test_blocked_spmm_equals_row_kernel(lib, k, skew):
+    """The column-blocked, output-stationary SpMM (persistent workgroups, LDS accumulators, entries regrouped on the host
+    by row group x column block x owner wave) against the one-wave-per-row CSR kernel on the same matrices: a MU
+    iteration and a linear Newton iteration use A F and A^T F of both X and Y.  `skew`: a heavy-tailed row-length
+    distribution with a few dense rows and empty rows (nnz-balanced groups close early; a column block can be empty)."""
+    rng = np.random.RandomState(17 + k)
+    m, d, p = 1100, 700, 300
+    if skew:
+        per_row = np.minimum(d, (rng.pareto(1.1, m) * 2).astype(int))
+        per_row[:3] = d
+        per_row[100:140] = 0
+        indptr = np.concatenate([[0], np.cumsum(per_row)])
+        idx = np.concatenate([np.sort(rng.choice(d, n, replace=False)) for n in per_row if n > 0] or [np.zeros(0, int)])
+        X = sp.csr_matrix((np.abs(rng.randn(indptr[-1])) + 0.1, idx, indptr), shape=(m, d))
+        Y = sp.random(d, p, density=0.05, random_state=rng, format="csr", data_rvs=lambda n: np.abs(rng.randn(n)) + 0.1)
+        U0, V0, Z0 = (0.3 * np.abs(rng.randn(n, k)) for n in (m, d, p))
+    else:
+        X, Y, U0, V0, Z0 = _sparse_problem(k, m, d, p, k, 0.02)
+    outs = []
+    for blocked in (0, 2):
+        ctx = lib.Context(0)
+        ctx.set_option("sparse_mode", 2)
+        ctx.set_option("spmm_blocked", blocked)
+        ctx.set_option("spmm_block_cols", 64)      # several column blocks even at these sizes
+        ctx.set_problem(m, d, p, k)
+        ctx.set_data(0, X); ctx.set_data(1, Y)
+        for w, F in enumerate((U0, V0, Z0)):
+            ctx.set_factor(w, F)
+        ctx.mu_step(0.01, 0.02, 7)
+        mu = [ctx.get_factor(w) for w in range(3)]
+        ctx.newton_step(0.4, 0.01, 0.1, "linear", "linear", 0, 7, 0.2, 1.0)
+        outs.append(mu + [ctx.get_factor(w) for w in range(3)])
+        ctx.close()
+    for i, (a, b) in enumerate(zip(*outs)):
+        # same products, a different (fixed) summation order; the Newton step multiplies that by cond(H) (1e3 .. 1e4 here)
+        tol = 2e-5 if i < 3 else 5e-3
+        np.testing.assert_allclose(a, b, rtol=tol, atol=tol * np.abs(b).max())
+    # and the blocked kernel is a pure function of its inputs
+    ctx = lib.Context(0)
+    ctx.set_option("sparse_mode", 2); ctx.set_option("spmm_blocked", 2); ctx.set_option("spmm_block_cols", 64)
+    ctx.set_problem(m, d, p, k)
+    ctx.set_data(0, X); ctx.set_data(1, Y)
+    for w, F in enumerate((U0, V0, Z0)):
+        ctx.set_factor(w, F)
+    ctx.mu_step(0.01, 0.02, 7)
+    ctx.newton_step(0.4, 0.01, 0.1, "linear", "linear", 0, 7, 0.2, 1.0)
+    for w in range(3):
+        np.testing.assert_array_equal(ctx.get_factor(w), outs[1][3 + w])
+    ctx.close()
