@@ -127,7 +127,7 @@ struct cmf_ctx {
     int opt_sparse = 0;               // 0 auto, 1 always expand to dense, 2 always native CSR
     int opt_spmm_blocked = 1;         // column-blocked output-stationary SpMM: 0 never | 1 when the gathered operand exceeds L2 | 2 always
     int64_t opt_spmm_block_cols = 0;  // gathered rows per column block (0: 2 MB worth)
-    int64_t opt_spmm_stretch = 0;     // entries of a group between two re-alignments of its XCD class (0: 16384)
+    int64_t opt_spmm_stretch = 0;     // entries of a group between two re-alignments of its XCD class (0: 8192)
     DevBuf spmm_bar;                  // rendezvous counters of the blocked SpMM (8 x 16 bytes)
     float *F[3] = {nullptr, nullptr, nullptr};
     int64_t frows[3] = {0, 0, 0}, frows_pad[3] = {0, 0, 0};
@@ -358,10 +358,13 @@ static int sum_slabs(cmf_ctx *c, float *dst, const float *src, int64_t n, int ns
 
 static int mu_apply(cmf_ctx *c, float *F, const float *num, const float *den, int64_t n, double l1, double l2);
 
-struct MuEpilogue { // fused multiplicative update of the factor-side product F G (gemm_kernel, mu_num != null)
-    const float *num = nullptr;
-    float *F = nullptr;
-    double l1 = 0.0, l2 = 0.0;
+struct Epilogue { // fused factor update in the epilogue of a factor-side product (gemm_kernel, epi != 0)
+    int kind = 0;           // EPI_MU | EPI_GRAD | EPI_APPLY
+    const float *F = nullptr, *P = nullptr;
+    float *out = nullptr;
+    double a = 0.0, b = 0.0, c = 0.0;
+    int64_t rows = 0;
+    int kvalid = 0, nn = 0;
 };
 
 // C[mout x n] (+)= op(A) * B.  mode NN: A is [mout_pad x kred]; TN: A is [kred x >=mout].
@@ -370,7 +373,7 @@ struct MuEpilogue { // fused multiplicative update of the factor-side product F 
 // `A` is a factor-sized operand when lda == k_pad (Grams, F*G, step products): those launches
 // use the ROLE=1 symbol and the CMF_K_GEMM_SMALL timing class.
 static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *B, int64_t ldb, float *out,
-                int64_t mout, int64_t n, int64_t kred, bool accumulate = false, const MuEpilogue *mu = nullptr) {
+                int64_t mout, int64_t n, int64_t kred, bool accumulate = false, const Epilogue *mu = nullptr) {
     const bool data_pass = (lda != c->kp);
     if (kred % 32 || n % 32) return fail(CMF_EINVAL, "gemm: unpadded extent (k=%lld n=%lld)", (long long)kred, (long long)n);
     GemmPlan pl = plan_gemm(c, mout, n, kred, mu == nullptr);
@@ -387,7 +390,9 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
     const bool direct = (pl.nsplit == 1 && !accumulate);
     if (mu) {
         if (mode != MODE_NN || pl.ntiles_n != 1 || pl.nsplit != 1) return fail(CMF_EINVAL, "fused update needs one N tile and no split");
-        a.mu_num = mu->num; a.mu_out = mu->F; a.mu_l1 = (float)mu->l1; a.mu_l2 = (float)mu->l2; a.mu_eps = 1.1920928955078125e-07f;
+        a.epi = mu->kind; a.epi_F = mu->F; a.epi_P = mu->P; a.epi_out = mu->out;
+        a.epi_a = (float)mu->a; a.epi_b = (float)mu->b; a.epi_c = (float)mu->c;
+        a.epi_rows = mu->rows; a.epi_kvalid = mu->kvalid; a.epi_nn = mu->nn;
         a.C = out; // unused
     } else if (direct) {
         a.C = out;
@@ -428,9 +433,9 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
 // product has a single N tile (k_pad <= 256), else product + elementwise kernel
 static int mu_update(cmf_ctx *c, float *F, const float *G, const float *num, int64_t rows_pad, double l1, double l2) {
     if (c->opt_fused_mu && c->kp <= 256) {
-        MuEpilogue mu;
-        mu.num = num; mu.F = F; mu.l1 = l1; mu.l2 = l2;
-        return gemm(c, MODE_NN, F, c->kp, G, c->kp, c->den, rows_pad, c->kp, c->kp, false, &mu);
+        Epilogue e;
+        e.kind = EPI_MU; e.F = F; e.P = num; e.out = F; e.a = l1; e.b = l2; e.c = 1.1920928955078125e-07;
+        return gemm(c, MODE_NN, F, c->kp, G, c->kp, c->den, rows_pad, c->kp, c->kp, false, &e);
     }
     CHK(gemm(c, MODE_NN, F, c->kp, G, c->kp, c->den, rows_pad, c->kp, c->kp));
     return mu_apply(c, F, num, c->den, rows_pad * c->kp, l1, l2);

@@ -58,12 +58,21 @@ struct GemmArgs {
     float *red_out;
     unsigned *ticket;    // one zero-initialised word per output tile; reset by the last arriver
     int red_acc;
-    // ---- fused multiplicative update (NN, factor-side, one N tile): mu_num != null ----
-    // acc = F G is the MU denominator: F <- F * num / reg(acc)   (cmf_solvers.py:212-228), written to mu_out (= A, in place)
-    const float *mu_num;
-    float *mu_out;
-    float mu_l1, mu_l2, mu_eps;
+    // ---- fused factor update (NN, factor-side product with one N tile): epi != 0 ----
+    //  EPI_MU     acc = F G is the MU denominator: F <- F * P / reg(acc)                    (cmf_solvers.py:212-228)
+    //             epi_F = F (= A), epi_P = numerator, a = l1, b = l2, c = eps, written to epi_out (= F, in place)
+    //  EPI_GRAD   acc = F G: grad = a acc - a P + b sign(F) + c F                            (:399-400, :436-440)
+    //             epi_F = F (= A), epi_P = data term, a = scale, b = l1, c = l2, written to epi_out
+    //  EPI_APPLY  acc = grad H^-1 is the Newton step: F <- clamp(F - acc), zero outside the valid block   (:321-326)
+    //             epi_F = F, written to epi_out (= F)
+    int epi;
+    const float *epi_F, *epi_P;
+    float *epi_out;
+    float epi_a, epi_b, epi_c;
+    int64_t epi_rows;
+    int epi_kvalid, epi_nn;
 };
+enum { EPI_NONE = 0, EPI_MU = 1, EPI_GRAD = 2, EPI_APPLY = 3 };
 
 // write-through (sc1) stores: the bytes leave the XCD's L2 at once, so a workgroup on another XCD can read them after
 // the storing wave's s_waitcnt vmcnt(0) and a ticket, with no release fence (MI355X_MICROARCH.md, publish-large)
@@ -465,35 +474,54 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
         typedef float vecN __attribute__((ext_vector_type(C::TN)));
         const int nsplit = (int)gridDim.z;
         const bool in_red = g.red_out != nullptr;
-        if (ROLE == 1 && MODE == MODE_NN && g.mu_num) {
-            // fused multiplicative update: acc is the denominator F G of this row segment (cmf_solvers.py:212-228).
-            // F and the numerator of EIGHT rows are fetched before any arithmetic: one latency per batch instead of one per row
+        if (ROLE == 1 && MODE == MODE_NN && g.epi != EPI_NONE) {
+            // fused factor update.  F and the second operand of EIGHT rows are fetched before any arithmetic: one latency per
+            // batch instead of one per row
 #pragma unroll
             for (int i = 0; i < C::TM; ++i)
 #pragma unroll
                 for (int r0 = 0; r0 < 16; r0 += 8) {
-                    vecN f[8], nu[8];
+                    vecN f[8], pv[8];
                     int64_t off[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const int r = r0 + q;
                         const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
                         off[q] = (row0 + wrow0 + 32 * i + rr) * g.ldc + n0 + wcol0 + C::TN * l31;
-                        f[q] = *reinterpret_cast<const vecN *>(g.A + off[q]);
-                        nu[q] = *reinterpret_cast<const vecN *>(g.mu_num + off[q]);
+                        f[q] = *reinterpret_cast<const vecN *>(g.epi_F + off[q]);
+                        if (g.epi != EPI_APPLY) pv[q] = *reinterpret_cast<const vecN *>(g.epi_P + off[q]);
                     }
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
+                        const int r = r0 + q;
+                        const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int64_t row = row0 + wrow0 + 32 * i + rr;
                         vecN o;
 #pragma unroll
                         for (int j = 0; j < C::TN; ++j) {
-                            float d = acc[i][j][r0 + q];
-                            if (g.mu_l1 > 0.f) d += g.mu_l1;
-                            if (g.mu_l2 > 0.f) d = d + g.mu_l2 * f[q][j];
-                            if (d == 0.f) d = g.mu_eps;
-                            o[j] = f[q][j] * (nu[q][j] / d);
+                            const float av = acc[i][j][r], fv = f[q][j];
+                            float res;
+                            if (g.epi == EPI_MU) {
+                                float d = av;
+                                if (g.epi_a > 0.f) d += g.epi_a;
+                                if (g.epi_b > 0.f) d = d + g.epi_b * fv;
+                                if (d == 0.f) d = g.epi_c;
+                                res = fv * (pv[q][j] / d);
+                            } else if (g.epi == EPI_GRAD) {
+                                const float sg = (fv > 0.f) ? 1.f : ((fv < 0.f) ? -1.f : 0.f);
+                                float gval = g.epi_a * av;
+                                gval += -g.epi_a * pv[q][j];
+                                res = gval + g.epi_b * sg + g.epi_c * fv;
+                            } else {
+                                res = 0.f;
+                                if (row < g.epi_rows && (int)(n0 + wcol0 + C::TN * l31 + j) < g.epi_kvalid) {
+                                    res = fv - av;
+                                    if (g.epi_nn && res < 0.f) res = 0.f;
+                                }
+                            }
+                            o[j] = res;
                         }
-                        *reinterpret_cast<vecN *>(g.mu_out + off[q]) = o;
+                        *reinterpret_cast<vecN *>(g.epi_out + off[q]) = o;
                     }
                 }
         } else {

@@ -350,29 +350,37 @@ static int shared_inverse64(cmf_ctx *c, const double *H64, int n, double pert, b
     const int rp = (int)std::max<int64_t>(1, std::min<int64_t>(32, ((int64_t)150 * 1024 - 128 * (int64_t)n) / (8 * ((int64_t)n + 2))));
     const size_t tri_lds = ((size_t)16 * n + (size_t)rp * (n + 2)) * sizeof(double);
     auto inverse_from = [&](const double *L) -> int { // Hinv = L^-T L^-1
-        CHK(allow_big_lds(c, reinterpret_cast<const void *>(&tri_inverse64_kernel), 152 * 1024));
-        hipLaunchKernelGGL(tri_inverse64_kernel, dim3((unsigned)(kp / 16)), dim3(256), tri_lds, c->stream, L, n, kp, Xt, kp, kp, rp);
+        if (kp <= 128) {
+            hipLaunchKernelGGL((tri_inverse64_reg_kernel<8>), dim3((unsigned)(kp / 16)), dim3(256), 0, c->stream, L, n, kp, Xt, kp, kp);
+        } else if (kp <= 256) {
+            hipLaunchKernelGGL((tri_inverse64_reg_kernel<16>), dim3((unsigned)(kp / 16)), dim3(256), 0, c->stream, L, n, kp, Xt, kp, kp);
+        } else {
+            CHK(allow_big_lds(c, reinterpret_cast<const void *>(&tri_inverse64_kernel), 152 * 1024));
+            hipLaunchKernelGGL(tri_inverse64_kernel, dim3((unsigned)(kp / 16)), dim3(256), tri_lds, c->stream, L, n, kp, Xt, kp, kp, rp);
+        }
         HIPCHK(hipGetLastError());
         return gemm64(c, true, Xt, Xt, nullptr, nullptr, 1.0, 0.0, 0.0, c->Hinv, n);
     };
-    hipLaunchKernelGGL(chol64_kernel, dim3(2), dim3(1024), 0, c->stream, H64, n, kp, W0, (int64_t)kk, kp, pert, 0.0, flags);
+    auto launch_chol = [&](const double *Hm, int nwg, double sh0, double sh1) {
+        if (n <= 128) hipLaunchKernelGGL((chol64_reg_kernel<4>), dim3(nwg), dim3(1024), 0, c->stream, Hm, n, kp, W0, (int64_t)kk, kp, sh0, sh1, flags);
+        else if (n <= 256) hipLaunchKernelGGL((chol64_reg_kernel<8>), dim3(nwg), dim3(1024), 0, c->stream, Hm, n, kp, W0, (int64_t)kk, kp, sh0, sh1, flags);
+        else hipLaunchKernelGGL(chol64_kernel, dim3(nwg), dim3(1024), 0, c->stream, Hm, n, kp, W0, (int64_t)kk, kp, sh0, sh1, flags);
+    };
+    launch_chol(H64, 2, pert, 0.0);
     HIPCHK(hipGetLastError());
-    // the spectral clamp needs c = min(||B||_F, ||B||_inf) of B = H - pert I on the host (iteration count): form it now so
-    // that ONE read-back serves both decisions
     CHK(ensure(c, c->ns64, 6 * kk * sizeof(double) + 16));
     double *Bm = (double *)c->ns64.p, *X = Bm + kk, *X2 = X + kk, *Y = X2 + kk, *Z = Y + kk, *M = Z + kk;
     double *cnorm = M + kk;
-    if (psd) {
-        hipLaunchKernelGGL(ns64_prepare_kernel, dim3(1), dim3(1024), 0, c->stream, H64, Bm, X, n, kp, pert, cnorm);
-        HIPCHK(hipGetLastError());
-    }
     int hflags[2] = {0, 0};
     double hc = 1.0;
     HIPCHK(hipMemcpyAsync(hflags, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    if (psd) HIPCHK(hipMemcpyAsync(&hc, cnorm, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (!hflags[0] && !hflags[1]) return inverse_from(W1); // lambda_min >= pert: the clamp is the identity
     if (psd) {
+        hipLaunchKernelGGL(ns64_prepare_kernel, dim3(1), dim3(1024), 0, c->stream, H64, Bm, X, n, kp, pert, cnorm);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&hc, cnorm, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
         // M = max(H, pert I) = (sign(B) B + B) / 2 + pert I, sign(B) by odd polynomials of X0 = B / c (see ns_clamp_images);
         // float64 resolves eigenvalues down to 1e-6 pert from the threshold
         const double delta = 1e-6 * pert;
@@ -390,7 +398,7 @@ static int shared_inverse64(cmf_ctx *c, const double *H64, int n, double pert, b
             std::swap(X, X2);
         }
         CHK(gemm64(c, false, X, Bm, M, Bm, 0.5, 0.5, pert));
-        hipLaunchKernelGGL(chol64_kernel, dim3(1), dim3(1024), 0, c->stream, (const double *)M, n, kp, W0, (int64_t)kk, kp, 0.0, 0.0, flags);
+        launch_chol((const double *)M, 1, 0.0, 0.0);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(hflags, flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -416,6 +424,11 @@ static int shared_step(cmf_ctx *c, int which, double pert, bool non_negative) {
         }
     }
     if (!done) CHK(safe_inverse_dev(c, c->Hm, c->Hinv, 1, c->k, c->kp, pert, c->hess_psd));
+    if (c->opt_fused_mu && c->kp <= 256) { // F <- clamp(F - grad H^-1) in the epilogue of the step product
+        Epilogue e;
+        e.kind = EPI_APPLY; e.F = c->F[which]; e.out = c->F[which]; e.rows = c->frows[which]; e.kvalid = c->k; e.nn = non_negative ? 1 : 0;
+        return gemm(c, MODE_NN, c->den, c->kp, c->Hinv, c->kp, c->num, rows, c->kp, c->kp, false, &e);
+    }
     CHK(gemm(c, MODE_NN, c->den, c->kp, c->Hinv, c->kp, c->num, rows, c->kp, c->kp));
     return launch_ew(c, newton_apply_kernel, rows * c->kp, c->F[which], (const float *)c->num, c->frows[which], c->kp, c->k,
                      rows * c->kp, non_negative ? 1 : 0);
@@ -453,9 +466,15 @@ static int sweep_side_shared(cmf_ctx *c, bool is_u, double scale, double l1, dou
     }
     if (is_u) CHK(data_times(c, 0, false, V, c->num)); // X V
     else CHK(data_times(c, 1, true, V, c->num));       // Y^T V
-    CHK(gemm(c, MODE_NN, F, c->kp, c->G2, c->kp, c->den, rows, c->kp, c->kp));           // F (V^T V)
-    CHK(launch_ew(c, newton_grad_kernel, rows * c->kp, c->den, (const float *)c->den, (float)scale, (const float *)c->num,
-                  (float)-scale, (const float *)F, (float)l1, (float)l2, rows * c->kp));
+    if (c->opt_fused_mu && c->kp <= 256) { // grad = s (F G - T O) + l1 sign F + l2 F in the epilogue of F (V^T V)
+        Epilogue e;
+        e.kind = EPI_GRAD; e.F = F; e.P = c->num; e.out = c->den; e.a = scale; e.b = l1; e.c = l2;
+        CHK(gemm(c, MODE_NN, F, c->kp, c->G2, c->kp, c->den, rows, c->kp, c->kp, false, &e));
+    } else {
+        CHK(gemm(c, MODE_NN, F, c->kp, c->G2, c->kp, c->den, rows, c->kp, c->kp));           // F (V^T V)
+        CHK(launch_ew(c, newton_grad_kernel, rows * c->kp, c->den, (const float *)c->den, (float)scale, (const float *)c->num,
+                      (float)-scale, (const float *)F, (float)l1, (float)l2, rows * c->kp));
+    }
     if (f64) CHK(launch_hess64(c, (const double *)c->g64a.p, scale, nullptr, 0.0, l2));
     else CHK(launch_ew(c, axpby_diag_kernel, (int64_t)c->kp * c->kp, c->Hm, (const float *)c->G2, (float)scale,
                        (const float *)nullptr, 0.f, (float)l2, c->kp, c->k));
@@ -502,9 +521,15 @@ extern "C" int cmf_newton_v_apply(cmf_ctx *c, const float *buf, double l1, doubl
     float *V = c->F[CMF_V];
     const bool mix64 = c->gmix64_valid; // armed by cmf_newton_step only
     c->gmix64_valid = false;
-    CHK(gemm(c, MODE_NN, V, c->kp, Gs, c->kp, c->den, c->dp, c->kp, c->kp)); // V Gmix
-    CHK(launch_ew(c, newton_grad_kernel, c->dp * c->kp, c->den, (const float *)c->den, 1.0f, P, -1.0f, (const float *)V,
-                  (float)l1, (float)l2, c->dp * c->kp));
+    if (c->opt_fused_mu && c->kp <= 256) {
+        Epilogue e;
+        e.kind = EPI_GRAD; e.F = V; e.P = P; e.out = c->den; e.a = 1.0; e.b = l1; e.c = l2;
+        CHK(gemm(c, MODE_NN, V, c->kp, Gs, c->kp, c->den, c->dp, c->kp, c->kp, false, &e)); // V Gmix - P + reg
+    } else {
+        CHK(gemm(c, MODE_NN, V, c->kp, Gs, c->kp, c->den, c->dp, c->kp, c->kp)); // V Gmix
+        CHK(launch_ew(c, newton_grad_kernel, c->dp * c->kp, c->den, (const float *)c->den, 1.0f, P, -1.0f, (const float *)V,
+                      (float)l1, (float)l2, c->dp * c->kp));
+    }
     if (use_shared64(c)) {
         CHK(ensure_shared64(c));
         if (mix64) {

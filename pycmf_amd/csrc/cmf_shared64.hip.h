@@ -395,6 +395,90 @@ __global__ __launch_bounds__(1024) void chol64_kernel(const double *H, int n, in
     }
 }
 
+// Register-resident Cholesky for n <= 32 NB (NB = 4: n <= 128, NB = 8: n <= 256): the float64 twin of chol_solve_kernel's
+// factorisation.  1024 threads as a 32 x 32 grid; thread (ti, tc) owns the elements (i, c) = (32 a + ti, 32 b + tc), b <= a,
+// of the lower triangle: NB (NB + 1) / 2 doubles (36 at n = 256) that never leave its registers.  A column step: the
+// owners of column j publish it UNscaled, with the pivot, into one of two LDS buffers; after ONE barrier every thread
+// fetches its NB row values and NB column values and applies the rank-1 update divided by the pivot (so it needs no
+// scaled column), while the owners scale their own column.  256 steps of ~450 cycles: ~50 us, against 530 us for the
+// blocked kernel below working out of L2.  Workgroup b factors H - shift_b I; L goes to W_b (lower triangle).
+template <int NB>
+__global__ __launch_bounds__(1024) void chol64_reg_kernel(const double *H, int n, int ldh, double *Wbase, int64_t wstride, int ld,
+                                                         double shift0, double shift1, int *flag) {
+    constexpr int CB = 32 * NB + 2;
+    __shared__ __attribute__((aligned(16))) double col[2 * CB];
+    __shared__ double red[16];
+    const int t = threadIdx.x, ti = t & 31, tc = t >> 5, lane = t & 63, wid = t >> 6;
+    double *W = Wbase + (int64_t)blockIdx.x * wstride;
+    const double shift = blockIdx.x == 0 ? shift0 : shift1;
+    double dmax = 0.0;
+    for (int i = t; i < n; i += 1024) dmax = fmax(dmax, fabs(H[(int64_t)i * ldh + i]));
+    for (int off = 32; off > 0; off >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
+    if (lane == 0) red[wid] = dmax;
+    __syncthreads();
+    dmax = 0.0;
+    for (int q = 0; q < 16; ++q) dmax = fmax(dmax, red[q]);
+    const double floor_ = shift != 0.0 ? 1.0e-13 * dmax : 0.0;
+    double M[NB][NB];
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            const int i = 32 * a + ti, c = 32 * b + tc;
+            double v = (i == c) ? 1.0 : 0.0; // identity outside the valid block
+            if (i < n && c < n) v = H[(int64_t)c * ldh + i] - (i == c ? shift : 0.0); // H symmetric: read along the row of c
+            M[a][b] = v;
+        }
+    if (t == 0) flag[blockIdx.x] = 0;
+    bool ok = true;
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) {
+        for (int jl = 0; jl < 32; ++jl) {
+            const int j = 32 * jb + jl;
+            if (j >= n) break;
+            double *cb = col + (jl & 1) * CB;
+            if (tc == jl) { // owners of column j: rows i = 32 a + ti
+#pragma unroll
+                for (int a = 0; a < NB; ++a) cb[a * 32 + ti] = (a >= jb && 32 * a + ti > j) ? M[a][jb] : 0.0; // [a][ti]: conflict-free
+                if (ti == jl) cb[32 * NB] = M[jb][jb]; // the pivot sits in thread (jl, jl)
+            }
+            __syncthreads();
+            const double d = cb[32 * NB];
+            if (!(d > floor_)) { ok = false; break; }
+            const double inv = 1.0 / d;
+            double li[NB], lc[NB];
+#pragma unroll
+            for (int a = 0; a < NB; ++a) { li[a] = cb[a * 32 + ti]; lc[a] = cb[a * 32 + tc] * inv; }
+#pragma unroll
+            for (int a = jb; a < NB; ++a)
+#pragma unroll
+                for (int b = jb; b <= a; ++b)
+                    if (b > jb || tc > jl) M[a][b] -= li[a] * lc[b];
+            if (tc == jl) { // scale the finished column: L[i][j] = A[i][j] / sqrt(d), L[j][j] = sqrt(d)
+                const double is = 1.0 / sqrt(d);
+#pragma unroll
+                for (int a = jb; a < NB; ++a) {
+                    const int i = 32 * a + ti;
+                    if (i > j) M[a][jb] *= is;
+                    else if (i == j) M[a][jb] = sqrt(d);
+                }
+            }
+        }
+        if (!ok) break;
+    }
+    if (!ok) {
+        if (t == 0) flag[blockIdx.x] = 1;
+        return;
+    }
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            const int i = 32 * a + ti, c = 32 * b + tc;
+            if (i < n && c <= i) W[(int64_t)i * ld + c] = M[a][b];
+        }
+}
+
 // Xt[c][i] = (L^-1)[i][c]  (row c of Xt = column c of the inverse of the lower-triangular L; zero for i < c).
 // Workgroup = 16 columns x 16 lanes; rows of L pass through LDS rp at a time; y lives in LDS ([n][16]).
 // Rows of Xt beyond n are zero.
@@ -429,6 +513,73 @@ __global__ __launch_bounds__(256) void tri_inverse64_kernel(const double *L, int
         const int cc = idx / kp, i = idx % kp;
         if (c0 + cc < kp) Xt[(int64_t)(c0 + cc) * ldx + i] = (i < n && c0 + cc < n) ? Y[i * 16 + cc] : 0.0;
     }
+}
+
+// 16-lane sums of doubles on the VALU (DPP row operations on the two halves of the double) instead of ds_bpermute
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double group16_sum_f64_dpp(double v) {
+    v += dpp_move_f64<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_move_f64<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dpp_move_f64<0x141>(v); // row_half_mirror
+    v += dpp_move_f64<0x140>(v); // row_mirror
+    return v;
+}
+
+// The same inverse with the solution in REGISTERS (n <= 16 NM; NM = 8: n <= 128, NM = 16: n <= 256): lane q of a column's
+// 16-lane group holds y_u for the rows u = q (mod 16).  A row step is 16 (NM) LDS reads of the staged row of L, NM fused
+// multiply-adds, four DPP additions and one multiplication by the pre-inverted diagonal -- no barrier inside a panel
+// (the 16 lanes of a column sit in one wave), ~250 cycles per row instead of ~2000.
+template <int NM>
+__global__ __launch_bounds__(256) void tri_inverse64_reg_kernel(const double *L, int n, int ld, double *Xt, int ldx, int kp) {
+    constexpr int RP = 32;
+    __shared__ __attribute__((aligned(16))) double Ls[RP * (16 * NM + 2)];
+    __shared__ double dinv[RP];
+    constexpr int LP = 16 * NM + 2;
+    const int t = threadIdx.x, q = t & 15, cl = t >> 4;
+    const int c0 = blockIdx.x * 16, c = c0 + cl;
+    double y[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) y[m] = 0.0;
+    for (int i0 = (c0 / RP) * RP; i0 < n; i0 += RP) {
+        const int nr = n - i0 < RP ? n - i0 : RP;
+        __syncthreads();
+        for (int idx = t; idx < RP * 16 * NM; idx += 256) {
+            const int r = idx / (16 * NM), col = idx % (16 * NM);
+            Ls[r * LP + col] = (r < nr && col < i0 + r && col < n) ? L[(int64_t)(i0 + r) * ld + col] : 0.0; // strictly lower part
+        }
+        if (t < RP) dinv[t] = t < nr ? 1.0 / L[(int64_t)(i0 + t) * ld + i0 + t] : 0.0;
+        __syncthreads();
+        for (int r = 0; r < nr; ++r) {
+            const int i = i0 + r;
+            if (i < c0) continue; // rows above this block of columns: y stays 0 (uniform over the workgroup)
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int m = 0; m < NM; m += 2) {
+                s0 += Ls[r * LP + q + 16 * m] * y[m];
+                s1 += Ls[r * LP + q + 16 * (m + 1)] * y[m + 1];
+            }
+            const double s = group16_sum_f64_dpp(s0 + s1);
+            const double val = (i >= c && c < n) ? ((i == c ? 1.0 : 0.0) - s) * dinv[r] : 0.0;
+            const int qi = i & 15, mi = i >> 4;
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+                if (m == mi && q == qi) y[m] = val;
+        }
+    }
+    if (c < kp) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int u = q + 16 * m;
+            if (u < kp) Xt[(int64_t)c * ldx + u] = (u < n && c < n) ? y[m] : 0.0;
+        }
+    }
+    // columns of a k_pad wider than 16 NM (cannot happen: k_pad <= 16 NM by construction of the caller)
 }
 
 // C = alpha op(A) op(B) + beta D + gamma I, all kp x kp float64 (pitch kp), kp a multiple of 32.

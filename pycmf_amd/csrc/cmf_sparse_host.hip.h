@@ -43,9 +43,9 @@ static int bcsr_build_upload(cmf_ctx *c, CsrDev &dst, const int64_t *indptr, con
             for (int64_t q = indptr[r]; q < indptr[r + 1]; ++q) kcnt[(size_t)(base + indices[q] / B) + 1]++;
         }
     for (int64_t i = 0; i < nkey; ++i) kcnt[i + 1] += kcnt[i];
-    // stretches between two re-alignments of an XCD class: about 16k entries of a 128-row group (~150 us), whole blocks
+    // stretches between two re-alignments of an XCD class: about 8k entries of a group (~80 us; 16k: +0.5 ms on X^T U at C5, 32k: +1.7 ms), whole blocks
     const double per_block = (double)nnz / (double)std::max<int64_t>(ngroups * nblocks, 1);
-    const double stretch = c->opt_spmm_stretch > 0 ? (double)c->opt_spmm_stretch : 16384.0;
+    const double stretch = c->opt_spmm_stretch > 0 ? (double)c->opt_spmm_stretch : 8192.0;
     const int64_t kblk = std::max<int64_t>(1, (int64_t)(stretch / std::max(per_block, 1.0)));
     const int64_t nsync = (nblocks + kblk - 1) / kblk;
     std::vector<int64_t> seg((size_t)(ngroups * 8 * nsync) + 1);
