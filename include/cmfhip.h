@@ -114,6 +114,16 @@ int cmf_fill_factor_synthetic(cmf_ctx *ctx, int which, uint64_t seed, int64_t ro
  * initialisers' randomized SVD (sklearn randomized_svd called at pycmf/cmf.py:126,:149) run through
  * this on the data already resident on the device (dense MFMA GEMM or native CSR SpMM).            */
 int cmf_data_matmul_f64(cmf_ctx *ctx, int which, int trans, const double *B, int64_t b_rows, int ncols, double *out);
+/* Initialisers on the device copy (pycmf/cmf.py:41-202).
+ * cmf_rsvd: randomized truncated SVD of X (which 0) or Y (which 1) as sklearn.utils.extmath.randomized_svd computes it for
+ * _initialize_mf (cmf.py:126, :149): `omega` is the Gaussian test matrix (cols x size row-major float64 when transpose == 0,
+ * rows x size when transpose != 0 -- sklearn's 'auto' transposition -- drawn by the caller from NumPy's RandomState),
+ * n_iter normalised power iterations (CholeskyQR2 in float64 in place of sklearn's LU: the same subspace), then the SVD of
+ * the small matrix.  Outputs, float64 row-major: U (rows x k), S (k), Vt (k x cols).  Sign convention left to the caller.
+ * cmf_data_sum: sum of all entries of X and Y (M.mean() of the 'random' / 'nndsvda' / 'nndsvdar' rules, cmf.py:111, :186). */
+int cmf_rsvd(cmf_ctx *ctx, int which, int transpose, int k, int size, int n_iter, const double *omega,
+             double *U, double *S, double *Vt);
+int cmf_data_sum(cmf_ctx *ctx, double *sum_x, double *sum_y);
 /* read back a block of X or Y (tests) */
 int cmf_get_data_f32(cmf_ctx *ctx, int which, float *ptr, int64_t rs, int64_t cs);
 

@@ -40,6 +40,8 @@ PROTOTYPES = {
     "cmf_fill_factor_synthetic": [_vp, _i32, C.c_uint64, _i64, _dbl],
     "cmf_get_data_f32": [_vp, _i32, _pf, _i64, _i64],
     "cmf_data_matmul_f64": [_vp, _i32, _i32, _pd, _i64, _i32, _pd],
+    "cmf_rsvd": [_vp, _i32, _i32, _i32, _i32, _i32, _pd, _pd, _pd, _pd],
+    "cmf_data_sum": [_vp, _pd, _pd],
     "cmf_set_factor_f64": [_vp, _i32, _pd, _i64, _i64],
     "cmf_get_factor_f64": [_vp, _i32, _pd, _i64, _i64],
     "cmf_mu_step": [_vp, _dbl, _dbl, _i32],
@@ -216,6 +218,22 @@ class Context:
         check(self._lib.cmf_data_matmul_f64(self._h, which, 1 if trans else 0, B.ctypes.data_as(_pd), B.shape[0], B.shape[1],
                                             out.ctypes.data_as(_pd)))
         return out
+
+    def rsvd(self, which, transpose, k, size, n_iter, omega):
+        """Randomized truncated SVD of X / Y on the device copy; returns (U, S, Vt) float64."""
+        m, d, p, _ = self.shape
+        rows, cols = ((m, d), (d, p))[which]
+        omega = np.ascontiguousarray(omega, dtype=np.float64)
+        assert omega.shape == ((rows if transpose else cols), size)
+        U, S, Vt = np.empty((rows, k)), np.empty(k), np.empty((k, cols))
+        check(self._lib.cmf_rsvd(self._h, which, 1 if transpose else 0, k, size, n_iter, omega.ctypes.data_as(_pd),
+                                 U.ctypes.data_as(_pd), S.ctypes.data_as(_pd), Vt.ctypes.data_as(_pd)))
+        return U, S, Vt
+
+    def data_sum(self):
+        sx, sy = C.c_double(0), C.c_double(0)
+        check(self._lib.cmf_data_sum(self._h, C.byref(sx), C.byref(sy)))
+        return sx.value, sy.value
 
     def fill_data_synthetic(self, which, seed, row0=0, col0=0):
         check(self._lib.cmf_fill_data_synthetic(self._h, which, seed, row0, col0))

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace cmfk;
@@ -171,6 +172,12 @@ struct cmf_ctx {
     int64_t launches[CMF_K_COUNT] = {0};
     double flops[CMF_K_COUNT] = {0};
     std::vector<hipEvent_t> markers;      // cmf_marker: per-iteration time series of a bench run
+    // host <-> device staging: two pinned 64 MB buffers, filled / drained by several host threads while the other one is
+    // on the wire (upload_strided / download_strided)
+    void *pin[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    bool pin_busy[2] = {false, false};
+    double sp_sum[2] = {0.0, 0.0};        // sum of the stored values of a native sparse input
 };
 
 struct DeviceGuard {
@@ -582,6 +589,10 @@ extern "C" int cmf_ctx_destroy(cmf_ctx *c) {
     for (auto &e : c->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto e : c->evpool) (void)hipEventDestroy(e);
     for (auto e : c->markers) (void)hipEventDestroy(e);
+    for (int b = 0; b < 2; ++b) {
+        if (c->pin[b]) (void)hipHostFree(c->pin[b]);
+        if (c->pin_ev[b]) (void)hipEventDestroy(c->pin_ev[b]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return CMF_OK;
@@ -724,22 +735,96 @@ static int ensure_dense(cmf_ctx *c, int which) {
     return CMF_OK;
 }
 
+static constexpr size_t PIN_BYTES = (size_t)64 << 20;
+static int pin_buffers(cmf_ctx *c) {
+    for (int b = 0; b < 2; ++b) {
+        if (!c->pin[b]) HIPCHK(hipHostMalloc(&c->pin[b], PIN_BYTES, hipHostMallocDefault));
+        if (!c->pin_ev[b]) HIPCHK(hipEventCreateWithFlags(&c->pin_ev[b], hipEventDisableTiming));
+    }
+    return CMF_OK;
+}
+// run fn(i0, i1) over [0, n) on up to `want` host threads (inline when the work is small)
+template <typename F>
+static void parallel_rows(int64_t n, int64_t work_per_row, int want, F &&fn) {
+    int nt = (int)std::min<int64_t>(want, std::max<int64_t>(1, (n * work_per_row) >> 19)); // >= 512k elements per thread
+    nt = (int)std::min<int64_t>(nt, n);
+    if (nt <= 1) { fn((int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back([&, t]() { fn(n * t / nt, n * (t + 1) / nt); });
+    for (auto &x : th) x.join();
+}
+static int host_threads() {
+    const unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::min<unsigned>(16, std::max<unsigned>(1, hc));
+}
+
+// Host matrix (any element strides, float64 or float32) -> padded float32 device matrix.  Rows are converted and packed by
+// several host threads into one of two pinned staging buffers while the previous chunk is on the wire (float32 bytes:
+// half the PCIe traffic of the float64 source).
 template <typename T>
 static int upload_strided(cmf_ctx *c, float *dst, int64_t ld, int64_t rows, int64_t cols, const T *src, int64_t rs, int64_t cs) {
     if (rows == 0 || cols == 0) return CMF_OK;
-    const int64_t chunk_rows = std::max<int64_t>(1, std::min<int64_t>(rows, (int64_t)(64 << 20) / (cols * (int64_t)sizeof(float))));
-    std::vector<float> stage((size_t)chunk_rows * cols);
-    for (int64_t r0 = 0; r0 < rows; r0 += chunk_rows) {
+    CHK(pin_buffers(c));
+    const int64_t chunk_rows = std::max<int64_t>(1, std::min<int64_t>(rows, (int64_t)PIN_BYTES / (cols * (int64_t)sizeof(float))));
+    if (cols * (int64_t)sizeof(float) > (int64_t)PIN_BYTES) return fail(CMF_EUNSUPPORTED, "row of %lld columns exceeds the staging buffer", (long long)cols);
+    const int nthr = host_threads();
+    int k = 0;
+    for (int64_t r0 = 0; r0 < rows; r0 += chunk_rows, ++k) {
+        const int b = k & 1;
+        if (c->pin_busy[b]) { HIPCHK(hipEventSynchronize(c->pin_ev[b])); c->pin_busy[b] = false; }
         const int64_t nr = std::min(chunk_rows, rows - r0);
-        for (int64_t i = 0; i < nr; ++i) {
-            const T *srow = src + (r0 + i) * rs;
-            float *drow = stage.data() + i * cols;
-            if (cs == 1) for (int64_t j = 0; j < cols; ++j) drow[j] = (float)srow[j];
-            else for (int64_t j = 0; j < cols; ++j) drow[j] = (float)srow[j * cs];
-        }
-        HIPCHK(hipMemcpy2DAsync(dst + r0 * ld, ld * sizeof(float), stage.data(), cols * sizeof(float), cols * sizeof(float), nr,
+        float *stage = (float *)c->pin[b];
+        parallel_rows(nr, cols, nthr, [&](int64_t i0, int64_t i1) {
+            for (int64_t i = i0; i < i1; ++i) {
+                const T *srow = src + (r0 + i) * rs;
+                float *drow = stage + i * cols;
+                if (cs == 1) for (int64_t j = 0; j < cols; ++j) drow[j] = (float)srow[j];
+                else for (int64_t j = 0; j < cols; ++j) drow[j] = (float)srow[j * cs];
+            }
+        });
+        HIPCHK(hipMemcpy2DAsync(dst + r0 * ld, ld * sizeof(float), stage, cols * sizeof(float), cols * sizeof(float), nr,
                                 hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipEventRecord(c->pin_ev[b], c->stream));
+        c->pin_busy[b] = true;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->pin_busy[0] = c->pin_busy[1] = false;
+    return CMF_OK;
+}
+
+// padded float32 device matrix -> host matrix (any strides), through the same pinned buffers
+template <typename T>
+static int download_strided(cmf_ctx *c, const float *srcd, int64_t ld, int64_t rows, int64_t cols, T *dst, int64_t rs, int64_t cs) {
+    if (rows == 0 || cols == 0) return CMF_OK;
+    CHK(pin_buffers(c));
+    if (cols * (int64_t)sizeof(float) > (int64_t)PIN_BYTES) return fail(CMF_EUNSUPPORTED, "row of %lld columns exceeds the staging buffer", (long long)cols);
+    const int64_t chunk_rows = std::max<int64_t>(1, std::min<int64_t>(rows, (int64_t)PIN_BYTES / (cols * (int64_t)sizeof(float))));
+    const int nthr = host_threads();
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->pin_busy[0] = c->pin_busy[1] = false;
+    auto issue = [&](int64_t r0, int b) -> int {
+        const int64_t nr = std::min(chunk_rows, rows - r0);
+        HIPCHK(hipMemcpy2DAsync(c->pin[b], cols * sizeof(float), srcd + r0 * ld, ld * sizeof(float), cols * sizeof(float), nr,
+                                hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipEventRecord(c->pin_ev[b], c->stream));
+        return CMF_OK;
+    };
+    CHK(issue(0, 0));
+    int k = 0;
+    for (int64_t r0 = 0; r0 < rows; r0 += chunk_rows, ++k) {
+        const int b = k & 1;
+        if (r0 + chunk_rows < rows) CHK(issue(r0 + chunk_rows, b ^ 1)); // next chunk travels while this one is unpacked
+        HIPCHK(hipEventSynchronize(c->pin_ev[b]));
+        const int64_t nr = std::min(chunk_rows, rows - r0);
+        const float *stage = (const float *)c->pin[b];
+        parallel_rows(nr, cols, nthr, [&](int64_t i0, int64_t i1) {
+            for (int64_t i = i0; i < i1; ++i) {
+                T *drow = dst + (r0 + i) * rs;
+                const float *srow = stage + i * cols;
+                if (cs == 1) for (int64_t j = 0; j < cols; ++j) drow[j] = (T)srow[j];
+                else for (int64_t j = 0; j < cols; ++j) drow[j * cs] = (T)srow[j];
+            }
+        });
     }
     return CMF_OK;
 }
@@ -816,12 +901,7 @@ extern "C" int cmf_get_data_f32(cmf_ctx *c, int which, float *ptr, int64_t rs, i
     CHK(data_dims(c, which, &r, &cc, &rp, &cp, &slot));
     if (!*slot && c->sparse[which]) CHK(need_dense(c, which));
     if (!*slot) return fail(CMF_EINVAL, "data %d not set", which);
-    std::vector<float> host((size_t)r * cc);
-    HIPCHK(hipMemcpy2DAsync(host.data(), cc * sizeof(float), *slot, cp * sizeof(float), cc * sizeof(float), r, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    for (int64_t i = 0; i < r; ++i)
-        for (int64_t j = 0; j < cc; ++j) ptr[i * rs + j * cs] = host[i * cc + j];
-    return CMF_OK;
+    return download_strided<float>(c, *slot, cp, r, cc, ptr, rs, cs);
 }
 
 static int launch_fill(cmf_ctx *c, float *A, int64_t ld, int64_t rows, int64_t cols, uint64_t seed, int64_t row0, int64_t col0, float scale) {
@@ -864,16 +944,7 @@ extern "C" int cmf_get_factor_f64(cmf_ctx *c, int which, double *ptr, int64_t rs
     NEED_PROBLEM(c);
     if (which < 0 || which > 2 || !ptr) return fail(CMF_EINVAL, "bad factor argument");
     DeviceGuard dg(c->device);
-    const int64_t r = c->frows[which];
-    std::vector<float> host((size_t)std::max<int64_t>(r, 1) * c->k);
-    if (r > 0) {
-        HIPCHK(hipMemcpy2DAsync(host.data(), c->k * sizeof(float), c->F[which], c->kp * sizeof(float), c->k * sizeof(float), r,
-                                hipMemcpyDeviceToHost, c->stream));
-    }
-    HIPCHK(hipStreamSynchronize(c->stream));
-    for (int64_t i = 0; i < r; ++i)
-        for (int j = 0; j < c->k; ++j) ptr[i * rs + j * cs] = (double)host[i * c->k + j];
-    return CMF_OK;
+    return download_strided<double>(c, c->F[which], c->kp, c->frows[which], c->k, ptr, rs, cs);
 }
 
 extern "C" int cmf_get_geometry(cmf_ctx *c, int64_t *mp, int64_t *dp, int64_t *pp, int *kp) {
@@ -1199,3 +1270,4 @@ extern "C" int cmf_kernel_timing_reset(cmf_ctx *c) {
 }
 
 #include "cmf_newton.hip.h"
+#include "cmf_init.hip.h"

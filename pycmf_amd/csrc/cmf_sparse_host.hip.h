@@ -152,6 +152,9 @@ static int set_data_csr_native(cmf_ctx *c, int which, const int64_t *indptr, con
     }
     c->sparse[which] = true;
     c->sp_sq[which] = sq;
+    double sm = 0.0;
+    for (int64_t q = 0; q < nnz; ++q) sm += (double)vals[q];
+    c->sp_sum[which] = sm;
     return CMF_OK;
 }
 

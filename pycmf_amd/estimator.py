@@ -86,8 +86,8 @@ def collective_matrix_factorization(X, Y, U=None, V=None, Z=None,
     # 'svd' / 'nndsvd*' can use the device copy for its products (the solver later reuses the upload).
     op_x = op_y = None
     big = [M is not None and M.shape[0] * M.shape[1] >= DEVICE_SVD_MIN_CELLS for M in (X, Y)]
-    needs_svd = [i not in ('custom', 'random') for i in (x_init, y_init)]
-    if X is not None and Y is not None and any(b and n for b, n in zip(big, needs_svd)):
+    needs_dev = [i != 'custom' for i in (x_init, y_init)]   # every non-custom rule reads the data: mean and / or SVD
+    if X is not None and Y is not None and any(b and n for b, n in zip(big, needs_dev)):
         ctx = solver_object.bind_data(X, Y, n_components)
         if ctx is not None:
             op_x = DeviceOperand(ctx, 0, X.shape)

@@ -1,4 +1,6 @@
-"""Factor initialisation on the host (one-shot pre-step, not accelerated).
+"""Factor initialisation.  Small inputs follow the reference on the host; for large ones the passes over the data (the
+randomized SVD behind 'svd' / 'nndsvd*', the mean behind 'random' / 'nndsvda' / 'nndsvdar') run on the GPU copy of X / Y
+(SURVEY 8(f) F2); the O((m + d) k) bookkeeping (NNDSVD's sign split, NumPy's random draws) stays on the host.
 
 Behavioural counterpart of ``_initialize_mf`` / ``_init_custom`` / ``_check_init``
 (pycmf/cmf.py:30-212); pinned by tests/golden/g5_init.npz.  Returns ``(A, B.T)``
@@ -19,8 +21,7 @@ DEVICE_SVD_MIN_CELLS = 4_000_000
 
 
 class DeviceOperand:
-    """X or Y as it already sits on the GPU: ``dot(B)`` = M @ B and ``tdot(B)`` = M.T @ B computed by
-    libcmfhip (MFMA GEMM or native CSR SpMM, float32) for a host matrix B."""
+    """X or Y as it already sits on the GPU (libcmfhip): the initialisers' passes over the data run there."""
 
     def __init__(self, ctx, which, shape):
         self.ctx, self.which, self.shape = ctx, which, shape
@@ -31,29 +32,29 @@ class DeviceOperand:
     def tdot(self, B):
         return self.ctx.data_matmul(self.which, True, B)
 
+    def mean(self):
+        return self.ctx.data_sum()[self.which] / (float(self.shape[0]) * float(self.shape[1]))
+
+    def rsvd(self, transpose, k, size, n_iter, omega):
+        return self.ctx.rsvd(self.which, transpose, k, size, n_iter, omega)
+
 
 def randomized_svd_device(op, n_components, random_state=None, n_oversamples=10):
     """Randomized truncated SVD (Halko, Martinsson & Tropp 2011, Alg. 4.3/4.4 + 5.1) with the same
     defaults as ``sklearn.utils.extmath.randomized_svd`` -- n_iter 'auto' (7 when k < 0.1 min(shape),
-    else 4), LU-normalised power iterations, final QR, 'auto' transposition, u-based sign flip -- and the
-    same Gaussian test matrix for a given ``random_state``; only the products with the data matrix
-    run on the GPU (in float32), the tall-skinny LU / QR / small SVD stay on the host in float64."""
-    from scipy import linalg
+    else 4), normalised power iterations, 'auto' transposition, u-based sign flip -- and the same Gaussian test
+    matrix for a given ``random_state``.  Everything but the draw of that matrix and the eigen-decomposition of
+    one (k + 10)^2 matrix runs on the GPU copy of the data (``cmf_rsvd``: MFMA / SpMM passes, CholeskyQR2 in float64
+    where sklearn normalises with a pivoted LU -- the same subspace)."""
     n_samples, n_features = op.shape
-    size = n_components + n_oversamples
+    size = min(n_components + n_oversamples, min(op.shape))
+    n_components = min(n_components, size)
     n_iter = 7 if n_components < 0.1 * min(op.shape) else 4
     transpose = n_samples < n_features
-    fwd, bwd = (op.tdot, op.dot) if transpose else (op.dot, op.tdot)   # products with A and A.T, A = M.T if transpose
     cols = n_samples if transpose else n_features
     rng = check_random_state(random_state)
-    Q = rng.normal(size=(cols, size))
-    for _ in range(n_iter):
-        Q, _ = linalg.lu(fwd(Q), permute_l=True, check_finite=False)
-        Q, _ = linalg.lu(bwd(Q), permute_l=True, check_finite=False)
-    Q, _ = linalg.qr(fwd(Q), mode="economic", check_finite=False)
-    B = bwd(Q).T                                                         # Q.T @ A
-    Uhat, s, Vt = linalg.svd(B, full_matrices=False, lapack_driver="gesdd", check_finite=False)
-    U = Q @ Uhat
+    omega = rng.normal(size=(cols, n_components + n_oversamples))[:, :size]
+    U, s, Vt = op.rsvd(transpose, n_components, size, n_iter, omega)
     # svd_flip (u-based decision when not transposed, v-based when transposed), as sklearn does
     if not transpose:
         signs = np.sign(U[np.argmax(np.abs(U), axis=0), range(U.shape[1])])
@@ -62,9 +63,7 @@ def randomized_svd_device(op, n_components, random_state=None, n_oversamples=10)
     signs[signs == 0] = 1.0
     U *= signs
     Vt *= signs[:, None]
-    if transpose:
-        return Vt[:n_components, :].T, s[:n_components], U[:, :n_components].T
-    return U[:, :n_components], s[:n_components], Vt[:n_components, :]
+    return U, s, Vt
 
 
 def _rsvd(M, k, random_state, operand):
@@ -89,9 +88,16 @@ def validate_custom(A, shape, whom, non_negative):
             raise ValueError('Array passed to %s is full of zeros.' % whom)
 
 
-def _random_pair(M, k, random_state, non_negative):
+def _mean(M, operand):
+    """M.mean() -- from the device copy when there is one (a pass over a 17 GB matrix on the host costs seconds)."""
+    if operand is not None and M.shape[0] * M.shape[1] >= DEVICE_SVD_MIN_CELLS:
+        return operand.mean()
+    return M.mean()
+
+
+def _random_pair(M, k, random_state, non_negative, operand=None):
     # scale so that A @ B has roughly the mean of M (cmf.py:110-117)
-    scale = np.sqrt(np.abs(M.mean()) / k)
+    scale = np.sqrt(np.abs(_mean(M, operand)) / k)
     rng = check_random_state(random_state)
     A = scale * rng.randn(M.shape[0], k)
     B = scale * rng.randn(k, M.shape[1])
@@ -141,12 +147,12 @@ def _nndsvd_pair(M, k, variant, random_state, eps, operand=None):
     A[A < eps] = 0
     B[B < eps] = 0
     if variant == "nndsvda":
-        avg = M.mean()
+        avg = _mean(M, operand)
         A[A == 0] = avg
         B[B == 0] = avg
     elif variant == "nndsvdar":
         rng = check_random_state(random_state)
-        avg = M.mean()
+        avg = _mean(M, operand)
         A[A == 0] = abs(avg * rng.randn(len(A[A == 0])) / 100)
         B[B == 0] = abs(avg * rng.randn(len(B[B == 0])) / 100)
     return A, B
@@ -167,7 +173,7 @@ def initialize_mf(M, n_components, init=None, eps=1e-6, random_state=None, non_n
             init = 'random'
 
     if init == 'random':
-        A, B = _random_pair(M, n_components, random_state, non_negative)
+        A, B = _random_pair(M, n_components, random_state, non_negative, operand)
     elif init == 'svd':
         if non_negative:
             raise ValueError('SVD initialization incompatible with NMF (use nndsvd instead)')
