@@ -39,12 +39,17 @@ def collective_matrix_factorization(X, Y, U=None, V=None, Z=None,
                                     update_U=True, update_V=True, update_Z=True,
                                     x_link="linear", y_link="linear",
                                     hessian_pertubation=0.2, sg_sample_ratio=1.,
-                                    device=0, sg_sampler="numpy", _return_solver=False):
+                                    device=0, sg_sampler="numpy", n_gpus=1, _return_solver=False):
     """Factorise X ~ f(U V^T) and Y ~ f(V Z^T) with a shared V on an MI355X.
 
     Same contract as the reference function (pycmf/cmf.py:215-456): returns
     ``(U, V, Z, n_iter)``; with ``x_init='custom'`` / ``y_init='custom'`` the given
     U/V/Z are the starting point (and U, Z are updated in place).
+
+    ``n_gpus > 1``: data-parallel fit on that many GPUs of the node: one worker process per GPU takes a
+    row block of X / U and a column block of Y / Z, V is reassembled by RCCL once per iteration
+    (pycmf_amd/multi_gpu.py).  This process touches no GPU; the initial factors come from the host initialisers.  With
+    ``sg_sample_ratio < 1`` the workers draw their samples with the device sampler.
     """
     if n_components is None:
         n_components = max(X.shape[1], Y.shape[1])
@@ -87,7 +92,7 @@ def collective_matrix_factorization(X, Y, U=None, V=None, Z=None,
     op_x = op_y = None
     big = [M is not None and M.shape[0] * M.shape[1] >= DEVICE_SVD_MIN_CELLS for M in (X, Y)]
     needs_dev = [i != 'custom' for i in (x_init, y_init)]   # every non-custom rule reads the data: mean and / or SVD
-    if X is not None and Y is not None and any(b and n for b, n in zip(big, needs_dev)):
+    if n_gpus <= 1 and X is not None and Y is not None and any(b and n for b, n in zip(big, needs_dev)):
         ctx = solver_object.bind_data(X, Y, n_components)
         if ctx is not None:
             op_x = DeviceOperand(ctx, 0, X.shape)
@@ -117,6 +122,22 @@ def collective_matrix_factorization(X, Y, U=None, V=None, Z=None,
         V = V_from_y
 
     U, V, Z = _writable_f64(U), _writable_f64(V), _writable_f64(Z)
+    if n_gpus > 1:
+        if not (update_U and update_V and update_Z):
+            raise ValueError("n_gpus > 1 fits all three factors; use n_gpus=1 for transform / partial updates")
+        from .multi_gpu import fit_multi_gpu
+        U, V, Z = (np.ascontiguousarray(F) for F in (U, V, Z))
+        params = dict(l1_reg=l1_reg, l2_reg=l2_reg, max_iter=max_iter, tol=tol, verbose=verbose,
+                      alpha=(0.5 if solver == "mu" else float(alpha)), x_link=x_link, y_link=y_link,
+                      U_non_negative=bool(U_non_negative), V_non_negative=bool(V_non_negative),
+                      Z_non_negative=bool(Z_non_negative), hessian_pertubation=hessian_pertubation,
+                      sg_sample_ratio=sg_sample_ratio,
+                      random_state=(int(random_state) if isinstance(random_state, (int, np.integer)) else None))
+        n_iter, result = fit_multi_gpu(X, Y, U, V, Z, solver, int(n_gpus), params)
+        solver_object.release()
+        if _return_solver:
+            return U, V, Z, n_iter, result
+        return U, V, Z, n_iter
     U, V, Z, n_iter = solver_object.fit_iterative_update(X, Y, U, V, Z)
     if _return_solver:
         return U, V, Z, n_iter, solver_object
@@ -137,8 +158,10 @@ class CMF(BaseEstimator, TransformerMixin):
     attributes ``reconstruction_err_``, ``n_components_``, ``x_weights``,
     ``components``, ``y_weights``, ``n_iter_`` (:697-704).
 
-    Extra keywords: ``device`` (GPU ordinal, default 0) and ``sg_sampler`` ('numpy' = the
-    reference's host RNG stream, default; 'device' = counter-based sampler on the GPU).
+    Extra keywords: ``device`` (GPU ordinal, default 0), ``sg_sampler`` ('numpy' = the
+    reference's host RNG stream, default; 'device' = counter-based sampler on the GPU) and
+    ``n_gpus`` (default 1; N > 1 = ``fit`` runs data-parallel on N GPUs of the node, one worker process
+    per GPU, V reassembled by one RCCL all-reduce per iteration; ``transform`` always uses one GPU).
     """
 
     def __init__(self, n_components=None, x_init=None, y_init=None, solver='mu', alpha='auto',
@@ -146,7 +169,7 @@ class CMF(BaseEstimator, TransformerMixin):
                  random_state=None, l1_reg=0., l2_reg=0., verbose=0,
                  U_non_negative=True, V_non_negative=True, Z_non_negative=True,
                  x_link="linear", y_link="linear", hessian_pertubation=0.2, sg_sample_ratio=1.,
-                 device=0, sg_sampler="numpy"):
+                 device=0, sg_sampler="numpy", n_gpus=1):
         self.n_components = n_components
         self.x_init = x_init
         self.y_init = y_init
@@ -168,6 +191,7 @@ class CMF(BaseEstimator, TransformerMixin):
         self.sg_sample_ratio = sg_sample_ratio
         self.device = device
         self.sg_sampler = sg_sampler
+        self.n_gpus = n_gpus
 
     def _kwargs(self):
         return dict(solver=self.solver, beta_loss=self.beta_loss, tol=self.tol, max_iter=self.max_iter,
@@ -186,7 +210,7 @@ class CMF(BaseEstimator, TransformerMixin):
                              "found X.shape = {}, Y.shape = {}".format(X.shape, Y.shape))
         U, V, Z, n_iter_, solver_object = collective_matrix_factorization(
             X=X, Y=Y, U=U, V=V, Z=Z, n_components=self.n_components,
-            x_init=self.x_init, y_init=self.y_init, alpha=self.alpha,
+            x_init=self.x_init, y_init=self.y_init, alpha=self.alpha, n_gpus=self.n_gpus,
             _return_solver=True, **self._kwargs())
         # unweighted sum of the two residual norms, evaluated on the device where the
         # data and the final factors still live (cmf.py:697-698)

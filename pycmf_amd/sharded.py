@@ -301,7 +301,7 @@ def make_torch_sharded_newton(ctx, world, device, alpha, nn_mask=0, pert=0.2, ti
 
 
 def fit_mu_sharded(X_rows, Y_cols, U_rows, V, Z_rows, l1_reg=0.0, l2_reg=0.0, max_iter=200, tol=1e-4,
-                   device=0, verbose=0):
+                   device=0, verbose=0, stats=None):
     """Data-parallel MU fit: call from every rank of an initialised ``torch.distributed`` group.
 
     Rank g passes its row block of X (and the matching rows of U), the matching column block of Y (and rows
@@ -326,12 +326,15 @@ def fit_mu_sharded(X_rows, Y_cols, U_rows, V, Z_rows, l1_reg=0.0, l2_reg=0.0, ma
             ctx.set_factor(which, F)
         drv = make_torch_sharded_mu(ctx, world, dev)
 
-        def global_error():
+        def global_sq():
             ex2, ey2 = ctx.residual_sq("linear", "linear")
             t = torch.tensor([ex2, ey2], dtype=torch.float64, device=dev)
             if world > 1:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            ex2, ey2 = (float(v) for v in t.tolist())
+            return tuple(float(v) for v in t.tolist())
+
+        def global_error():
+            ex2, ey2 = global_sq()
             return 0.5 * np.sqrt(ex2) + 0.5 * np.sqrt(ey2)
 
         previous = at_init = global_error()
@@ -346,6 +349,8 @@ def fit_mu_sharded(X_rows, Y_cols, U_rows, V, Z_rows, l1_reg=0.0, l2_reg=0.0, ma
                     break
                 previous = err
         torch.cuda.synchronize(dev)
+        if stats is not None:   # squared global residuals of the final factors (reconstruction_err_ of the front end)
+            stats["ex2"], stats["ey2"] = global_sq()
         for which, F in ((_lib.CMF_U, U_rows), (_lib.CMF_V, V), (_lib.CMF_Z, Z_rows)):
             ctx.get_factor_into(which, F)
         ctx.close()
@@ -355,7 +360,7 @@ def fit_mu_sharded(X_rows, Y_cols, U_rows, V, Z_rows, l1_reg=0.0, l2_reg=0.0, ma
 def fit_newton_sharded(X_rows, X_cols, Y_cols, Y_rows, U_rows, V, Z_rows, alpha=0.5, l1_reg=0.0, l2_reg=0.0,
                        x_link="linear", y_link="linear", U_non_negative=True, V_non_negative=True, Z_non_negative=True,
                        hessian_pertubation=0.2, sg_sample_ratio=1.0, random_state=None, max_iter=200, tol=1e-4,
-                       device=0, verbose=0):
+                       device=0, verbose=0, stats=None):
     """Row-sharded Newton fit: call from every rank of an initialised ``torch.distributed`` group.
 
     Rank g passes its row block of X and the SAME rows of U, the matching column block of Y with its rows of Z, and
@@ -400,12 +405,15 @@ def fit_newton_sharded(X_rows, X_cols, Y_cols, Y_rows, U_rows, V, Z_rows, alpha=
                                              x_link, y_link, nn_mask, hessian_pertubation, sg_sample_ratio, rank=rank)
         # the V-sweep context needs U and Z whole before its first sweep: the gathers of the first step provide them
 
-        def global_error():
+        def global_sq():
             ex2, ey2 = ctx_uz.residual_sq(x_link, y_link)
             t = torch.tensor([ex2, ey2], dtype=torch.float64, device=dev)
             if world > 1:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            ex2, ey2 = (float(v) for v in t.tolist())
+            return tuple(float(v) for v in t.tolist())
+
+        def global_error():
+            ex2, ey2 = global_sq()
             return alpha * np.sqrt(ex2) + (1 - alpha) * np.sqrt(ey2)
 
         seed = (int(random_state) if isinstance(random_state, (int, np.integer)) else 0) << 20
@@ -422,6 +430,8 @@ def fit_newton_sharded(X_rows, X_cols, Y_cols, Y_rows, U_rows, V, Z_rows, alpha=
                     break
                 previous = err
         torch.cuda.synchronize(dev)
+        if stats is not None:
+            stats["ex2"], stats["ey2"] = global_sq()
         ctx_uz.get_factor_into(_lib.CMF_U, U_rows)
         ctx_uz.get_factor_into(_lib.CMF_V, V)
         ctx_uz.get_factor_into(_lib.CMF_Z, Z_rows)

@@ -174,3 +174,28 @@ def test_bench_rccl_single_rank():
     assert out["collective"]["backend"] == "rccl" and out["collective"]["calls_per_iteration"] == 1
     ref = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "tiny", "--no-cpu-baseline"], {})
     assert out["rel_residual"] == ref["rel_residual"]      # a 1-rank all-reduce is the identity: bit-identical iterates
+
+
+@pytest.mark.parametrize("solver,kw", [("mu", {}), ("newton", dict(y_link="logit", U_non_negative=False, V_non_negative=False,
+                                                                 Z_non_negative=False, l2_reg=0.05, alpha=0.4))])
+def test_cmf_n_gpus_through_the_drop_in_api(solver, kw, monkeypatch):
+    """``CMF(n_gpus=2).fit`` -- worker processes started by the front end, one rank per GPU (both on GPU 0 here, gloo
+    instead of RCCL) -- against ``CMF(n_gpus=1)`` from the same initial factors: same iteration count, same factors,
+    same reconstruction_err_; sklearn's clone carries n_gpus."""
+    from sklearn.base import clone
+    from pycmf_amd import CMF
+    monkeypatch.setenv("PYCMF_AMD_SAME_DEVICE", "1")
+    monkeypatch.setenv("PYCMF_AMD_DIST_BACKEND", "gloo")
+    rng = np.random.RandomState(3)
+    m, d, p, k = 260, 150, 90, 6
+    X = np.abs(rng.randn(m, d))
+    Y = rng.rand(d, p) if kw.get("y_link") == "logit" else np.abs(rng.randn(d, p))
+    est = CMF(n_components=k, solver=solver, x_init="random", y_init="random", random_state=0, max_iter=30, n_gpus=2, **kw)
+    U2, V2, Z2 = clone(est).fit_transform(X, Y)
+    two = clone(est); two.fit(X, Y)
+    one = clone(est).set_params(n_gpus=1); U1, V1, Z1 = one.fit_transform(X, Y)
+    assert two.n_iter_ == one.n_iter_
+    np.testing.assert_allclose(two.reconstruction_err_, one.reconstruction_err_, rtol=1e-4)
+    tol = 2e-4 if solver == "mu" else 2e-3
+    for a, b in ((U2, U1), (V2, V1), (Z2, Z1)):
+        np.testing.assert_allclose(a, b, rtol=0, atol=tol * np.abs(b).max())

@@ -74,10 +74,11 @@ def test_driver_validation_messages():
 def test_estimator_params_roundtrip():
     from sklearn.base import clone
     from pycmf_amd import CMF
-    m = CMF(n_components=7, solver="newton", alpha=0.25, sg_sample_ratio=0.5, hessian_pertubation=0.3, device=1)
+    m = CMF(n_components=7, solver="newton", alpha=0.25, sg_sample_ratio=0.5, hessian_pertubation=0.3, device=1, n_gpus=8)
     p = clone(m).get_params()
     assert p["n_components"] == 7 and p["solver"] == "newton" and p["alpha"] == 0.25
-    assert p["sg_sample_ratio"] == 0.5 and p["hessian_pertubation"] == 0.3 and p["device"] == 1
+    assert p["sg_sample_ratio"] == 0.5 and p["hessian_pertubation"] == 0.3 and p["device"] == 1 and p["n_gpus"] == 8
+    assert CMF().get_params()["n_gpus"] == 1
     d = CMF().get_params()  # reference defaults, pycmf/cmf.py:620-624
     assert (d["solver"], d["alpha"], d["tol"], d["max_iter"]) == ("mu", "auto", 1e-4, 600)
     assert d["x_link"] == d["y_link"] == "linear" and d["hessian_pertubation"] == 0.2 and d["sg_sample_ratio"] == 1.
@@ -137,6 +138,22 @@ def test_shard_bounds_cover_and_balance():
             c = -(-n // w)
             assert blocks[-1][1] == n and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
             assert all(lo == min(r * c, n) and hi - lo <= c for r, (lo, hi) in enumerate(blocks))
+
+
+def test_multi_gpu_partition_covers_the_problem():
+    """pycmf_amd.multi_gpu.partition: contiguous covers of the rows of X / U, V and the columns of Y / Z for every
+    solver and input kind (nnz-balanced row blocks for CSR X under MU, equal blocks for the row-sharded Newton)."""
+    import scipy.sparse as sp
+    from pycmf_amd.multi_gpu import partition
+    rng = np.random.RandomState(0)
+    X = sp.random(103, 40, density=0.2, random_state=rng, format="csr")
+    Y = rng.rand(40, 17)
+    for world in (2, 3, 8):
+        for A, solver in ((X, "mu"), (X.toarray(), "mu"), (X, "newton"), (X.toarray(), "newton")):
+            rows, vrows, cols = partition(A, Y, solver, world)
+            for off, n in ((rows, 103), (cols, 17)) + (((vrows, 40),) if vrows is not None else ()):
+                assert off[0] == 0 and off[-1] == n and len(off) == world + 1 and np.all(np.diff(off) >= 0)
+            assert (vrows is None) == (solver == "mu")
 
 
 def test_nnz_balanced_bounds_on_skewed_rows():
