@@ -86,48 +86,66 @@ def algorithmic_flops(w):
 
 
 def cpu_baseline(w, budget_s=20.0):
-    """CPU oracle (reference operation order, float64, all BLAS threads) on a bounded sample of
-    the same workload, scaled to the bench shape by the algorithmic-work ratio."""
+    """CPU oracle (reference operation order incl. the wasteful (U V^T) V, float64, all BLAS threads) per BASELINE.md
+    section 3: MU workloads time BASELINE config C2 IN FULL (16384 x 8192 / 8192 x 4096, k = 128: 3 warm-up + 5 timed
+    update_step) and scale to the bench shape by the reference-order flop ratio 8 k d (m + p) (C4 itself needs 140 GB of
+    float64 temporaries and minutes of data generation: 'scaled from C2', never a full C4 iteration here); Newton
+    workloads, whose per-row Python loop makes full shapes impractical, time a reduced shape and scale by algorithmic work."""
     import numpy as np
     from oracle import cmf_oracle as O
     k = w["k"]
     if w["solver"] == "mu":
-        ms = ds = ps = 4096
+        ms, ds, ps, ks = 16384, 8192, 4096, 128
+        if w["m"] * w["d"] < ms * ds:     # debug shapes: the shape itself
+            ms, ds, ps, ks = w["m"], w["d"], w["p"], k
     else:
-        ms, ds, ps = 96, 64, 32  # per-row eigh(k x k) in Python: keep it to a few hundred rows
+        ms, ds, ps, ks = 96, 64, 32, k  # per-row eigh(k x k) in Python: keep it to a few hundred rows
     rng = np.random.RandomState(42)
     X, Y = np.abs(rng.randn(ms, ds)), np.abs(rng.randn(ds, ps))
     if w.get("y_link") == "logit":
         Y = 1.0 / (1.0 + np.exp(-Y))
-    sc = np.sqrt(X.mean() / k)
-    U, V, Z = (sc * np.abs(rng.randn(n, k)) for n in (ms, ds, ps))
+    sc = np.sqrt(X.mean() / ks)
+    U, V, Z = (sc * np.abs(rng.randn(n, ks)) for n in (ms, ds, ps))
     if w["solver"] == "mu":
         def step():
             O.mu_update_step(X, Y, U, V, Z)
+        warm, timed = 3, 5
     else:
         np.random.seed(0)
 
         def step():
             O.newton_update_step(X, Y, U, V, Z, 0.5, 0.0, 0.1, w["x_link"], w["y_link"],
                                  False, False, False, ratio=w.get("ratio", 1.0), pert=0.2)
-    step()
+        warm, timed = 1, None
+    for _ in range(warm):
+        step()
     t0 = time.perf_counter()
     iters = 0
     while True:
         step()
         iters += 1
         el = time.perf_counter() - t0
-        if el > budget_s or (iters >= 3 and el > budget_s / 2):
+        if (timed is not None and iters >= timed) or el > budget_s or (timed is None and iters >= 3 and el > budget_s / 2):
             break
+    blas = "unknown"
+    threads = os.cpu_count() or 1
     try:
         from threadpoolctl import threadpool_info
-        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [os.cpu_count() or 1])
+        info = [i for i in threadpool_info() if i.get("user_api") == "blas"]
+        if info:
+            threads = max(i.get("num_threads", 1) for i in info)
+            blas = ", ".join(sorted({"%s %s" % (i.get("internal_api", "?"), i.get("version", "?")) for i in info}))
     except Exception:
-        threads = os.cpu_count() or 1
-    sample = {key: val for key, val in w.items() if key != "nnz_per_row"}
-    sample.update(m=ms, d=ds, p=ps)
-    ratio = algorithmic_flops(sample) / algorithmic_flops(w)
-    return iters / el, (ms, ds, ps), iters, el, threads, ratio
+        pass
+    if w["solver"] == "mu":   # reference-order flops: 8 k d (m + p) (+ Grams / applies, the same order in both shapes)
+        ref = lambda m_, d_, p_, k_: 8.0 * k_ * d_ * (m_ + p_) + 4.0 * k_ * k_ * (m_ + d_ + p_)
+        ratio = ref(ms, ds, ps, ks) / ref(w["m"], w["d"], w["p"], k)
+    else:
+        sample = {key: val for key, val in w.items() if key != "nnz_per_row"}
+        sample.update(m=ms, d=ds, p=ps)
+        ratio = algorithmic_flops(sample) / algorithmic_flops(w)
+    return dict(its=iters / el, shape=(ms, ds, ps, ks), iters=iters, seconds=el, threads=threads, blas=blas,
+                cpu_count=os.cpu_count() or 1, ratio=ratio)
 
 
 def launch_ranks(n, argv):
@@ -345,11 +363,12 @@ def main():
     dom = max(("gemm_nn", "gemm_tn", "spmm", "rowhess"), key=lambda c: classes[c][0])
     dms, dn, dfl = classes[dom]
     if dom == "spmm":
-        # HBM-bound gather kernel.  Algorithmic (compulsory) bytes of one A*F product: CSR arrays once
-        # + the dense operand once + the output once; the k_pad*4-byte factor-row gather per nonzero
-        # is served by L2 / Infinity Cache and reported separately.
+        # HBM-bound gather kernel (column-blocked, output-stationary SpMM).  Algorithmic (compulsory) bytes of one A*F
+        # product: the regrouped entry list once (16 B per non-zero) + the gathered operand once + the output once;
+        # the k_pad*4-byte factor-row gather per non-zero is served by the XCD L2s (rows of a 2 MB column block are
+        # shared by the workgroups of an XCD) and reported separately.
         nnz = float(r1 - r0) * w["nnz_per_row"]
-        comp = nnz * 8.0 + ((r1 - r0) + d) * kp * 4.0
+        comp = nnz * 16.0 + ((r1 - r0) + d) * kp * 4.0
         achieved = comp / (dms / max(dn, 1) * 1e-3) / 1e9
         spmm_traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
@@ -358,13 +377,17 @@ def main():
                 spmm_traffic = json.load(open(tpath)).get("spmm")
             except Exception:
                 spmm_traffic = None
-        roof = {"bound": "hbm", "kernel": "cmfk::spmm_csr_kernel<64, 1>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+        roof = {"bound": "hbm", "kernel": "cmfk::spmm_blocked_kernel<%d>  (A F and A^T F of the native CSR input)" % (kp // 64),
+                "achieved": achieved, "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": spmm_traffic,
                 "traffic_unit": "bytes per launch past L2 (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic_c5.json): "
                                 "Infinity-Cache hits of the factor-row gathers included",
-                "gathered_GBps": nnz * (kp * 4.0 + 8.0) / (dms / max(dn, 1) * 1e-3) / 1e9,
-                "note": "achieved = compulsory HBM bytes (CSR + dense operand + output) / launch time; the "
-                        "per-nonzero factor-row gathers (gathered_GBps) are served by L2 / Infinity Cache",
+                "gathered_GBps": nnz * (kp * 4.0 + 16.0) / (dms / max(dn, 1) * 1e-3) / 1e9,
+                "gather_peak_GBps": 17800.0,
+                "gather_frac": nnz * (kp * 4.0 + 16.0) / (dms / max(dn, 1) * 1e-3) / 1e9 / 17800.0,
+                "note": "achieved = compulsory HBM bytes (entry list + gathered operand + output) / launch time; the bound that "
+                        "matters is the per-nonzero factor-row gather (gathered_GBps) against the measured L2 row-gather rate "
+                        "of the chip, 16.8-18.8 TB/s (MI355X_MICROARCH.md, Indexed rows: gather into LDS)",
                 "avg_launch_ms": dms / max(dn, 1), "launches": dn}
     else:
         achieved = dfl / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
@@ -449,15 +472,20 @@ def main():
                        "bf16 planes, six products on the bf16 matrix pipe, fp32-equivalent to 4e-7): 23.3-24.0 it/s, "
                        "profiles/r01_c4_n1_bench_bf16x6.json, DESIGN.md section 4")
     if world == 1 and not args.no_cpu_baseline:
-        cits, shp, n_it, el, threads, work_ratio = cpu_baseline(w)
+        cb = cpu_baseline(w)
+        full = w["solver"] == "mu"
         out["cpu_baseline"] = {
-            "value": cits * work_ratio,
+            "value": cb["its"] * cb["ratio"],
             "unit": "it/s",
-            "cores": threads,
+            "cores": cb["threads"],
+            "host_cpu_count": cb["cpu_count"],
+            "blas": cb["blas"],
             "kind": "port",
-            "sample": "oracle/cmf_oracle %s step (NumPy float64, reference operation order), m,d,p=%s k=%d, "
-                      "%d iterations in %.1f s = %.3f it/s, scaled to the bench shape by the algorithmic-work ratio "
-                      "%.3g" % (w["solver"], shp, k, n_it, el, cits, work_ratio),
+            "sample": ("oracle/cmf_oracle %s update_step (NumPy float64, reference operation order) at m,d,p,k=%s%s: %d timed "
+                       "iterations in %.1f s = %.3f it/s on %d BLAS threads; scaled to the bench shape by the %s ratio %.3g"
+                       % (w["solver"], cb["shape"], " (BASELINE config C2 in full)" if full and cb["shape"][0] == 16384 else "",
+                          cb["iters"], cb["seconds"], cb["its"], cb["threads"],
+                          "reference-order flop" if full else "algorithmic-work", cb["ratio"])),
         }
     print(json.dumps(out))
     if use_dist:

@@ -341,3 +341,29 @@ def test_fit_with_device_assisted_init():
         m = CMF(n_components=6, solver="mu", random_state=0, max_iter=200)
         m.fit(X, Y)
     assert m.reconstruction_err_ < 0.05 * (np.linalg.norm(X) + np.linalg.norm(Y))
+
+
+def test_driver_level_init_and_v_merge_match_reference():
+    """g5 drv_*: what the reference's driver hands to the solver -- 'random' init of both sides from ONE seed
+    (RandomState re-created per call, pycmf/cmf.py:110-117), V = mean of the two V candidates (:425-430) -- observed
+    through one MU iteration from it."""
+    from pycmf_amd import collective_matrix_factorization
+    g = load_golden("g5_init")
+    U, V, Z, n_it = collective_matrix_factorization(g["M"], g["drv_Y"], n_components=4, x_init="random", y_init="random",
+                                                    solver="mu", max_iter=1, random_state=3)
+    assert n_it == 1
+    for a, name in ((U, "drv_U1"), (V, "drv_V1"), (Z, "drv_Z1")):
+        np.testing.assert_allclose(a, g[name], rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("solver", solvers)
+def test_fit_from_the_reference_default_init(solver):
+    """g4 fc_*_nndsvdar_*: the reference's own default path (nndsvdar init from random_state=0, then the solver loop):
+    same stopping iteration, same reconstruction error."""
+    g = load_golden("g4_fit_level")
+    m = CMF(n_components=5, solver=solver, x_init="nndsvdar", y_init="nndsvdar", random_state=0, max_iter=1000)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.fit(g["fc_X"], g["fc_Y"])
+    assert m.n_iter_ == int(g["fc_%s_nndsvdar_n_iter" % solver])
+    np.testing.assert_allclose(m.reconstruction_err_, float(g["fc_%s_nndsvdar_err" % solver]), rtol=1e-4 if solver == "mu" else 5e-3)
