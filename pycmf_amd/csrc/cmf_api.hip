@@ -104,6 +104,7 @@ struct cmf_ctx {
     int opt_pipe_small = 4; // staging schedule of the factor-side products (0 or 4; 4 measured +5..15 %, tools/ab_small.py)
     int opt_pipe = 4;      // GEMM staging schedule (see gemm_kernel PIPE); 4 measured best (tools/ab_gemm.py)
     int opt_split = -1;    // force split-K factor (<=0: heuristic)
+    int opt_rounds = 1;    // split-K heuristic of the data passes: aim at this many workgroups per CU (A/B option: 2 measured within noise of 1 at C2)
     int opt_arith_min_tiles = 8;   // ... only for operands of at least this many 256-row tiles
     int opt_arith = 0;     // data passes at k_pad = 256: 0 fp32 MFMA | 1 bf16x6 (three bf16 planes per operand, fp32-equivalent)
     int opt_ns = 1;        // flagged per-row Hessians at k_pad = 256: Newton-Schulz spectral clamp (0: Jacobi)
@@ -290,7 +291,7 @@ struct GemmPlan {
     int64_t klen;
 };
 
-static GemmPlan plan_gemm(const cmf_ctx *c, int64_t mout, int64_t n, int64_t kred, bool allow_split) {
+static GemmPlan plan_gemm(const cmf_ctx *c, int64_t mout, int64_t n, int64_t kred, bool allow_split, bool data_pass = false) {
     GemmPlan pl;
     pl.bn = n >= 256 ? 256 : (int)n; // n in {32,64,128} or a multiple of 256
     pl.ntiles_n = (int)(n / pl.bn);
@@ -300,7 +301,10 @@ static GemmPlan plan_gemm(const cmf_ctx *c, int64_t mout, int64_t n, int64_t kre
     if (allow_split && c->opt_split > 0) {
         s = std::min<int64_t>(c->opt_split, std::max<int64_t>(1, kred / 32));
     } else if (allow_split && tiles < (int64_t)(c->num_cu * 3) / 4) {
-        s = (c->num_cu + tiles / 2) / tiles;
+        // a GEMM with too few output tiles splits its reduction so that every CU gets a workgroup (`gemm_rounds` = r: r
+        // per CU for the data passes -- at C2 two rounds measured within run-to-run noise of one, three and four slower)
+        const int64_t want = (int64_t)c->num_cu * (data_pass ? std::max(1, c->opt_rounds) : 1);
+        s = (want + tiles / 2) / tiles;
         const int64_t maxs = std::max<int64_t>(1, kred / 128);
         s = std::max<int64_t>(1, std::min(s, maxs));
     }
@@ -383,7 +387,7 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
                 int64_t mout, int64_t n, int64_t kred, bool accumulate = false, const Epilogue *mu = nullptr) {
     const bool data_pass = (lda != c->kp);
     if (kred % 32 || n % 32) return fail(CMF_EINVAL, "gemm: unpadded extent (k=%lld n=%lld)", (long long)kred, (long long)n);
-    GemmPlan pl = plan_gemm(c, mout, n, kred, mu == nullptr);
+    GemmPlan pl = plan_gemm(c, mout, n, kred, mu == nullptr, data_pass);
     GemmArgs a;
     memset(&a, 0, sizeof a);
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb;
@@ -614,6 +618,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_pipe_small = (int)value;
     } else if (!strcmp(name, "gemm_split")) {
         c->opt_split = (int)value;
+    } else if (!strcmp(name, "gemm_rounds")) {
+        c->opt_rounds = (int)std::max<int64_t>(1, value);
     } else if (!strcmp(name, "z_logit_hessian_l2")) {
         c->opt_zlogit_l2 = value != 0;
     } else if (!strcmp(name, "row_diag")) {

@@ -95,3 +95,88 @@ def test_single_rank_bench_never_imports_torch():
                           "--warmup", "1", "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "torch imported: False" in out.stdout, out.stdout
+
+
+def test_csr_input_is_validated_canonicalised_and_left_alone(lib):
+    """malformed indptr is rejected before anything reads through it; duplicate entries are merged (||A||^2 of
+    the sparse error expansion is a sum over MERGED entries, like scipy's sum_duplicates); re-setting data on one problem
+    frees the previous images; the caller's matrix is never canonicalised in place."""
+    import scipy.sparse as sp
+    m, d, p, k = 6, 5, 3, 2
+    ctx = lib.Context(0)
+    ctx.set_option("sparse_mode", 2)
+    ctx.set_problem(m, d, p, k)
+    h = ctx._h
+    ip = np.array([0, 2, 1, 3, 3, 3, 3], dtype=np.int64)           # not monotonic
+    idx = np.array([0, 1, 2], dtype=np.int32)
+    val = np.ones(3)
+    rc = ctx._lib.cmf_set_data_csr(h, 0, ip.ctypes.data_as(lib._pi64), idx.ctypes.data_as(lib._pi32), val.ctypes.data_as(lib._pd), 3)
+    assert rc == 1 and b"not monotonic" in ctx._lib.cmf_last_error()
+    ip = np.array([0, 1, 2, 3, 3, 3, 2], dtype=np.int64)           # indptr[rows] != nnz (and not monotonic at the end)
+    rc = ctx._lib.cmf_set_data_csr(h, 0, ip.ctypes.data_as(lib._pi64), idx.ctypes.data_as(lib._pi32), val.ctypes.data_as(lib._pd), 3)
+    assert rc == 1
+    # duplicates and unsorted columns, straight through the C ABI (the Python wrapper would canonicalise a copy first)
+    ip = np.array([0, 3, 3, 4, 4, 4, 4], dtype=np.int64)
+    idx = np.array([4, 1, 4, 2], dtype=np.int32)                    # row 0: (4, 2.0) (1, 1.0) (4, 3.0)
+    val = np.array([2.0, 1.0, 3.0, 4.0])
+    for _ in range(2):                                              # twice: the second call replaces the first image
+        assert ctx._lib.cmf_set_data_csr(h, 0, ip.ctypes.data_as(lib._pi64), idx.ctypes.data_as(lib._pi32), val.ctypes.data_as(lib._pd), 4) == 0
+    ctx.set_data(1, np.ones((d, p)))
+    x2, _ = ctx.data_sq()
+    assert x2 == 1.0 + 25.0 + 16.0                                  # (2 + 3)^2 for the merged entry
+    dense = np.zeros((m, d)); dense[0, 4] = 5.0; dense[0, 1] = 1.0; dense[2, 2] = 4.0
+    np.testing.assert_array_equal(ctx.get_data(0), dense.astype(np.float32))
+    # the wrapper leaves a non-canonical caller matrix untouched
+    A = sp.csr_matrix((val.copy(), idx.copy(), ip.copy()), shape=(m, d))
+    assert not A.has_canonical_format
+    before = (A.data.copy(), A.indices.copy(), A.indptr.copy())
+    ctx.set_data(0, A)
+    for a, b in zip(before, (A.data, A.indices, A.indptr)):
+        np.testing.assert_array_equal(a, b)
+    ctx.close()
+
+
+def test_scratch_survives_set_problem_and_diagnostics_are_gated(lib):
+    """cmf_scratch_alloc buffers live until cmf_scratch_free / cmf_ctx_destroy (a re-sized problem does not free
+    them under the drivers that hold one); the timing-only knobs that produce wrong results need CMF_DIAG=1."""
+    ctx = lib.Context(0)
+    ctx.set_problem(40, 30, 20, 4)
+    buf = ctx.scratch(4 * ctx.v_buf_elems())
+    ctx.set_problem(50, 30, 20, 4)                                  # used to free the scratch behind the driver's back
+    rng = np.random.RandomState(0)
+    ctx.set_data(0, np.abs(rng.randn(50, 30))); ctx.set_data(1, np.abs(rng.randn(30, 20)))
+    for w, n in enumerate((50, 30, 20)):
+        ctx.set_factor(w, np.abs(rng.randn(n, 4)))
+    ctx.mu_v_partials(buf.data_ptr())                               # writes the (still live) buffer
+    ctx.mu_v_apply(buf.data_ptr(), 0.0, 0.0)
+    assert np.isfinite(ctx.get_factor(1)).all()
+    buf.release()                                                   # and it is still known to the context
+    with pytest.raises(ValueError, match="CMF_DIAG=1"):
+        ctx.set_option("row_diag", 1)
+    with pytest.raises(ValueError, match="CMF_DIAG=1"):
+        ctx.set_option("chol_diag", 2)
+    ctx.set_option("row_diag", 0)
+    ctx.close()
+
+
+def test_strided_and_float32_uploads_round_trip(lib):
+    """The pinned, multi-threaded staging path with every host layout the reference can hand over (C-ordered,
+    F-ordered views from `B.T`, sliced, float32): what comes back is the float32 rounding of what went in, factors are
+    written back into the caller's (strided) arrays in place."""
+    rng = np.random.RandomState(1)
+    m, d, p, k = 700, 2300, 90, 70                                  # 1.6e6 cells: several host threads, rows not a multiple of anything
+    big = rng.randn(2 * d, 2 * d)
+    ctx = lib.Context(0)
+    ctx.set_problem(m, d, p, k)
+    for X in (big[:m, :d], np.asfortranarray(big[:m, :d]), big[:2 * m:2, ::2], big[:m, :d].astype(np.float32), big.T[:m, :d]):
+        ctx.set_data(0, X)
+        np.testing.assert_array_equal(ctx.get_data(0), np.asarray(X, dtype=np.float32))
+    F = rng.randn(k, m)
+    Ft = F.T                                                         # F-ordered view, like the reference's Z
+    ctx.set_factor(0, Ft)
+    out = np.zeros((2 * m, 2 * k))
+    view = out[::2, ::2]
+    ctx.get_factor_into(0, view)
+    np.testing.assert_array_equal(view, Ft.astype(np.float32).astype(np.float64))
+    assert (out[1::2] == 0).all() and (out[:, 1::2] == 0).all()
+    ctx.close()
