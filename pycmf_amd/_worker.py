@@ -23,6 +23,26 @@ def main(job):
     meta = json.load(open(os.path.join(job, "job.json")))
     P, rows, cols = meta["params"], meta["rows"], meta["cols"]
     X, Y = _load(os.path.join(job, "X")), _load(os.path.join(job, "Y"))
+    if P.get("init"):
+        # initial factors on rank 0's GPU: the device-side initialisers need the whole matrices resident once
+        if rank == 0:
+            import warnings
+            from pycmf_amd import _lib
+            from pycmf_amd.estimator import initial_factors
+            from pycmf_amd.factor_init import DeviceOperand
+            I = P["init"]
+            Xw = X if sp.issparse(X) else np.asarray(X)
+            Yw = Y if sp.issparse(Y) else np.asarray(Y)
+            ctx = _lib.Context(local)
+            ctx.set_problem(Xw.shape[0], Xw.shape[1], Yw.shape[1], I["n_components"])
+            ctx.set_data(0, Xw); ctx.set_data(1, Yw)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                U0, V0, Z0 = initial_factors(Xw, Yw, None, None, None, op_x=DeviceOperand(ctx, 0, Xw.shape),
+                                             op_y=DeviceOperand(ctx, 1, Yw.shape), **I)
+            ctx.close()
+            np.savez(os.path.join(job, "factors.npz"), U=U0, V=V0, Z=Z0)
+        dist.barrier()
     F = np.load(os.path.join(job, "factors.npz"))
     r0, r1, c0, c1 = rows[rank], rows[rank + 1], cols[rank], cols[rank + 1]
     dense = lambda A: np.ascontiguousarray(A) if not sp.issparse(A) else A

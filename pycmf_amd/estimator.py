@@ -99,6 +99,50 @@ def collective_matrix_factorization(X, Y, U=None, V=None, Z=None,
             op_y = DeviceOperand(ctx, 1, Y.shape)
 
     # ---- initial factors (cmf.py:402-430)
+    init_spec = dict(x_init=x_init, y_init=y_init, n_components=n_components, random_state=random_state, x_link=x_link,
+                     y_link=y_link, U_non_negative=U_non_negative, V_non_negative=V_non_negative, Z_non_negative=Z_non_negative)
+    # n_gpus > 1 and inputs large enough for the device-side initialisers: rank 0 of the workers computes them on ITS GPU
+    # (this process touches none); custom starts are validated here as always
+    defer_init = (n_gpus > 1 and X is not None and Y is not None and any(b and n for b, n in zip(big, needs_dev))
+                  and isinstance(random_state, (int, np.integer, type(None))))
+    if defer_init and (x_init == 'custom' or y_init == 'custom'):
+        defer_init = False
+    if defer_init:
+        U, V, Z = (np.zeros((n, n_components)) for n in (X.shape[0], X.shape[1], Y.shape[1]))
+    else:
+        U, V, Z = initial_factors(X, Y, U, V, Z, op_x=op_x, op_y=op_y, **init_spec)
+
+    U, V, Z = _writable_f64(U), _writable_f64(V), _writable_f64(Z)
+    if n_gpus > 1:
+        if not (update_U and update_V and update_Z):
+            raise ValueError("n_gpus > 1 fits all three factors; use n_gpus=1 for transform / partial updates")
+        from .multi_gpu import fit_multi_gpu
+        U, V, Z = (np.ascontiguousarray(F) for F in (U, V, Z))
+        params = dict(l1_reg=l1_reg, l2_reg=l2_reg, max_iter=max_iter, tol=tol, verbose=verbose,
+                      alpha=(0.5 if solver == "mu" else float(alpha)), x_link=x_link, y_link=y_link,
+                      U_non_negative=bool(U_non_negative), V_non_negative=bool(V_non_negative),
+                      Z_non_negative=bool(Z_non_negative), hessian_pertubation=hessian_pertubation,
+                      sg_sample_ratio=sg_sample_ratio,
+                      random_state=(int(random_state) if isinstance(random_state, (int, np.integer)) else None))
+        if defer_init:
+            params["init"] = dict(init_spec, random_state=(None if random_state is None else int(random_state)))
+        n_iter, result = fit_multi_gpu(X, Y, U, V, Z, solver, int(n_gpus), params)
+        solver_object.release()
+        if _return_solver:
+            return U, V, Z, n_iter, result
+        return U, V, Z, n_iter
+    U, V, Z, n_iter = solver_object.fit_iterative_update(X, Y, U, V, Z)
+    if _return_solver:
+        return U, V, Z, n_iter, solver_object
+    solver_object.release()
+    return U, V, Z, n_iter
+
+
+def initial_factors(X, Y, U, V, Z, x_init, y_init, n_components, random_state, x_link, y_link,
+                    U_non_negative, V_non_negative, Z_non_negative, op_x=None, op_y=None):
+    """Initial U, V, Z as the reference's driver forms them (pycmf/cmf.py:402-430): per-side rule ('custom' validates the
+    given arrays, a logit link forces 'random'), then the V merge.  ``op_x`` / ``op_y``: device copies of X / Y for the
+    initialisers' passes over the data."""
     if x_init == 'custom':
         if X is not None:
             U = init_custom(U, X, n_components, 0, non_negative=U_non_negative, random_state=random_state)
@@ -120,29 +164,7 @@ def collective_matrix_factorization(X, Y, U=None, V=None, Z=None,
         V = (V + V_from_y) / 2
     elif Z_non_negative and not U_non_negative:
         V = V_from_y
-
-    U, V, Z = _writable_f64(U), _writable_f64(V), _writable_f64(Z)
-    if n_gpus > 1:
-        if not (update_U and update_V and update_Z):
-            raise ValueError("n_gpus > 1 fits all three factors; use n_gpus=1 for transform / partial updates")
-        from .multi_gpu import fit_multi_gpu
-        U, V, Z = (np.ascontiguousarray(F) for F in (U, V, Z))
-        params = dict(l1_reg=l1_reg, l2_reg=l2_reg, max_iter=max_iter, tol=tol, verbose=verbose,
-                      alpha=(0.5 if solver == "mu" else float(alpha)), x_link=x_link, y_link=y_link,
-                      U_non_negative=bool(U_non_negative), V_non_negative=bool(V_non_negative),
-                      Z_non_negative=bool(Z_non_negative), hessian_pertubation=hessian_pertubation,
-                      sg_sample_ratio=sg_sample_ratio,
-                      random_state=(int(random_state) if isinstance(random_state, (int, np.integer)) else None))
-        n_iter, result = fit_multi_gpu(X, Y, U, V, Z, solver, int(n_gpus), params)
-        solver_object.release()
-        if _return_solver:
-            return U, V, Z, n_iter, result
-        return U, V, Z, n_iter
-    U, V, Z, n_iter = solver_object.fit_iterative_update(X, Y, U, V, Z)
-    if _return_solver:
-        return U, V, Z, n_iter, solver_object
-    solver_object.release()
-    return U, V, Z, n_iter
+    return U, V, Z
 
 
 def _writable_f64(F):

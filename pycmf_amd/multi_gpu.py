@@ -5,7 +5,9 @@ keywords) to a scratch directory and starts N worker processes -- one rank per G
 'nccl' (RCCL over xGMI), rendezvous on 127.0.0.1.  Rank g memory-maps the job, takes its row block of X / U and column
 block of Y / Z (CSR X is cut into nnz-balanced row blocks for the MU solver) and runs
 ``fit_mu_sharded`` / ``fit_newton_sharded`` (pycmf_amd/sharded.py: the reference's outer loop, pycmf/cmf_solvers.py:132-195,
-with one all-reduce per iteration for V).  The parent reassembles U, V, Z in the caller's arrays.
+with one all-reduce per iteration for V).  For large inputs with a non-custom init, rank 0 first computes the initial
+factors with the device-side initialisers on its GPU (whole X, Y resident once, released before the fit).  The parent
+reassembles U, V, Z in the caller's arrays.
 
 Test hooks (a 1-GPU box): PYCMF_AMD_SAME_DEVICE=1 puts every rank on GPU 0 and PYCMF_AMD_DIST_BACKEND=gloo replaces RCCL,
 which refuses two ranks on one device.
@@ -78,7 +80,8 @@ def fit_multi_gpu(X, Y, U, V, Z, solver, n_gpus, params, timeout=None):
     try:
         _save(os.path.join(job, "X"), X)
         _save(os.path.join(job, "Y"), Y)
-        np.savez(os.path.join(job, "factors.npz"), U=U, V=V, Z=Z)
+        if not params.get("init"):   # else rank 0 computes the start on its GPU and writes this file
+            np.savez(os.path.join(job, "factors.npz"), U=U, V=V, Z=Z)
         rows, vrows, cols = partition(X, Y, solver, n_gpus)
         meta = dict(solver=solver, params=params, rows=[int(v) for v in rows], cols=[int(v) for v in cols],
                     vrows=None if vrows is None else [int(v) for v in vrows])

@@ -199,3 +199,22 @@ def test_cmf_n_gpus_through_the_drop_in_api(solver, kw, monkeypatch):
     tol = 2e-4 if solver == "mu" else 2e-3
     for a, b in ((U2, U1), (V2, V1), (Z2, Z1)):
         np.testing.assert_allclose(a, b, rtol=0, atol=tol * np.abs(b).max())
+
+
+def test_cmf_n_gpus_initialises_on_rank0_for_large_inputs(monkeypatch):
+    """Inputs above DEVICE_SVD_MIN_CELLS with a non-custom init: the parent skips the host initialisers and rank 0 computes the
+    start with the device-side ones (whole X, Y on its GPU once) -- the same start, hence the same fit, as n_gpus=1."""
+    from pycmf_amd import CMF
+    monkeypatch.setenv("PYCMF_AMD_SAME_DEVICE", "1")
+    monkeypatch.setenv("PYCMF_AMD_DIST_BACKEND", "gloo")
+    rng = np.random.RandomState(5)
+    U, V, Z = np.abs(rng.randn(2600, 6)), np.abs(rng.randn(1700, 6)), np.abs(rng.randn(60, 6))
+    X, Y = U @ V.T + 0.01 * np.abs(rng.randn(2600, 1700)), V @ Z.T           # 4.4e6 cells
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        two = CMF(n_components=6, solver="mu", random_state=0, max_iter=40, n_gpus=2).fit(X, Y)
+        one = CMF(n_components=6, solver="mu", random_state=0, max_iter=40, n_gpus=1).fit(X, Y)
+    assert two.n_iter_ == one.n_iter_
+    np.testing.assert_allclose(two.reconstruction_err_, one.reconstruction_err_, rtol=1e-3)
+    np.testing.assert_allclose(two.components, one.components, rtol=0, atol=2e-3 * np.abs(one.components).max())
