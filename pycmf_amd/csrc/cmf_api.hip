@@ -138,11 +138,13 @@ struct cmf_ctx {
     float *num = nullptr, *den = nullptr; // max(mp,dp,pp) x kp
     float *G = nullptr, *G2 = nullptr, *Hm = nullptr, *Hinv = nullptr, *Eye = nullptr; // kp x kp
     float *vbuf = nullptr;                // dp*kp + kp*kp
-    DevBuf slabs;                         // split-K partial tiles (grow-only)
+    DevBuf slabs, slabs_b;                // split-K partial tiles (grow-only); second set for a product whose slabs must outlive the next one
+    int slab_sel = 0;                     // which set gemm() writes
     DevBuf tickets;                       // one arrival counter per output tile of a split-K GEMM (zero between launches)
     int opt_inred = 0;                    // 0: split-K partials summed by a chip-wide kernel | 1: by the last-arriving workgroup of each tile
                                           // inside the GEMM kernel (A/B option; measured slower)
     int opt_fused_mu = 1;                 // 1: F <- F num / reg(F G) in the epilogue of the F G product | 0: separate kernel
+    int opt_small_tile = 1;               // 1: k_pad 64 / 128 factor updates on 64-row tiles (factor_update_kernel) | 0: gemm_kernel's 256-row tile
     DevBuf resid;                         // Newton residual / weights scratch (grow-only)
     DevBuf resid2, resid3;                // sigma' / sample weights (X side, Y side)
     DevBuf kr1, kr2;                      // Khatri-Rao squares of factors
@@ -369,9 +371,16 @@ static int sum_slabs(cmf_ctx *c, float *dst, const float *src, int64_t n, int ns
 
 static int mu_apply(cmf_ctx *c, float *F, const float *num, const float *den, int64_t n, double l1, double l2);
 
+struct SlabRef { // a split-K result left unreduced for a consumer that sums the slabs itself (factor_update_kernel)
+    const float *base = nullptr;
+    int nslab = 0;
+    int64_t stride = 0;
+};
+
 struct Epilogue { // fused factor update in the epilogue of a factor-side product (gemm_kernel, epi != 0)
     int kind = 0;           // EPI_MU | EPI_GRAD | EPI_APPLY
     const float *F = nullptr, *P = nullptr;
+    const SlabRef *Pslabs = nullptr, *Pslabs2 = nullptr; // P (additionally) as unreduced slabs (small-tile kernel only)
     float *out = nullptr;
     double a = 0.0, b = 0.0, c = 0.0;
     int64_t rows = 0;
@@ -384,8 +393,9 @@ struct Epilogue { // fused factor update in the epilogue of a factor-side produc
 // `A` is a factor-sized operand when lda == k_pad (Grams, F*G, step products): those launches
 // use the ROLE=1 symbol and the CMF_K_GEMM_SMALL timing class.
 static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *B, int64_t ldb, float *out,
-                int64_t mout, int64_t n, int64_t kred, bool accumulate = false, const Epilogue *mu = nullptr) {
+                int64_t mout, int64_t n, int64_t kred, bool accumulate = false, const Epilogue *mu = nullptr, SlabRef *defer = nullptr) {
     const bool data_pass = (lda != c->kp);
+    DevBuf &slabbuf = c->slab_sel ? c->slabs_b : c->slabs;
     if (kred % 32 || n % 32) return fail(CMF_EINVAL, "gemm: unpadded extent (k=%lld n=%lld)", (long long)kred, (long long)n);
     GemmPlan pl = plan_gemm(c, mout, n, kred, mu == nullptr, data_pass);
     GemmArgs a;
@@ -413,8 +423,8 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
         a.C = out;
     } else {
         const size_t need = (size_t)pl.nsplit * rows_store * n * sizeof(float);
-        CHK(ensure(c, c->slabs, need));
-        a.C = (float *)c->slabs.p;
+        CHK(ensure(c, slabbuf, need));
+        a.C = (float *)slabbuf.p;
         a.slab_stride = rows_store * n;
         if (in_kernel) {
             const size_t ntile = (size_t)pl.tiles_m * pl.ntiles_n;
@@ -436,13 +446,54 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
             else CHK((launch_gemm_mode<MODE_TN, 1>(c, a, pl)));
         }
     }
-    if (!direct && !in_kernel) CHK(sum_slabs(c, out, (const float *)c->slabs.p, rows_store * n, pl.nsplit, a.slab_stride, accumulate));
+    if (!direct && !in_kernel) {
+        if (defer && !accumulate) { // the consumer sums the slabs (valid until the next GEMM reuses the slab workspace)
+            defer->base = (const float *)slabbuf.p; defer->nslab = pl.nsplit; defer->stride = a.slab_stride;
+            return CMF_OK;
+        }
+        CHK(sum_slabs(c, out, (const float *)slabbuf.p, rows_store * n, pl.nsplit, a.slab_stride, accumulate));
+    }
+    if (defer) *defer = SlabRef();
+    return CMF_OK;
+}
+
+// rows x k_pad x k_pad product with a fused factor update on 64-row tiles (k_pad 64 / 128): see factor_update_kernel
+static bool small_tile_ok(const cmf_ctx *c, int64_t rows_pad) {
+    return c->opt_fused_mu && c->opt_small_tile && (c->kp == 64 || c->kp == 128) && rows_pad * c->kp <= ((int64_t)1 << 27);
+}
+static int factor_update(cmf_ctx *c, const float *A, const float *B, const Epilogue &e, int64_t rows_pad) {
+    FactorUpdArgs g;
+    memset(&g, 0, sizeof g);
+    g.A = A; g.B = B; g.epi = e.kind; g.F = e.F; g.P = e.P; g.out = e.out;
+    if (e.Pslabs && e.Pslabs->nslab > 0) { g.S1 = e.Pslabs->base; g.n1 = e.Pslabs->nslab; g.stride1 = e.Pslabs->stride; }
+    if (e.Pslabs2 && e.Pslabs2->nslab > 0) { g.S2 = e.Pslabs2->base; g.n2 = e.Pslabs2->nslab; g.stride2 = e.Pslabs2->stride; }
+    g.a = (float)e.a; g.b = (float)e.b; g.c = (float)e.c; g.rows_valid = e.rows; g.kvalid = e.kvalid; g.nn = e.nn;
+    Timed tm(c, CMF_K_GEMM_SMALL, 2.0 * (double)rows_pad * c->kp * c->kp);
+    const dim3 grid((unsigned)(rows_pad / 64));
+    if (c->kp == 128) {
+        const size_t lds = (size_t)(128 * 128 + 64 * 132) * sizeof(float);
+        CHK(allow_big_lds(c, reinterpret_cast<const void *>(&factor_update_kernel<128>), (int)lds));
+        hipLaunchKernelGGL((factor_update_kernel<128>), grid, dim3(256), lds, c->stream, g);
+    } else {
+        const size_t lds = (size_t)(64 * 64 + 64 * 68) * sizeof(float);
+        hipLaunchKernelGGL((factor_update_kernel<64>), grid, dim3(256), lds, c->stream, g);
+    }
+    HIPCHK(hipGetLastError());
     return CMF_OK;
 }
 
 // F <- F * num / reg(F G)   (MUSolver._regularized_delta, cmf_solvers.py:212-228): one launch when the factor-side
 // product has a single N tile (k_pad <= 256), else product + elementwise kernel
-static int mu_update(cmf_ctx *c, float *F, const float *G, const float *num, int64_t rows_pad, double l1, double l2) {
+static int mu_update(cmf_ctx *c, float *F, const float *G, const float *num, int64_t rows_pad, double l1, double l2,
+                     const SlabRef *num_slabs = nullptr, const SlabRef *num_slabs2 = nullptr) {
+    if (small_tile_ok(c, rows_pad)) {
+        Epilogue e;
+        e.kind = EPI_MU; e.F = F; e.out = F; e.a = l1; e.b = l2; e.c = 1.1920928955078125e-07;
+        // a deferred product left `num` unwritten: its value is the sum of its slabs
+        e.P = (num_slabs && num_slabs->nslab > 0) ? nullptr : num;
+        e.Pslabs = num_slabs; e.Pslabs2 = num_slabs2;
+        return factor_update(c, F, G, e, rows_pad);
+    }
     if (c->opt_fused_mu && c->kp <= 256) {
         Epilogue e;
         e.kind = EPI_MU; e.F = F; e.P = num; e.out = F; e.a = l1; e.b = l2; e.c = 1.1920928955078125e-07;
@@ -563,7 +614,7 @@ static void release_problem(cmf_ctx *c) {
     c->X = c->Y = nullptr;
     c->F[0] = c->F[1] = c->F[2] = nullptr;
     c->num = c->den = c->G = c->G2 = c->Hm = c->Hinv = c->Eye = c->vbuf = nullptr;
-    c->slabs = DevBuf(); c->tickets = DevBuf(); c->resid = DevBuf(); c->resid2 = DevBuf(); c->resid3 = DevBuf(); c->dpart = DevBuf();
+    c->slabs = DevBuf(); c->slabs_b = DevBuf(); c->slab_sel = 0; c->tickets = DevBuf(); c->resid = DevBuf(); c->resid2 = DevBuf(); c->resid3 = DevBuf(); c->dpart = DevBuf();
     c->kr1 = DevBuf(); c->kr2 = DevBuf(); c->hrows = DevBuf(); c->mask1 = DevBuf(); c->mask2 = DevBuf();
     c->lists1 = DevBuf(); c->lists2 = DevBuf();
     c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf();
@@ -651,6 +702,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_chol = value != 0;
     } else if (!strcmp(name, "split_reduce_in_kernel")) {
         c->opt_inred = value != 0;
+    } else if (!strcmp(name, "small_tile_update")) {
+        c->opt_small_tile = value != 0;
     } else if (!strcmp(name, "fused_mu_update")) {
         c->opt_fused_mu = value != 0;
     } else if (!strcmp(name, "shared_hessian_f64")) {
@@ -1051,13 +1104,15 @@ extern "C" int cmf_mu_uz_update(cmf_ctx *c, double l1, double l2, int mask) {
     CHK(gemm(c, MODE_TN, c->F[CMF_V], c->kp, c->F[CMF_V], c->kp, c->G2, c->kp, c->kp, c->dp));
     if (mask & CMF_UPD_U) {
         if (!have_data(c, 0)) return fail(CMF_EINVAL, "X must be set before a U update");
-        CHK(data_times(c, 0, false, c->F[CMF_V], c->num));
-        CHK(mu_update(c, c->F[CMF_U], c->G2, c->num, c->mp, l1, l2));
+        SlabRef sl;
+        CHK(data_times(c, 0, false, c->F[CMF_V], c->num, false, small_tile_ok(c, c->mp) ? &sl : nullptr));
+        CHK(mu_update(c, c->F[CMF_U], c->G2, c->num, c->mp, l1, l2, &sl));
     }
     if (mask & CMF_UPD_Z) {
         if (!have_data(c, 1)) return fail(CMF_EINVAL, "Y must be set before a Z update");
-        CHK(data_times(c, 1, true, c->F[CMF_V], c->num));
-        CHK(mu_update(c, c->F[CMF_Z], c->G2, c->num, c->pp, l1, l2));
+        SlabRef sl;
+        CHK(data_times(c, 1, true, c->F[CMF_V], c->num, false, small_tile_ok(c, c->pp) ? &sl : nullptr));
+        CHK(mu_update(c, c->F[CMF_Z], c->G2, c->num, c->pp, l1, l2, &sl));
     }
     return CMF_OK;
 }
@@ -1112,7 +1167,35 @@ static int run_graphed(cmf_ctx *c, StepGraph &g, const double *key, int nkey, F 
     return CMF_OK;
 }
 
+// V update of the single-GPU step with both numerator products left as slabs for the update kernel (no slab-sum launches,
+// no round trip of P through HBM): cmf_solvers.py:242-246, :253-255
+static int mu_v_fused(cmf_ctx *c, double l1, double l2) {
+    float *P = c->vbuf, *Gs = c->vbuf + c->dp * c->kp;
+    SlabRef s1, s2;
+    // the Gram first: its own split goes through slab set 0, which the deferred products below must own until the update
+    CHK(gemm(c, MODE_TN, c->F[CMF_U], c->kp, c->F[CMF_U], c->kp, Gs, c->kp, c->kp, c->mp + c->pp));
+    CHK(data_times(c, 0, true, c->F[CMF_U], P, false, &s1));           // X^T U: slabs (set 0) or, unsplit, P itself
+    const float *direct = s1.nslab > 0 ? nullptr : P;
+    if (s1.nslab > 0) {
+        c->slab_sel = 1;                                                // Y Z must not overwrite the slabs of X^T U
+        const int rc = data_times(c, 1, false, c->F[CMF_Z], c->num, false, &s2);
+        c->slab_sel = 0;
+        CHK(rc);
+        if (s2.nslab == 0) direct = c->num;                            // unsplit: its value sits in c->num
+    } else {
+        CHK(data_times(c, 1, false, c->F[CMF_Z], P, true));            // accumulate onto P as usual
+    }
+    Epilogue e;
+    e.kind = EPI_MU; e.F = c->F[CMF_V]; e.out = c->F[CMF_V]; e.a = l1; e.b = l2; e.c = 1.1920928955078125e-07;
+    e.P = direct; e.Pslabs = &s1; e.Pslabs2 = &s2;
+    return factor_update(c, c->F[CMF_V], Gs, e, c->dp);
+}
+
 static int mu_step_eager(cmf_ctx *c, double l1, double l2, int mask) {
+    if ((mask & CMF_UPD_V) && small_tile_ok(c, c->dp) && c->X && c->Y && !c->opt_arith) {
+        CHK(mu_v_fused(c, l1, l2));
+        return cmf_mu_uz_update(c, l1, l2, mask);
+    }
     if (mask & CMF_UPD_V) {
         CHK(cmf_mu_v_partials(c, c->vbuf));
         CHK(cmf_mu_v_apply(c, c->vbuf, l1, l2));

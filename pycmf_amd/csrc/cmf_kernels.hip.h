@@ -703,6 +703,142 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// ------------------------------------------------------------------ factor update with a small row tile (k_pad 64 / 128)
+// The factor-side products of an update step are rows x k_pad x k_pad: at mid sizes (C2: U has 16384 rows) the 256-row tile
+// of gemm_kernel gives 64 workgroups that each spend their time waiting for four dependent K-steps -- 29 us for 1.7 us of
+// MFMA work.  Here one 256-thread workgroup owns 64 rows: the whole right operand (k_pad x k_pad) and its 64 x k_pad left
+// tile are fetched in ONE round, then 2 x k_pad / 2 MFMAs per wave run back to back, then the update is applied as in
+// gemm_kernel's fused epilogues (EPI_MU / EPI_GRAD / EPI_APPLY).  The second operand P of the epilogue may arrive as the
+// UNREDUCED split-K slabs of the data pass that produced it (P = sum of nslab slabs, summed here in slab order -- the same
+// values sum_slabs_kernel would have written, without its launch and its round trip through HBM).
+struct FactorUpdArgs {
+    const float *A;      // left operand rows x KP (F for EPI_MU / EPI_GRAD, the gradient for EPI_APPLY), pitch KP
+    const float *B;      // KP x KP right operand (Gram or inverse Hessian), pitch KP
+    int epi;             // EPI_MU | EPI_GRAD | EPI_APPLY
+    const float *F;      // factor (epilogue operand), pitch KP
+    const float *P;      // second epilogue operand (nullable when it arrives as slabs only)
+    const float *S1, *S2; // ... plus the unreduced split-K slabs of up to two data passes: P_total = P + sum S1 + sum S2
+    int n1, n2;
+    int64_t stride1, stride2;
+    float *out;
+    float a, b, c;
+    int64_t rows_valid;
+    int kvalid, nn;
+};
+
+template <int KP>
+__global__ __launch_bounds__(256) void factor_update_kernel(FactorUpdArgs g) {
+    static_assert(KP == 64 || KP == 128, "small-tile factor update: k_pad 64 or 128");
+    constexpr int LA = KP + 4;             // A tile pitch: 16-byte slot (KP / 4 + 1) * row: ds_read_b128 of 16 rows is conflict-free
+    constexpr int NB = KP / 64;            // 32-column blocks per wave (wave tile 32 x KP / 2)
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    float *Bs = fsm;                       // [KP][KP]
+    float *As = fsm + KP * KP;             // [64][LA]
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int wr = (w & 1) * 32, wc = (w >> 1) * (KP / 2);
+    {   // every global load of the workgroup is issued before the first LDS store: ONE memory latency for both operands
+        constexpr int NBL = KP * KP / 4 / 256, NAL = 64 * KP / 4 / 256;
+        f32x4 gb[NBL], ab[NAL];
+#pragma unroll
+        for (int q = 0; q < NBL; ++q) gb[q] = reinterpret_cast<const f32x4 *>(g.B)[t + 256 * q];
+#pragma unroll
+        for (int q = 0; q < NAL; ++q) {
+            const int idx = t + 256 * q;
+            ab[q] = *reinterpret_cast<const f32x4 *>(g.A + (row0 + idx / (KP / 4)) * KP + 4 * (idx % (KP / 4)));
+        }
+#pragma unroll
+        for (int q = 0; q < NBL; ++q) reinterpret_cast<f32x4 *>(Bs)[t + 256 * q] = gb[q];
+#pragma unroll
+        for (int q = 0; q < NAL; ++q) {
+            const int idx = t + 256 * q;
+            *reinterpret_cast<f32x4 *>(As + (idx / (KP / 4)) * LA + 4 * (idx % (KP / 4))) = ab[q];
+        }
+    }
+    __syncthreads();
+    f32x16 acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll 4
+    for (int q = 0; q < KP / 4; ++q) { // four k per chunk: two MFMA steps
+        const f32x4 a4 = *reinterpret_cast<const f32x4 *>(As + (wr + l31) * LA + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = 4 * q + 2 * e + lh;
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2 * e + lh], Bs[k * KP + wc + 32 * j + l31], acc[j], 0, 0, 0);
+        }
+    }
+    // epilogue: element (row, col) = (row0 + wr + (r & 3) + 8 (r >> 2) + 4 lh, wc + 32 j + l31): 32 lanes = 128 contiguous bytes
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int col = wc + 32 * j + l31;
+        float fv[16], pv[16];
+        const float *Fb = g.F + (row0 + wr + 4 * lh) * KP + col;   // register r: + ((r & 3) + 8 (r >> 2)) rows
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fv[r] = Fb[((r & 3) + 8 * (r >> 2)) * KP];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pv[r] = 0.f;
+        if (g.epi != EPI_APPLY) {
+            const int64_t eoff = (row0 + wr + 4 * lh) * KP + col;
+            auto add_slabs = [&](const float *base, int ns, int64_t stride) {
+                const float *Pb = base + eoff;
+                int sidx = 0;
+                for (; sidx + 4 <= ns; sidx += 4) { // 64 independent loads in flight, summed in slab order
+                    float part[4][16];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) part[u][r] = Pb[(int64_t)(sidx + u) * stride + ((r & 3) + 8 * (r >> 2)) * KP];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) pv[r] += part[u][r];
+                }
+                for (; sidx < ns; ++sidx) {
+                    float part[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part[r] = Pb[(int64_t)sidx * stride + ((r & 3) + 8 * (r >> 2)) * KP];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pv[r] += part[r];
+                }
+            };
+            if (g.P) add_slabs(g.P, 1, 0);
+            if (g.n1 > 0) add_slabs(g.S1, g.n1, g.stride1);
+            if (g.n2 > 0) add_slabs(g.S2, g.n2, g.stride2);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + wr + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float av = acc[j][r], f = fv[r];
+            float res;
+            if (g.epi == EPI_MU) {
+                float d = av;
+                if (g.a > 0.f) d += g.a;
+                if (g.b > 0.f) d = d + g.b * f;
+                if (d == 0.f) d = g.c;
+                res = f * (pv[r] / d);
+            } else if (g.epi == EPI_GRAD) {
+                const float sg = (f > 0.f) ? 1.f : ((f < 0.f) ? -1.f : 0.f);
+                float gval = g.a * av;
+                gval += -g.a * pv[r];
+                res = gval + g.b * sg + g.c * f;
+            } else {
+                res = 0.f;
+                if (row < g.rows_valid && col < g.kvalid) {
+                    res = f - av;
+                    if (g.nn && res < 0.f) res = 0.f;
+                }
+            }
+            g.out[row * KP + col] = res;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ elementwise
 // dst[i] = (accumulate ? dst[i] : 0) + sum_s src[s*stride + i]      (float4 lanes)
 __global__ void sum_slabs_kernel(float *dst, const float *src, int64_t n4, int nslab,

@@ -427,6 +427,7 @@ static int shared_step(cmf_ctx *c, int which, double pert, bool non_negative) {
     if (c->opt_fused_mu && c->kp <= 256) { // F <- clamp(F - grad H^-1) in the epilogue of the step product
         Epilogue e;
         e.kind = EPI_APPLY; e.F = c->F[which]; e.out = c->F[which]; e.rows = c->frows[which]; e.kvalid = c->k; e.nn = non_negative ? 1 : 0;
+        if (small_tile_ok(c, rows)) return factor_update(c, c->den, c->Hinv, e, rows);
         return gemm(c, MODE_NN, c->den, c->kp, c->Hinv, c->kp, c->num, rows, c->kp, c->kp, false, &e);
     }
     CHK(gemm(c, MODE_NN, c->den, c->kp, c->Hinv, c->kp, c->num, rows, c->kp, c->kp));
@@ -469,7 +470,8 @@ static int sweep_side_shared(cmf_ctx *c, bool is_u, double scale, double l1, dou
     if (c->opt_fused_mu && c->kp <= 256) { // grad = s (F G - T O) + l1 sign F + l2 F in the epilogue of F (V^T V)
         Epilogue e;
         e.kind = EPI_GRAD; e.F = F; e.P = c->num; e.out = c->den; e.a = scale; e.b = l1; e.c = l2;
-        CHK(gemm(c, MODE_NN, F, c->kp, c->G2, c->kp, c->den, rows, c->kp, c->kp, false, &e));
+        if (small_tile_ok(c, rows)) CHK(factor_update(c, F, c->G2, e, rows));
+        else CHK(gemm(c, MODE_NN, F, c->kp, c->G2, c->kp, c->den, rows, c->kp, c->kp, false, &e));
     } else {
         CHK(gemm(c, MODE_NN, F, c->kp, c->G2, c->kp, c->den, rows, c->kp, c->kp));           // F (V^T V)
         CHK(launch_ew(c, newton_grad_kernel, rows * c->kp, c->den, (const float *)c->den, (float)scale, (const float *)c->num,
@@ -524,7 +526,8 @@ extern "C" int cmf_newton_v_apply(cmf_ctx *c, const float *buf, double l1, doubl
     if (c->opt_fused_mu && c->kp <= 256) {
         Epilogue e;
         e.kind = EPI_GRAD; e.F = V; e.P = P; e.out = c->den; e.a = 1.0; e.b = l1; e.c = l2;
-        CHK(gemm(c, MODE_NN, V, c->kp, Gs, c->kp, c->den, c->dp, c->kp, c->kp, false, &e)); // V Gmix - P + reg
+        if (small_tile_ok(c, c->dp)) CHK(factor_update(c, V, Gs, e, c->dp));
+        else CHK(gemm(c, MODE_NN, V, c->kp, Gs, c->kp, c->den, c->dp, c->kp, c->kp, false, &e)); // V Gmix - P + reg
     } else {
         CHK(gemm(c, MODE_NN, V, c->kp, Gs, c->kp, c->den, c->dp, c->kp, c->kp)); // V Gmix
         CHK(launch_ew(c, newton_grad_kernel, c->dp * c->kp, c->den, (const float *)c->den, 1.0f, P, -1.0f, (const float *)V,

@@ -287,15 +287,16 @@ static int data_times_bf16x6(cmf_ctx *c, int which, bool trans, const float *A, 
     return CMF_OK;
 }
 
-static int data_times(cmf_ctx *c, int which, bool trans, const float *B, float *out, bool accumulate = false) {
+static int data_times(cmf_ctx *c, int which, bool trans, const float *B, float *out, bool accumulate = false, SlabRef *defer = nullptr) {
+    if (defer) *defer = SlabRef();
     const int64_t rp = which == 0 ? c->mp : c->dp, cp = which == 0 ? c->dp : c->pp;
     if (c->sparse[which] && !(which == 0 ? c->X : c->Y)) return spmm(c, c->sp[which][trans ? 1 : 0], B, out, trans ? cp : rp, accumulate);
     const float *A = which == 0 ? c->X : c->Y;
     if (!A) return fail(CMF_EINVAL, "%s has not been set", which == 0 ? "X" : "Y");
     // optional arithmetic (k_pad = 256 or 128; tiny operands stay on the fp32 kernels)
     if (c->opt_arith == 1 && (c->kp == 256 || c->kp == 128) && (trans ? cp : rp) >= (int64_t)c->opt_arith_min_tiles * 256) return data_times_bf16x6(c, which, trans, A, B, out, accumulate);
-    if (!trans) return gemm(c, MODE_NN, A, cp, B, c->kp, out, rp, c->kp, cp, accumulate);
-    return gemm(c, MODE_TN, A, cp, B, c->kp, out, cp, c->kp, rp, accumulate);
+    if (!trans) return gemm(c, MODE_NN, A, cp, B, c->kp, out, rp, c->kp, cp, accumulate, nullptr, defer);
+    return gemm(c, MODE_TN, A, cp, B, c->kp, out, cp, c->kp, rp, accumulate, nullptr, defer);
 }
 
 static bool have_data(const cmf_ctx *c, int which) { return (which == 0 ? c->X : c->Y) != nullptr || c->sparse[which]; }

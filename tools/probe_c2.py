@@ -27,7 +27,7 @@ def run(m, d, p, k, split, steps=6, **opts):
     ctx.close()
 
 for rep in range(2):
-    for r in (1, 2, 3, 4):
-        run(16384, 8192, 4096, 128, -1, gemm_rounds=r)
-run(8192, 65536, 8192, 256, -1, 3, gemm_rounds=1)   # the C4 shard of one of 8 ranks
-run(8192, 65536, 8192, 256, -1, 3, gemm_rounds=2)
+    run(16384, 8192, 4096, 128, -1)
+    run(16384, 8192, 4096, 128, -1, small_tile_update=0)
+run(4096, 2048, 1024, 64, -1)
+run(4096, 2048, 1024, 64, -1, small_tile_update=0)
