@@ -213,6 +213,17 @@ class ShardedNewtonRows:
             self._gather(1)
 
 
+class SingleGpuStep:
+    """world == 1: no partial buffer, no collective -- the context's own fused step (what ``CMF.fit`` runs on one GPU:
+    ``cmf_mu_step`` / ``cmf_newton_step``)."""
+
+    def __init__(self, fn):
+        self._fn = fn
+
+    def step(self, l1=0.0, l2=0.0, mask=7):
+        self._fn(l1, l2, mask)
+
+
 class TorchCollectives:
     """torch.distributed collectives (backend 'nccl' = RCCL over xGMI) ordered EXPLICITLY on the stream the context
     launches on: every call runs under ``torch.cuda.stream(ExternalStream(ctx stream))``, so a driver's ``step()``
@@ -279,7 +290,7 @@ def make_torch_sharded_mu(ctx, world, device, timed=False):
     the partial buffer is context scratch."""
     backend = HipShardBackend(ctx)
     if world == 1:
-        return ShardedMU(backend, ctx.scratch(4 * backend.buf_elems()), 1, None)
+        return SingleGpuStep(lambda l1, l2, mask: ctx.mu_step(l1, l2, mask))
     import torch
     buf = torch.zeros(backend.buf_elems(), dtype=torch.float32, device=device)
     coll = TorchCollectives(ctx, device, timed)
@@ -291,7 +302,7 @@ def make_torch_sharded_mu(ctx, world, device, timed=False):
 def make_torch_sharded_newton(ctx, world, device, alpha, nn_mask=0, pert=0.2, timed=False):
     backend = HipNewtonShardBackend(ctx, alpha, nn_mask, pert)
     if world == 1:
-        return ShardedNewtonLinear(backend, ctx.scratch(4 * backend.buf_elems()), 1, None)
+        return SingleGpuStep(lambda l1, l2, mask: ctx.newton_step(alpha, l1, l2, "linear", "linear", nn_mask, mask, pert, 1.0))
     import torch
     buf = torch.zeros(backend.buf_elems(), dtype=torch.float32, device=device)
     coll = TorchCollectives(ctx, device, timed)
