@@ -954,8 +954,11 @@ extern "C" int cmf_newton_step(cmf_ctx *c, double alpha, double l1, double l2, i
                                double pert, double ratio, const int32_t *u_idx, const int32_t *z_idx, const int32_t *vx_idx,
                                const int32_t *vy_idx) {
     NEED_PROBLEM(c);
-    if (x_link == CMF_LINK_LINEAR && y_link == CMF_LINK_LINEAR && ratio >= 1.0 && have_data(c, 0) && have_data(c, 1)) {
-        // all three sweeps take the shared-Hessian form: a fixed launch sequence -> graph replay
+    if (x_link == CMF_LINK_LINEAR && y_link == CMF_LINK_LINEAR && ratio >= 1.0 && have_data(c, 0) && have_data(c, 1) &&
+        c->opt_graph && use_shared64(c) && c->k <= 64) {
+        // all three sweeps take the shared-Hessian form and the float64 inverse of k <= 64 decides everything on the device:
+        // a fixed launch sequence with no host round trip -> graph replay.  (Larger k read two flags back per inverse:
+        // those steps are not captured.)
         DeviceGuard dg(c->device);
         const double key[6] = {alpha, l1, l2, (double)nn_mask, (double)upd, pert};
         return run_graphed(c, c->newton_graph, key, 6, [&]() {

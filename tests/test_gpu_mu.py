@@ -173,3 +173,31 @@ def test_synthetic_fill_is_partition_independent(lib):
     np.testing.assert_array_equal(part.get_data(1), Yf[:, 60:100])
     assert Xf.min() >= 0 and abs(Xf.mean() - 0.7979) < 0.02 and abs((Xf ** 2).mean() - 1.0) < 0.03
     full.close(); part.close()
+
+
+@pytest.mark.parametrize("solver", ["mu", "newton"])
+def test_graph_replay_matches_eager(lib, solver):
+    """cmf_set_option("graph", 1): the MU step and the linear-link Newton step (k <= 64: the float64 shared inverse decides
+    on the device, no host round trip) are captured into a hipGraph on their second call and replayed from then on; the
+    iterates must be the eager ones bit for bit."""
+    rng = np.random.RandomState(4)
+    m, d, p, k = 300, 200, 120, 24
+    X, Y = np.abs(rng.randn(m, d)), np.abs(rng.randn(d, p))
+    F0 = [0.3 * np.abs(rng.randn(n, k)) + 0.05 for n in (m, d, p)]
+    outs = []
+    for graph in (0, 1):
+        ctx = lib.Context(0)
+        ctx.set_option("graph", graph)
+        ctx.set_problem(m, d, p, k)
+        ctx.set_data(0, X); ctx.set_data(1, Y)
+        for w, F in enumerate(F0):
+            ctx.set_factor(w, F)
+        for _ in range(6):
+            if solver == "mu":
+                ctx.mu_step(0.01, 0.02, 7)
+            else:
+                ctx.newton_step(0.5, 0.01, 0.3, "linear", "linear", 7, 7, 0.2, 1.0)
+        outs.append([ctx.get_factor(w) for w in range(3)])
+        ctx.close()
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
