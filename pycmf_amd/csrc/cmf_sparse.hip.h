@@ -90,11 +90,12 @@ struct BcsrView {
     int nsync;              // stretches per list: the class re-aligns between stretches (every few column blocks)
 };
 
+constexpr int BCSR_NW = 8;  // waves per workgroup (host layout and kernel agree on it)
 template <int VEC> // floats per lane; k_pad = 64 * VEC
-__global__ __launch_bounds__(512) void spmm_blocked_kernel(BcsrView A, const float *F, float *out, int accumulate, unsigned *bar) {
+__global__ __launch_bounds__(64 * BCSR_NW) void spmm_blocked_kernel(BcsrView A, const float *F, float *out, int accumulate, unsigned *bar) {
     typedef float vec __attribute__((ext_vector_type(VEC)));
     constexpr int KP = 64 * VEC;
-    constexpr int CH = 16; // gathers issued together; two chunks are in flight (32 KB per wave at k_pad = 256)
+    constexpr int CH = BCSR_NW == 8 ? 16 : 8; // gathers issued together; two chunks are in flight (32 KB per wave at k_pad = 256)
     extern __shared__ __attribute__((aligned(16))) float lacc[]; // [rows of the group][KP]
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(512) void spmm_blocked_kernel(BcsrView A, const flo
         if (gi >= groups_q) break;
         const int g = q + 8 * gi;
         const int r0 = A.grow[g], nrows = A.grow[g + 1] - r0;
-        for (int r = w; r < nrows; r += 8) {
+        for (int r = w; r < nrows; r += BCSR_NW) {
             vec z;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) z[e] = 0.f;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(512) void spmm_blocked_kernel(BcsrView A, const flo
         // this wave's entry list for the group: sorted by (column block, row, column), cut into nsync stretches of a few
         // column blocks.  The metadata of 64 entries arrives by ONE coalesced vector load (lane u holds entry u) and is
         // broadcast with v_readlane; gathers go out 16 at a time, the next chunk's before the current chunk is consumed.
-        const int64_t *segw = A.seg + ((int64_t)g * 8 + w) * A.nsync;
+        const int64_t *segw = A.seg + ((int64_t)g * BCSR_NW + w) * A.nsync;
         int cur = -1;
         vec racc;
 #pragma unroll
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(512) void spmm_blocked_kernel(BcsrView A, const flo
         }
         }
         flush();
-        for (int r = w; r < nrows; r += 8) {
+        for (int r = w; r < nrows; r += BCSR_NW) {
             vec v = *reinterpret_cast<const vec *>(lacc + r * KP + lane * VEC);
             vec *dst = reinterpret_cast<vec *>(out + (int64_t)(r0 + r) * KP + lane * VEC);
             if (accumulate) v += *dst;

@@ -33,13 +33,13 @@ static int bcsr_build_upload(cmf_ctx *c, CsrDev &dst, const int64_t *indptr, con
     grow.push_back((int32_t)rows);
     const int64_t ngroups = (int64_t)grow.size() - 1;
     const int64_t nblocks = std::max<int64_t>(1, (cols + B - 1) / B);
-    if (ngroups * nblocks * 8 > ((int64_t)1 << 31)) return CMF_EUNSUPPORTED; // sort table too large: keep the plain CSR kernel
+    if (ngroups * nblocks * cmfk::BCSR_NW > ((int64_t)1 << 31)) return CMF_EUNSUPPORTED; // sort table too large: keep the plain CSR kernel
     // counting sort by key (group, wave, block); inside a key the CSR order (row, column) is kept
-    const int64_t nkey = ngroups * 8 * nblocks;
+    const int64_t nkey = ngroups * cmfk::BCSR_NW * nblocks;
     std::vector<int64_t> kcnt((size_t)nkey + 1, 0);
     for (int64_t g = 0; g < ngroups; ++g)
         for (int64_t r = grow[g]; r < grow[g + 1]; ++r) {
-            const int64_t base = (g * 8 + ((r - grow[g]) & 7)) * nblocks;
+            const int64_t base = (g * cmfk::BCSR_NW + ((r - grow[g]) & (cmfk::BCSR_NW - 1))) * nblocks;
             for (int64_t q = indptr[r]; q < indptr[r + 1]; ++q) kcnt[(size_t)(base + indices[q] / B) + 1]++;
         }
     for (int64_t i = 0; i < nkey; ++i) kcnt[i + 1] += kcnt[i];
@@ -48,15 +48,15 @@ static int bcsr_build_upload(cmf_ctx *c, CsrDev &dst, const int64_t *indptr, con
     const double stretch = c->opt_spmm_stretch > 0 ? (double)c->opt_spmm_stretch : 8192.0;
     const int64_t kblk = std::max<int64_t>(1, (int64_t)(stretch / std::max(per_block, 1.0)));
     const int64_t nsync = (nblocks + kblk - 1) / kblk;
-    std::vector<int64_t> seg((size_t)(ngroups * 8 * nsync) + 1);
-    for (int64_t i = 0; i < ngroups * 8; ++i)
+    std::vector<int64_t> seg((size_t)(ngroups * cmfk::BCSR_NW * nsync) + 1);
+    for (int64_t i = 0; i < ngroups * cmfk::BCSR_NW; ++i)
         for (int64_t st = 0; st < nsync; ++st) seg[(size_t)(i * nsync + st)] = kcnt[(size_t)(i * nblocks + std::min(st * kblk, nblocks))];
-    seg[(size_t)(ngroups * 8 * nsync)] = nnz;
+    seg[(size_t)(ngroups * cmfk::BCSR_NW * nsync)] = nnz;
     std::vector<cmfk::BcsrEntry> ent((size_t)std::max<int64_t>(nnz, 1));
     for (int64_t g = 0; g < ngroups; ++g)
         for (int64_t r = grow[g]; r < grow[g + 1]; ++r) {
             const int32_t rl = (int32_t)(r - grow[g]);
-            const int64_t base = (g * 8 + (rl & 7)) * nblocks;
+            const int64_t base = (g * cmfk::BCSR_NW + (rl & (cmfk::BCSR_NW - 1))) * nblocks;
             for (int64_t q = indptr[r]; q < indptr[r + 1]; ++q) {
                 const int64_t pos = kcnt[(size_t)(base + indices[q] / B)]++;
                 ent[pos] = cmfk::BcsrEntry{indices[q], rl, vals[q], 0};
@@ -182,7 +182,7 @@ static int spmm(cmf_ctx *c, const CsrDev &A, const float *F, float *out, int64_t
 #define CMF_SPMMB(V_)                                                                                                     \
     do {                                                                                                                  \
         CHK(allow_big_lds(c, reinterpret_cast<const void *>(&spmm_blocked_kernel<V_>), 156 * 1024));                      \
-        hipLaunchKernelGGL((spmm_blocked_kernel<V_>), dim3(grid), dim3(512), lds, c->stream, bv, F, out, accumulate ? 1 : 0, \
+        hipLaunchKernelGGL((spmm_blocked_kernel<V_>), dim3(grid), dim3(64 * cmfk::BCSR_NW), lds, c->stream, bv, F, out, accumulate ? 1 : 0, \
                            (unsigned *)c->spmm_bar.p);                                                                   \
     } while (0)
         if (width == 256) CMF_SPMMB(4);
