@@ -346,6 +346,7 @@ def main():
 
     names = ("gemm_nn", "gemm_tn", "gemm_small", "gemm_nt", "spmm", "rowhess", "eigen", "elementwise")
     classes = {c: tuple(sum(v) for v in zip(*(c_.kernel_time(c) for c_ in ctxs))) for c in names}
+    rh_samples = tuple(sum(v) for v in zip(*(c_.rowhess_samples() for c_ in ctxs)))
     for c_ in ctxs:
         c_.kernel_timing(False)
     ex2, ey2 = ctx.residual_sq(w.get("x_link", "linear"), w.get("y_link", "linear"))
@@ -391,6 +392,11 @@ def main():
                 "avg_launch_ms": dms / max(dn, 1), "launches": dn}
     else:
         achieved = dfl / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
+        reference_order = achieved
+        if dom == "rowhess" and rh_samples[0] > 0:
+            # linear sampled sides share partial outer-product sums between rows (option row_classes): the kernel is priced
+            # on the sample rows it actually gathers, the rate in the reference's own count is reported beside it
+            achieved *= rh_samples[1] / rh_samples[0]
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
         if world == 1 and os.path.exists(tpath):
@@ -400,7 +406,7 @@ def main():
                 traffic = None
         if dom == "rowhess":
             kname = ("cmfk::row_hess_kernel<%d>  (fused per-row gradient + Hessian over the sampled rows; flops "
-                     "credited for the symmetric half of each H_i, k(k+1) per sample)" % kp)
+                     "credited for the symmetric half of each H_i, k(k+1) per sample row gathered)" % kp)
         else:
             kname = "cmfk::gemm_kernel<%d, %d, 0, 4>  (%s data pass)" % (
                 0 if dom == "gemm_nn" else 1, 256 if k >= 256 else kp,
@@ -417,8 +423,16 @@ def main():
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/traffic_%s.json)" % args.workload,
-                "algorithmic_flops_per_launch": dfl / max(dn, 1),
+                "algorithmic_flops_per_launch": dfl / max(dn, 1) * (achieved / reference_order if reference_order > 0 else 1.0),
                 "avg_launch_ms": dms / max(dn, 1), "launches": dn}
+        if dom == "rowhess":
+            roof["sample_rows_reference"] = rh_samples[0] / args.steps
+            roof["sample_rows_gathered"] = rh_samples[1] / args.steps
+            roof["reference_order_tflops"] = reference_order
+            roof["note"] = ("sample_rows_reference = outer products the reference runs per iteration (one per row and sampled "
+                            "index); sample_rows_gathered = what the kernel runs: with a linear link the rows of a group of 4 "
+                            "share the sums of the samples they have in common (shared partial sums, DESIGN.md section 4); "
+                            "achieved / frac price the kernel on the gathered rows, reference_order_tflops on the reference's count")
     if dom == "rowhess" and bf16x6 and kp == 256:
         roof["kernel"] = ("cmfk::row_hess6_kernel  (fused per-row gradient + Hessian; Hessian on v_mfma_f32_32x32x16_bf16 from three "
                           "bf16 planes of sqrt(w) o, six products per block; flops credited for the symmetric half, k(k+1) per sample)")

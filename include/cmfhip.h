@@ -193,6 +193,11 @@ int cmf_safe_invert_f64(cmf_ctx *ctx, const double *H, double *out, int k, doubl
 int cmf_kernel_timing(cmf_ctx *ctx, int enable);
 int cmf_kernel_time(cmf_ctx *ctx, int kernel_class, double *ms, int64_t *launches, double *flops);
 int cmf_kernel_timing_reset(cmf_ctx *ctx);
+/* per-row Newton accounting since the last reset, counted while timing is enabled: `credited` = sample rows of the
+ * algorithm (sum over updated rows of their list lengths, pycmf/cmf_solvers.py:414-428 runs one outer product per such
+ * pair), `gathered` = sample rows that actually went through the outer-product kernel (fewer when linear sampled sides
+ * share partial sums between rows: option "row_classes")                                                           */
+int cmf_rowhess_samples(cmf_ctx *ctx, double *credited, double *gathered);
 /* stream markers (bench.py's per-iteration time series, auditable beside the whole-region clock): cmf_marker records an
  * event on the launch stream; cmf_marker_times waits for the stream, writes the elapsed ms of every marker since the
  * first one (at most cap entries), stores the marker count in *n and clears the list                                */

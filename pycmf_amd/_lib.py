@@ -63,6 +63,7 @@ PROTOTYPES = {
     "cmf_kernel_timing": [_vp, _i32],
     "cmf_kernel_time": [_vp, _i32, _pd, _pi64, _pd],
     "cmf_kernel_timing_reset": [_vp],
+    "cmf_rowhess_samples": [_vp, _pd, _pd],
     "cmf_marker": [_vp],
     "cmf_marker_times": [_vp, _pd, _i64, _pi64],
     "cmf_get_stream": [_vp, C.POINTER(_vp)],
@@ -366,6 +367,12 @@ class Context:
         ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
         check(self._lib.cmf_kernel_time(self._h, KERNEL_CLASSES.get(cls, cls), C.byref(ms), C.byref(n), C.byref(fl)))
         return ms.value, n.value, fl.value
+
+    def rowhess_samples(self):
+        """(sample rows credited by the algorithm, sample rows gathered by the outer-product kernel) since the last reset."""
+        a, b = C.c_double(0), C.c_double(0)
+        check(self._lib.cmf_rowhess_samples(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def marker(self):
         check(self._lib.cmf_marker(self._h))

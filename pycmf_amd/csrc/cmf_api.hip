@@ -151,6 +151,8 @@ struct cmf_ctx {
     DevBuf hrows;                         // chunk of per-row Hessians / inverses
     DevBuf mask1, mask2;                  // stochastic sample masks (bytes)
     DevBuf lists1, lists2;                // device copies of the per-row sample index lists
+    DevBuf cls_idx[2], cls_off[2], cls_cnt[2], hclass; // shared partial sums of linear sampled sides: class lists and class images
+    int opt_rowclasses = 4;               // rows per group of the shared-partial-sum form (0 / 1: row by row)
     DevBuf idxbuf;                        // uploaded sample index lists
     DevBuf eigws;                         // Jacobi workspace when k_pad > 128
     DevBuf eigflag, eigcopy;              // Cholesky fast path: per-matrix fallback flags, input copy
@@ -162,7 +164,8 @@ struct cmf_ctx {
     bool gmix64_valid = false;            // gmix64 = alpha U^T U + (1 - alpha) Z^T Z of the partials just formed (single-GPU step)
     int opt_shared64 = 1;                 // 1: shared Hessian in float64 (default) | 0: float32 Grams + float32 inverse (round-1 path)
     DevBuf dpart;                         // double partial sums
-    double *dscalar = nullptr;            // 4 doubles
+    double *dscalar = nullptr;            // 8 slots of 8 bytes; slot 7: sample rows gathered by class launches (unsigned long long)
+    double rh_credited = 0.0, rh_gathered = 0.0; // per-row Newton accounting while timing is on: sample rows of the algorithm / gathered by row launches
     std::vector<void *> owned;            // problem-scoped allocations (released by the next cmf_set_problem)
     std::vector<void *> scratch;          // cmf_scratch_alloc buffers: live until cmf_scratch_free / cmf_ctx_destroy
     std::set<const void *> lds_opt_in;    // kernels whose >64 KB dynamic-LDS attribute is set on THIS device
@@ -617,6 +620,8 @@ static void release_problem(cmf_ctx *c) {
     c->slabs = DevBuf(); c->slabs_b = DevBuf(); c->slab_sel = 0; c->tickets = DevBuf(); c->resid = DevBuf(); c->resid2 = DevBuf(); c->resid3 = DevBuf(); c->dpart = DevBuf();
     c->kr1 = DevBuf(); c->kr2 = DevBuf(); c->hrows = DevBuf(); c->mask1 = DevBuf(); c->mask2 = DevBuf();
     c->lists1 = DevBuf(); c->lists2 = DevBuf();
+    for (int q = 0; q < 2; ++q) { c->cls_idx[q] = DevBuf(); c->cls_off[q] = DevBuf(); c->cls_cnt[q] = DevBuf(); }
+    c->hclass = DevBuf();
     c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf();
     c->nsidx = DevBuf(); c->nsws = DevBuf();
     c->spmm_bar = DevBuf();
@@ -682,6 +687,9 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_rowsym = (int)value;
     } else if (!strcmp(name, "row_kernel")) {
         c->opt_rowkernel = value != 0;
+    } else if (!strcmp(name, "row_classes")) {
+        if (value < 0 || value > 4) return fail(CMF_EINVAL, "row_classes: 0 (off) or 2..4 rows per group");
+        c->opt_rowclasses = (int)value;
     } else if (!strcmp(name, "sample_row_offset_u")) {
         c->sample_off[CMF_U] = value;
     } else if (!strcmp(name, "sample_row_offset_v")) {
@@ -1355,6 +1363,18 @@ extern "C" int cmf_kernel_timing_reset(cmf_ctx *c) {
     DeviceGuard dg(c->device);
     CHK(flush_timing(c));
     for (int i = 0; i < CMF_K_COUNT; ++i) { c->ms[i] = 0; c->launches[i] = 0; c->flops[i] = 0; }
+    c->rh_credited = c->rh_gathered = 0.0;
+    HIPCHK(hipMemsetAsync(c->dscalar + 7, 0, 8, c->stream));
+    return CMF_OK;
+}
+extern "C" int cmf_rowhess_samples(cmf_ctx *c, double *credited, double *gathered) {
+    if (!c) return fail(CMF_EINVAL, "null context");
+    DeviceGuard dg(c->device);
+    unsigned long long dev = 0;
+    HIPCHK(hipMemcpyAsync(&dev, c->dscalar + 7, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (credited) *credited = c->rh_credited;
+    if (gathered) *gathered = c->rh_gathered + (double)dev;
     return CMF_OK;
 }
 

@@ -807,11 +807,18 @@ static int launch_row_hess_kp(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
     return CMF_OK;
 }
 
-static int launch_row_hess(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
+static int launch_row_hess(cmf_ctx *c, const RowHessArgs &a, int64_t nrows, double class_samples = -1.0) {
     if (nrows <= 0) return CMF_OK;
     // algorithmic credit: H_i is symmetric, so k_pad (k_pad + 1) / 2 multiply-adds per sample ("the
-    // symmetric half may be credited as half"), plus the dot product and the gradient accumulation (2 k_pad each)
-    Timed tm(c, CMF_K_ROWHESS, (double)nrows * (double)a.s * ((double)c->kp * (c->kp + 1.0) + 4.0 * c->kp));
+    // symmetric half may be credited as half"), plus the dot product and the gradient accumulation (2 k_pad each).
+    // A class launch is credited with the sample rows of the factor rows it serves (Hessian part only: their gradient
+    // is a pair of GEMMs); what it gathers is counted on the device (cmf_rowhess_samples).
+    const double samples = class_samples >= 0.0 ? class_samples : (double)nrows * (double)a.s;
+    if (c->timing) {
+        c->rh_credited += samples;
+        if (class_samples < 0.0) c->rh_gathered += samples;
+    }
+    Timed tm(c, CMF_K_ROWHESS, samples * ((double)c->kp * (c->kp + 1.0) + (class_samples >= 0.0 ? 0.0 : 4.0 * c->kp)));
     switch (c->kp) {
     case 32: return launch_row_hess_kp<32>(c, a, nrows);
     case 64: return launch_row_hess_kp<64>(c, a, nrows);
@@ -852,7 +859,37 @@ struct RowSide {
     int64_t t_row = 0, t_col = 0;
     double scale = 1.0;
     int link = 0;
+    int cls = 0;                // > 0: shared partial sums over groups of `cls` rows (linear link, sampled; cmf_rowhess.hip.h)
+    int64_t n = 0;              // candidates the lists draw from
+    int slot = 0;               // which of the two class-list buffers
 };
+
+// Rows per group for the shared-partial-sum form of a linear, sampled side, or 0: worth it when the distinct samples of a
+// group, n (1 - (1 - rho)^R), are well below the R rho n of the row-by-row form.
+static int class_group_rows(const cmf_ctx *c, int link, bool sampled, int64_t per, int64_t n) {
+    if (!sampled || link != CMF_LINK_LINEAR || c->opt_rowclasses < 2 || per <= 0 || n <= 0 || n > 131072) return 0;
+    const int R = std::min(c->opt_rowclasses, 4);
+    const double rho = (double)per / (double)n;
+    const double factor = (1.0 - std::pow(1.0 - rho, R)) / (R * rho);
+    return factor < 0.8 ? R : 0;
+}
+
+// gradient part of a linear, sampled side as two GEMMs: s (mask o (L R^T - T)) times the other factor, into c->num
+static int class_side_gradient(cmf_ctx *c, bool x_side, bool by_row, const int32_t *dev_lists, int64_t nlists, int64_t per, double scale,
+                               int which, bool accumulate) {
+    DevBuf &mb = x_side ? c->mask1 : c->mask2;
+    const int64_t rows_pad = x_side ? c->mp : c->dp, cols_pad = x_side ? c->dp : c->pp;
+    CHK(ensure(c, mb, (size_t)rows_pad * cols_pad));
+    HIPCHK(hipMemsetAsync(mb.p, 0, (size_t)rows_pad * cols_pad, c->stream));
+    CHK(launch_ew(c, scatter_mask_kernel, nlists * per, (uint8_t *)mb.p, cols_pad, dev_lists, nlists, per, by_row ? 1 : 0));
+    CHK(ensure(c, c->resid, (size_t)rows_pad * cols_pad * sizeof(float)));
+    float *R = (float *)c->resid.p;
+    CHK(residual_images(c, x_side, CMF_LINK_LINEAR, scale, (const uint8_t *)mb.p, R, nullptr, false));
+    if (which == CMF_U) return gemm(c, MODE_NN, R, c->dp, c->F[CMF_V], c->kp, c->num, c->mp, c->kp, c->dp, accumulate);
+    if (which == CMF_Z) return gemm(c, MODE_TN, R, c->pp, c->F[CMF_V], c->kp, c->num, c->pp, c->kp, c->dp, accumulate);
+    if (x_side) return gemm(c, MODE_TN, R, c->dp, c->F[CMF_U], c->kp, c->num, c->dp, c->kp, c->mp, accumulate);
+    return gemm(c, MODE_NN, R, c->pp, c->F[CMF_Z], c->kp, c->num, c->dp, c->kp, c->pp, accumulate);
+}
 
 // finish a sweep of factor `which` whose per-row parts come from up to two fused sides;
 // c->num must already hold any shared-side gradient part if `grad_preloaded`
@@ -860,10 +897,28 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
                              double l1, double l2, double pert, bool nn) {
     const int64_t rows_pad = c->frows_pad[which], rows = c->frows[which];
     const int64_t kk = (int64_t)c->kp * c->kp;
-    const int64_t chunk = hessian_chunk_rows(c, rows_pad);
+    int64_t chunk = hessian_chunk_rows(c, rows_pad);
+    for (const RowSide *sd : {&s1, &s2})
+        if (sd->active && sd->cls == 3 && chunk < rows_pad) chunk = std::max<int64_t>(768, chunk / 768 * 768); // chunks start on a group boundary
     CHK(ensure(c, c->hrows, (size_t)chunk * kk * sizeof(float)));
     float *Hc = (float *)c->hrows.p;
     float *grad = c->num, *step = c->den;
+    // class sides: the class lists of every group of rows, once per sweep
+    for (const RowSide *sd : {&s1, &s2}) {
+        if (!sd->active || !sd->cls) continue;
+        const int R = sd->cls, NC1 = (1 << R) - 1;
+        const int64_t ngroups = (rows + R - 1) / R, cap = std::min<int64_t>(sd->n, (int64_t)R * sd->per);
+        DevBuf &ci = c->cls_idx[sd->slot], &co = c->cls_off[sd->slot], &cc = c->cls_cnt[sd->slot];
+        CHK(ensure(c, ci, (size_t)ngroups * cap * sizeof(int32_t)));
+        CHK(ensure(c, co, (size_t)ngroups * NC1 * sizeof(int64_t)));
+        CHK(ensure(c, cc, (size_t)ngroups * NC1 * sizeof(int32_t)));
+        const size_t lds = (size_t)((sd->n + 3) / 4) * 4;
+        CHK(allow_big_lds(c, reinterpret_cast<const void *>(&class_lists_kernel), (int)lds));
+        Timed tm(c, CMF_K_ELEMWISE);
+        hipLaunchKernelGGL(class_lists_kernel, dim3((unsigned)ngroups), dim3(256), lds, c->stream, sd->lists, sd->per, rows, (int)sd->n, R,
+                           (int32_t *)ci.p, cap, (int64_t *)co.p, (int32_t *)cc.p, c->timing ? (unsigned long long *)(c->dscalar + 7) : nullptr);
+        HIPCHK(hipGetLastError());
+    }
     for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
         const int64_t nr = std::min(chunk, rows - r0);
         bool have_h = false, have_g = grad_preloaded;
@@ -872,9 +927,32 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
             RowHessArgs a;
             memset(&a, 0, sizeof a);
             a.O = sd->O; a.F = c->F[which];
+            a.scale = (float)sd->scale; a.link = sd->link;
+            if (sd->cls) {
+                // one launch forms the class images of the chunk's groups, a second one adds up each row's classes
+                const int R = sd->cls, NC1 = (1 << R) - 1;
+                const int64_t g0 = r0 / R, ng = (nr + R - 1) / R;
+                CHK(ensure(c, c->hclass, (size_t)((chunk + R - 1) / R) * NC1 * kk * sizeof(float)));
+                a.idx = (const int32_t *)c->cls_idx[sd->slot].p;
+                a.cls_off = (const int64_t *)c->cls_off[sd->slot].p + g0 * NC1;
+                a.cls_cnt = (const int32_t *)c->cls_cnt[sd->slot].p + g0 * NC1;
+                a.T = c->F[which]; a.t_row = 0; a.t_col = 0; // never used: the gradient of a class side comes from GEMMs
+                a.H = (float *)c->hclass.p; a.G = nullptr; a.accumulate = 0; a.row0 = 0; a.nrows = ng * NC1;
+                a.kvalid = c->k;
+                CHK(launch_row_hess(c, a, ng * NC1, (double)nr * (double)sd->per));
+                {
+                    Timed tm(c, CMF_K_ELEMWISE);
+                    const int64_t total = nr * kk / 4;
+                    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, (int64_t)c->num_cu * 32);
+                    hipLaunchKernelGGL(class_sum_kernel, dim3(grid), dim3(256), 0, c->stream, Hc, (const float *)c->hclass.p, have_h ? nullptr : S,
+                                       have_h ? 0.f : (float)diag, nr, r0, R, c->kp, c->k, have_h ? 1 : 0);
+                    HIPCHK(hipGetLastError());
+                }
+                have_h = true;
+                continue;
+            }
             a.idx = sd->lists; a.idx_stride = sd->per; a.s = (int)sd->per;
             a.T = sd->T; a.t_row = sd->t_row; a.t_col = sd->t_col;
-            a.scale = (float)sd->scale; a.link = sd->link;
             a.H = Hc; a.G = grad; a.accumulate = 0; a.row0 = r0; a.nrows = nr;
             // H and G accumulate independently: encode as two flags in one int (bit0: H, bit1: G)
             a.accumulate = (have_h ? 1 : 0) | (have_g ? 2 : 0);
@@ -902,9 +980,11 @@ static int sweep_side_fused(cmf_ctx *c, bool is_u, int link, double scale, doubl
     if (is_u) { sd.T = c->X; sd.t_row = c->dp; sd.t_col = 1; }
     else { sd.T = c->Y; sd.t_row = 1; sd.t_col = c->pp; }
     sd.scale = scale; sd.link = link;
+    sd.n = c->d; sd.cls = class_group_rows(c, link, sampled, per, c->d);
+    if (sd.cls) CHK(class_side_gradient(c, is_u, is_u, sd.lists, c->frows[which], per, scale, which, false));
     // the logit Hessian of U carries no l2 term (:427-428); Z always does (:501-506)
     const double diag = (link == CMF_LINK_LOGIT && (is_u || !c->opt_zlogit_l2)) ? 0.0 : l2;
-    return fused_rows_finish(c, which, sd, RowSide(), nullptr, diag, false, l1, l2, pert, nn);
+    return fused_rows_finish(c, which, sd, RowSide(), nullptr, diag, sd.cls != 0, l1, l2, pert, nn);
 }
 
 static int sweep_v_fused(cmf_ctx *c, double alpha, double l1, double l2, int x_link, int y_link, double pert, bool nn,
@@ -936,12 +1016,16 @@ static int sweep_v_fused(cmf_ctx *c, double alpha, double l1, double l2, int x_l
         sx.per = sampled ? per_x : c->m;
         if (sampled) CHK(sample_lists(c, c->lists1, c->mask1, vx_idx, c->d, per_x, c->m, 2, &sx.lists));
         sx.T = c->X; sx.t_row = 1; sx.t_col = c->dp; sx.scale = alpha; sx.link = x_link;
+        sx.n = c->m; sx.slot = 0; sx.cls = class_group_rows(c, x_link, sampled, per_x, c->m);
+        if (sx.cls) { CHK(class_side_gradient(c, true, false, sx.lists, c->d, per_x, alpha, CMF_V, preloaded)); preloaded = true; }
     }
     if (!y_shared) {
         sy.active = true; sy.O = c->F[CMF_Z];
         sy.per = sampled ? per_y : c->p;
         if (sampled) CHK(sample_lists(c, c->lists2, c->mask2, vy_idx, c->d, per_y, c->p, 3, &sy.lists));
         sy.T = c->Y; sy.t_row = c->pp; sy.t_col = 1; sy.scale = 1.0 - alpha; sy.link = y_link;
+        sy.n = c->p; sy.slot = 1; sy.cls = class_group_rows(c, y_link, sampled, per_y, c->p);
+        if (sy.cls) { CHK(class_side_gradient(c, false, true, sy.lists, c->d, per_y, 1.0 - alpha, CMF_V, preloaded)); preloaded = true; }
     }
     return fused_rows_finish(c, CMF_V, sx, sy, S, l2, preloaded, l1, l2, pert, nn);
 }

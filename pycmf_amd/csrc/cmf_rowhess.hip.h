@@ -36,6 +36,10 @@ struct RowHessArgs {
     int kvalid;
     int64_t row0;         // first row of this launch (blockIdx.x + row0 = i)
     int64_t nrows;        // rows in this launch; H, G are indexed by blockIdx.x (H) / i (G)
+    // CLASS mode (cls_cnt != null; linear link, see row_classes below): "row" b of the launch is a partial sum shared by
+    // several factor rows -- its list starts at idx + cls_off[b] and holds cls_cnt[b] samples; only H is produced
+    const int64_t *cls_off;
+    const int32_t *cls_cnt;
 };
 
 template <int KP>
@@ -84,15 +88,17 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
 
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int64_t i = g.row0 + blockIdx.x;
+    const bool cls = g.cls_cnt != nullptr;
+    const int64_t i = cls ? 0 : g.row0 + blockIdx.x;
+    const int ns = cls ? g.cls_cnt[blockIdx.x] : g.s;        // samples of this row
     const int trow = t / C::LPR, tl16 = t % C::LPR;          // this thread's tile row and lane within the row
     const bool loader = t < 32 * C::LPR;                      // k_pad = 32: half of the threads cover the tile
     f32x4 u4[C::CPT];
 #pragma unroll
     for (int q = 0; q < C::CPT; ++q) u4[q] = *reinterpret_cast<const f32x4 *>(g.F + i * KP + 4 * (q * C::LPR + tl16));
-    const int32_t *list = g.idx ? g.idx + i * g.idx_stride : nullptr;
+    const int32_t *list = cls ? g.idx + g.cls_off[blockIdx.x] : (g.idx ? g.idx + i * g.idx_stride : nullptr);
     const float *Ti = g.T + i * g.t_row;
-    const int nt = (g.s + 31) / 32;
+    const int nt = (ns + 31) / 32;
 
     const int wm = wid / C::WN, wn = wid % C::WN;
     const bool mfma_wave = wid < C::WM * C::WN;
@@ -136,11 +142,11 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
 
     auto load_idx = [&](int tl) {
         const int q = 32 * tl + trow;
-        const int qc = q < g.s ? q : g.s - 1;
+        const int qc = q < ns ? q : ns - 1;
         jn = list ? list[qc] : qc;
     };
     auto gather = [&](int tl) {
-        vv = 32 * tl + trow < g.s;
+        vv = 32 * tl + trow < ns;
         const float *src = g.O + (int64_t)jn * KP + 4 * tl16;
 #pragma unroll
         for (int q = 0; q < C::CPT; ++q) rr[q] = *reinterpret_cast<const f32x4 *>(src + 4 * q * C::LPR);
@@ -353,6 +359,7 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
             }
     }
     // ---- gradient part: sum the per-thread partials that share a column chunk
+    if (cls) return;
     __syncthreads();
     constexpr int NREP = 32;          // one partial per tile row
     float *gr = rsm;                  // [NREP][KP] staging (the tiles are dead now)
@@ -366,6 +373,95 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
         for (int rep = 0; rep < NREP; ++rep) sacc += gr[rep * KP + t];
         float *dst = g.G + i * KP + t;
         *dst = sacc + ((g.accumulate & 2) ? *dst : 0.f);
+    }
+}
+
+// ---- shared partial sums for linear-link sides with per-row sampling ("row classes") -----------------------------------
+// With a linear link the Hessian weights do not depend on the row: H_i = s sum_{j in S_i} o_j o_j^T (cmf_solvers.py:414-428
+// with the identity link: d2 = 1).  R consecutive rows split the candidates j into 2^R - 1 classes by the set of rows whose
+// list holds j; the outer-product sum of a class is formed ONCE and every row adds up the 2^(R-1) classes it belongs to.
+// At sg_sample_ratio = 0.5 and R = 4 that is 15/16 n samples per four rows instead of 2 n: 2.13x fewer MFMAs for the same sums.
+//
+// class_lists_kernel: one workgroup per group of R rows; membership patterns in an LDS byte per candidate, then the
+// class lists in ascending candidate order (deterministic): cidx[g * cap + ...], class q = pattern q + 1 of group g at
+// coff / ccnt [g * (2^R - 1) + q].
+__global__ __launch_bounds__(256) void class_lists_kernel(const int32_t *lists, int64_t per, int64_t nlists, int n, int R, int32_t *cidx,
+                                                          int64_t cap, int64_t *coff, int32_t *ccnt, unsigned long long *gathered) {
+    extern __shared__ unsigned patw[]; // one byte per candidate
+    __shared__ int hist[16 * 256];     // [pattern][thread]: entries of the thread's candidate range with that pattern
+    __shared__ int tot[16], cbase[16];
+    const int t = threadIdx.x, NC = 1 << R;
+    const int64_t grp = blockIdx.x;
+    const int nw = (n + 3) / 4;
+    for (int w = t; w < nw; w += 256) patw[w] = 0u;
+    for (int x = t; x < 16 * 256; x += 256) hist[x] = 0;
+    __syncthreads();
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = grp * R + r;
+        if (row >= nlists) break;
+        const int32_t *l = lists + row * per;
+        for (int64_t q = t; q < per; q += 256) {
+            const int j = l[q];
+            atomicOr(&patw[j >> 2], 1u << (8 * (j & 3) + r));
+        }
+    }
+    __syncthreads();
+    const uint8_t *pat = reinterpret_cast<const uint8_t *>(patw);
+    const int L = (n + 255) / 256;
+    const int j0 = t * L < n ? t * L : n, j1 = j0 + L < n ? j0 + L : n;
+    for (int j = j0; j < j1; ++j) hist[pat[j] * 256 + t]++;
+    __syncthreads();
+    if (t >= 1 && t < NC) { // exclusive prefix over the threads' ranges, per pattern
+        int run = 0;
+        for (int x = 0; x < 256; ++x) {
+            const int v = hist[t * 256 + x];
+            hist[t * 256 + x] = run;
+            run += v;
+        }
+        tot[t] = run;
+    }
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int q = 1; q < NC; ++q) {
+            cbase[q] = run;
+            coff[grp * (NC - 1) + q - 1] = grp * cap + run;
+            ccnt[grp * (NC - 1) + q - 1] = tot[q];
+            run += tot[q];
+        }
+        if (gathered) atomicAdd(gathered, (unsigned long long)run); // accounting only (cmf_rowhess_samples)
+    }
+    __syncthreads();
+    int32_t *out = cidx + grp * cap;
+    for (int j = j0; j < j1; ++j) {
+        const int q = pat[j];
+        if (q) out[cbase[q] + hist[q * 256 + t]++] = j;
+    }
+}
+
+// H_row = sum of the class images the row belongs to (+ S + diag I when it starts H, += otherwise).  C holds the images
+// of the groups of this chunk: group (grow0 + row) / R - grow0 / R, class q at [(group * (2^R - 1) + q) * kp^2].
+__global__ __launch_bounds__(256) void class_sum_kernel(float *H, const float *C, const float *S, float diag, int64_t nrows, int64_t grow0,
+                                                        int R, int kp, int kvalid, int accumulate) {
+    const int64_t kk4 = (int64_t)kp * kp / 4, total = nrows * kk4;
+    const int NC = 1 << R;
+    const int64_t g0 = grow0 / R;
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = x / kk4, e4 = x % kk4;
+        const int64_t grp = (grow0 + row) / R - g0;
+        const int bit = (int)((grow0 + row) % R);
+        const float *base = C + grp * (NC - 1) * kk4 * 4 + e4 * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 1; q < NC; ++q)
+            if ((q >> bit) & 1) acc += *reinterpret_cast<const f32x4 *>(base + (int64_t)(q - 1) * kk4 * 4);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(H + row * kk4 * 4 + e4 * 4);
+        if (accumulate) acc += *dst;
+        else {
+            const int e = (int)(e4 * 4), r = e / kp, c0 = e % kp;
+            if (S) acc += *reinterpret_cast<const f32x4 *>(S + e);
+            if (r < kvalid && r >= c0 && r < c0 + 4) acc[r - c0] += diag;
+        }
+        *dst = acc;
     }
 }
 

@@ -40,7 +40,9 @@ __global__ __launch_bounds__(512, 2) void row_hess6_kernel(RowHessArgs g) {
     else if (wty == 1) { fblk[0] = sbase; fblk[1] = sbase + 1; fblk[2] = sbase + 2; fblk[3] = sbase + 3; fblk[4] = sbase + 3; }
     else { fblk[0] = sbase + 1; fblk[1] = sbase + 2; fblk[2] = sbase + 3; fblk[3] = sbase + 3; fblk[4] = sbase + 3; }
 
-    const int64_t i = g.row0 + blockIdx.x;
+    const bool cls = g.cls_cnt != nullptr; // class mode, see cmf_rowhess.hip.h
+    const int64_t i = cls ? 0 : g.row0 + blockIdx.x;
+    const int ns = cls ? g.cls_cnt[blockIdx.x] : g.s;
     const int trow = t >> 4, tl16 = t & 15; // staging: one gathered row per thread, 4 chunks of 4 floats at columns 4 (16 q + tl16)
     f32x4 u4[4], gacc[4];
 #pragma unroll
@@ -48,9 +50,9 @@ __global__ __launch_bounds__(512, 2) void row_hess6_kernel(RowHessArgs g) {
         u4[q] = *reinterpret_cast<const f32x4 *>(g.F + i * KP + 4 * (16 * q + tl16));
         gacc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const int32_t *list = g.idx ? g.idx + i * g.idx_stride : nullptr;
+    const int32_t *list = cls ? g.idx + g.cls_off[blockIdx.x] : (g.idx ? g.idx + i * g.idx_stride : nullptr);
     const float *Ti = g.T + i * g.t_row;
-    const int nt = (g.s + 31) / 32;
+    const int nt = (ns + 31) / 32;
     f32x16 hs[5];
 #pragma unroll
     for (int n = 0; n < 5; ++n)
@@ -63,11 +65,11 @@ __global__ __launch_bounds__(512, 2) void row_hess6_kernel(RowHessArgs g) {
     bool vv = false;
     auto load_idx = [&](int tl) __attribute__((always_inline)) {
         const int q = 32 * tl + trow;
-        const int qc = q < g.s ? q : g.s - 1;
+        const int qc = q < ns ? q : ns - 1;
         jn = list ? list[qc] : qc;
     };
     auto gather = [&](int tl) __attribute__((always_inline)) {
-        vv = 32 * tl + trow < g.s;
+        vv = 32 * tl + trow < ns;
         const float *src = g.O + (int64_t)jn * KP + 4 * tl16;
 #pragma unroll
         for (int q = 0; q < 4; ++q) rr[q] = *reinterpret_cast<const f32x4 *>(src + 64 * q);
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(512, 2) void row_hess6_kernel(RowHessArgs g) {
     else if (wty == 1) emit(IntC<1>{});
     else emit(IntC<2>{});
     // ---- gradient part: one partial per tile row, summed through LDS (the tiles are dead now)
+    if (cls) return;
     __syncthreads();
     float *gr = reinterpret_cast<float *>(r6l);
 #pragma unroll

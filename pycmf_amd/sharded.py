@@ -279,6 +279,7 @@ def make_torch_sharded_newton_rows(ctx_uz, ctx_v, bounds, shape, world, device, 
             raise ValueError("row-sharded Newton needs block_bounds partitions (got rows [%d, %d) of %d)" % (lo, hi, n))
     staging = [torch.zeros((max(world * -(-n // world), 1), backend.k_pad), dtype=torch.float32, device=device)
                for n in shape]
+    torch.cuda.synchronize(device)   # the fills ran on PyTorch's stream; everything after this runs on the contexts' stream
     coll = TorchCollectives(ctx_uz, device, timed) if world > 1 else None
     drv = ShardedNewtonRows(backend, staging, world, rank, coll.all_gather if coll else None)
     drv.collectives = coll
@@ -293,6 +294,7 @@ def make_torch_sharded_mu(ctx, world, device, timed=False):
         return SingleGpuStep(lambda l1, l2, mask: ctx.mu_step(l1, l2, mask))
     import torch
     buf = torch.zeros(backend.buf_elems(), dtype=torch.float32, device=device)
+    torch.cuda.synchronize(device)   # the fill ran on PyTorch's stream; the context launches on its own
     coll = TorchCollectives(ctx, device, timed)
     drv = ShardedMU(backend, buf, world, coll.all_reduce)
     drv.collectives = coll
@@ -305,6 +307,7 @@ def make_torch_sharded_newton(ctx, world, device, alpha, nn_mask=0, pert=0.2, ti
         return SingleGpuStep(lambda l1, l2, mask: ctx.newton_step(alpha, l1, l2, "linear", "linear", nn_mask, mask, pert, 1.0))
     import torch
     buf = torch.zeros(backend.buf_elems(), dtype=torch.float32, device=device)
+    torch.cuda.synchronize(device)
     coll = TorchCollectives(ctx, device, timed)
     drv = ShardedNewtonLinear(backend, buf, world, coll.all_reduce)
     drv.collectives = coll

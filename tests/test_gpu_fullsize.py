@@ -101,6 +101,7 @@ def test_c4_full_size_mu_properties(lib):
         c0, c1 = shard_bounds(p, 2, r)
         sc = _synthetic(lib, m, d, p, k, r0, c0, r1 - r0, c1 - c0)
         buf = torch.zeros(sc.v_buf_elems(), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()   # the fill runs on PyTorch's stream, the context launches on its own
         sc.mu_v_partials(buf.data_ptr())
         shards.append((sc, buf, r0, r1, c0, c1))
     for sc, *_ in shards:
@@ -182,6 +183,7 @@ def test_c5_full_size_sparse_shard_independence(lib):
         ctx = make(r0, r1, c0, c1)
         be = HipNewtonShardBackend(ctx, alpha, 0, pert)
         buf = torch.zeros(be.buf_elems(), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()   # the fill runs on PyTorch's stream, the context launches on its own
         be.update_uz(l1, l2, 7)
         be.partials(buf)
         shards.append((ctx, be, buf, r0, r1, c0, c1))

@@ -143,6 +143,7 @@ def test_sharded_protocol_matches_unsharded(lib, world):
         ctx.set_factor(0, U0[r0:r1]); ctx.set_factor(1, V0); ctx.set_factor(2, Z0[c0:c1])
         ctxs.append(ctx); bounds.append((r0, r1, c0, c1))
         bufs.append(torch.zeros(ctx.v_buf_elems(), dtype=torch.float32, device="cuda:0"))
+    torch.cuda.synchronize()   # the fills run on PyTorch's stream, the contexts launch on their own
     for _ in range(2):
         for ctx, b in zip(ctxs, bufs):
             ctx.mu_v_partials(b.data_ptr())
