@@ -138,7 +138,8 @@ class HipNewtonRowsBackend:
       ctx_v   problem (m, d_g, p):    X columns / Y rows of the rank, U and Z whole -> sweeps V_g
     All three sweeps are row-parallel (pycmf/cmf_solvers.py:394-508), so each context runs the unsharded kernels
     on its rows; what moves between ranks is factor rows only: U, Z before the V sweep, V after it.  The device
-    sampler keys by GLOBAL row index (sample_row_offset_*), so the iteration is bit-identical to the unsharded one.
+    sampler keys by GLOBAL row index (sample_row_offset_*), so the iteration is bit-identical to the unsharded one row by
+    row (float32 rounding apart where linear sampled sides share partial sums within each shard's groups of rows).
     """
 
     def __init__(self, ctx_uz, ctx_v, bounds, shape, alpha, x_link, y_link, nn_mask=0, pert=0.2, ratio=1.0):
