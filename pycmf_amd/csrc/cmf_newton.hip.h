@@ -784,6 +784,12 @@ static int launch_row_hess_kp(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
     } else if (KP == 256 && c->opt_arith == 1 && c->opt_rowsym && a.scale >= 0.f) { // optional arithmetic: bf16 planes, six products
         CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess6_kernel), R6_LDS_BYTES));
         hipLaunchKernelGGL(row_hess6_kernel, dim3((unsigned)nrows), dim3(512), R6_LDS_BYTES, c->stream, a);
+    } else if (KP == 256 && c->opt_rowsym == 3 && a.scale >= 0.f && a.cls_cnt && a.cls_upper) { // class launch, upper blocks only
+        constexpr int KS = KP == 256 ? 256 : 0;
+        if constexpr (KS == 256) {
+            CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<256, 1, 0, 3, 1>), (int)Cfg::LDS_BYTES));
+            hipLaunchKernelGGL((row_hess_kernel<256, 1, 0, 3, 1>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
+        }
     } else if (KP == 256 && c->opt_rowsym == 3 && a.scale >= 0.f) { // non-negative weights: single sqrt-weighted image
         constexpr int KS = KP == 256 ? 256 : 0;
         if constexpr (KS == 256) {
@@ -939,13 +945,22 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
                 a.T = c->F[which]; a.t_row = 0; a.t_col = 0; // never used: the gradient of a class side comes from GEMMs
                 a.H = (float *)c->hclass.p; a.G = nullptr; a.accumulate = 0; a.row0 = 0; a.nrows = ng * NC1;
                 a.kvalid = c->k;
+                // k_pad = 256 with the single-image symmetric kernel: class images hold their 36 upper blocks only
+                const bool upper = c->kp == 256 && c->opt_rowsym == 3 && sd->scale >= 0.0 && c->opt_arith != 1 && c->opt_rowdiag == 0;
+                a.cls_upper = upper ? 1 : 0;
                 CHK(launch_row_hess(c, a, ng * NC1, (double)nr * (double)sd->per));
                 {
                     Timed tm(c, CMF_K_ELEMWISE);
-                    const int64_t total = nr * kk / 4;
-                    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, (int64_t)c->num_cu * 32);
-                    hipLaunchKernelGGL(class_sum_kernel, dim3(grid), dim3(256), 0, c->stream, Hc, (const float *)c->hclass.p, have_h ? nullptr : S,
-                                       have_h ? 0.f : (float)diag, nr, r0, R, c->kp, c->k, have_h ? 1 : 0);
+                    if (upper) {
+                        const unsigned grid = (unsigned)std::min<int64_t>(nr * 36, (int64_t)c->num_cu * 16);
+                        hipLaunchKernelGGL(class_sum_blocks_kernel, dim3(grid), dim3(256), 0, c->stream, Hc, (const float *)c->hclass.p,
+                                           have_h ? nullptr : S, have_h ? 0.f : (float)diag, nr, r0, R, c->k, have_h ? 1 : 0);
+                    } else {
+                        const int64_t total = nr * kk / 4;
+                        const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, (int64_t)c->num_cu * 32);
+                        hipLaunchKernelGGL(class_sum_kernel, dim3(grid), dim3(256), 0, c->stream, Hc, (const float *)c->hclass.p, have_h ? nullptr : S,
+                                           have_h ? 0.f : (float)diag, nr, r0, R, c->kp, c->k, have_h ? 1 : 0);
+                    }
                     HIPCHK(hipGetLastError());
                 }
                 have_h = true;

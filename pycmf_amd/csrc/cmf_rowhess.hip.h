@@ -40,6 +40,7 @@ struct RowHessArgs {
     // several factor rows -- its list starts at idx + cls_off[b] and holds cls_cnt[b] samples; only H is produced
     const int64_t *cls_off;
     const int32_t *cls_cnt;
+    int cls_upper;        // class launch of the k_pad = 256 symmetric kernel: store the 36 upper blocks only
 };
 
 template <int KP>
@@ -77,10 +78,13 @@ struct IntC {
     static constexpr int value = V;
 };
 
-template <int KP, int STAGGER = 1, int DIAG = 0, int SYM = 0>
+// CLS = 1 (with SYM = 3): class launches only (cls_cnt set) -- no targets, no dot products, no gradient, constant weight;
+// only the 36 upper blocks are stored (class_sum_blocks_kernel mirrors them when it adds up a row's classes).
+template <int KP, int STAGGER = 1, int DIAG = 0, int SYM = 0, int CLS = 0>
 __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
     using C = RowHessCfg<KP>;
     static_assert(!SYM || KP == 256, "the symmetric block map is laid out for k_pad = 256");
+    static_assert(!CLS || SYM == 3, "the class-only build exists for the single-image symmetric kernel");
     const bool late = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >= 4;
     extern __shared__ __attribute__((aligned(16))) float rsm[];
     auto tile_of = [&](int b) { return rsm + 2 * b * C::TILE; };             // raw rows o_j      (B operand)
@@ -150,14 +154,21 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
         const float *src = g.O + (int64_t)jn * KP + 4 * tl16;
 #pragma unroll
         for (int q = 0; q < C::CPT; ++q) rr[q] = *reinterpret_cast<const f32x4 *>(src + 4 * q * C::LPR);
-        tt = Ti[(int64_t)jn * g.t_col];
+        if constexpr (!CLS) tt = Ti[(int64_t)jn * g.t_col];
     };
     // registers -> (z, r, w, gradient) -> LDS tile.  Branch-free in the link:
     // f = lk sigmoid(z) + (1 - lk) z, w = lk f (1 - f) + (1 - lk), lk = 0 / 1 -- exact, one term is always zero.
     const float lk = g.link ? 1.0f : 0.0f, nlk = 1.0f - lk;
+    const float cls_sq = __builtin_amdgcn_sqrtf(fmaxf(g.scale, 0.0f));
     auto stage = [&](int nb) {
         float *rdst = tile_of(nb) + trow * KP + 4 * tl16;
         float *wdst = wtile_of(nb) + trow * KP + 4 * tl16;
+        if constexpr (CLS) { // linear link: every sample of the class weighs s
+            const float sq = vv ? cls_sq : 0.0f;
+#pragma unroll
+            for (int q = 0; q < C::CPT; ++q) *reinterpret_cast<f32x4 *>(rdst + 4 * q * C::LPR) = sq * rr[q];
+            return;
+        }
         if constexpr (DIAG == 4) { // diagnostic: LDS writes only
 #pragma unroll
             for (int q = 0; q < C::CPT; ++q) {
@@ -315,6 +326,10 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
                     const int row = 32 * ba + 4 * lh + (r & 3) + 8 * (r >> 2);
                     float *dst = blk + ((r & 3) + 8 * (r >> 2)) * KP;
                     float v = hs[n][r];
+                    if constexpr (CLS) {
+                        *dst = v;
+                        continue;
+                    }
                     if (g.accumulate & 1) v += *dst;
                     else { // the launch that starts H_i also adds the shared part and the diagonal (S is symmetric)
                         if (g.S) v += g.S[row * KP + col];
@@ -323,7 +338,7 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
                     hs[n][r] = v;
                     *dst = v;
                 }
-                if (ba != bb) { // mirror image: row = this lane's column, four consecutive columns per register quad
+                if (!CLS && ba != bb) { // mirror image: row = this lane's column, four consecutive columns per register quad
                     float *tb = Hi + (32 * bb + l31) * KP + 32 * ba + 4 * lh;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
@@ -359,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
             }
     }
     // ---- gradient part: sum the per-thread partials that share a column chunk
-    if (cls) return;
+    if (CLS || cls) return;
     __syncthreads();
     constexpr int NREP = 32;          // one partial per tile row
     float *gr = rsm;                  // [NREP][KP] staging (the tiles are dead now)
@@ -462,6 +477,47 @@ __global__ __launch_bounds__(256) void class_sum_kernel(float *H, const float *C
             if (r < kvalid && r >= c0 && r < c0 + 4) acc[r - c0] += diag;
         }
         *dst = acc;
+    }
+}
+
+// The same for k_pad = 256 class images that hold only their 36 upper 32 x 32 blocks (row_hess_kernel<..., CLS = 1>): one
+// workgroup per (row, block) item sums the row's classes, stores the block and -- through an LDS transpose -- its mirror image.
+__global__ __launch_bounds__(256) void class_sum_blocks_kernel(float *H, const float *C, const float *S, float diag, int64_t nrows,
+                                                               int64_t grow0, int R, int kvalid, int accumulate) {
+    constexpr int KP = 256;
+    constexpr int64_t KK = (int64_t)KP * KP;
+    __shared__ float tile[32][33];
+    const int NC = 1 << R;
+    const int64_t g0 = grow0 / R, items = nrows * 36;
+    const int t = threadIdx.x, r = t >> 3, c4 = t & 7;
+    for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const int64_t row = item / 36;
+        int rem = (int)(item % 36), ba = 0;
+        while (rem >= 8 - ba) { rem -= 8 - ba; ++ba; }
+        const int bb = ba + rem;
+        const int64_t grp = (grow0 + row) / R - g0;
+        const int bit = (int)((grow0 + row) % R);
+        const int off = (32 * ba + r) * KP + 32 * bb + 4 * c4;
+        const float *base = C + grp * (NC - 1) * KK + off;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 1; q < NC; ++q)
+            if ((q >> bit) & 1) acc += *reinterpret_cast<const f32x4 *>(base + (int64_t)(q - 1) * KK);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(H + row * KK + off);
+        if (accumulate) acc += *dst; // H is symmetric: the mirror image below receives the same totals
+        else {
+            if (S) acc += *reinterpret_cast<const f32x4 *>(S + off);
+            const int gr = 32 * ba + r;
+            if (ba == bb && (r >> 2) == c4 && gr < kvalid) acc[r & 3] += diag;
+        }
+        *dst = acc;
+        if (ba != bb) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[r][4 * c4 + e] = acc[e];
+            __syncthreads();
+            const f32x4 m = {tile[4 * c4][r], tile[4 * c4 + 1][r], tile[4 * c4 + 2][r], tile[4 * c4 + 3][r]};
+            *reinterpret_cast<f32x4 *>(H + row * KK + (32 * bb + r) * KP + 32 * ba + 4 * c4) = m;
+            __syncthreads();
+        }
     }
 }
 
