@@ -338,10 +338,13 @@ __device__ __forceinline__ void chol_load(CholRegs<NB> &R, const float *H, int n
 // With RHS the forward substitution L y = g rides along (vec holds g on entry, y on exit), between the two
 // barriers the column step has anyway.
 template <int NB>
-__device__ __forceinline__ void chol_col_io(float *p, float (&v)[NB], bool write) {
+__device__ __forceinline__ void chol_col_io(float *p, float (&v)[NB], bool write, int first = 0) {
+    // `first`: entries below it are neither produced nor consumed any more (blocks above the current block column): whole
+    // quads under it are skipped -- the column steps are bound by LDS traffic, and late block columns need few entries
     if constexpr (NB >= 4) {
 #pragma unroll
         for (int k = 0; k < NB / 4; ++k) {
+            if (4 * k + 3 < first) continue;
             f32x4 *q = reinterpret_cast<f32x4 *>(p + 4 * k);
             if (write) *q = f32x4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
             else { const f32x4 x = *q; v[4 * k] = x[0]; v[4 * k + 1] = x[1]; v[4 * k + 2] = x[2]; v[4 * k + 3] = x[3]; }
@@ -381,7 +384,7 @@ __device__ __forceinline__ bool chol_factor(CholRegs<NB> &R, int n, float floor_
                         else if (i == j) R.M[a][jb] = ljj;
                     }
                 }
-                chol_col_io<NB>(cb + ti * NB, sc, true);
+                chol_col_io<NB>(cb + ti * NB, sc, true, jb);
                 if (ti == 0) cb[16 * NB] = piv;
                 if constexpr (RHS) {
                     const float yj = vec[j] * inv;
@@ -396,8 +399,8 @@ __device__ __forceinline__ bool chol_factor(CholRegs<NB> &R, int n, float floor_
             __syncthreads();
             if (!(cb[16 * NB] > floor_)) { ok = false; break; }
             float li[NB], lc[NB];
-            chol_col_io<NB>(cb + ti * NB, li, false);
-            chol_col_io<NB>(cb + tc * NB, lc, false);
+            chol_col_io<NB>(cb + ti * NB, li, false, jb);
+            chol_col_io<NB>(cb + tc * NB, lc, false, jb);
 #pragma unroll
             for (int a = jb; a < NB; ++a)
 #pragma unroll

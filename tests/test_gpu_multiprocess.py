@@ -128,9 +128,11 @@ def test_row_sharded_newton_fit_two_processes(tmp_path):
         o = np.load(str(tmp_path / "out") + "%d.npz" % r)
         r0, r1, c0, c1 = o["r"]
         assert int(o["n_iter"]) == n_ref
-        np.testing.assert_allclose(o["V"], Vr, rtol=1e-5, atol=1e-7)
-        np.testing.assert_allclose(o["U"], Ur[r0:r1], rtol=1e-5, atol=1e-7)
-        np.testing.assert_allclose(o["Z"], Zr[c0:c1], rtol=1e-5, atol=1e-7)
+        # the linear sampled X side shares partial sums inside each shard's groups of four rows: same terms, another order
+        # (float32 rounding per step, 20 steps); row_classes = 0 is bit-identical (test_gpu_newton.py)
+        np.testing.assert_allclose(o["V"], Vr, rtol=1e-5, atol=2e-5 * np.abs(Vr).max())
+        np.testing.assert_allclose(o["U"], Ur[r0:r1], rtol=1e-5, atol=2e-5 * np.abs(Ur).max())
+        np.testing.assert_allclose(o["Z"], Zr[c0:c1], rtol=1e-5, atol=2e-5 * np.abs(Zr).max())
 
 
 def _run_bench(args, env_extra, timeout=1800):
