@@ -151,8 +151,8 @@ struct cmf_ctx {
     DevBuf hrows;                         // chunk of per-row Hessians / inverses
     DevBuf mask1, mask2;                  // stochastic sample masks (bytes)
     DevBuf lists1, lists2;                // device copies of the per-row sample index lists
-    DevBuf cls_idx[2], cls_off[2], cls_cnt[2], hclass; // shared partial sums of linear sampled sides: class lists and class images
-    int opt_rowclasses = 4;               // rows per group of the shared-partial-sum form (0 / 1: row by row)
+    DevBuf cls_idx[2], cls_off[2], cls_cnt[2], cls_pat[2], hclass; // shared partial sums of linear sampled sides: class lists, pattern bytes, class images
+    int opt_rowclasses = -1;              // rows per group of the shared-partial-sum form: -1 automatic, 0 / 1 row by row, 2..6 forced
     DevBuf idxbuf;                        // uploaded sample index lists
     DevBuf eigws;                         // Jacobi workspace when k_pad > 128
     DevBuf eigflag, eigcopy;              // Cholesky fast path: per-matrix fallback flags, input copy
@@ -620,7 +620,7 @@ static void release_problem(cmf_ctx *c) {
     c->slabs = DevBuf(); c->slabs_b = DevBuf(); c->slab_sel = 0; c->tickets = DevBuf(); c->resid = DevBuf(); c->resid2 = DevBuf(); c->resid3 = DevBuf(); c->dpart = DevBuf();
     c->kr1 = DevBuf(); c->kr2 = DevBuf(); c->hrows = DevBuf(); c->mask1 = DevBuf(); c->mask2 = DevBuf();
     c->lists1 = DevBuf(); c->lists2 = DevBuf();
-    for (int q = 0; q < 2; ++q) { c->cls_idx[q] = DevBuf(); c->cls_off[q] = DevBuf(); c->cls_cnt[q] = DevBuf(); }
+    for (int q = 0; q < 2; ++q) { c->cls_idx[q] = DevBuf(); c->cls_off[q] = DevBuf(); c->cls_cnt[q] = DevBuf(); c->cls_pat[q] = DevBuf(); }
     c->hclass = DevBuf();
     c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf();
     c->nsidx = DevBuf(); c->nsws = DevBuf();
@@ -688,7 +688,7 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "row_kernel")) {
         c->opt_rowkernel = value != 0;
     } else if (!strcmp(name, "row_classes")) {
-        if (value < 0 || value > 4) return fail(CMF_EINVAL, "row_classes: 0 (off) or 2..4 rows per group");
+        if (value < -1 || value > 6) return fail(CMF_EINVAL, "row_classes: -1 (automatic), 0 (off) or 2..6 rows per group");
         c->opt_rowclasses = (int)value;
     } else if (!strcmp(name, "sample_row_offset_u")) {
         c->sample_off[CMF_U] = value;

@@ -873,21 +873,60 @@ struct RowSide {
 // Rows per group for the shared-partial-sum form of a linear, sampled side, or 0: worth it when the distinct samples of a
 // group, n (1 - (1 - rho)^R), are well below the R rho n of the row-by-row form.
 static int class_group_rows(const cmf_ctx *c, int link, bool sampled, int64_t per, int64_t n) {
-    if (!sampled || link != CMF_LINK_LINEAR || c->opt_rowclasses < 2 || per <= 0 || n <= 0 || n > 131072) return 0;
-    const int R = std::min(c->opt_rowclasses, 4);
+    if (!sampled || link != CMF_LINK_LINEAR || c->opt_rowclasses == 0 || c->opt_rowclasses == 1 || per <= 0 || n <= 0 || n > 131072) return 0;
+    int R = std::min(c->opt_rowclasses, 6);
+    if (R < 0) { // automatic: as many rows per group as leave the 2^R - 1 classes ~256 samples each (8 K-steps of the row kernel
+        R = 2;   // per class image written and read back: C3 measured 301 / 285 / 282 ms per iteration at R = 4 / 5 / 6)
+        while (R < 6 && (n >> (R + 1)) >= 256) ++R;
+    }
     const double rho = (double)per / (double)n;
     const double factor = (1.0 - std::pow(1.0 - rho, R)) / (R * rho);
     return factor < 0.8 ? R : 0;
 }
 
-// gradient part of a linear, sampled side as two GEMMs: s (mask o (L R^T - T)) times the other factor, into c->num
-static int class_side_gradient(cmf_ctx *c, bool x_side, bool by_row, const int32_t *dev_lists, int64_t nlists, int64_t per, double scale,
-                               int which, bool accumulate) {
+// class lists (and pattern bytes) of a class side, once per sweep
+static int build_class_lists(cmf_ctx *c, const RowSide &sd, int64_t rows) {
+    const int R = sd.cls, NC1 = (1 << R) - 1;
+    const int64_t ngroups = (rows + R - 1) / R, cap = std::min<int64_t>(sd.n, (int64_t)R * sd.per);
+    DevBuf &ci = c->cls_idx[sd.slot], &co = c->cls_off[sd.slot], &cc = c->cls_cnt[sd.slot], &cp = c->cls_pat[sd.slot];
+    CHK(ensure(c, ci, (size_t)ngroups * cap * sizeof(int32_t)));
+    CHK(ensure(c, co, (size_t)ngroups * NC1 * sizeof(int64_t)));
+    CHK(ensure(c, cc, (size_t)ngroups * NC1 * sizeof(int32_t)));
+    CHK(ensure(c, cp, (size_t)ngroups * sd.n));
+    const int nw = (int)((sd.n + 3) / 4), W = (nw + 255) / 256;
+    const size_t lds = (size_t)W * 256 * 4 + (size_t)256 * ((1 << R) + 1) * sizeof(int);
+    CHK(allow_big_lds(c, reinterpret_cast<const void *>(&class_lists_kernel), (int)lds));
+    Timed tm(c, CMF_K_ELEMWISE);
+    hipLaunchKernelGGL(class_lists_kernel, dim3((unsigned)ngroups), dim3(256), lds, c->stream, sd.lists, sd.per, rows, (int)sd.n, R,
+                       (int32_t *)ci.p, cap, (int64_t *)co.p, (int32_t *)cc.p, c->timing ? (unsigned long long *)(c->dscalar + 7) : nullptr,
+                       (uint8_t *)cp.p);
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
+// gradient part of a linear, sampled side as two GEMMs: s (mask o (L R^T - T)) times the other factor, into c->num.
+// The byte mask comes from the pattern bytes build_class_lists left behind.
+static int class_side_gradient(cmf_ctx *c, bool x_side, bool by_row, const RowSide &sd, int64_t nlists, double scale, int which,
+                               bool accumulate) {
     DevBuf &mb = x_side ? c->mask1 : c->mask2;
     const int64_t rows_pad = x_side ? c->mp : c->dp, cols_pad = x_side ? c->dp : c->pp;
     CHK(ensure(c, mb, (size_t)rows_pad * cols_pad));
     HIPCHK(hipMemsetAsync(mb.p, 0, (size_t)rows_pad * cols_pad, c->stream));
-    CHK(launch_ew(c, scatter_mask_kernel, nlists * per, (uint8_t *)mb.p, cols_pad, dev_lists, nlists, per, by_row ? 1 : 0));
+    {
+        Timed tm(c, CMF_K_ELEMWISE);
+        const int R = sd.cls;
+        const int64_t ngroups = (nlists + R - 1) / R;
+        const uint8_t *patg = (const uint8_t *)c->cls_pat[sd.slot].p;
+        if (by_row) {
+            const unsigned grid = (unsigned)std::min<int64_t>((ngroups * sd.n + 255) / 256, (int64_t)c->num_cu * 32);
+            hipLaunchKernelGGL(mask_rows_from_patterns_kernel, dim3(grid), dim3(256), 0, c->stream, (uint8_t *)mb.p, cols_pad, patg, ngroups, (int)sd.n,
+                               R, nlists);
+        } else {
+            hipLaunchKernelGGL(mask_cols_from_patterns_kernel, dim3((unsigned)((sd.n + 63) / 64), (unsigned)((ngroups + 31) / 32)), dim3(256), 0,
+                               c->stream, (uint8_t *)mb.p, cols_pad, patg, ngroups, (int)sd.n, R, nlists);
+        }
+        HIPCHK(hipGetLastError());
+    }
     CHK(ensure(c, c->resid, (size_t)rows_pad * cols_pad * sizeof(float)));
     float *R = (float *)c->resid.p;
     CHK(residual_images(c, x_side, CMF_LINK_LINEAR, scale, (const uint8_t *)mb.p, R, nullptr, false));
@@ -905,26 +944,13 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
     const int64_t kk = (int64_t)c->kp * c->kp;
     int64_t chunk = hessian_chunk_rows(c, rows_pad);
     for (const RowSide *sd : {&s1, &s2})
-        if (sd->active && sd->cls == 3 && chunk < rows_pad) chunk = std::max<int64_t>(768, chunk / 768 * 768); // chunks start on a group boundary
+        if (sd->active && sd->cls && chunk < rows_pad) { // chunks start on a group boundary: multiples of lcm(256, R)
+            const int64_t q = (sd->cls % 3 == 0 ? 768 : (sd->cls == 5 ? 1280 : 256));
+            chunk = std::max<int64_t>(q, chunk / q * q);
+        }
     CHK(ensure(c, c->hrows, (size_t)chunk * kk * sizeof(float)));
     float *Hc = (float *)c->hrows.p;
     float *grad = c->num, *step = c->den;
-    // class sides: the class lists of every group of rows, once per sweep
-    for (const RowSide *sd : {&s1, &s2}) {
-        if (!sd->active || !sd->cls) continue;
-        const int R = sd->cls, NC1 = (1 << R) - 1;
-        const int64_t ngroups = (rows + R - 1) / R, cap = std::min<int64_t>(sd->n, (int64_t)R * sd->per);
-        DevBuf &ci = c->cls_idx[sd->slot], &co = c->cls_off[sd->slot], &cc = c->cls_cnt[sd->slot];
-        CHK(ensure(c, ci, (size_t)ngroups * cap * sizeof(int32_t)));
-        CHK(ensure(c, co, (size_t)ngroups * NC1 * sizeof(int64_t)));
-        CHK(ensure(c, cc, (size_t)ngroups * NC1 * sizeof(int32_t)));
-        const size_t lds = (size_t)((sd->n + 3) / 4) * 4;
-        CHK(allow_big_lds(c, reinterpret_cast<const void *>(&class_lists_kernel), (int)lds));
-        Timed tm(c, CMF_K_ELEMWISE);
-        hipLaunchKernelGGL(class_lists_kernel, dim3((unsigned)ngroups), dim3(256), lds, c->stream, sd->lists, sd->per, rows, (int)sd->n, R,
-                           (int32_t *)ci.p, cap, (int64_t *)co.p, (int32_t *)cc.p, c->timing ? (unsigned long long *)(c->dscalar + 7) : nullptr);
-        HIPCHK(hipGetLastError());
-    }
     for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
         const int64_t nr = std::min(chunk, rows - r0);
         bool have_h = false, have_g = grad_preloaded;
@@ -952,9 +978,9 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
                 {
                     Timed tm(c, CMF_K_ELEMWISE);
                     if (upper) {
-                        const unsigned grid = (unsigned)std::min<int64_t>(nr * 36, (int64_t)c->num_cu * 16);
+                        const unsigned grid = (unsigned)std::min<int64_t>(ng * 36, (int64_t)c->num_cu * 16);
                         hipLaunchKernelGGL(class_sum_blocks_kernel, dim3(grid), dim3(256), 0, c->stream, Hc, (const float *)c->hclass.p,
-                                           have_h ? nullptr : S, have_h ? 0.f : (float)diag, nr, r0, R, c->k, have_h ? 1 : 0);
+                                           have_h ? nullptr : S, have_h ? 0.f : (float)diag, nr, R, c->k, have_h ? 1 : 0);
                     } else {
                         const int64_t total = nr * kk / 4;
                         const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, (int64_t)c->num_cu * 32);
@@ -996,7 +1022,10 @@ static int sweep_side_fused(cmf_ctx *c, bool is_u, int link, double scale, doubl
     else { sd.T = c->Y; sd.t_row = 1; sd.t_col = c->pp; }
     sd.scale = scale; sd.link = link;
     sd.n = c->d; sd.cls = class_group_rows(c, link, sampled, per, c->d);
-    if (sd.cls) CHK(class_side_gradient(c, is_u, is_u, sd.lists, c->frows[which], per, scale, which, false));
+    if (sd.cls) {
+        CHK(build_class_lists(c, sd, c->frows[which]));
+        CHK(class_side_gradient(c, is_u, is_u, sd, c->frows[which], scale, which, false));
+    }
     // the logit Hessian of U carries no l2 term (:427-428); Z always does (:501-506)
     const double diag = (link == CMF_LINK_LOGIT && (is_u || !c->opt_zlogit_l2)) ? 0.0 : l2;
     return fused_rows_finish(c, which, sd, RowSide(), nullptr, diag, sd.cls != 0, l1, l2, pert, nn);
@@ -1032,7 +1061,11 @@ static int sweep_v_fused(cmf_ctx *c, double alpha, double l1, double l2, int x_l
         if (sampled) CHK(sample_lists(c, c->lists1, c->mask1, vx_idx, c->d, per_x, c->m, 2, &sx.lists));
         sx.T = c->X; sx.t_row = 1; sx.t_col = c->dp; sx.scale = alpha; sx.link = x_link;
         sx.n = c->m; sx.slot = 0; sx.cls = class_group_rows(c, x_link, sampled, per_x, c->m);
-        if (sx.cls) { CHK(class_side_gradient(c, true, false, sx.lists, c->d, per_x, alpha, CMF_V, preloaded)); preloaded = true; }
+        if (sx.cls) {
+            CHK(build_class_lists(c, sx, c->d));
+            CHK(class_side_gradient(c, true, false, sx, c->d, alpha, CMF_V, preloaded));
+            preloaded = true;
+        }
     }
     if (!y_shared) {
         sy.active = true; sy.O = c->F[CMF_Z];
@@ -1040,7 +1073,11 @@ static int sweep_v_fused(cmf_ctx *c, double alpha, double l1, double l2, int x_l
         if (sampled) CHK(sample_lists(c, c->lists2, c->mask2, vy_idx, c->d, per_y, c->p, 3, &sy.lists));
         sy.T = c->Y; sy.t_row = c->pp; sy.t_col = 1; sy.scale = 1.0 - alpha; sy.link = y_link;
         sy.n = c->p; sy.slot = 1; sy.cls = class_group_rows(c, y_link, sampled, per_y, c->p);
-        if (sy.cls) { CHK(class_side_gradient(c, false, true, sy.lists, c->d, per_y, 1.0 - alpha, CMF_V, preloaded)); preloaded = true; }
+        if (sy.cls) {
+            CHK(build_class_lists(c, sy, c->d));
+            CHK(class_side_gradient(c, false, true, sy, c->d, 1.0 - alpha, CMF_V, preloaded));
+            preloaded = true;
+        }
     }
     return fused_rows_finish(c, CMF_V, sx, sy, S, l2, preloaded, l1, l2, pert, nn);
 }

@@ -399,38 +399,65 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
 //
 // class_lists_kernel: one workgroup per group of R rows; membership patterns in an LDS byte per candidate, then the
 // class lists in ascending candidate order (deterministic): cidx[g * cap + ...], class q = pattern q + 1 of group g at
-// coff / ccnt [g * (2^R - 1) + q].
+// coff / ccnt [g * (2^R - 1) + q].  patg (optional): the pattern bytes themselves, [group][n] -- the sample mask of the
+// group's rows in 1/R of the bytes (mask_from_patterns_kernel expands it for the gradient GEMM's epilogue).
+// LDS layout: thread t owns the candidate words t W .. t W + W - 1 (4 candidates each, ascending), stored transposed
+// (word w at (w % W) 256 + w / W) so that the 256 threads walk their ranges bank-conflict-free; hist[x][p] (pitch 2^R + 1)
+// counts thread x's candidates of pattern p, prefix-summed over x in 256 / 2^R segments per pattern.
 __global__ __launch_bounds__(256) void class_lists_kernel(const int32_t *lists, int64_t per, int64_t nlists, int n, int R, int32_t *cidx,
-                                                          int64_t cap, int64_t *coff, int32_t *ccnt, unsigned long long *gathered) {
-    extern __shared__ unsigned patw[]; // one byte per candidate
-    __shared__ int hist[16 * 256];     // [pattern][thread]: entries of the thread's candidate range with that pattern
-    __shared__ int tot[16], cbase[16];
-    const int t = threadIdx.x, NC = 1 << R;
+                                                          int64_t cap, int64_t *coff, int32_t *ccnt, unsigned long long *gathered,
+                                                          uint8_t *patg) {
+    extern __shared__ unsigned patw[]; // W * 256 pattern words, then hist[256][NC + 1]
+    __shared__ int tot[64], cbase[64], segoff[256]; // segoff[seg * NC + p]
+    const int t = threadIdx.x, NC = 1 << R, HP = NC + 1;
     const int64_t grp = blockIdx.x;
-    const int nw = (n + 3) / 4;
-    for (int w = t; w < nw; w += 256) patw[w] = 0u;
-    for (int x = t; x < 16 * 256; x += 256) hist[x] = 0;
+    const int nw = (n + 3) / 4, W = (nw + 255) / 256;
+    int *hist = reinterpret_cast<int *>(patw + W * 256);
+    for (int w = t; w < W * 256; w += 256) patw[w] = 0u;
+    for (int x = t; x < 256 * HP; x += 256) hist[x] = 0;
     __syncthreads();
     for (int r = 0; r < R; ++r) {
         const int64_t row = grp * R + r;
         if (row >= nlists) break;
         const int32_t *l = lists + row * per;
         for (int64_t q = t; q < per; q += 256) {
-            const int j = l[q];
-            atomicOr(&patw[j >> 2], 1u << (8 * (j & 3) + r));
+            const int j = l[q], w = j >> 2;
+            atomicOr(&patw[(w % W) * 256 + w / W], 1u << (8 * (j & 3) + r));
         }
     }
     __syncthreads();
-    const uint8_t *pat = reinterpret_cast<const uint8_t *>(patw);
-    const int L = (n + 255) / 256;
-    const int j0 = t * L < n ? t * L : n, j1 = j0 + L < n ? j0 + L : n;
-    for (int j = j0; j < j1; ++j) hist[pat[j] * 256 + t]++;
+    if (patg) { // pattern bytes out, candidate order
+        uint8_t *pg = patg + grp * (int64_t)n;
+        for (int j = t; j < n; j += 256) {
+            const int w = j >> 2;
+            pg[j] = (uint8_t)((patw[(w % W) * 256 + w / W] >> (8 * (j & 3))) & 0xffu);
+        }
+    }
+    for (int i = 0; i < W; ++i) {
+        const unsigned word = patw[i * 256 + t];
+        const int j = 4 * (t * W + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (j + e < n) hist[t * HP + ((word >> (8 * e)) & 0xffu)]++;
+    }
     __syncthreads();
-    if (t >= 1 && t < NC) { // exclusive prefix over the threads' ranges, per pattern
+    // exclusive prefix over x (threads) for every pattern: thread (p, seg) scans the NC entries of its segment
+    const int pp = t & (NC - 1), seg = t / NC, segs = 256 / NC;
+    {
         int run = 0;
-        for (int x = 0; x < 256; ++x) {
-            const int v = hist[t * 256 + x];
-            hist[t * 256 + x] = run;
+        for (int x = seg * NC; x < (seg + 1) * NC; ++x) {
+            const int v = hist[x * HP + pp];
+            hist[x * HP + pp] = run;
+            run += v;
+        }
+        segoff[seg * NC + pp] = run; // segment total for now
+    }
+    __syncthreads();
+    if (t < NC) { // segment totals -> segment offsets and the pattern total
+        int run = 0;
+        for (int sg = 0; sg < segs; ++sg) {
+            const int v = segoff[sg * NC + t];
+            segoff[sg * NC + t] = run;
             run += v;
         }
         tot[t] = run;
@@ -448,9 +475,52 @@ __global__ __launch_bounds__(256) void class_lists_kernel(const int32_t *lists, 
     }
     __syncthreads();
     int32_t *out = cidx + grp * cap;
-    for (int j = j0; j < j1; ++j) {
-        const int q = pat[j];
-        if (q) out[cbase[q] + hist[q * 256 + t]++] = j;
+    const int myseg = t / NC;
+    for (int i = 0; i < W; ++i) {
+        const unsigned word = patw[i * 256 + t];
+        const int j = 4 * (t * W + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int q = (int)((word >> (8 * e)) & 0xffu);
+            if (q && j + e < n) out[cbase[q] + segoff[myseg * NC + q] + hist[t * HP + q]++] = j + e;
+        }
+    }
+}
+
+// byte mask of a class side from the groups' pattern bytes (what scatter_mask_kernel builds from the lists, without its
+// scattered byte stores).  by_row = 1: list i holds columns of image row i -> mask[i][j];  by_row = 0: list i holds rows
+// of image column i -> mask[j][i].  i = g R + r  <->  bit r of patg[g][j].
+__global__ __launch_bounds__(256) void mask_rows_from_patterns_kernel(uint8_t *mask, int64_t ld, const uint8_t *patg, int64_t ngroups, int n,
+                                                                      int R, int64_t nlists) {
+    const int64_t total = ngroups * (int64_t)n;
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = x / n, j = x % n;
+        const unsigned pb = patg[x];
+        for (int r = 0; r < R; ++r) {
+            const int64_t i = g * R + r;
+            if (i < nlists) mask[i * ld + j] = (uint8_t)((pb >> r) & 1u);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void mask_cols_from_patterns_kernel(uint8_t *mask, int64_t ld, const uint8_t *patg, int64_t ngroups, int n,
+                                                                      int R, int64_t nlists) {
+    // tile: 32 groups x 64 candidates through LDS; a candidate's 32 R mask bytes are contiguous in its image row
+    __shared__ uint8_t tile[32][68];
+    const int t = threadIdx.x;
+    const int64_t g0 = (int64_t)blockIdx.y * 32, j0 = (int64_t)blockIdx.x * 64;
+    for (int x = t; x < 32 * 64; x += 256) {
+        const int gg = x >> 6, jj = x & 63;
+        uint8_t v = 0;
+        if (g0 + gg < ngroups && j0 + jj < n) v = patg[(g0 + gg) * (int64_t)n + j0 + jj];
+        tile[gg][jj] = v;
+    }
+    __syncthreads();
+    const int jj = t >> 2, part = t & 3;
+    if (j0 + jj >= n) return;
+    uint8_t *dst = mask + (j0 + jj) * ld + g0 * R;
+    for (int b = part * 8 * R; b < (part + 1) * 8 * R; ++b) {
+        const int gg = b / R, r = b % R;
+        if ((g0 + gg) * R + r < nlists) dst[b] = (uint8_t)((tile[gg][jj] >> r) & 1u);
     }
 }
 
@@ -481,42 +551,54 @@ __global__ __launch_bounds__(256) void class_sum_kernel(float *H, const float *C
 }
 
 // The same for k_pad = 256 class images that hold only their 36 upper 32 x 32 blocks (row_hess_kernel<..., CLS = 1>): one
-// workgroup per (row, block) item sums the row's classes, stores the block and -- through an LDS transpose -- its mirror image.
+// workgroup per (group, block) item reads every class block of the group ONCE, adds it to the running sums of the rows it
+// belongs to (classes in ascending order for every row: the order does not depend on R or on the grid), then stores each
+// row's block and -- through an LDS transpose -- its mirror image.  nrows rows starting at a group boundary.
 __global__ __launch_bounds__(256) void class_sum_blocks_kernel(float *H, const float *C, const float *S, float diag, int64_t nrows,
-                                                               int64_t grow0, int R, int kvalid, int accumulate) {
-    constexpr int KP = 256;
+                                                               int R, int kvalid, int accumulate) {
+    constexpr int KP = 256, RMAX = 6;
     constexpr int64_t KK = (int64_t)KP * KP;
     __shared__ float tile[32][33];
     const int NC = 1 << R;
-    const int64_t g0 = grow0 / R, items = nrows * 36;
+    const int64_t ngroups = (nrows + R - 1) / R, items = ngroups * 36;
     const int t = threadIdx.x, r = t >> 3, c4 = t & 7;
     for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
-        const int64_t row = item / 36;
+        const int64_t grp = item / 36;
         int rem = (int)(item % 36), ba = 0;
         while (rem >= 8 - ba) { rem -= 8 - ba; ++ba; }
         const int bb = ba + rem;
-        const int64_t grp = (grow0 + row) / R - g0;
-        const int bit = (int)((grow0 + row) % R);
         const int off = (32 * ba + r) * KP + 32 * bb + 4 * c4;
         const float *base = C + grp * (NC - 1) * KK + off;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int q = 1; q < NC; ++q)
-            if ((q >> bit) & 1) acc += *reinterpret_cast<const f32x4 *>(base + (int64_t)(q - 1) * KK);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(H + row * KK + off);
-        if (accumulate) acc += *dst; // H is symmetric: the mirror image below receives the same totals
-        else {
-            if (S) acc += *reinterpret_cast<const f32x4 *>(S + off);
-            const int gr = 32 * ba + r;
-            if (ba == bb && (r >> 2) == c4 && gr < kvalid) acc[r & 3] += diag;
-        }
-        *dst = acc;
-        if (ba != bb) {
+        f32x4 acc[RMAX];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) tile[r][4 * c4 + e] = acc[e];
-            __syncthreads();
-            const f32x4 m = {tile[4 * c4][r], tile[4 * c4 + 1][r], tile[4 * c4 + 2][r], tile[4 * c4 + 3][r]};
-            *reinterpret_cast<f32x4 *>(H + row * KK + (32 * bb + r) * KP + 32 * ba + 4 * c4) = m;
-            __syncthreads();
+        for (int m = 0; m < RMAX; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 1; q < NC; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(base + (int64_t)(q - 1) * KK);
+#pragma unroll
+            for (int m = 0; m < RMAX; ++m)
+                if ((q >> m) & 1) acc[m] += v; // bits >= R are never set
+        }
+#pragma unroll
+        for (int m = 0; m < RMAX; ++m) {
+            const int64_t row = grp * R + m;
+            if (m >= R || row >= nrows) break; // uniform over the workgroup
+            f32x4 a = acc[m];
+            f32x4 *dst = reinterpret_cast<f32x4 *>(H + row * KK + off);
+            if (accumulate) a += *dst; // H is symmetric: the mirror image below receives the same totals
+            else {
+                if (S) a += *reinterpret_cast<const f32x4 *>(S + off);
+                const int gr = 32 * ba + r;
+                if (ba == bb && (r >> 2) == c4 && gr < kvalid) a[r & 3] += diag;
+            }
+            *dst = a;
+            if (ba != bb) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tile[r][4 * c4 + e] = a[e];
+                __syncthreads();
+                const f32x4 mm = {tile[4 * c4][r], tile[4 * c4 + 1][r], tile[4 * c4 + 2][r], tile[4 * c4 + 3][r]};
+                *reinterpret_cast<f32x4 *>(H + row * KK + (32 * bb + r) * KP + 32 * ba + 4 * c4) = mm;
+                __syncthreads();
+            }
         }
     }
 }

@@ -221,7 +221,7 @@ def test_shared_partial_sums_match_the_oracle_and_the_row_form(lib, links, shape
     O.newton_update_step(X, Y, Ur, Vr, Zr, 0.4, 0.01, 0.3, xl, yl, False, False, False, ratio=ratio, pert=0.2, masks=masks)
     lists = (np.array(masks["U"]), np.array(masks["Z"]), np.array([a for a, _ in masks["V"]]), np.array([b for _, b in masks["V"]]))
     got = {}
-    for R in (0, 2, 3, 4):
+    for R in (0, 2, 3, 4, 5, 6, -1):
         ctx = lib.Context(0)
         ctx.set_option("row_classes", R)
         ctx.set_problem(m, d, p, k)
@@ -231,7 +231,7 @@ def test_shared_partial_sums_match_the_oracle_and_the_row_form(lib, links, shape
         ctx.newton_step(0.4, 0.01, 0.3, xl, yl, 0, 7, 0.2, ratio, *lists)
         got[R] = [ctx.get_factor(w) for w in range(3)]
         ctx.close()
-    for R in (2, 3, 4):
+    for R in (2, 3, 4, 5, 6, -1):
         for a, b, o in zip(got[R], got[0], (Ur, Vr, Zr)):
             np.testing.assert_allclose(a, b, rtol=0, atol=2e-4 * np.abs(b).max())   # float32 sums in another order, then solved
             np.testing.assert_allclose(a, o, rtol=0, atol=2e-3 * np.abs(o).max())
@@ -357,7 +357,7 @@ def test_symmetric_block_row_kernel_matches_full(lib):
 
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("xl,yl,ratio,classes", [("linear", "logit", 0.5, 0), ("logit", "linear", 1.0, 4), ("linear", "linear", 0.7, 0),
-                                                 ("linear", "logit", 0.5, 4), ("linear", "linear", 0.7, 3)])
+                                                 ("linear", "logit", 0.5, 4), ("linear", "linear", 0.7, 3), ("linear", "logit", 0.5, 6)])
 def test_row_sharded_newton_is_bit_identical(lib, world, xl, yl, ratio, classes):
     """per-row Newton sweeps sharded by rows (two contexts per rank: U/Z sweeps on the rank's rows of X
     and columns of Y, V sweep on its columns of X and rows of Y; factor rows exchanged in between).  `world` ranks
