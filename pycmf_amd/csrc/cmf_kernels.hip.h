@@ -666,7 +666,19 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
                 }
         } else
 #pragma unroll
-        for (int i = 0; i < C::TM; ++i)
+        for (int i = 0; i < C::TM; ++i) {
+            // byte mask (masked-dense Newton formulation, gradient of the shared-partial-sum sides): all targets and mask
+            // bytes of this block row of the wave tile are fetched before the arithmetic -- one latency, not 64
+            float tv[16][C::TN];
+            uint8_t mv[16][C::TN];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j) {
+                    const int rr = 32 * i + (r & 3) + 8 * (r >> 2);
+                    tv[r][j] = Tp ? Tp[rr * ldt + 32 * j] : 0.0f;
+                    mv[r][j] = Mp[rr * ldm + 32 * j];
+                }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = 32 * i + (r & 3) + 8 * (r >> 2);
@@ -674,10 +686,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
                 for (int j = 0; j < C::TN; ++j) {
                     const float s = acc[i][j][r];
                     const float f = g.link ? sigmoidf_(s) : s;
-                    const float tv = Tp ? Tp[rr * ldt + 32 * j] : 0.0f;
                     float mk = (rr < rlim && 32 * j < clim) ? 1.0f : 0.0f;
-                    if (Mp) mk *= (float)Mp[rr * ldm + 32 * j];
-                    const float res = f - tv;
+                    mk *= (float)mv[r][j];
+                    const float res = f - tv[r][j];
                     if (g.sq_out) sq += mk * res * res;
                     if (Rp) Rp[rr * ldr + 32 * j] = g.scale_r * mk * res;
                     if (Wp) {
@@ -686,6 +697,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
                     }
                 }
             }
+        }
         if (g.sq_out) {
             double v = (double)sq;
 #pragma unroll

@@ -420,9 +420,16 @@ __global__ __launch_bounds__(256) void class_lists_kernel(const int32_t *lists, 
         const int64_t row = grp * R + r;
         if (row >= nlists) break;
         const int32_t *l = lists + row * per;
-        for (int64_t q = t; q < per; q += 256) {
-            const int j = l[q], w = j >> 2;
-            atomicOr(&patw[(w % W) * 256 + w / W], 1u << (8 * (j & 3) + r));
+        for (int64_t q0 = t; q0 < per; q0 += 256 * 8) { // eight list entries in flight per thread (one workgroup per CU: nothing else hides the latency)
+            int jv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) jv[u] = q0 + 256 * u < per ? l[q0 + 256 * u] : -1;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (jv[u] >= 0) {
+                    const int w = jv[u] >> 2;
+                    atomicOr(&patw[(w % W) * 256 + w / W], 1u << (8 * (jv[u] & 3) + r));
+                }
         }
     }
     __syncthreads();
@@ -515,12 +522,19 @@ __global__ __launch_bounds__(256) void mask_cols_from_patterns_kernel(uint8_t *m
         tile[gg][jj] = v;
     }
     __syncthreads();
-    const int jj = t >> 2, part = t & 3;
-    if (j0 + jj >= n) return;
-    uint8_t *dst = mask + (j0 + jj) * ld + g0 * R;
-    for (int b = part * 8 * R; b < (part + 1) * 8 * R; ++b) {
-        const int gg = b / R, r = b % R;
-        if ((g0 + gg) * R + r < nlists) dst[b] = (uint8_t)((tile[gg][jj] >> r) & 1u);
+    // a candidate's 32 R bytes = 8 R words, consecutive lanes -> consecutive words of one image row
+    const int wpr = 8 * R;
+    for (int x = t; x < 64 * wpr; x += 256) {
+        const int jj = x / wpr, wi = x % wpr;
+        if (j0 + jj >= n) break;
+        if (g0 * R + 4 * wi >= ld) continue; // past the padded width of the image row
+        unsigned word = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int b = 4 * wi + e, gg = b / R, r = b % R;
+            if ((g0 + gg) * R + r < nlists) word |= (unsigned)((tile[gg][jj] >> r) & 1u) << (8 * e);
+        }
+        *reinterpret_cast<unsigned *>(mask + (j0 + jj) * ld + g0 * R + 4 * wi) = word;
     }
 }
 
