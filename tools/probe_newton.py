@@ -20,6 +20,8 @@ ctx.set_option("row_stagger", int(os.environ.get("ROW_STAGGER", "1")))
 ctx.set_option("row_diag", int(os.environ.get("ROW_DIAG", "0")))
 ctx.set_option("gemm_arith", int(os.environ.get("GEMM_ARITH", "0")))
 ctx.set_option("row_classes", int(os.environ.get("ROW_CLASSES", "-1")))
+if os.environ.get("CHOL_DIAG"):
+    ctx.set_option("chol_diag", int(os.environ["CHOL_DIAG"]))
 ctx.set_problem(m, d, p, k)
 ctx.fill_data_synthetic(0, 42); ctx.fill_data_synthetic(1, 43)
 sc = (0.8 / k) ** 0.5
