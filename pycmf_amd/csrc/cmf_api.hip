@@ -152,6 +152,8 @@ struct cmf_ctx {
     DevBuf mask1, mask2;                  // stochastic sample masks (bytes)
     DevBuf lists1, lists2;                // device copies of the per-row sample index lists
     DevBuf cls_idx[2], cls_off[2], cls_cnt[2], cls_pat[2], hclass; // shared partial sums of linear sampled sides: class lists, pattern bytes, class images
+    DevBuf certimg, certflag;             // per half group: the part of the Hessians common to its rows, and whether it alone passes the threshold test
+    int opt_rowcert = 1;                  // use those certificates (0: every row runs its own threshold test)
     int opt_rowclasses = -1;              // rows per group of the shared-partial-sum form: -1 automatic, 0 / 1 row by row, 2..6 forced
     DevBuf idxbuf;                        // uploaded sample index lists
     DevBuf eigws;                         // Jacobi workspace when k_pad > 128
@@ -621,7 +623,7 @@ static void release_problem(cmf_ctx *c) {
     c->kr1 = DevBuf(); c->kr2 = DevBuf(); c->hrows = DevBuf(); c->mask1 = DevBuf(); c->mask2 = DevBuf();
     c->lists1 = DevBuf(); c->lists2 = DevBuf();
     for (int q = 0; q < 2; ++q) { c->cls_idx[q] = DevBuf(); c->cls_off[q] = DevBuf(); c->cls_cnt[q] = DevBuf(); c->cls_pat[q] = DevBuf(); }
-    c->hclass = DevBuf();
+    c->hclass = DevBuf(); c->certimg = DevBuf(); c->certflag = DevBuf();
     c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf();
     c->nsidx = DevBuf(); c->nsws = DevBuf();
     c->spmm_bar = DevBuf();
@@ -687,6 +689,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_rowsym = (int)value;
     } else if (!strcmp(name, "row_kernel")) {
         c->opt_rowkernel = value != 0;
+    } else if (!strcmp(name, "row_certificates")) {
+        c->opt_rowcert = value != 0;
     } else if (!strcmp(name, "row_classes")) {
         if (value < -1 || value > 6) return fail(CMF_EINVAL, "row_classes: -1 (automatic), 0 (off) or 2..6 rows per group");
         c->opt_rowclasses = (int)value;

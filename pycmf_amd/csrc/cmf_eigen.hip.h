@@ -459,7 +459,8 @@ __device__ __forceinline__ void chol_forward(const CholRegs<NB> &R, int n, float
 template <int NB>
 __global__ __launch_bounds__(256, 2) void chol_solve_kernel(const float *Hin, const float *grad, float *step, int *need_jacobi,
                                                             int n, int kp, int64_t stride, float pert, int nmat, int diag = 0,
-                                                            const int *rowidx = nullptr, int sub = 1) {
+                                                            const int *rowidx = nullptr, int sub = 1, const int *cert = nullptr,
+                                                            int cert_rows = 1, int cert_split = 0) {
     __shared__ __attribute__((aligned(16))) float col[2 * (16 * NB + 4)]; // two buffers of (published column + pivot slot)
     __shared__ float vec[16 * NB];
     __shared__ float stage[16 * 17 + 16]; // diagonal block + block right-hand side of the back substitution
@@ -483,6 +484,10 @@ __global__ __launch_bounds__(256, 2) void chol_solve_kernel(const float *Hin, co
     const float floor_ = 4.0e-6f * dmax;
 
     CholRegs<NB> R;
+    // certificate (cmf_newton.hip.h, fused_rows_finish): a positive semi-definite part of this matrix, shared with the
+    // neighbouring rows of its group, was already shown to exceed the threshold -- so does the matrix; no test of its own
+    const bool certified = cert && cert[(mat / cert_rows) * 2 + ((mat % cert_rows) >= cert_split ? 1 : 0)] == 0;
+    if (!certified) {
     chol_load<NB>(R, H, n, ldh, pert, t);
     if (diag == 3) { // keep the loaded values alive
         float sink = 0.f;
@@ -496,6 +501,7 @@ __global__ __launch_bounds__(256, 2) void chol_solve_kernel(const float *Hin, co
     if (!chol_factor<NB>(R, n, floor_, col, t)) { // lambda_min < pert: the clamp matters -> Jacobi
         if (t == 0) need_jacobi[orow] = 1;
         return;
+    }
     }
     if (t == 0) need_jacobi[orow] = 0;
     if (diag == 1) return; // timing diagnostics (cmf_set_option "chol_diag"): 1 = PD test only, 2 = no back substitution,

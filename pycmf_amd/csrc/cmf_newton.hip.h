@@ -231,7 +231,12 @@ static int ns_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, f
 // step_i = grad_i * safe_inverse(H_i) for a chunk of per-row Hessians (H is clobbered):
 // register-resident Cholesky solve for the rows with lambda_min >= pert, Jacobi + row product
 // for the flagged rest.
-static int safe_solve_rows(cmf_ctx *c, float *Hc, const float *grad, float *step, int64_t nr, int n, int kp, double pert) {
+struct RowCert { // per-group positive-definiteness certificates of a chunk (fused_rows_finish), or none
+    const int *flags = nullptr; // [2 * groups]: 0 = the shared part alone already exceeds the threshold
+    int rows = 1, split = 0;    // rows per group, rows in its first half
+};
+static int safe_solve_rows(cmf_ctx *c, float *Hc, const float *grad, float *step, int64_t nr, int n, int kp, double pert,
+                           const RowCert &cert = RowCert()) {
     if (nr <= 0) return CMF_OK;
     const int64_t stride = (int64_t)kp * kp;
     if (!c->opt_chol || n > 256) { // general path only
@@ -249,7 +254,8 @@ static int safe_solve_rows(cmf_ctx *c, float *Hc, const float *grad, float *step
         if (n <= 32) hipLaunchKernelGGL((chol_solve_kernel<2>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag);
         else if (n <= 64) hipLaunchKernelGGL((chol_solve_kernel<4>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag);
         else if (n <= 128) hipLaunchKernelGGL((chol_solve_kernel<8>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag);
-        else hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag);
+        else hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag,
+                                (const int *)nullptr, 1, cert.flags, cert.rows, cert.split);
         HIPCHK(hipGetLastError());
         // flagged matrices, k_pad = 128 / 256, Hessians positive semi-definite by construction (weights >= 0):
         // spectral clamp by Newton-Schulz (MFMA) + a second Cholesky solve; clears the flags it serves
@@ -954,6 +960,7 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
     for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
         const int64_t nr = std::min(chunk, rows - r0);
         bool have_h = false, have_g = grad_preloaded;
+        RowCert cert;
         for (const RowSide *sd : {&s1, &s2}) {
             if (!sd->active) continue;
             RowHessArgs a;
@@ -978,9 +985,25 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
                 {
                     Timed tm(c, CMF_K_ELEMWISE);
                     if (upper) {
+                        // certificates: the samples common to all rows of half a group form a positive semi-definite part of
+                        // each of those rows' Hessians (every other contribution is one too when the weights are >= 0).  If
+                        // part + diag I already exceeds the perturbation threshold, so does each row: one test for the half
+                        // group instead of one per row.  Worth it when the part has enough samples to be well conditioned.
+                        const int split = (R + 1) / 2;
+                        const bool want_cert = c->hess_psd && c->opt_rowcert && !cert.flags && diag >= 0.0 && !c->opt_choldiag &&
+                                               (double)sd->n * std::pow((double)sd->per / (double)sd->n, split) >= 4.0 * c->k;
+                        float *certimg = nullptr;
+                        if (want_cert) {
+                            CHK(ensure(c, c->certimg, (size_t)((chunk + R - 1) / R) * 2 * kk * sizeof(float)));
+                            CHK(ensure(c, c->certflag, (size_t)((chunk + R - 1) / R) * 2 * sizeof(int)));
+                            certimg = (float *)c->certimg.p;
+                        }
                         const unsigned grid = (unsigned)std::min<int64_t>(ng * 36, (int64_t)c->num_cu * 16);
                         hipLaunchKernelGGL(class_sum_blocks_kernel, dim3(grid), dim3(256), 0, c->stream, Hc, (const float *)c->hclass.p,
-                                           have_h ? nullptr : S, have_h ? 0.f : (float)diag, nr, R, c->k, have_h ? 1 : 0);
+                                           have_h ? nullptr : S, have_h ? 0.f : (float)diag, nr, R, c->k, have_h ? 1 : 0, certimg, split);
+                        if (want_cert) {
+                            cert.flags = (const int *)c->certflag.p; cert.rows = R; cert.split = split;
+                        }
                     } else {
                         const int64_t total = nr * kk / 4;
                         const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, (int64_t)c->num_cu * 32);
@@ -1004,7 +1027,14 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
         if (!have_h) CHK(launch_ew(c, hessian_finalize_kernel, nr * kk, Hc, S, (float)diag, nr, c->kp, c->k, 0));
         CHK(launch_ew(c, newton_grad_kernel, nr * c->kp, grad + r0 * c->kp, (const float *)(grad + r0 * c->kp), 1.0f, (const float *)nullptr, 0.f,
                       (const float *)(c->F[which] + r0 * c->kp), (float)l1, (float)l2, nr * c->kp));
-        CHK(safe_solve_rows(c, Hc, grad + r0 * c->kp, step + r0 * c->kp, nr, c->k, c->kp, pert));
+        if (cert.flags) { // test the certificates (threshold test only): part + diag I - pert I positive definite?
+            Timed tm(c, CMF_K_EIGEN);
+            const int64_t ncert = 2 * ((nr + cert.rows - 1) / cert.rows);
+            hipLaunchKernelGGL((chol_solve_kernel<16>), dim3((unsigned)ncert), dim3(256), 0, c->stream, (const float *)c->certimg.p, (const float *)nullptr,
+                               (float *)nullptr, (int *)c->certflag.p, c->k, c->kp, kk, (float)(pert - diag), (int)ncert, 1);
+            HIPCHK(hipGetLastError());
+        }
+        CHK(safe_solve_rows(c, Hc, grad + r0 * c->kp, step + r0 * c->kp, nr, c->k, c->kp, pert, cert));
     }
     return launch_ew(c, newton_apply_kernel, rows_pad * c->kp, c->F[which], (const float *)step, rows, c->kp, c->k, rows_pad * c->kp,
                      nn ? 1 : 0);

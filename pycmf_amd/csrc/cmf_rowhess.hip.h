@@ -568,8 +568,11 @@ __global__ __launch_bounds__(256) void class_sum_kernel(float *H, const float *C
 // workgroup per (group, block) item reads every class block of the group ONCE, adds it to the running sums of the rows it
 // belongs to (classes in ascending order for every row: the order does not depend on R or on the grid), then stores each
 // row's block and -- through an LDS transpose -- its mirror image.  nrows rows starting at a group boundary.
+// cert (optional): per group two more sums over classes, the samples common to ALL rows of its first `split` rows and to
+// all of the remaining ones -- a positive semi-definite part of each of those rows' Hessians (upper blocks only: what the
+// Cholesky kernel reads), image [2 group + half].
 __global__ __launch_bounds__(256) void class_sum_blocks_kernel(float *H, const float *C, const float *S, float diag, int64_t nrows,
-                                                               int R, int kvalid, int accumulate) {
+                                                               int R, int kvalid, int accumulate, float *cert, int split) {
     constexpr int KP = 256, RMAX = 6;
     constexpr int64_t KK = (int64_t)KP * KP;
     __shared__ float tile[32][33];
@@ -583,14 +586,21 @@ __global__ __launch_bounds__(256) void class_sum_blocks_kernel(float *H, const f
         const int bb = ba + rem;
         const int off = (32 * ba + r) * KP + 32 * bb + 4 * c4;
         const float *base = C + grp * (NC - 1) * KK + off;
-        f32x4 acc[RMAX];
+        f32x4 acc[RMAX], pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < RMAX; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int ma = (1 << split) - 1, mb = (NC - 1) ^ ma;
         for (int q = 1; q < NC; ++q) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(base + (int64_t)(q - 1) * KK);
 #pragma unroll
             for (int m = 0; m < RMAX; ++m)
                 if ((q >> m) & 1) acc[m] += v; // bits >= R are never set
+            if ((q & ma) == ma) pa += v;
+            if ((q & mb) == mb) pb += v;
+        }
+        if (cert) {
+            *reinterpret_cast<f32x4 *>(cert + (2 * grp) * KK + off) = pa;
+            *reinterpret_cast<f32x4 *>(cert + (2 * grp + 1) * KK + off) = pb;
         }
 #pragma unroll
         for (int m = 0; m < RMAX; ++m) {

@@ -237,6 +237,37 @@ def test_shared_partial_sums_match_the_oracle_and_the_row_form(lib, links, shape
             np.testing.assert_allclose(a, o, rtol=0, atol=2e-3 * np.abs(o).max())
 
 
+@pytest.mark.parametrize("l2,rank", [(0.05, 0), (0.01, 150)])
+def test_group_certificates_do_not_change_the_step(lib, l2, rank):
+    """Rows of half a class group share the threshold test of _safe_invert (pycmf/cmf_solvers.py:346-356) when the part of
+    their Hessians they have in common already exceeds the perturbation (a positive semi-definite part bounds lambda_min
+    from below).  The step must be the one every row's own test gives: bit-identical here, both when the certificates hold
+    (well-conditioned factors) and when they fail and every row falls back to its own test (rank-deficient V, l2 under
+    the perturbation: the rows take the clamp route)."""
+    from oracle import cmf_oracle as O
+    m, d, p, k, ratio = 64, 6000, 40, 200, 0.5
+    rng = np.random.RandomState(21)
+    X, Y = np.abs(rng.randn(m, d)), rng.rand(d, p)
+    sc = (0.8 / k) ** 0.5
+    U0, V0, Z0 = sc * rng.randn(m, k), sc * rng.randn(d, k), sc * rng.randn(p, k)
+    if rank:
+        V0[:, rank:] = 0.0     # V^T D V has rank <= 150 < k for every sample set
+    got = {}
+    for certs in (1, 0):
+        ctx = lib.Context(0)
+        ctx.set_option("row_certificates", certs)
+        ctx.set_problem(m, d, p, k)
+        ctx.set_data(0, X); ctx.set_data(1, Y)
+        for w, F in enumerate((U0, V0, Z0)):
+            ctx.set_factor(w, F)
+        ctx.newton_step_device_sampled(0.5, 0.0, l2, "linear", "logit", 0, 1, 0.2, ratio, 7)   # the U sweep
+        got[certs] = ctx.get_factor(0)
+        ctx.close()
+    assert np.isfinite(got[1]).all()
+    np.testing.assert_array_equal(got[1], got[0])
+    assert np.abs(got[1] - U0).max() > 0
+
+
 @pytest.mark.parametrize("name", ["lin_log_nn", "log_log_free", "lin_log_free_sg"])
 def test_cython_variant_matches_compiled_reference(lib, name):
     """HipNewtonSolver(cython_variant=True) reproduces the reference's Cython twin (g7 fixture)."""
