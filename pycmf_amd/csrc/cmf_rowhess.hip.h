@@ -279,6 +279,44 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
         }
     };
 
+    // the last tile of a list when it holds fewer than 29 samples: only the K-steps that carry samples (two per MFMA, four per
+    // turn of this loop; the rows behind them are staged as zeros anyway).  Class lists of ~256 samples end in a half-empty
+    // tile on average: 6 % of their K-steps.
+    auto sym_tail = [&](auto typ, int cb, int nsteps) {
+        constexpr int TY = decltype(typ)::value;
+        constexpr int NP = sym_np(TY), NA = sym_na(TY), NB = sym_nb(TY);
+        const float *Rt = tile_of(cb) + l31;
+        const float *Wt = wtile_of(cb) + l31;
+        float a[2][2], b[2][5];
+        auto ld_frag = [&](int sidx, float *da, float *db) {
+            const int kk = 2 * sidx + lh;
+            if constexpr (SYM == 3) {
+#pragma unroll
+                for (int f = 0; f < s3_nf(TY); ++f) db[f] = Rt[kk * KP + 32 * (TY == 0 ? (f == 0 ? ablk[0] : bblk[f - 1]) : bblk[f])];
+            } else {
+#pragma unroll
+                for (int x = 0; x < NA; ++x) da[x] = Wt[kk * KP + 32 * ablk[x]];
+#pragma unroll
+                for (int y = 0; y < NB; ++y) db[y] = Rt[kk * KP + 32 * bblk[y]];
+            }
+        };
+        auto mm = [&](const float *fa, const float *fb) {
+#pragma unroll
+            for (int n = 0; n < NP; ++n) {
+                if constexpr (SYM == 3) hs[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[s3_ai(TY, n)], fb[s3_bi(TY, n)], hs[n], 0, 0, 0);
+                else hs[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sym_ai(TY, n)], fb[sym_bi(TY, n)], hs[n], 0, 0, 0);
+            }
+        };
+        ld_frag(0, a[0], b[0]);
+        for (int sidx = 0; sidx < nsteps; sidx += 2) { // sidx + 1 <= 15 always (nsteps <= 14)
+            ld_frag(sidx + 1, a[1], b[1]);
+            mm(a[0], b[0]);
+            ld_frag(sidx + 2, a[0], b[0]);
+            mm(a[1], b[1]);
+        }
+    };
+    const int tail_steps = nt > 0 ? (ns - 32 * (nt - 1) + 1) / 2 : 0; // K-steps of the last tile that carry samples (1..16)
+
     if (nt > 0) {
         if (loader) {
             load_idx(0);
@@ -294,10 +332,12 @@ __global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
         if constexpr (SYM) {
             // the three wave types run their own copy of the loop (same barrier count in each)
             auto run = [&](auto typ) {
-                for (int tl = 0; tl < nt; ++tl) {
+                const int full = tail_steps <= 14 ? nt - 1 : nt;
+                for (int tl = 0; tl < full; ++tl) {
                     sym_tile(typ, tl & 1, tl + 1 < nt, (tl + 1) & 1, tl + 2 < nt, tl + 2, tl + 3 < nt, tl + 3);
                     __syncthreads();
                 }
+                if (full < nt) sym_tail(typ, (nt - 1) & 1, tail_steps);
             };
             if (wty == 0) run(IntC<0>{});
             else if (wty == 1) run(IntC<1>{});
