@@ -323,8 +323,8 @@ def main():
     for it in range(args.warmup):
         do_step(it)
     for c_ in ctxs:
-        c_.kernel_timing(True)
-        c_.kernel_timing_reset()
+        c_.kernel_timing(2)        # HIP events around the data-pass launches only (the class the roofline prices): an event pair per
+        c_.kernel_timing_reset()   # launch serialises the stream for a few microseconds, 7 % of a C2 iteration when every launch has one
     if coll:
         coll.stream.synchronize()
         coll.reset()
@@ -347,6 +347,15 @@ def main():
     names = ("gemm_nn", "gemm_tn", "gemm_small", "gemm_nt", "spmm", "rowhess", "eigen", "elementwise")
     classes = {c: tuple(sum(v) for v in zip(*(c_.kernel_time(c) for c_ in ctxs))) for c in names}
     rh_samples = tuple(sum(v) for v in zip(*(c_.rowhess_samples() for c_ in ctxs)))
+    # the other kernel classes: a few more iterations OUTSIDE the timed region with events around every launch
+    extra = min(args.steps, 3)
+    for c_ in ctxs:
+        c_.kernel_timing(1)
+        c_.kernel_timing_reset()
+    for it in range(extra):
+        do_step(args.warmup + args.steps + it)
+    sync_all()
+    other = {c: tuple(sum(v) for v in zip(*(c_.kernel_time(c) for c_ in ctxs))) for c in names}
     for c_ in ctxs:
         c_.kernel_timing(False)
     ex2, ey2 = ctx.residual_sq(w.get("x_link", "linear"), w.get("y_link", "linear"))
@@ -441,7 +450,9 @@ def main():
     elif dom == "rowhess" and kp == 256 and "row_symmetric=0" not in args.option:
         # the MFMAs cover 36 whole 32x32 blocks (the diagonal blocks are computed in full)
         roof["mfma_executed_tflops"] = achieved * (36 * 2048.0 + 4 * kp) / (kp * (kp + 1.0) + 4 * kp)
-    roof["per_class_ms_per_step"] = {c: v[0] / args.steps for c, v in classes.items() if v[1]}
+    roof["per_class_ms_per_step"] = {c: v[0] / extra for c, v in other.items() if v[1]}
+    roof["per_class_note"] = ("%d extra iterations after the timed region with HIP events around every launch; inside the timed region "
+                              "only the data-pass classes carry events (what achieved / avg_launch_ms are computed from)" % extra)
     out = {
         "metric": "factor-update iterations/s (%s solver: one full update_step per iteration)" % w["solver"],
         "value": its,

@@ -357,7 +357,8 @@ class Context:
         return g.value, u.value
 
     def kernel_timing(self, enable):
-        check(self._lib.cmf_kernel_timing(self._h, 1 if enable else 0))
+        """False / 0 off, True / 1 every launch, 2 the data-pass classes only (see cmfhip.h)."""
+        check(self._lib.cmf_kernel_timing(self._h, int(enable)))
 
     def kernel_timing_reset(self):
         check(self._lib.cmf_kernel_timing_reset(self._h))

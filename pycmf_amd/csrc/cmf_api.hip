@@ -173,7 +173,7 @@ struct cmf_ctx {
     std::set<const void *> lds_opt_in;    // kernels whose >64 KB dynamic-LDS attribute is set on THIS device
 
     // timing
-    bool timing = false;
+    int timing = 0;                       // 0 off | 1 events around every launch | 2 around the data-pass classes only
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> evpool;
     double ms[CMF_K_COUNT] = {0};
@@ -217,7 +217,8 @@ struct Timed {
     bool on = false;
     double flops = 0.0;
     Timed(cmf_ctx *c_, int cls_, double flops_ = 0.0) : c(c_), cls(cls_), flops(flops_) {
-        if (c->timing && ev_get(c, &a) == CMF_OK && ev_get(c, &b) == CMF_OK) {
+        const bool want = c->timing == 1 || (c->timing == 2 && (cls == CMF_K_GEMM_NN || cls == CMF_K_GEMM_TN || cls == CMF_K_SPMM || cls == CMF_K_ROWHESS));
+        if (want && ev_get(c, &a) == CMF_OK && ev_get(c, &b) == CMF_OK) {
             on = true;
             (void)hipEventRecord(a, c->stream);
         }
@@ -1350,7 +1351,7 @@ extern "C" int cmf_kernel_timing(cmf_ctx *c, int enable) {
     if (!c) return fail(CMF_EINVAL, "null context");
     DeviceGuard dg(c->device);
     CHK(flush_timing(c));
-    c->timing = enable != 0;
+    c->timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
     return CMF_OK;
 }
 extern "C" int cmf_kernel_time(cmf_ctx *c, int cls, double *ms, int64_t *launches, double *flops) {
