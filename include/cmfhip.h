@@ -84,7 +84,12 @@ int cmf_sync(cmf_ctx *ctx);
  * "newton_schulz" 1 | 0 (k_pad = 256: rows whose eigenvalue clamp acts go through the GEMM-only
  * spectral clamp | through the Jacobi eigen-solver),
  * "sample_row_offset_u|v|z" n = global index of this context's first U / V / Z row in the keys of
- * the device sampler (a row shard then draws what the unsharded problem draws for its rows)        */
+ * the device sampler (a row shard then draws what the unsharded problem draws for its rows),
+ * "row_classes" -1 (automatic, default) | 0 | 2..6: linear-link sides with sg_sample_ratio < 1 -- groups of that many
+ * consecutive rows share the outer-product sums of the samples they have in common (same H_i as row by row, sums in
+ * another order; cmf_solvers.py:414-428 with the identity link) | every row gathers its own list,
+ * "row_certificates" 1 (default) | 0: half such a group shares one threshold test of _safe_invert (cmf_solvers.py:346-356)
+ * through the positive semi-definite part of their Hessians the rows have in common | every row runs its own         */
 int cmf_set_option(cmf_ctx *ctx, const char *name, int64_t value);
 
 /* ---- problem ---------------------------------------------------------- */

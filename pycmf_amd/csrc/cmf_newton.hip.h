@@ -878,13 +878,19 @@ struct RowSide {
 
 // Rows per group for the shared-partial-sum form of a linear, sampled side, or 0: worth it when the distinct samples of a
 // group, n (1 - (1 - rho)^R), are well below the R rho n of the row-by-row form.
+static size_t class_lists_lds(int64_t n, int R) { // class_lists_kernel: pattern words (transposed, W per thread) + hist[256][2^R + 1]
+    const int64_t nw = (n + 3) / 4, W = (nw + 255) / 256;
+    return (size_t)W * 256 * 4 + (size_t)256 * ((1 << R) + 1) * sizeof(int);
+}
 static int class_group_rows(const cmf_ctx *c, int link, bool sampled, int64_t per, int64_t n) {
     if (!sampled || link != CMF_LINK_LINEAR || c->opt_rowclasses == 0 || c->opt_rowclasses == 1 || per <= 0 || n <= 0 || n > 131072) return 0;
     int R = std::min(c->opt_rowclasses, 6);
     if (R < 0) { // automatic: as many rows per group as leave the 2^R - 1 classes ~256 samples each (8 K-steps of the row kernel
-        R = 2;   // per class image written and read back: C3 measured 301 / 285 / 282 ms per iteration at R = 4 / 5 / 6)
+        R = 2;   // per class image written and read back: C3 measured 297 / 273 / 269 ms per iteration at R = 4 / 5 / 6)
         while (R < 6 && (n >> (R + 1)) >= 256) ++R;
     }
+    while (R >= 2 && class_lists_lds(n, R) > (size_t)150 * 1024) --R; // the list kernel's LDS image of the candidates
+    if (R < 2) return 0;
     const double rho = (double)per / (double)n;
     const double factor = (1.0 - std::pow(1.0 - rho, R)) / (R * rho);
     return factor < 0.8 ? R : 0;
@@ -899,8 +905,7 @@ static int build_class_lists(cmf_ctx *c, const RowSide &sd, int64_t rows) {
     CHK(ensure(c, co, (size_t)ngroups * NC1 * sizeof(int64_t)));
     CHK(ensure(c, cc, (size_t)ngroups * NC1 * sizeof(int32_t)));
     CHK(ensure(c, cp, (size_t)ngroups * sd.n));
-    const int nw = (int)((sd.n + 3) / 4), W = (nw + 255) / 256;
-    const size_t lds = (size_t)W * 256 * 4 + (size_t)256 * ((1 << R) + 1) * sizeof(int);
+    const size_t lds = class_lists_lds(sd.n, R);
     CHK(allow_big_lds(c, reinterpret_cast<const void *>(&class_lists_kernel), (int)lds));
     Timed tm(c, CMF_K_ELEMWISE);
     hipLaunchKernelGGL(class_lists_kernel, dim3((unsigned)ngroups), dim3(256), lds, c->stream, sd.lists, sd.per, rows, (int)sd.n, R,
@@ -950,9 +955,14 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
     const int64_t kk = (int64_t)c->kp * c->kp;
     int64_t chunk = hessian_chunk_rows(c, rows_pad);
     for (const RowSide *sd : {&s1, &s2})
-        if (sd->active && sd->cls && chunk < rows_pad) { // chunks start on a group boundary: multiples of lcm(256, R)
-            const int64_t q = (sd->cls % 3 == 0 ? 768 : (sd->cls == 5 ? 1280 : 256));
-            chunk = std::max<int64_t>(q, chunk / q * q);
+        if (sd->active && sd->cls) {
+            // class images of a chunk: (2^R - 1) / R images per row; keep them under 16 GiB (C3, R = 6: 5376 rows per chunk)
+            const int64_t per_row = (((int64_t)1 << sd->cls) - 1) * kk * (int64_t)sizeof(float) / sd->cls;
+            chunk = std::min(chunk, std::max<int64_t>(256, (((int64_t)16 << 30) / per_row) / 256 * 256));
+            if (chunk < rows_pad) { // chunks start on a group boundary: multiples of lcm(256, R)
+                const int64_t q = (sd->cls % 3 == 0 ? 768 : (sd->cls == 5 ? 1280 : 256));
+                chunk = std::max<int64_t>(q, chunk / q * q);
+            }
         }
     CHK(ensure(c, c->hrows, (size_t)chunk * kk * sizeof(float)));
     float *Hc = (float *)c->hrows.p;

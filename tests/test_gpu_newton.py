@@ -237,6 +237,30 @@ def test_shared_partial_sums_match_the_oracle_and_the_row_form(lib, links, shape
             np.testing.assert_allclose(a, o, rtol=0, atol=2e-3 * np.abs(o).max())
 
 
+def test_shared_partial_sums_with_many_candidates(lib):
+    """100 000 candidates per list: the class-list kernel keeps one LDS byte per candidate plus its histograms, so the
+    automatic group size backs off until that fits (and beyond 131 072 candidates the side runs row by row); same U sweep
+    as the row-by-row form either way."""
+    m, d, p, k, ratio = 10, 100000, 6, 8, 0.5
+    rng = np.random.RandomState(5)
+    X, Y = np.abs(rng.randn(m, d)), np.abs(rng.randn(d, p))
+    U0, V0, Z0 = 0.1 * rng.randn(m, k), 0.1 * rng.randn(d, k), 0.1 * rng.randn(p, k)
+    got = {}
+    for R in (-1, 6, 0):
+        ctx = lib.Context(0)
+        ctx.set_option("row_classes", R)
+        ctx.set_problem(m, d, p, k)
+        ctx.set_data(0, X); ctx.set_data(1, Y)
+        for w, F in enumerate((U0, V0, Z0)):
+            ctx.set_factor(w, F)
+        ctx.newton_step_device_sampled(0.5, 0.0, 0.3, "linear", "linear", 0, 1, 0.2, ratio, 3)   # U sweep: lists over d
+        got[R] = ctx.get_factor(0)
+        ctx.close()
+    for R in (-1, 6):
+        np.testing.assert_allclose(got[R], got[0], rtol=0, atol=2e-4 * np.abs(got[0]).max())
+    assert np.abs(got[0] - U0).max() > 0
+
+
 @pytest.mark.parametrize("l2,rank", [(0.05, 0), (0.01, 150)])
 def test_group_certificates_do_not_change_the_step(lib, l2, rank):
     """Rows of half a class group share the threshold test of _safe_invert (pycmf/cmf_solvers.py:346-356) when the part of
