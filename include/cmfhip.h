@@ -88,6 +88,8 @@ int cmf_sync(cmf_ctx *ctx);
  * "row_classes" -1 (automatic, default) | 0 | 2..6: linear-link sides with sg_sample_ratio < 1 -- groups of that many
  * consecutive rows share the outer-product sums of the samples they have in common (same H_i as row by row, sums in
  * another order; cmf_solvers.py:414-428 with the identity link) | every row gathers its own list,
+ * "direct_newton_step" 1 (default) | 0: linear shared-Hessian sweeps with l1 = 0 whose inverse is the plain one (k > 64)
+ * update F <- clamp(s (T O) H^-1) in one product | form the gradient and subtract the step,
  * "row_certificates" 1 (default) | 0: half such a group shares one threshold test of _safe_invert (cmf_solvers.py:346-356)
  * through the positive semi-definite part of their Hessians the rows have in common | every row runs its own         */
 int cmf_set_option(cmf_ctx *ctx, const char *name, int64_t value);

@@ -153,6 +153,7 @@ struct cmf_ctx {
     DevBuf lists1, lists2;                // device copies of the per-row sample index lists
     DevBuf cls_idx[2], cls_off[2], cls_cnt[2], cls_pat[2], hclass; // shared partial sums of linear sampled sides: class lists, pattern bytes, class images
     DevBuf certimg, certflag;             // per half group: the part of the Hessians common to its rows, and whether it alone passes the threshold test
+    int opt_direct_step = 1;              // linear shared-Hessian sweeps with l1 = 0 and an unclamped inverse: F <- clamp(s (T O) H^-1) in one product
     int opt_rowcert = 1;                  // use those certificates (0: every row runs its own threshold test)
     int opt_rowclasses = -1;              // rows per group of the shared-partial-sum form: -1 automatic, 0 / 1 row by row, 2..6 forced
     DevBuf idxbuf;                        // uploaded sample index lists
@@ -690,6 +691,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_rowsym = (int)value;
     } else if (!strcmp(name, "row_kernel")) {
         c->opt_rowkernel = value != 0;
+    } else if (!strcmp(name, "direct_newton_step")) {
+        c->opt_direct_step = value != 0;
     } else if (!strcmp(name, "row_certificates")) {
         c->opt_rowcert = value != 0;
     } else if (!strcmp(name, "row_classes")) {

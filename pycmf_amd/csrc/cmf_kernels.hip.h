@@ -64,6 +64,7 @@ struct GemmArgs {
     //  EPI_GRAD   acc = F G: grad = a acc - a P + b sign(F) + c F                            (:399-400, :436-440)
     //             epi_F = F (= A), epi_P = data term, a = scale, b = l1, c = l2, written to epi_out
     //  EPI_APPLY  acc = grad H^-1 is the Newton step: F <- clamp(F - acc), zero outside the valid block   (:321-326)
+    //  EPI_DIRECT acc = (T O) H^-1 with the plain inverse: F <- clamp(a acc) -- the same point, F - (F H - a T O) H^-1 = a T O H^-1
     //             epi_F = F, written to epi_out (= F)
     int epi;
     const float *epi_F, *epi_P;
@@ -72,7 +73,7 @@ struct GemmArgs {
     int64_t epi_rows;
     int epi_kvalid, epi_nn;
 };
-enum { EPI_NONE = 0, EPI_MU = 1, EPI_GRAD = 2, EPI_APPLY = 3 };
+enum { EPI_NONE = 0, EPI_MU = 1, EPI_GRAD = 2, EPI_APPLY = 3, EPI_DIRECT = 4 };
 
 // write-through (sc1) stores: the bytes leave the XCD's L2 at once, so a workgroup on another XCD can read them after
 // the storing wave's s_waitcnt vmcnt(0) and a ticket, with no release fence (MI355X_MICROARCH.md, publish-large)
@@ -488,8 +489,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
                         const int r = r0 + q;
                         const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
                         off[q] = (row0 + wrow0 + 32 * i + rr) * g.ldc + n0 + wcol0 + C::TN * l31;
-                        f[q] = *reinterpret_cast<const vecN *>(g.epi_F + off[q]);
-                        if (g.epi != EPI_APPLY) pv[q] = *reinterpret_cast<const vecN *>(g.epi_P + off[q]);
+                        if (g.epi != EPI_DIRECT) f[q] = *reinterpret_cast<const vecN *>(g.epi_F + off[q]);
+                        else
+#pragma unroll
+                            for (int j = 0; j < C::TN; ++j) f[q][j] = 0.f;
+                        if (g.epi != EPI_APPLY && g.epi != EPI_DIRECT) pv[q] = *reinterpret_cast<const vecN *>(g.epi_P + off[q]);
                     }
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
                             } else {
                                 res = 0.f;
                                 if (row < g.epi_rows && (int)(n0 + wcol0 + C::TN * l31 + j) < g.epi_kvalid) {
-                                    res = fv - av;
+                                    res = g.epi == EPI_DIRECT ? g.epi_a * av : fv - av;
                                     if (g.epi_nn && res < 0.f) res = 0.f;
                                 }
                             }
@@ -792,10 +796,10 @@ __global__ __launch_bounds__(256) void factor_update_kernel(FactorUpdArgs g) {
         float fv[16], pv[16];
         const float *Fb = g.F + (row0 + wr + 4 * lh) * KP + col;   // register r: + ((r & 3) + 8 (r >> 2)) rows
 #pragma unroll
-        for (int r = 0; r < 16; ++r) fv[r] = Fb[((r & 3) + 8 * (r >> 2)) * KP];
+        for (int r = 0; r < 16; ++r) fv[r] = g.epi != EPI_DIRECT ? Fb[((r & 3) + 8 * (r >> 2)) * KP] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) pv[r] = 0.f;
-        if (g.epi != EPI_APPLY) {
+        if (g.epi != EPI_APPLY && g.epi != EPI_DIRECT) {
             const int64_t eoff = (row0 + wr + 4 * lh) * KP + col;
             auto add_slabs = [&](const float *base, int ns, int64_t stride) {
                 const float *Pb = base + eoff;
@@ -842,7 +846,7 @@ __global__ __launch_bounds__(256) void factor_update_kernel(FactorUpdArgs g) {
             } else {
                 res = 0.f;
                 if (row < g.rows_valid && col < g.kvalid) {
-                    res = f - av;
+                    res = g.epi == EPI_DIRECT ? g.a * av : f - av;
                     if (g.nn && res < 0.f) res = 0.f;
                 }
             }

@@ -337,8 +337,9 @@ static int gemm64(cmf_ctx *c, bool trans_b, const double *A, const double *B, do
 
 // c->Hinv (float32, zero on the padding) = safe_inverse(H64) for the one shared Hessian, formed and inverted in float64
 // (reference: _safe_invert, cmf_solvers.py:346-356, on a float64 matrix)
-static int shared_inverse64(cmf_ctx *c, const double *H64, int n, double pert, bool psd) {
+static int shared_inverse64(cmf_ctx *c, const double *H64, int n, double pert, bool psd, bool *plain = nullptr) {
     const int kp = c->kp;
+    if (plain) *plain = false; // set when the host knows that lambda_min >= pert, i.e. the result is the plain inverse
     Timed tm(c, CMF_K_EIGEN);
     if (n <= 64) { // one launch, the branch on lambda_min is taken on the device
         const size_t lds = (size_t)(2 * n * n + n) * sizeof(double);
@@ -381,7 +382,10 @@ static int shared_inverse64(cmf_ctx *c, const double *H64, int n, double pert, b
     double hc = 1.0;
     HIPCHK(hipMemcpyAsync(hflags, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (!hflags[0] && !hflags[1]) return inverse_from(W1); // lambda_min >= pert: the clamp is the identity
+    if (!hflags[0] && !hflags[1]) { // lambda_min >= pert: the clamp is the identity
+        if (plain) *plain = true;
+        return inverse_from(W1);
+    }
     if (psd) {
         hipLaunchKernelGGL(ns64_prepare_kernel, dim3(1), dim3(1024), 0, c->stream, H64, Bm, X, n, kp, pert, cnorm);
         HIPCHK(hipGetLastError());
@@ -415,11 +419,11 @@ static int shared_inverse64(cmf_ctx *c, const double *H64, int n, double pert, b
 
 // F <- clamp(F - grad * safe_inverse(H)); grad lives in c->den, scratch in c->num.  H: c->h64 (float64) when the
 // float64 treatment is on, else c->Hm (float32).
-static int shared_step(cmf_ctx *c, int which, double pert, bool non_negative) {
-    const int64_t rows = c->frows_pad[which];
+static int shared_inverse(cmf_ctx *c, double pert, bool *plain = nullptr) {
+    if (plain) *plain = false;
     bool done = false;
     if (c->opt_shared64 && c->kp <= 1024) {
-        const int rc = shared_inverse64(c, (const double *)c->h64.p, c->k, pert, c->hess_psd);
+        const int rc = shared_inverse64(c, (const double *)c->h64.p, c->k, pert, c->hess_psd, plain);
         if (rc == CMF_OK) done = true;
         else if (rc != CMF_EUNSUPPORTED) return rc;
         else { // not positive semi-definite by construction (alpha outside [0, 1]): |lambda| route of the float32 eigen-solver
@@ -430,6 +434,10 @@ static int shared_step(cmf_ctx *c, int which, double pert, bool non_negative) {
         }
     }
     if (!done) CHK(safe_inverse_dev(c, c->Hm, c->Hinv, 1, c->k, c->kp, pert, c->hess_psd));
+    return CMF_OK;
+}
+static int shared_apply(cmf_ctx *c, int which, bool non_negative) {
+    const int64_t rows = c->frows_pad[which];
     if (c->opt_fused_mu && c->kp <= 256) { // F <- clamp(F - grad H^-1) in the epilogue of the step product
         Epilogue e;
         e.kind = EPI_APPLY; e.F = c->F[which]; e.out = c->F[which]; e.rows = c->frows[which]; e.kvalid = c->k; e.nn = non_negative ? 1 : 0;
@@ -439,6 +447,10 @@ static int shared_step(cmf_ctx *c, int which, double pert, bool non_negative) {
     CHK(gemm(c, MODE_NN, c->den, c->kp, c->Hinv, c->kp, c->num, rows, c->kp, c->kp));
     return launch_ew(c, newton_apply_kernel, rows * c->kp, c->F[which], (const float *)c->num, c->frows[which], c->kp, c->k,
                      rows * c->kp, non_negative ? 1 : 0);
+}
+static int shared_step(cmf_ctx *c, int which, double pert, bool non_negative) {
+    CHK(shared_inverse(c, pert));
+    return shared_apply(c, which, non_negative);
 }
 
 static bool use_shared64(const cmf_ctx *c) { return c->opt_shared64 && c->kp <= 1024; }
@@ -471,8 +483,22 @@ static int sweep_side_shared(cmf_ctx *c, bool is_u, double scale, double l1, dou
     } else {
         CHK(gemm(c, MODE_TN, V, c->kp, V, c->kp, c->G2, c->kp, c->kp, c->dp)); // V^T V
     }
+    // H and its safe inverse first: when the host learns that the clamp did not act (lambda_min >= pert, the Cholesky route
+    // of k > 64) and l1 = 0, the update is ONE product -- with H = s G + l2 I the step is (F H - s T O) H^-1 = F - s T O H^-1,
+    // so F - step = s (T O) H^-1: no F G product, no cancellation against F
+    if (f64) CHK(launch_hess64(c, (const double *)c->g64a.p, scale, nullptr, 0.0, l2));
+    else CHK(launch_ew(c, axpby_diag_kernel, (int64_t)c->kp * c->kp, c->Hm, (const float *)c->G2, (float)scale,
+                       (const float *)nullptr, 0.f, (float)l2, c->kp, c->k));
+    bool plain = false;
+    CHK(shared_inverse(c, pert, &plain));
     if (is_u) CHK(data_times(c, 0, false, V, c->num)); // X V
     else CHK(data_times(c, 1, true, V, c->num));       // Y^T V
+    if (plain && l1 == 0.0 && c->opt_direct_step && c->opt_fused_mu && c->kp <= 256) {
+        Epilogue e;
+        e.kind = EPI_DIRECT; e.F = F; e.out = F; e.a = scale; e.rows = c->frows[which]; e.kvalid = c->k; e.nn = nn ? 1 : 0;
+        if (small_tile_ok(c, rows)) return factor_update(c, c->num, c->Hinv, e, rows);
+        return gemm(c, MODE_NN, c->num, c->kp, c->Hinv, c->kp, c->den, rows, c->kp, c->kp, false, &e);
+    }
     if (c->opt_fused_mu && c->kp <= 256) { // grad = s (F G - T O) + l1 sign F + l2 F in the epilogue of F (V^T V)
         Epilogue e;
         e.kind = EPI_GRAD; e.F = F; e.P = c->num; e.out = c->den; e.a = scale; e.b = l1; e.c = l2;
@@ -483,10 +509,7 @@ static int sweep_side_shared(cmf_ctx *c, bool is_u, double scale, double l1, dou
         CHK(launch_ew(c, newton_grad_kernel, rows * c->kp, c->den, (const float *)c->den, (float)scale, (const float *)c->num,
                       (float)-scale, (const float *)F, (float)l1, (float)l2, rows * c->kp));
     }
-    if (f64) CHK(launch_hess64(c, (const double *)c->g64a.p, scale, nullptr, 0.0, l2));
-    else CHK(launch_ew(c, axpby_diag_kernel, (int64_t)c->kp * c->kp, c->Hm, (const float *)c->G2, (float)scale,
-                       (const float *)nullptr, 0.f, (float)l2, c->kp, c->k));
-    return shared_step(c, which, pert, nn);
+    return shared_apply(c, which, nn);
 }
 
 extern "C" int cmf_newton_v_partials(cmf_ctx *c, double alpha, float *buf) {

@@ -169,3 +169,35 @@ def test_large_n_components_shared_hessian(lib):
     O.newton_update_step(X, Y, U, V, Z, 0.5, 0.0, 0.3, "linear", "linear", False, False, False, 1.0, 0.2)
     for a, b in zip(got, (U, V, Z)):
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-3 * np.abs(b).max())
+
+
+@pytest.mark.parametrize("k,nn", [(100, False), (200, True)])
+def test_direct_step_of_unclamped_linear_sweeps(lib, k, nn):
+    """Linear link, l1 = 0, shared Hessian H = s G + l2 I with lambda_min >= pert (the clamp of _safe_invert,
+    pycmf/cmf_solvers.py:346-356, is the identity): F - (F H - s T O) H^-1 = s (T O) H^-1, so the sweep is one product
+    (option direct_newton_step, default on for k > 64).  Same iterates as the two-product form and as the oracle, with and
+    without the non-negativity clamp."""
+    from oracle import cmf_oracle as O
+    rng = np.random.RandomState(k)
+    m, d, p = 600, 500, 260
+    X, Y = np.abs(rng.randn(m, d)), np.abs(rng.randn(d, p))
+    sc = (1.0 / k) ** 0.5
+    U0, V0, Z0 = sc * np.abs(rng.randn(m, k)), sc * np.abs(rng.randn(d, k)), sc * np.abs(rng.randn(p, k))
+    U, V, Z = U0.copy(), V0.copy(), Z0.copy()
+    for _ in range(2):
+        O.newton_update_step(X, Y, U, V, Z, 0.5, 0.0, 0.4, "linear", "linear", nn, nn, nn, 1.0, 0.2)
+    got = {}
+    for direct in (1, 0):
+        ctx = lib.Context(0)
+        ctx.set_option("direct_newton_step", direct)
+        ctx.set_problem(m, d, p, k)
+        ctx.set_data(0, X); ctx.set_data(1, Y)
+        for w, F in enumerate((U0, V0, Z0)):
+            ctx.set_factor(w, F)
+        for _ in range(2):
+            ctx.newton_step(0.5, 0.0, 0.4, "linear", "linear", 7 if nn else 0, 7, 0.2, 1.0)
+        got[direct] = [ctx.get_factor(w) for w in range(3)]
+        ctx.close()
+    for a, b, o in zip(got[1], got[0], (U, V, Z)):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-4 * np.abs(b).max())   # the two-product form cancels F H against s T O in float32
+        np.testing.assert_allclose(a, o, rtol=0, atol=2e-4 * np.abs(o).max())
