@@ -552,16 +552,8 @@ extern "C" int cmf_newton_v_apply(cmf_ctx *c, const float *buf, double l1, doubl
     float *V = c->F[CMF_V];
     const bool mix64 = c->gmix64_valid; // armed by cmf_newton_step only
     c->gmix64_valid = false;
-    if (c->opt_fused_mu && c->kp <= 256) {
-        Epilogue e;
-        e.kind = EPI_GRAD; e.F = V; e.P = P; e.out = c->den; e.a = 1.0; e.b = l1; e.c = l2;
-        if (small_tile_ok(c, c->dp)) CHK(factor_update(c, V, Gs, e, c->dp));
-        else CHK(gemm(c, MODE_NN, V, c->kp, Gs, c->kp, c->den, c->dp, c->kp, c->kp, false, &e)); // V Gmix - P + reg
-    } else {
-        CHK(gemm(c, MODE_NN, V, c->kp, Gs, c->kp, c->den, c->dp, c->kp, c->kp)); // V Gmix
-        CHK(launch_ew(c, newton_grad_kernel, c->dp * c->kp, c->den, (const float *)c->den, 1.0f, P, -1.0f, (const float *)V,
-                      (float)l1, (float)l2, c->dp * c->kp));
-    }
+    // H = Gmix + l2 I and its safe inverse first (see sweep_side_shared): an unclamped inverse and l1 = 0 make the sweep one
+    // product, V - (V H - P) H^-1 = P H^-1
     if (use_shared64(c)) {
         CHK(ensure_shared64(c));
         if (mix64) {
@@ -576,7 +568,26 @@ extern "C" int cmf_newton_v_apply(cmf_ctx *c, const float *buf, double l1, doubl
         CHK(launch_ew(c, axpby_diag_kernel, (int64_t)c->kp * c->kp, c->Hm, Gs, 1.0f, (const float *)nullptr, 0.f, (float)l2,
                       c->kp, c->k));
     }
-    return shared_step(c, CMF_V, pert, (nn_mask & CMF_NN_V) != 0);
+    bool plain = false;
+    CHK(shared_inverse(c, pert, &plain));
+    const bool nnv = (nn_mask & CMF_NN_V) != 0;
+    if (plain && l1 == 0.0 && c->opt_direct_step && c->opt_fused_mu && c->kp <= 256) {
+        Epilogue e;
+        e.kind = EPI_DIRECT; e.F = V; e.out = V; e.a = 1.0; e.rows = c->frows[CMF_V]; e.kvalid = c->k; e.nn = nnv ? 1 : 0;
+        if (small_tile_ok(c, c->dp)) return factor_update(c, P, c->Hinv, e, c->dp);
+        return gemm(c, MODE_NN, P, c->kp, c->Hinv, c->kp, c->den, c->dp, c->kp, c->kp, false, &e);
+    }
+    if (c->opt_fused_mu && c->kp <= 256) {
+        Epilogue e;
+        e.kind = EPI_GRAD; e.F = V; e.P = P; e.out = c->den; e.a = 1.0; e.b = l1; e.c = l2;
+        if (small_tile_ok(c, c->dp)) CHK(factor_update(c, V, Gs, e, c->dp));
+        else CHK(gemm(c, MODE_NN, V, c->kp, Gs, c->kp, c->den, c->dp, c->kp, c->kp, false, &e)); // V Gmix - P + reg
+    } else {
+        CHK(gemm(c, MODE_NN, V, c->kp, Gs, c->kp, c->den, c->dp, c->kp, c->kp)); // V Gmix
+        CHK(launch_ew(c, newton_grad_kernel, c->dp * c->kp, c->den, (const float *)c->den, 1.0f, P, -1.0f, (const float *)V,
+                      (float)l1, (float)l2, c->dp * c->kp));
+    }
+    return shared_apply(c, CMF_V, nnv);
 }
 
 extern "C" int cmf_newton_uz_update(cmf_ctx *c, double alpha, double l1, double l2, int nn_mask, int upd, double pert) {
