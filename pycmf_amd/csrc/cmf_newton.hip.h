@@ -827,8 +827,9 @@ static int launch_row_hess_kp(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
     } else if (KP == 256 && c->opt_rowsym == 3 && a.scale >= 0.f && a.cls_cnt && a.cls_upper) { // class launch, upper blocks only
         constexpr int KS = KP == 256 ? 256 : 0;
         if constexpr (KS == 256) {
-            CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<256, 1, 0, 3, 1>), (int)Cfg::LDS_BYTES));
-            hipLaunchKernelGGL((row_hess_kernel<256, 1, 0, 3, 1>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
+            constexpr size_t lds = Cfg::LDS_BYTES / 2; // one image per stage: two workgroups per CU
+            CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<256, 1, 0, 3, 1>), (int)lds));
+            hipLaunchKernelGGL((row_hess_kernel<256, 1, 0, 3, 1>), dim3((unsigned)nrows), dim3(512), lds, c->stream, a);
         }
     } else if (KP == 256 && c->opt_rowsym == 3 && a.scale >= 0.f) { // non-negative weights: single sqrt-weighted image
         constexpr int KS = KP == 256 ? 256 : 0;

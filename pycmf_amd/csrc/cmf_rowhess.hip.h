@@ -80,14 +80,16 @@ struct IntC {
 
 // CLS = 1 (with SYM = 3): class launches only (cls_cnt set) -- no targets, no dot products, no gradient, constant weight;
 // only the 36 upper blocks are stored (class_sum_blocks_kernel mirrors them when it adds up a row's classes).
+// The class-only build is compiled for FOUR waves per SIMD (<= 128 VGPRs: 80 of them accumulators) and uses one 32 KB image per
+// stage (64 KB of LDS): two workgroups share a CU, and one multiplies while the other sits at its per-tile barrier.
 template <int KP, int STAGGER = 1, int DIAG = 0, int SYM = 0, int CLS = 0>
-__global__ __launch_bounds__(512, 2) void row_hess_kernel(RowHessArgs g) {
+__global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs g) {
     using C = RowHessCfg<KP>;
     static_assert(!SYM || KP == 256, "the symmetric block map is laid out for k_pad = 256");
     static_assert(!CLS || SYM == 3, "the class-only build exists for the single-image symmetric kernel");
     const bool late = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >= 4;
     extern __shared__ __attribute__((aligned(16))) float rsm[];
-    auto tile_of = [&](int b) { return rsm + 2 * b * C::TILE; };             // raw rows o_j      (B operand)
+    auto tile_of = [&](int b) { return rsm + (CLS ? 1 : 2) * b * C::TILE; }; // raw rows o_j      (B operand)
     auto wtile_of = [&](int b) { return rsm + (2 * b + 1) * C::TILE; };      // rows w_j * o_j    (A operand)
 
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
