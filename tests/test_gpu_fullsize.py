@@ -123,13 +123,18 @@ def test_c4_full_size_mu_properties(lib):
 
 def test_c3_full_size_newton_properties(lib):
     """BASELINE configs[2] (32768 x 16384 / 16384 x 8192, k = 256, y logit, sg_sample_ratio 0.5, device sampler):
-    the step is a pure function of the seed, and the two row-kernel variants agree."""
+    the step is a pure function of the seed, the two row-kernel variants agree, and so do the forms of the linear sampled
+    X side -- row by row, shared partial sums over groups of 4 and of 6 rows (the default), with and without the groups'
+    threshold certificates."""
     m, d, p, k = 32768, 16384, 8192, 256
     args = (0.5, 0.0, 0.1, "linear", "logit", 0, 7, 0.2, 0.5)
     out = {}
-    for name, sym, seed in (("a", 1, 1000), ("b", 1, 1000), ("full", 0, 1000), ("other", 1, 1001)):
+    for name, sym, seed, classes, certs in (("a", 1, 1000, -1, 1), ("b", 1, 1000, -1, 1), ("full", 0, 1000, -1, 1), ("other", 1, 1001, -1, 1),
+                                            ("rows", 1, 1000, 0, 1), ("four", 1, 1000, 4, 1), ("nocert", 1, 1000, -1, 0)):
         ctx = _synthetic(lib, m, d, p, k)
         ctx.set_option("row_symmetric", sym)
+        ctx.set_option("row_classes", classes)
+        ctx.set_option("row_certificates", certs)
         ctx.newton_step_device_sampled(*args, seed)
         out[name] = [ctx.get_factor(w) for w in range(3)]
         assert all(np.isfinite(F).all() for F in out[name])
@@ -139,6 +144,11 @@ def test_c3_full_size_newton_properties(lib):
         # fp32 Hessians summed in a different order, then solved
         np.testing.assert_allclose(out["full"][w], out["a"][w], rtol=1e-3, atol=1e-4 * np.abs(out["a"][w]).max())
         assert np.abs(out["other"][w] - out["a"][w]).max() > 1e-6 * np.abs(out["a"][w]).max()
+        # the same sums in another order (float32), then solved
+        np.testing.assert_allclose(out["rows"][w], out["a"][w], rtol=0, atol=1e-4 * np.abs(out["a"][w]).max())
+        np.testing.assert_allclose(out["four"][w], out["a"][w], rtol=0, atol=1e-4 * np.abs(out["a"][w]).max())
+        # a certificate only replaces a test it implies: nothing changes
+        np.testing.assert_array_equal(out["nocert"][w], out["a"][w])
 
 
 def test_c5_full_size_sparse_shard_independence(lib):
