@@ -821,9 +821,6 @@ static int launch_row_hess_kp(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
             else CMF_ROWDIAG(3, 0);
         }
 #undef CMF_ROWDIAG
-    } else if (KP == 256 && c->opt_arith == 1 && c->opt_rowsym && a.scale >= 0.f) { // optional arithmetic: bf16 planes, six products
-        CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess6_kernel), R6_LDS_BYTES));
-        hipLaunchKernelGGL(row_hess6_kernel, dim3((unsigned)nrows), dim3(512), R6_LDS_BYTES, c->stream, a);
     } else if (KP == 256 && c->opt_rowsym == 3 && a.scale >= 0.f && a.cls_cnt && a.cls_upper) { // class launch, upper blocks only
         constexpr int KS = KP == 256 ? 256 : 0;
         if constexpr (KS == 256) {
@@ -831,6 +828,9 @@ static int launch_row_hess_kp(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
             CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<256, 1, 0, 3, 1>), (int)lds));
             hipLaunchKernelGGL((row_hess_kernel<256, 1, 0, 3, 1>), dim3((unsigned)nrows), dim3(512), lds, c->stream, a);
         }
+    } else if (KP == 256 && c->opt_arith == 1 && c->opt_rowsym && a.scale >= 0.f) { // optional arithmetic: bf16 planes, six products
+        CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess6_kernel), R6_LDS_BYTES));
+        hipLaunchKernelGGL(row_hess6_kernel, dim3((unsigned)nrows), dim3(512), R6_LDS_BYTES, c->stream, a);
     } else if (KP == 256 && c->opt_rowsym == 3 && a.scale >= 0.f) { // non-negative weights: single sqrt-weighted image
         constexpr int KS = KP == 256 ? 256 : 0;
         if constexpr (KS == 256) {
@@ -1024,7 +1024,7 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
                 a.H = (float *)c->hclass.p; a.G = nullptr; a.accumulate = 0; a.row0 = 0; a.nrows = ng * NC1;
                 a.kvalid = c->k;
                 // k_pad = 256 with the single-image symmetric kernel: class images hold their 36 upper blocks only
-                const bool upper = c->kp == 256 && c->opt_rowsym == 3 && sd->scale >= 0.0 && c->opt_arith != 1 && c->opt_rowdiag == 0;
+                const bool upper = c->kp == 256 && c->opt_rowsym == 3 && sd->scale >= 0.0 && c->opt_rowdiag == 0;
                 a.cls_upper = upper ? 1 : 0;
                 CHK(launch_row_hess(c, a, ng * NC1, (double)nr * (double)sd->per));
                 {
