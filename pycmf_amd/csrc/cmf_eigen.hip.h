@@ -622,6 +622,17 @@ __global__ void scatter_mask_kernel(uint8_t *mask, int64_t ld, const int32_t *id
     }
 }
 
+// caller-supplied sample lists: any index outside [0, n) sets *bad (the gather kernels index factor rows, LDS bytes and
+// mask bytes with them)
+__global__ void index_range_kernel(const int32_t *idx, int64_t total, int n, int *bad) {
+    int seen = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = idx[i];
+        if (v < 0 || v >= n) seen = 1;
+    }
+    if (seen) *bad = 1;
+}
+
 // Device-side sampler ("throughput mode" of sg_sample_ratio < 1): for every list l pick exactly
 // `s` of the `n` candidates uniformly at random, as the reference's permutation(n)[:s] does
 // (cmf_solvers.py:328-344), but from a counter-based hash instead of NumPy's MT19937 stream.

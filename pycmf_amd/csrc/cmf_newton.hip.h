@@ -630,6 +630,20 @@ extern "C" int cmf_safe_invert_f64(cmf_ctx *c, const double *H, double *out, int
 }
 
 // ---- per-row machinery --------------------------------------------------------------------
+// host-supplied index lists, already on the device: every entry must lie in [0, n)
+static int check_index_lists(cmf_ctx *c, const int32_t *dev_idx, int64_t total, int64_t n) {
+    int *flag = (int *)(c->dscalar + 6);
+    HIPCHK(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, (int64_t)c->num_cu * 8);
+    hipLaunchKernelGGL(index_range_kernel, dim3(grid), dim3(256), 0, c->stream, dev_idx, total, (int)n, flag);
+    HIPCHK(hipGetLastError());
+    int bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (bad) return fail(CMF_EINVAL, "sample index list holds an index outside [0, %lld)", (long long)n);
+    return CMF_OK;
+}
+
 // `n` = number of candidates per list (the extent sampled from)
 static int build_mask(cmf_ctx *c, DevBuf &mb, int64_t rows_pad, int64_t cols_pad, const int32_t *idx, int64_t nlists,
                       int64_t per, bool by_row, int64_t n = 0, int salt = 0) {
@@ -646,7 +660,7 @@ static int build_mask(cmf_ctx *c, DevBuf &mb, int64_t rows_pad, int64_t cols_pad
     }
     CHK(ensure(c, c->idxbuf, (size_t)nlists * per * sizeof(int32_t)));
     HIPCHK(hipMemcpyAsync(c->idxbuf.p, idx, (size_t)nlists * per * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream)); // idx is caller memory: do not outlive the call
+    CHK(check_index_lists(c, (const int32_t *)c->idxbuf.p, nlists * per, n > 0 ? n : (by_row ? cols_pad : rows_pad))); // also waits: idx is caller memory
     return launch_ew(c, scatter_mask_kernel, nlists * per, (uint8_t *)mb.p, cols_pad, (const int32_t *)c->idxbuf.p, nlists, per,
                      by_row ? 1 : 0);
 }
@@ -891,7 +905,7 @@ static int sample_lists(cmf_ctx *c, DevBuf &lb, DevBuf &mb, const int32_t *host_
         HIPCHK(hipGetLastError());
     } else {
         HIPCHK(hipMemcpyAsync(lb.p, host_idx, (size_t)nlists * per * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream)); // host_idx is caller memory
+        CHK(check_index_lists(c, (const int32_t *)lb.p, nlists * per, n)); // also waits: host_idx is caller memory
     }
     *out = (const int32_t *)lb.p;
     return CMF_OK;

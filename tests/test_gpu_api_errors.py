@@ -180,3 +180,28 @@ def test_strided_and_float32_uploads_round_trip(lib):
     np.testing.assert_array_equal(view, Ft.astype(np.float32).astype(np.float64))
     assert (out[1::2] == 0).all() and (out[:, 1::2] == 0).all()
     ctx.close()
+
+
+def test_sample_index_out_of_range_is_rejected(lib):
+    """Caller-supplied sample lists (sg_sample_ratio < 1, NumPy stream): an index outside the candidates is an error, not
+    a gather from somewhere else (both formulations of the per-row sweeps)."""
+    rng = np.random.RandomState(0)
+    m, d, p, k = 12, 10, 6, 4
+    X, Y = np.abs(rng.randn(m, d)), np.abs(rng.randn(d, p))
+    for row_kernel in (1, 0):
+        ctx = lib.Context(0)
+        ctx.set_option("row_kernel", row_kernel)
+        ctx.set_problem(m, d, p, k)
+        ctx.set_data(0, X); ctx.set_data(1, Y)
+        for w, n in enumerate((m, d, p)):
+            ctx.set_factor(w, 0.1 * rng.randn(n, k))
+        u = np.tile(np.arange(5, dtype=np.int32), (m, 1)); z = np.tile(np.arange(5, dtype=np.int32), (p, 1))
+        vx = np.tile(np.arange(6, dtype=np.int32), (d, 1)); vy = np.tile(np.arange(3, dtype=np.int32), (d, 1))
+        ctx.newton_step(0.5, 0.0, 0.1, "linear", "logit", 0, 7, 0.2, 0.5, u, z, vx, vy)      # in range: fine
+        bad = u.copy(); bad[3, 2] = d
+        with pytest.raises(ValueError, match="outside"):
+            ctx.newton_step(0.5, 0.0, 0.1, "linear", "logit", 0, 1, 0.2, 0.5, bad, z, vx, vy)
+        neg = vx.copy(); neg[0, 0] = -1
+        with pytest.raises(ValueError, match="outside"):
+            ctx.newton_step(0.5, 0.0, 0.1, "linear", "logit", 0, 2, 0.2, 0.5, u, z, neg, vy)
+        ctx.close()
