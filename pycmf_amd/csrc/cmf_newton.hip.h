@@ -929,7 +929,7 @@ struct RowSide {
 // group, n (1 - (1 - rho)^R), are well below the R rho n of the row-by-row form.
 static size_t class_lists_lds(int64_t n, int R) { // class_lists_kernel: pattern words (transposed, W per thread) + hist[256][2^R + 1]
     const int64_t nw = (n + 3) / 4, W = (nw + 255) / 256;
-    return (size_t)W * 256 * 4 + (size_t)256 * ((1 << R) + 1) * sizeof(int);
+    return (size_t)W * 256 * 4 + (size_t)256 * ((1 << R) + 1) * sizeof(unsigned short);
 }
 static int class_group_rows(const cmf_ctx *c, int link, bool sampled, int64_t per, int64_t n) {
     if (!sampled || link != CMF_LINK_LINEAR || c->opt_rowclasses == 0 || c->opt_rowclasses == 1 || per <= 0 || n <= 0 || n > 131072) return 0;

@@ -444,17 +444,19 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
 // coff / ccnt [g * (2^R - 1) + q].  patg (optional): the pattern bytes themselves, [group][n] -- the sample mask of the
 // group's rows in 1/R of the bytes (mask_from_patterns_kernel expands it for the gradient GEMM's epilogue).
 // LDS layout: thread t owns the candidate words t W .. t W + W - 1 (4 candidates each, ascending), stored transposed
-// (word w at (w % W) 256 + w / W) so that the 256 threads walk their ranges bank-conflict-free; hist[x][p] (pitch 2^R + 1)
-// counts thread x's candidates of pattern p, prefix-summed over x in 256 / 2^R segments per pattern.
+// (word w at (w % W) 256 + w / W) so that the 256 threads walk their ranges bank-conflict-free; hist[x][p] (pitch 2^R + 1,
+// 16-bit: three workgroups per CU hide each other's list-read latency) counts thread x's candidates of pattern p,
+// prefix-summed over x in 256 / 2^R segments per pattern.
 __global__ __launch_bounds__(256) void class_lists_kernel(const int32_t *lists, int64_t per, int64_t nlists, int n, int R, int32_t *cidx,
                                                           int64_t cap, int64_t *coff, int32_t *ccnt, unsigned long long *gathered,
                                                           uint8_t *patg) {
-    extern __shared__ unsigned patw[]; // W * 256 pattern words, then hist[256][NC + 1]
+    extern __shared__ unsigned patw[]; // W * 256 pattern words, then hist[256][NC + 1] (16-bit: a count is at most 4 W, a
+                                       // prefix inside a segment of NC threads at most 4 W NC <= 32768 for n <= 131072)
     __shared__ int tot[64], cbase[64], segoff[256]; // segoff[seg * NC + p]
     const int t = threadIdx.x, NC = 1 << R, HP = NC + 1;
     const int64_t grp = blockIdx.x;
     const int nw = (n + 3) / 4, W = (nw + 255) / 256;
-    int *hist = reinterpret_cast<int *>(patw + W * 256);
+    unsigned short *hist = reinterpret_cast<unsigned short *>(patw + W * 256);
     for (int w = t; w < W * 256; w += 256) patw[w] = 0u;
     for (int x = t; x < 256 * HP; x += 256) hist[x] = 0;
     __syncthreads();
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(256) void class_lists_kernel(const int32_t *lists, 
         int run = 0;
         for (int x = seg * NC; x < (seg + 1) * NC; ++x) {
             const int v = hist[x * HP + pp];
-            hist[x * HP + pp] = run;
+            hist[x * HP + pp] = (unsigned short)run;
             run += v;
         }
         segoff[seg * NC + pp] = run; // segment total for now
