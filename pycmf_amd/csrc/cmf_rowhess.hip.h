@@ -464,12 +464,12 @@ __global__ __launch_bounds__(256) void class_lists_kernel(const int32_t *lists, 
         const int64_t row = grp * R + r;
         if (row >= nlists) break;
         const int32_t *l = lists + row * per;
-        for (int64_t q0 = t; q0 < per; q0 += 256 * 8) { // eight list entries in flight per thread (one workgroup per CU: nothing else hides the latency)
-            int jv[8];
+        for (int64_t q0 = t; q0 < per; q0 += 256 * 16) { // sixteen list entries in flight per thread: the loop is bound by their latency
+            int jv[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) jv[u] = q0 + 256 * u < per ? l[q0 + 256 * u] : -1;
+            for (int u = 0; u < 16; ++u) jv[u] = q0 + 256 * u < per ? l[q0 + 256 * u] : -1;
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 16; ++u)
                 if (jv[u] >= 0) {
                     const int w = jv[u] >> 2;
                     atomicOr(&patw[(w % W) * 256 + w / W], 1u << (8 * (jv[u] & 3) + r));
