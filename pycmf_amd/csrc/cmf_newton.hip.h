@@ -933,16 +933,20 @@ static size_t class_lists_lds(int64_t n, int R) { // class_lists_kernel: pattern
 }
 static int class_group_rows(const cmf_ctx *c, int link, bool sampled, int64_t per, int64_t n) {
     if (!sampled || link != CMF_LINK_LINEAR || c->opt_rowclasses == 0 || c->opt_rowclasses == 1 || per <= 0 || n <= 0 || n > 131072) return 0;
+    const bool automatic = c->opt_rowclasses < 0;
     int R = std::min(c->opt_rowclasses, 6);
-    if (R < 0) { // automatic: as many rows per group as leave the 2^R - 1 classes ~256 samples each (8 K-steps of the row kernel
-        R = 2;   // per class image written and read back: C3 measured 297 / 273 / 269 ms per iteration at R = 4 / 5 / 6)
+    if (automatic) { // as many rows per group as leave the 2^R - 1 classes ~256 samples each (8 K-steps of the row kernel per
+        R = 2;       // class image written and read back: C3 measured 297 / 273 / 269 ms per iteration at R = 4 / 5 / 6)
         while (R < 6 && (n >> (R + 1)) >= 256) ++R;
     }
     while (R >= 2 && class_lists_lds(n, R) > (size_t)150 * 1024) --R; // the list kernel's LDS image of the candidates
     if (R < 2) return 0;
-    const double rho = (double)per / (double)n;
-    const double factor = (1.0 - std::pow(1.0 - rho, R)) / (R * rho);
-    return factor < 0.8 ? R : 0;
+    if (automatic) { // worth it?  the class images, their sums, the lists and the gradient GEMMs cost 10-15 % of what the row kernel saves
+        const double rho = (double)per / (double)n;
+        const double factor = (1.0 - std::pow(1.0 - rho, R)) / (R * rho);
+        if (factor >= 0.7) return 0;
+    }
+    return R;
 }
 
 // class lists (and pattern bytes) of a class side, once per sweep
