@@ -637,8 +637,8 @@ __global__ void index_range_kernel(const int32_t *idx, int64_t total, int n, int
 // `s` of the `n` candidates uniformly at random, as the reference's permutation(n)[:s] does
 // (cmf_solvers.py:328-344), but from a counter-based hash instead of NumPy's MT19937 stream.
 // Candidate j of list l gets the key hash(seed, l, j); the s smallest keys win.  The s-th smallest
-// key is found exactly by a 3-level radix select (12 + 12 + 8 bits) on LDS histograms; ties on the
-// full 32-bit key are broken by candidate index.  One workgroup per list; keys are recomputed, never stored.
+// key is found exactly by a 3-level radix select (12 + 12 + 8 bits) on LDS histograms; the keys of a list are
+// pairwise distinct (bijective hash of the candidate index), so there are no ties to break.  One workgroup per list; keys are recomputed, never stored.
 // Key of candidate j of list l: a 64-bit mix of (seed, l) once per list picks the offset of an odd-multiplier walk over the
 // 32-bit integers, a 32-bit avalanche finaliser (two multiplies: "lowbias32") scrambles it.  Both maps are bijections, so the
 // keys of one list are pairwise distinct (no ties), and a candidate costs three 32-bit multiplies instead of two 64-bit mixes
@@ -662,8 +662,8 @@ __global__ __launch_bounds__(256) void sample_select_kernel(uint8_t *mask, int64
                                                             int n, int s, uint64_t seed, int64_t l0) {
     __shared__ unsigned hist[4096];
     __shared__ unsigned wsum[4];
-    __shared__ unsigned sel_prefix, sel_remaining, tie_budget;
-    __shared__ int wave_cnt[4];
+    __shared__ unsigned sel_prefix, sel_remaining;
+    __shared__ int wave_cnt[8];
     const int64_t l = blockIdx.x;
     if (l >= nlists) return;
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
@@ -716,41 +716,30 @@ __global__ __launch_bounds__(256) void sample_select_kernel(uint8_t *mask, int64
         known_mask |= ((unsigned)(nb - 1)) << shifts[lev];
         __syncthreads();
     }
-    // winners: key < prefix, plus the first `remaining` (by index) of the candidates with key == prefix
-    if (t == 0) tie_budget = remaining;
+    // winners: key < prefix, plus the candidate whose key IS the prefix (keys are pairwise distinct inside a list: it is
+    // the s-th smallest one; `remaining` is 0 only in the s > n fallback, where everything below the prefix wins)
     int base = 0; // winners emitted so far (uniform)
-    __syncthreads();
     for (int j0 = 0; j0 < n; j0 += 256) {
         const int j = j0 + t;
-        bool win = false, tie = false;
+        bool win = false;
         if (j < n) {
             const uint32_t k = sample_key(loff, (uint32_t)j);
-            win = k < prefix;
-            tie = (k == prefix);
-        }
-        // ties are rare (32-bit keys): resolve them serially in index order
-        if (__syncthreads_or(tie ? 1 : 0)) {
-            for (int q = 0; q < 256; ++q) {
-                if (t == q && tie) {
-                    if (tie_budget > 0) { win = true; tie_budget -= 1; }
-                }
-                __syncthreads();
-            }
+            win = k < prefix || (k == prefix && remaining > 0);
         }
         if (mask && j < n) {
             const int64_t off = by_row ? (l * ld + j) : ((int64_t)j * ld + l);
             mask[off] = win ? 1 : 0;
         }
-        if (lists) { // ordered compaction of this 256-candidate slice
+        if (lists) { // ordered compaction of this 256-candidate slice (wave counts double-buffered: one barrier per slice)
             const unsigned long long bal = __ballot(win);
-            if (lane == 0) wave_cnt[wid] = __popcll(bal);
+            int *wc = wave_cnt + 4 * ((j0 >> 8) & 1);
+            if (lane == 0) wc[wid] = __popcll(bal);
             __syncthreads();
             int off = base;
-            for (int w = 0; w < wid; ++w) off += wave_cnt[w];
+            for (int w = 0; w < wid; ++w) off += wc[w];
             off += __popcll(bal & ((1ull << lane) - 1ull));
             if (win && off < s) lists[l * (int64_t)s + off] = j;
-            base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-            __syncthreads();
+            base += wc[0] + wc[1] + wc[2] + wc[3];
         }
     }
 }
