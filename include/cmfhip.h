@@ -178,6 +178,17 @@ int cmf_newton_v_partials(cmf_ctx *ctx, double alpha, float *dev_buf);
 int cmf_newton_v_apply(cmf_ctx *ctx, const float *dev_buf, double l1, double l2,
                        int nn_mask, double hessian_pertubation);
 
+/* The same V sweep in its re-associated, cond(H)-independent form (default of cmf_newton_step; option
+ * "newton_reassoc"): the reference's  V - grad Hinv  with  grad = (V G - P) + l1 sign V + l2 V,  H = G + l2 I
+ * (cmf_solvers.py:436-450, :321-326) is evaluated as  V (I - H Hinv) + P' - l1 sign(V) Hinv  with
+ * P' = X^T (alpha U Hinv) + Y ((1 - alpha) Z Hinv), Hinv applied to the factors in float64 BEFORE the float32 data pass.
+ * A row-sharded run sums two buffers over the ranks: gbuf (k_pad^2 float64, device) between _gram and _products, pbuf
+ * (d_pad * k_pad float32, device, clobbered by _finish) between _products and _finish.                                   */
+int cmf_newton_v_gram(cmf_ctx *ctx, double alpha, double *dev_gbuf);
+int cmf_newton_v_products(cmf_ctx *ctx, double alpha, double l2, double hessian_pertubation,
+                          const double *dev_gbuf, float *dev_pbuf);
+int cmf_newton_v_finish(cmf_ctx *ctx, float *dev_pbuf, double l1, int nn_mask);
+
 /* ---- error metric: compute_factorization_error, cmf_solvers.py:36-42 --- */
 /* squared Frobenius residuals of the local shard:
  *   *ex2 = ||X - f(U V^T)||^2, *ey2 = ||Y - f(V Z^T)||^2                    */

@@ -55,6 +55,9 @@ PROTOTYPES = {
     "cmf_newton_uz_update": [_vp, _dbl, _dbl, _dbl, _i32, _i32, _dbl],
     "cmf_newton_v_partials": [_vp, _dbl, _vp],
     "cmf_newton_v_apply": [_vp, _vp, _dbl, _dbl, _i32, _dbl],
+    "cmf_newton_v_gram": [_vp, _dbl, _vp],
+    "cmf_newton_v_products": [_vp, _dbl, _dbl, _dbl, _vp, _vp],
+    "cmf_newton_v_finish": [_vp, _vp, _dbl, _i32],
     "cmf_residual_sq": [_vp, _i32, _i32, _pd, _pd],
     "cmf_data_sq": [_vp, _pd, _pd],
     "cmf_safe_invert_batch": [_vp, _pd, _pd, _i32, _i32, _dbl],
@@ -306,6 +309,15 @@ class Context:
 
     def newton_v_apply(self, dev_ptr, l1, l2, nn_mask, pert):
         check(self._lib.cmf_newton_v_apply(self._h, _vp(dev_ptr), l1, l2, nn_mask, pert))
+
+    def newton_v_gram(self, alpha, dev_gbuf):
+        check(self._lib.cmf_newton_v_gram(self._h, alpha, _vp(dev_gbuf)))
+
+    def newton_v_products(self, alpha, l2, pert, dev_gbuf, dev_pbuf):
+        check(self._lib.cmf_newton_v_products(self._h, alpha, l2, pert, _vp(dev_gbuf), _vp(dev_pbuf)))
+
+    def newton_v_finish(self, dev_pbuf, l1, nn_mask):
+        check(self._lib.cmf_newton_v_finish(self._h, _vp(dev_pbuf), l1, nn_mask))
 
     # ---- metrics
     def residual_sq(self, x_link="linear", y_link="linear"):

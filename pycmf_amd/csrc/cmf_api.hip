@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <numeric>
 #include <set>
 #include <string>
 #include <thread>
@@ -155,6 +156,7 @@ struct cmf_ctx {
     DevBuf certimg, certflag;             // per half group: the part of the Hessians common to its rows, and whether it alone passes the threshold test
     int opt_direct_step = 1;              // linear shared-Hessian sweeps with l1 = 0 and an unclamped inverse: F <- clamp(s (T O) H^-1) in one product
     int opt_rowcert = 1;                  // use those certificates (0: every row runs its own threshold test)
+    int64_t opt_rowchunk = 0;             // > 0: cap on the rows per Hessian chunk of the per-row sweeps (tests exercise chunk boundaries)
     int opt_rowclasses = -1;              // rows per group of the shared-partial-sum form: -1 automatic, 0 / 1 row by row, 2..6 forced
     DevBuf idxbuf;                        // uploaded sample index lists
     DevBuf eigws;                         // Jacobi workspace when k_pad > 128
@@ -166,6 +168,9 @@ struct cmf_ctx {
     DevBuf gslab64, w64, ns64;            // their split slabs, Cholesky workspaces + L^-1 image, Newton-Schulz images
     bool gmix64_valid = false;            // gmix64 = alpha U^T U + (1 - alpha) Z^T Z of the partials just formed (single-GPU step)
     int opt_shared64 = 1;                 // 1: shared Hessian in float64 (default) | 0: float32 Grams + float32 inverse (round-1 path)
+    DevBuf hinv64, opr;                   // float64 image of the shared safe inverse; pre-conditioned operands O Hinv of the re-associated sweeps
+    int opt_reassoc = 1;                  // 1: shared sweeps as F E + T (O Hinv) (cmf_newton.hip.h) | 0: gradient form F - grad Hinv
+    bool v_plain = false;                 // cmf_newton_v_products -> cmf_newton_v_finish: the inverse was not clamped (E = 0)
     DevBuf dpart;                         // double partial sums
     double *dscalar = nullptr;            // 8 slots of 8 bytes; slot 7: sample rows gathered by class launches (unsigned long long)
     double rh_credited = 0.0, rh_gathered = 0.0; // per-row Newton accounting while timing is on: sample rows of the algorithm / gathered by row launches
@@ -631,6 +636,7 @@ static void release_problem(cmf_ctx *c) {
     c->spmm_bar = DevBuf();
     c->g64a = DevBuf(); c->g64b = DevBuf(); c->gmix64 = DevBuf(); c->h64 = DevBuf();
     c->gslab64 = DevBuf(); c->w64 = DevBuf(); c->ns64 = DevBuf();
+    c->hinv64 = DevBuf(); c->opr = DevBuf(); c->v_plain = false;
     c->gmix64_valid = false;
     for (int w = 0; w < 2; ++w)
         for (int o = 0; o < 2; ++o) { c->bfp[w][o] = DevBuf(); c->bfp_valid[w][o] = false; }
@@ -698,6 +704,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "row_classes")) {
         if (value < -1 || value > 6) return fail(CMF_EINVAL, "row_classes: -1 (automatic), 0 (off) or 2..6 rows per group");
         c->opt_rowclasses = (int)value;
+    } else if (!strcmp(name, "row_chunk")) {
+        c->opt_rowchunk = std::max<int64_t>(0, value);
     } else if (!strcmp(name, "sample_row_offset_u")) {
         c->sample_off[CMF_U] = value;
     } else if (!strcmp(name, "sample_row_offset_v")) {
@@ -724,6 +732,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_fused_mu = value != 0;
     } else if (!strcmp(name, "shared_hessian_f64")) {
         c->opt_shared64 = value != 0;
+    } else if (!strcmp(name, "newton_reassoc")) {
+        c->opt_reassoc = value != 0;
     } else if (!strcmp(name, "spmm_blocked")) {
         if (value < 0 || value > 2) return fail(CMF_EINVAL, "spmm_blocked must be 0 (never), 1 (auto) or 2 (always); set before cmf_set_data_csr");
         c->opt_spmm_blocked = (int)value;

@@ -66,6 +66,8 @@ struct GemmArgs {
     //  EPI_APPLY  acc = grad H^-1 is the Newton step: F <- clamp(F - acc), zero outside the valid block   (:321-326)
     //  EPI_DIRECT acc = (T O) H^-1 with the plain inverse: F <- clamp(a acc) -- the same point, F - (F H - a T O) H^-1 = a T O H^-1
     //             epi_F = F, written to epi_out (= F)
+    //  EPI_COMBINE acc = F E, E = I - H Hinv (zero unless the safe inverse clamped): F <- clamp(acc + a P), P = T (O Hinv) --
+    //             the re-associated Newton sweep (cmf_newton.hip.h, sweep_side_shared); A = F, written to epi_out (= F)
     int epi;
     const float *epi_F, *epi_P;
     float *epi_out;
@@ -73,7 +75,7 @@ struct GemmArgs {
     int64_t epi_rows;
     int epi_kvalid, epi_nn;
 };
-enum { EPI_NONE = 0, EPI_MU = 1, EPI_GRAD = 2, EPI_APPLY = 3, EPI_DIRECT = 4 };
+enum { EPI_NONE = 0, EPI_MU = 1, EPI_GRAD = 2, EPI_APPLY = 3, EPI_DIRECT = 4, EPI_COMBINE = 5 };
 
 // write-through (sc1) stores: the bytes leave the XCD's L2 at once, so a workgroup on another XCD can read them after
 // the storing wave's s_waitcnt vmcnt(0) and a ticket, with no release fence (MI355X_MICROARCH.md, publish-large)
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
                         const int r = r0 + q;
                         const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
                         off[q] = (row0 + wrow0 + 32 * i + rr) * g.ldc + n0 + wcol0 + C::TN * l31;
-                        if (g.epi != EPI_DIRECT) f[q] = *reinterpret_cast<const vecN *>(g.epi_F + off[q]);
+                        if (g.epi != EPI_DIRECT && g.epi != EPI_COMBINE) f[q] = *reinterpret_cast<const vecN *>(g.epi_F + off[q]);
                         else
 #pragma unroll
                             for (int j = 0; j < C::TN; ++j) f[q][j] = 0.f;
@@ -519,7 +521,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
                             } else {
                                 res = 0.f;
                                 if (row < g.epi_rows && (int)(n0 + wcol0 + C::TN * l31 + j) < g.epi_kvalid) {
-                                    res = g.epi == EPI_DIRECT ? g.epi_a * av : fv - av;
+                                    res = g.epi == EPI_DIRECT ? g.epi_a * av : (g.epi == EPI_COMBINE ? av + g.epi_a * pv[q][j] : fv - av);
                                     if (g.epi_nn && res < 0.f) res = 0.f;
                                 }
                             }
@@ -796,7 +798,7 @@ __global__ __launch_bounds__(256) void factor_update_kernel(FactorUpdArgs g) {
         float fv[16], pv[16];
         const float *Fb = g.F + (row0 + wr + 4 * lh) * KP + col;   // register r: + ((r & 3) + 8 (r >> 2)) rows
 #pragma unroll
-        for (int r = 0; r < 16; ++r) fv[r] = g.epi != EPI_DIRECT ? Fb[((r & 3) + 8 * (r >> 2)) * KP] : 0.f;
+        for (int r = 0; r < 16; ++r) fv[r] = (g.epi != EPI_DIRECT && g.epi != EPI_COMBINE) ? Fb[((r & 3) + 8 * (r >> 2)) * KP] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) pv[r] = 0.f;
         if (g.epi != EPI_APPLY && g.epi != EPI_DIRECT) {
@@ -846,7 +848,7 @@ __global__ __launch_bounds__(256) void factor_update_kernel(FactorUpdArgs g) {
             } else {
                 res = 0.f;
                 if (row < g.rows_valid && col < g.kvalid) {
-                    res = g.epi == EPI_DIRECT ? g.a * av : f - av;
+                    res = g.epi == EPI_DIRECT ? g.a * av : (g.epi == EPI_COMBINE ? av + g.a * pv[r] : f - av);
                     if (g.nn && res < 0.f) res = 0.f;
                 }
             }
@@ -914,6 +916,37 @@ __global__ void newton_apply_kernel(float *F, const float *step, int64_t rows_va
             if (non_negative && v < 0.f) v = 0.f;
         }
         F[i] = v;
+    }
+}
+
+// re-associated Newton sweep (cmf_newton.hip.h): F <- clamp(acc + a P) on the valid block, 0 outside; acc (= F E) nullable
+__global__ void combine_clamp_kernel(float *F, const float *acc, const float *P, float a, int64_t rows_valid, int kp, int kvalid,
+                                     int64_t n4, int non_negative) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = (4 * i) / kp;
+        const int c0 = (int)((4 * i) % kp);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows_valid) {
+            const f32x4 pv = reinterpret_cast<const f32x4 *>(P)[i];
+            v = a * pv;
+            if (acc) v += reinterpret_cast<const f32x4 *>(acc)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (c0 + e >= kvalid) v[e] = 0.f;
+                else if (non_negative && v[e] < 0.f) v[e] = 0.f;
+            }
+        }
+        reinterpret_cast<f32x4 *>(F)[i] = v;
+    }
+}
+// out = sign(F)  (the l1 term of the gradient, cmf_solvers.py:400, as a GEMM operand)
+__global__ void sign_kernel(float *out, const float *F, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 f = reinterpret_cast<const f32x4 *>(F)[i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (f[e] > 0.f) ? 1.f : ((f[e] < 0.f) ? -1.f : 0.f);
+        reinterpret_cast<f32x4 *>(out)[i] = o;
     }
 }
 

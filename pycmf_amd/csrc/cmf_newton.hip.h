@@ -339,12 +339,13 @@ static int gemm64(cmf_ctx *c, bool trans_b, const double *A, const double *B, do
 // (reference: _safe_invert, cmf_solvers.py:346-356, on a float64 matrix)
 static int shared_inverse64(cmf_ctx *c, const double *H64, int n, double pert, bool psd, bool *plain = nullptr) {
     const int kp = c->kp;
+    CHK(ensure(c, c->hinv64, (size_t)kp * kp * sizeof(double)));
     if (plain) *plain = false; // set when the host knows that lambda_min >= pert, i.e. the result is the plain inverse
     Timed tm(c, CMF_K_EIGEN);
     if (n <= 64) { // one launch, the branch on lambda_min is taken on the device
         const size_t lds = (size_t)(2 * n * n + n) * sizeof(double);
         CHK(allow_big_lds(c, reinterpret_cast<const void *>(&safe_inverse64_small_kernel), 80 * 1024));
-        hipLaunchKernelGGL(safe_inverse64_small_kernel, dim3(1), dim3(256), lds, c->stream, H64, c->Hinv, n, kp, pert);
+        hipLaunchKernelGGL(safe_inverse64_small_kernel, dim3(1), dim3(256), lds, c->stream, H64, c->Hinv, n, kp, pert, (double *)c->hinv64.p);
         HIPCHK(hipGetLastError());
         return CMF_OK;
     }
@@ -366,7 +367,11 @@ static int shared_inverse64(cmf_ctx *c, const double *H64, int n, double pert, b
             hipLaunchKernelGGL(tri_inverse64_kernel, dim3((unsigned)(kp / 16)), dim3(256), tri_lds, c->stream, L, n, kp, Xt, kp, kp, rp);
         }
         HIPCHK(hipGetLastError());
-        return gemm64(c, true, Xt, Xt, nullptr, nullptr, 1.0, 0.0, 0.0, c->Hinv, n);
+        // float64 image for the re-associated sweeps (identity on the padding), float32 rounding for everything else
+        CHK(gemm64(c, true, Xt, Xt, (double *)c->hinv64.p, nullptr, 1.0, 0.0, 0.0, c->Hinv, n));
+        hipLaunchKernelGGL(pad_identity64_kernel, dim3((unsigned)std::min(256, (kp * kp + 255) / 256)), dim3(256), 0, c->stream, (double *)c->hinv64.p, kp, n);
+        HIPCHK(hipGetLastError());
+        return CMF_OK;
     };
     auto launch_chol = [&](const double *Hm, int nwg, double sh0, double sh1) {
         if (n <= 128) hipLaunchKernelGGL((chol64_reg_kernel<4>), dim3(nwg), dim3(1024), 0, c->stream, Hm, n, kp, W0, (int64_t)kk, kp, sh0, sh1, flags);
@@ -433,8 +438,67 @@ static int shared_inverse(cmf_ctx *c, double pert, bool *plain = nullptr) {
             HIPCHK(hipGetLastError());
         }
     }
-    if (!done) CHK(safe_inverse_dev(c, c->Hm, c->Hinv, 1, c->k, c->kp, pert, c->hess_psd));
+    if (!done) {
+        CHK(safe_inverse_dev(c, c->Hm, c->Hinv, 1, c->k, c->kp, pert, c->hess_psd));
+        if (c->opt_shared64 && c->kp <= 1024) { // float32 eigen-solver route: promote its result for the re-associated sweeps
+            const int64_t kk = (int64_t)c->kp * c->kp;
+            CHK(ensure(c, c->hinv64, (size_t)kk * sizeof(double)));
+            Timed tm(c, CMF_K_ELEMWISE);
+            hipLaunchKernelGGL(f32_to_f64_kernel, dim3(256), dim3(256), 0, c->stream, (double *)c->hinv64.p, (const float *)c->Hinv, kk);
+            hipLaunchKernelGGL(pad_identity64_kernel, dim3(256), dim3(256), 0, c->stream, (double *)c->hinv64.p, c->kp, c->k);
+            HIPCHK(hipGetLastError());
+        }
+    }
     return CMF_OK;
+}
+
+// ---- re-associated shared sweep ("pre-conditioned operand") -------------------------------------------------------
+// The reference's shared-Hessian sweep  F <- clamp(F - grad Hinv),  grad = s (F G - T O) + l1 sign F + l2 F,  H = s G + l2 I
+// (pycmf/cmf_solvers.py:396-410, :436-450, :321-326) is evaluated as
+//     F <- clamp( F E  +  T (s O Hinv)  -  l1 sign(F) Hinv ),      E = I - H Hinv  (zero unless _safe_invert clamped)
+// which is the same point in exact arithmetic.  In floating point it is not the same: grad is the small difference of two large
+// products and Hinv multiplies its rounding error by up to cond(H); here O Hinv and E are formed in float64 from the float64
+// Hessian (k x k work), and the float32 data contraction T (O') is the LAST operation, so its rounding error reaches the factor
+// unamplified.  Measured on the clamped non-negative case of tests/test_gpu_shared64.py (cond 1e4): residual distance to the
+// float64 CPU reference after 8 iterations 1.7e-3 -> 5e-7 (tools/emul_newton_precision.py reproduces both on the CPU).
+static bool use_reassoc(const cmf_ctx *c) { return c->opt_reassoc && c->opt_shared64 && c->kp <= 1024; }
+
+// out[rows_pad x k_pad] = scale * O Hinv64  (float64 matrix pipe, one rounding)
+static int factor_times_hinv(cmf_ctx *c, const float *O, int64_t rows_pad, double scale, float *out) {
+    Timed tm(c, CMF_K_GEMM_SMALL, 2.0 * (double)rows_pad * c->kp * c->kp);
+    if (c->kp == 32) hipLaunchKernelGGL((factor_times64_kernel<32>), dim3(1, (unsigned)(rows_pad / 64)), dim3(256), 0, c->stream, O, (const double *)c->hinv64.p, out, c->kp, scale);
+    else hipLaunchKernelGGL((factor_times64_kernel<64>), dim3((unsigned)(c->kp / 64), (unsigned)(rows_pad / 64)), dim3(256), 0, c->stream, O, (const double *)c->hinv64.p, out, c->kp, scale);
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+// c->Hm (float32) = E = I - H64 Hinv64 on the valid block, zero on the padding
+static int clamp_defect(cmf_ctx *c) {
+    Timed tm(c, CMF_K_EIGEN);
+    return gemm64(c, false, (const double *)c->h64.p, (const double *)c->hinv64.p, nullptr, nullptr, -1.0, 0.0, 1.0, c->Hm, c->k);
+}
+// F <- clamp(F E + P - l1 sign(F) Hinv);  P (rows_pad x k_pad, clobbered) = T (s O Hinv);  `plain`: E = 0 is known on the host
+static int reassoc_finish(cmf_ctx *c, int which, float *P, double l1, bool plain, bool nn) {
+    const int64_t rows = c->frows_pad[which];
+    float *F = c->F[which];
+    if (l1 != 0.0) { // P += sign(F) (-l1 Hinv)
+        float *sg = (P == c->den) ? c->num : c->den;
+        CHK(launch_ew(c, sign_kernel, rows * c->kp / 4, sg, (const float *)F, rows * c->kp / 4));
+        CHK(launch_ew(c, axpby_kernel, (int64_t)c->kp * c->kp, c->G, (const float *)c->Hinv, (float)-l1, (const float *)nullptr, 0.f, (int64_t)c->kp * c->kp));
+        CHK(gemm(c, MODE_NN, sg, c->kp, c->G, c->kp, P, rows, c->kp, c->kp, true));
+    }
+    if (plain)
+        return launch_ew(c, combine_clamp_kernel, rows * c->kp / 4, F, (const float *)nullptr, (const float *)P, 1.0f, c->frows[which], c->kp, c->k,
+                         rows * c->kp / 4, nn ? 1 : 0);
+    if (c->opt_fused_mu && c->kp <= 256) {
+        Epilogue e;
+        e.kind = EPI_COMBINE; e.F = F; e.P = P; e.out = F; e.a = 1.0; e.rows = c->frows[which]; e.kvalid = c->k; e.nn = nn ? 1 : 0;
+        if (small_tile_ok(c, rows)) return factor_update(c, F, c->Hm, e, rows);
+        return gemm(c, MODE_NN, F, c->kp, c->Hm, c->kp, F, rows, c->kp, c->kp, false, &e);
+    }
+    float *acc = (P == c->den) ? c->num : c->den;
+    CHK(gemm(c, MODE_NN, F, c->kp, c->Hm, c->kp, acc, rows, c->kp, c->kp));
+    return launch_ew(c, combine_clamp_kernel, rows * c->kp / 4, F, (const float *)acc, (const float *)P, 1.0f, c->frows[which], c->kp, c->k,
+                     rows * c->kp / 4, nn ? 1 : 0);
 }
 static int shared_apply(cmf_ctx *c, int which, bool non_negative) {
     const int64_t rows = c->frows_pad[which];
@@ -491,6 +555,15 @@ static int sweep_side_shared(cmf_ctx *c, bool is_u, double scale, double l1, dou
                        (const float *)nullptr, 0.f, (float)l2, c->kp, c->k));
     bool plain = false;
     CHK(shared_inverse(c, pert, &plain));
+    if (f64 && use_reassoc(c)) { // F <- clamp(F E + T (s V Hinv) - l1 sign(F) Hinv), see above
+        if (!plain) CHK(clamp_defect(c));
+        CHK(ensure(c, c->opr, (size_t)std::max(c->dp, c->mp + c->pp) * c->kp * sizeof(float)));
+        float *Op = (float *)c->opr.p;
+        CHK(factor_times_hinv(c, V, c->dp, scale, Op));
+        if (is_u) CHK(data_times(c, 0, false, Op, c->num)); // X (s V Hinv)
+        else CHK(data_times(c, 1, true, Op, c->num));       // Y^T (s V Hinv)
+        return reassoc_finish(c, which, c->num, l1, plain, nn);
+    }
     if (is_u) CHK(data_times(c, 0, false, V, c->num)); // X V
     else CHK(data_times(c, 1, true, V, c->num));       // Y^T V
     if (plain && l1 == 0.0 && c->opt_direct_step && c->opt_fused_mu && c->kp <= 256) {
@@ -588,6 +661,58 @@ extern "C" int cmf_newton_v_apply(cmf_ctx *c, const float *buf, double l1, doubl
                       (float)l1, (float)l2, c->dp * c->kp));
     }
     return shared_apply(c, CMF_V, nnv);
+}
+
+// ---- V sweep with the single shared Hessian, re-associated form, in three stages so that a row-sharded run can put its two
+// collectives between them (the shards' Grams must be summed BEFORE the data pass: a float64 all-reduce of k_pad^2 doubles, 512 KB
+// at k_pad = 256; then the usual all-reduce of the d x k partial):
+//   cmf_newton_v_gram      gbuf = alpha U^T U + (1 - alpha) Z^T Z of the local rows (float64, device)
+//   cmf_newton_v_products  H = gbuf + l2 I, safe inverse, pbuf = X^T (alpha U Hinv) + Y ((1 - alpha) Z Hinv) of the local rows
+//   cmf_newton_v_finish    V <- clamp(V E + pbuf - l1 sign(V) Hinv)
+// Reference: NewtonSolver._newton_update_V, sg_sample_ratio == 1, linear links (pycmf/cmf_solvers.py:436-450, :321-326).
+extern "C" int cmf_newton_v_gram(cmf_ctx *c, double alpha, double *gbuf) {
+    NEED_PROBLEM(c);
+    if (!gbuf) return fail(CMF_EINVAL, "null buffer");
+    if (!use_reassoc(c)) return fail(CMF_EUNSUPPORTED, "cmf_newton_v_gram needs the float64 shared Hessian (shared_hessian_f64, newton_reassoc) and k_pad <= 1024");
+    DeviceGuard dg(c->device);
+    CHK(ensure_shared64(c));
+    CHK(gram64(c, c->F[CMF_U], c->mp, (double *)c->g64a.p, nullptr));
+    CHK(gram64(c, c->F[CMF_Z], c->pp, (double *)c->g64b.p, nullptr));
+    Timed tm(c, CMF_K_ELEMWISE);
+    hipLaunchKernelGGL(hess64_build_kernel, dim3((unsigned)std::min(256, (c->kp * c->kp + 255) / 256)), dim3(256), 0, c->stream, gbuf,
+                       (const double *)c->g64a.p, alpha, (const double *)c->g64b.p, 1.0 - alpha, 0.0, c->kp, c->kp);
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
+extern "C" int cmf_newton_v_products(cmf_ctx *c, double alpha, double l2, double pert, const double *gbuf, float *pbuf) {
+    NEED_PROBLEM(c);
+    if (!gbuf || !pbuf) return fail(CMF_EINVAL, "null buffer");
+    if (!have_data(c, 0) || !have_data(c, 1)) return fail(CMF_EINVAL, "X and Y must be set before a V update");
+    if (!use_reassoc(c)) return fail(CMF_EUNSUPPORTED, "cmf_newton_v_products needs the float64 shared Hessian and k_pad <= 1024");
+    DeviceGuard dg(c->device);
+    c->hess_psd = (alpha >= 0.0 && alpha <= 1.0 && l2 >= 0.0);
+    CHK(ensure_shared64(c));
+    CHK(launch_hess64(c, gbuf, 1.0, nullptr, 0.0, l2));
+    bool plain = false;
+    CHK(shared_inverse(c, pert, &plain));
+    c->v_plain = plain;
+    if (!plain) CHK(clamp_defect(c));
+    CHK(ensure(c, c->opr, (size_t)std::max(c->dp, c->mp + c->pp) * c->kp * sizeof(float)));
+    float *Ou = (float *)c->opr.p, *Oz = Ou + c->mp * c->kp;
+    CHK(factor_times_hinv(c, c->F[CMF_U], c->mp, alpha, Ou));
+    CHK(factor_times_hinv(c, c->F[CMF_Z], c->pp, 1.0 - alpha, Oz));
+    CHK(data_times(c, 0, true, Ou, pbuf));         // X^T (alpha U Hinv)
+    return data_times(c, 1, false, Oz, pbuf, true); // + Y ((1 - alpha) Z Hinv)
+}
+
+extern "C" int cmf_newton_v_finish(cmf_ctx *c, float *pbuf, double l1, int nn_mask) {
+    NEED_PROBLEM(c);
+    if (!pbuf) return fail(CMF_EINVAL, "null buffer");
+    DeviceGuard dg(c->device);
+    const bool plain = c->v_plain;
+    c->v_plain = false;
+    return reassoc_finish(c, CMF_V, pbuf, l1, plain, (nn_mask & CMF_NN_V) != 0);
 }
 
 extern "C" int cmf_newton_uz_update(cmf_ctx *c, double alpha, double l1, double l2, int nn_mask, int upd, double pert) {
@@ -1007,16 +1132,20 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
     const int64_t rows_pad = c->frows_pad[which], rows = c->frows[which];
     const int64_t kk = (int64_t)c->kp * c->kp;
     int64_t chunk = hessian_chunk_rows(c, rows_pad);
-    for (const RowSide *sd : {&s1, &s2})
-        if (sd->active && sd->cls) {
-            // class images of a chunk: (2^R - 1) / R images per row; keep them under 16 GiB (C3, R = 6: 5376 rows per chunk)
-            const int64_t per_row = (((int64_t)1 << sd->cls) - 1) * kk * (int64_t)sizeof(float) / sd->cls;
-            chunk = std::min(chunk, std::max<int64_t>(256, (((int64_t)16 << 30) / per_row) / 256 * 256));
-            if (chunk < rows_pad) { // chunks start on a group boundary: multiples of lcm(256, R)
-                const int64_t q = (sd->cls % 3 == 0 ? 768 : (sd->cls == 5 ? 1280 : 256));
-                chunk = std::max<int64_t>(q, chunk / q * q);
+    if (c->opt_rowchunk > 0) chunk = std::min<int64_t>(chunk, rup(c->opt_rowchunk, 256)); // tests: force several chunks
+    {
+        // class images of a chunk: (2^R - 1) / R images per row; keep them under 16 GiB (C3, R = 6: 5376 rows per chunk).
+        // The memory cap is taken over BOTH class sides first; then ONE rounding to a common group boundary, lcm(256, R1, R2):
+        // every chunk must start on a group boundary of every class side (g0 = r0 / R below)
+        int64_t q = 256;
+        for (const RowSide *sd : {&s1, &s2})
+            if (sd->active && sd->cls) {
+                const int64_t per_row = (((int64_t)1 << sd->cls) - 1) * kk * (int64_t)sizeof(float) / sd->cls;
+                chunk = std::min(chunk, std::max<int64_t>(256, (((int64_t)16 << 30) / per_row) / 256 * 256));
+                q = std::lcm(q, (int64_t)sd->cls);
             }
-        }
+        if (chunk < rows_pad) chunk = std::max<int64_t>(q, chunk / q * q);
+    }
     CHK(ensure(c, c->hrows, (size_t)chunk * kk * sizeof(float)));
     float *Hc = (float *)c->hrows.p;
     float *grad = c->num, *step = c->den;
@@ -1253,11 +1382,22 @@ static int newton_step_impl(cmf_ctx *c, double alpha, double l1, double l2, int 
     }
     if (upd & CMF_UPD_V) {
         if (!have_data(c, 0) || !have_data(c, 1)) return fail(CMF_EINVAL, "X and Y must be set before a V update");
-        if (!(x_link == CMF_LINK_LINEAR && y_link == CMF_LINK_LINEAR && !sampled)) {
-            CHK(need_dense(c, 0));
-            CHK(need_dense(c, 1));
+        // a natively sparse side stays sparse while ITS part of the sweep is shared (linear link, no sampling): the fused V
+        // sweep serves it from the SpMM gradient + the shared Gram (sweep_v_fused) and never reads a dense image -- the
+        // reference's own sparse-X / logit-Y Newton workload (samples/toxic_comments.ipynb:853-856; cmf_solvers.py:432-486)
+        {
+            const bool xs = (x_link == CMF_LINK_LINEAR && !sampled), ys = (y_link == CMF_LINK_LINEAR && !sampled);
+            if (!(xs && ys)) {
+                if (!xs || !fused) CHK(need_dense(c, 0));
+                if (!ys || !fused) CHK(need_dense(c, 1));
+            }
         }
-        if (x_link == CMF_LINK_LINEAR && y_link == CMF_LINK_LINEAR && !sampled) {
+        if (x_link == CMF_LINK_LINEAR && y_link == CMF_LINK_LINEAR && !sampled && use_reassoc(c)) {
+            CHK(ensure_shared64(c));
+            CHK(cmf_newton_v_gram(c, alpha, (double *)c->gmix64.p));
+            CHK(cmf_newton_v_products(c, alpha, l2, pert, (const double *)c->gmix64.p, c->num));
+            CHK(cmf_newton_v_finish(c, c->num, l1, nn_mask));
+        } else if (x_link == CMF_LINK_LINEAR && y_link == CMF_LINK_LINEAR && !sampled) {
             CHK(cmf_newton_v_partials(c, alpha, c->vbuf));
             c->gmix64_valid = use_shared64(c); // no collective between the two halves: keep the float64 Gram mix
             CHK(cmf_newton_v_apply(c, c->vbuf, l1, l2, nn_mask, pert));

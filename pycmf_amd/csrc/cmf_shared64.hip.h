@@ -166,9 +166,10 @@ __device__ __forceinline__ bool chol64_lds(double *A, double *Lm, int n, double 
     return true;
 }
 
-// Hinv32 (kp x kp float, zero on the padding) = safe_inverse(H64) for ONE matrix of valid order n <= 64.
+// Hinv32 (kp x kp float, zero on the padding) = safe_inverse(H64) for ONE matrix of valid order n <= 64; optional float64 copy
+// (identity on the padding).
 // dynamic LDS: 2 n^2 + n doubles.
-__global__ __launch_bounds__(256) void safe_inverse64_small_kernel(const double *H, float *Hinv, int n, int kp, double pert) {
+__global__ __launch_bounds__(256) void safe_inverse64_small_kernel(const double *H, float *Hinv, int n, int kp, double pert, double *Hinv64) {
     extern __shared__ __attribute__((aligned(16))) double dsm[];
     double *A = dsm, *W = dsm + n * n, *inv = dsm + 2 * n * n;
     const int t = threadIdx.x, nt = 256, lane = t & 63, wid = t >> 6;
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(256) void safe_inverse64_small_kernel(const double 
             if (r < n && c < n)
                 for (int q = (r > c ? r : c); q < n; ++q) acc += A[q * n + r] * A[q * n + c];
             Hinv[idx] = (float)acc;
+            if (Hinv64) Hinv64[idx] = (r < n && c < n) ? acc : (r == c ? 1.0 : 0.0);
         }
         return;
     }
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(256) void safe_inverse64_small_kernel(const double 
         if (r < n && c < n)
             for (int j = 0; j < n; ++j) acc += inv[j] * Vt[j * n + r] * Vt[j * n + c];
         Hinv[idx] = (float)acc;
+        if (Hinv64) Hinv64[idx] = (r < n && c < n) ? acc : (r == c ? 1.0 : 0.0);
     }
 }
 
@@ -624,6 +627,91 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const double *A, const doub
         if (C) C[(int64_t)r * kp + c] = v;
         if (C32) C32[(int64_t)r * kp + c] = (r < nvalid && c < nvalid) ? (float)v : 0.f;
     }
+}
+
+// ------------------------------------------------------------------------------------------ factor times float64 matrix
+// O32[rows x kp] = scale * A32[rows x kp] * B64[kp x kp], float64 products and sums on v_mfma_f64_16x16x4_f64, rounded ONCE to
+// float32.  This is the "pre-conditioned operand" of the re-associated Newton sweep (cmf_newton.hip.h): with the safe inverse
+// Hinv of the ONE shared Hessian the reference's  F - grad Hinv,  grad = s (F G - T O) + l2 F  (pycmf/cmf_solvers.py:399-410,
+// :436-450, :321-326)  equals  F (I - H Hinv) + s T (O Hinv):  O Hinv is formed here in float64, so the float32 rounding of the
+// data contraction is no longer multiplied by cond(H).
+// Workgroup = 4 waves, output tile 64 x 64 (wave tile 32 x 32 = 2 x 2 MFMA blocks), the reduction in steps of 32 through LDS:
+// A tile [64][36] floats (k contiguous; 16 rows x 4 k of a ds_read_b32 group fall on 64 distinct banks), B tile [32][80] doubles
+// (the two 16-lane halves of a ds_read_b64 group read rows k and k + 1, 128 bytes apart mod 256).
+template <int NW>
+__global__ __launch_bounds__(256) void factor_times64_kernel(const float *A, const double *B, float *O, int kp, double scale) {
+    static_assert(NW == 64 || NW == 32, "column tile 64 (k_pad >= 64) or 32 (k_pad = 32)");
+    // wave (wi, wj) owns rows wi * 32 .. + 31 and columns wj * NW / 2 .. : 2 x JB MFMA blocks
+    constexpr int LA = 36, LB = NW + 16, WN = NW / 2, JB = WN / 16, BL = NW / 16; // BL: double2 loads of the B tile per thread
+    __shared__ __attribute__((aligned(16))) float As[64 * LA];
+    __shared__ __attribute__((aligned(16))) double Bs[32 * LB];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wi = w >> 1, wj = w & 1;
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int64_t m0 = (int64_t)blockIdx.y * 64;
+    const int n0 = blockIdx.x * NW;
+    f64x4 acc[2][JB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < JB; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < kp; k0 += 32) {
+        f32x4 av[2];
+        f64x2 bv[BL];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { // 64 rows x 8 float4
+            const int idx = t + 256 * q, r = idx >> 3, c4 = idx & 7;
+            av[q] = *reinterpret_cast<const f32x4 *>(A + (m0 + r) * kp + k0 + 4 * c4);
+        }
+#pragma unroll
+        for (int q = 0; q < BL; ++q) { // 32 rows x NW / 2 double2
+            const int idx = t + 256 * q, r = idx / (NW / 2), c2 = idx % (NW / 2);
+            bv[q] = *reinterpret_cast<const f64x2 *>(B + (int64_t)(k0 + r) * kp + n0 + 2 * c2);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = t + 256 * q, r = idx >> 3, c4 = idx & 7;
+            *reinterpret_cast<f32x4 *>(As + r * LA + 4 * c4) = av[q];
+        }
+#pragma unroll
+        for (int q = 0; q < BL; ++q) {
+            const int idx = t + 256 * q, r = idx / (NW / 2), c2 = idx % (NW / 2);
+            *reinterpret_cast<f64x2 *>(Bs + r * LB + 2 * c2) = bv[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            double a[2], b[JB];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) a[q] = (double)As[(wi * 32 + 16 * q + l15) * LA + 4 * s + lk];
+#pragma unroll
+            for (int q = 0; q < JB; ++q) b[q] = Bs[(4 * s + lk) * LB + wj * WN + 16 * q + l15];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < JB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                O[(m0 + wi * 32 + 16 * i + lk + 4 * reg) * kp + n0 + wj * WN + 16 * j + l15] = (float)(scale * acc[i][j][reg]);
+}
+
+// identity on the padding (rows / columns >= n) of a kp x kp float64 matrix
+__global__ __launch_bounds__(256) void pad_identity64_kernel(double *M, int kp, int n) {
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < kp * kp; idx += gridDim.x * 256) {
+        const int r = idx / kp, c = idx % kp;
+        if (r >= n || c >= n) M[idx] = (r == c) ? 1.0 : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void f32_to_f64_kernel(double *out, const float *in, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = (double)in[i];
 }
 
 // Newton-Schulz start: Bm = H - pert I on the valid block (padding: c on the diagonal), c = min(||B||_F, ||B||_inf),

@@ -569,3 +569,31 @@ def test_clamped_shared_hessian(lib, ns, k):
     got = ctx.get_factor(0)
     ctx.close()
     np.testing.assert_allclose(got, Ur, rtol=2e-3, atol=2e-3 * np.abs(Ur).max())
+
+
+def test_two_class_sides_with_different_group_sizes_across_chunks(lib):
+    """a V sweep with TWO linear sampled sides whose automatic group sizes differ (m in [4096, 8192): groups
+    of 4 rows; p >= 16384: groups of 6) and more V rows than one Hessian chunk holds.  Every chunk must start on a group
+    boundary of BOTH sides (multiples of lcm(256, 4, 6) = 768), otherwise rows past the first chunk receive the class images
+    of the wrong group.  Checked against the row-by-row form (row_classes = 0) on the same device-drawn lists
+    (pycmf/cmf_solvers.py:452-486 with identity links)."""
+    m, d, p, k, ratio = 4200, 2000, 16500, 8, 0.5
+    rng = np.random.RandomState(12)
+    X, Y = np.abs(rng.randn(m, d)).astype(np.float32), np.abs(rng.randn(d, p)).astype(np.float32)
+    U0, V0, Z0 = 0.2 * rng.randn(m, k), 0.2 * rng.randn(d, k), 0.2 * rng.randn(p, k)
+    got = {}
+    for R, chunk in ((0, 0), (-1, 256), (-1, 0)):
+        ctx = lib.Context(0)
+        ctx.set_option("row_classes", R)
+        ctx.set_option("row_chunk", chunk)
+        ctx.set_problem(m, d, p, k)
+        ctx.set_data(0, X); ctx.set_data(1, Y)
+        for w, F in enumerate((U0, V0, Z0)):
+            ctx.set_factor(w, F)
+        ctx.newton_step_device_sampled(0.5, 0.0, 0.3, "linear", "linear", 0, 2, 0.2, ratio, 7)   # V sweep only
+        got[(R, chunk)] = ctx.get_factor(1)
+        ctx.close()
+    ref = got[(0, 0)]
+    assert np.abs(ref - V0).max() > 0
+    for key in ((-1, 256), (-1, 0)):
+        np.testing.assert_allclose(got[key], ref, rtol=0, atol=2e-4 * np.abs(ref).max())

@@ -155,3 +155,33 @@ def test_blocked_spmm_equals_row_kernel(lib, k, skew):
     for w in range(3):
         np.testing.assert_array_equal(ctx.get_factor(w), outs[1][3 + w])
     ctx.close()
+
+
+@pytest.mark.parametrize("nn", [False, True])
+def test_native_csr_x_with_logit_y_newton_vs_oracle(lib, nn):
+    """The reference's own sparse Newton workload (samples/toxic_comments.ipynb:853-856: CSR X with x_link='linear',
+    y_link='logit', l1 and l2 regularisation, solver='newton'): X stays native CSR through all three sweeps -- U shared
+    (SpMM), Z per row over V, V with the X side from the SpMM gradient + shared Gram and the Y side per row
+    (pycmf/cmf_solvers.py:394-508) -- and lands on the float64 oracle."""
+    from oracle import cmf_oracle as O
+    rng = np.random.RandomState(21)
+    m, d, p, k = 3000, 2000, 40, 16
+    X = sp.random(m, d, density=0.01, random_state=rng, format="csr", data_rvs=lambda n: np.ones(n))   # binary bag of words
+    Y = (rng.rand(d, p) < 0.1).astype(np.float64)
+    sc = 0.2
+    draw = (lambda *s: np.abs(rng.randn(*s))) if nn else rng.randn
+    U0, V0, Z0 = sc * draw(m, k), sc * draw(d, k), sc * draw(p, k)
+    alpha, l1, l2 = 0.6, 0.02, 0.5
+    U, V, Z = U0.copy(), V0.copy(), Z0.copy()
+    for _ in range(2):
+        O.newton_update_step(X, Y, U, V, Z, alpha, l1, l2, "linear", "logit", nn, nn, nn, 1.0, 0.2)
+    ctx = _ctx(lib, X, Y, U0, V0, Z0, mode=2)
+    for _ in range(2):
+        ctx.newton_step(alpha, l1, l2, "linear", "logit", 7 if nn else 0, 7, 0.2, 1.0)
+    got = [ctx.get_factor(w) for w in range(3)]
+    ex2, ey2 = ctx.residual_sq("linear", "logit")
+    ctx.close()
+    for a, b in zip(got, (U, V, Z)):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-3 * np.abs(b).max())
+    np.testing.assert_allclose(np.sqrt(ex2), O.factorization_error(X, U, V.T, "linear"), rtol=1e-4)
+    np.testing.assert_allclose(np.sqrt(ey2), O.factorization_error(Y, V, Z.T, "logit"), rtol=1e-4)
