@@ -40,15 +40,23 @@ WORKLOADS = {
     "c2": dict(m=16384, d=8192, p=4096, k=128, solver="mu",
                desc="BASELINE configs[1]: CMF(n_components=128, solver='mu', linear link), dense "
                     "16384x8192 X, 8192x4096 Y, non-negative synthetic"),
-    "c3": dict(m=32768, d=16384, p=8192, k=256, solver="newton", x_link="linear", y_link="logit", ratio=0.5,
+    "c3": dict(m=32768, d=16384, p=8192, k=256, solver="newton", x_link="linear", y_link="logit", ratio=0.5, y_kind=1,
                desc="BASELINE configs[2]: CMF(n_components=256, solver='newton', y_link='logit', "
                     "sg_sample_ratio=0.5, device sampler) on dense 32768x16384 X, 16384x8192 Y"),
     "c5": dict(m=1000000, d=100000, p=64, k=256, solver="newton", x_link="linear", y_link="linear", ratio=1.0,
                nnz_per_row=100,
                desc="BASELINE configs[4]: CSR X 1e6 x 1e5 at 0.1% nnz (100 per row, values 1.0, native CSR), "
                     "dense Y 1e5 x 64, n_components=256, newton solver, linear links"),
+    "c5l": dict(m=1000000, d=100000, p=64, k=256, solver="newton", x_link="linear", y_link="logit", ratio=1.0,
+                nnz_per_row=100, l1=2.0, l2=5.0, nn_mask=3, y_kind=2, y_param=0.1,
+                desc="BASELINE configs[4] with the reference's own Newton settings (samples/toxic_comments.ipynb:853-856: "
+                     "x_link='linear', y_link='logit', l1_reg=2, l2_reg=5, U and V non-negative): CSR X 1e6 x 1e5 at 0.1% nnz "
+                     "(values 1.0, native CSR), dense Y 1e5 x 64 in {0,1} (10% ones), n_components=256"),
+    "tiny5l": dict(m=20000, d=3000, p=64, k=64, solver="newton", x_link="linear", y_link="logit", ratio=1.0,
+                   nnz_per_row=30, l1=0.02, l2=0.5, nn_mask=3, y_kind=2, y_param=0.1,
+                   desc="debug shape (native CSR X, y logit newton)"),
     "tiny": dict(m=2048, d=1024, p=512, k=64, solver="mu", desc="debug shape (mu)"),
-    "tiny3": dict(m=1536, d=1024, p=512, k=64, solver="newton", x_link="linear", y_link="logit", ratio=0.5,
+    "tiny3": dict(m=1536, d=1024, p=512, k=64, solver="newton", x_link="linear", y_link="logit", ratio=0.5, y_kind=1,
                   desc="debug shape (per-row newton, y logit, sg_sample_ratio 0.5, device sampler)"),
     "tiny5": dict(m=20000, d=3000, p=64, k=64, solver="newton", x_link="linear", y_link="linear", ratio=1.0,
                   nnz_per_row=30, desc="debug shape (native CSR X, linear newton)"),
@@ -102,8 +110,10 @@ def cpu_baseline(w, budget_s=20.0):
         ms, ds, ps, ks = 96, 64, 32, k  # per-row eigh(k x k) in Python: keep it to a few hundred rows
     rng = np.random.RandomState(42)
     X, Y = np.abs(rng.randn(ms, ds)), np.abs(rng.randn(ds, ps))
-    if w.get("y_link") == "logit":
-        Y = 1.0 / (1.0 + np.exp(-Y))
+    if w.get("y_kind") == 2:
+        Y = (rng.rand(ds, ps) < w.get("y_param", 0.1)).astype(np.float64)
+    elif w.get("y_link") == "logit":
+        Y = 1.0 / (1.0 + np.exp(-rng.randn(ds, ps)))
     sc = np.sqrt(X.mean() / ks)
     U, V, Z = (sc * np.abs(rng.randn(n, ks)) for n in (ms, ds, ps))
     if w["solver"] == "mu":
@@ -114,8 +124,9 @@ def cpu_baseline(w, budget_s=20.0):
         np.random.seed(0)
 
         def step():
-            O.newton_update_step(X, Y, U, V, Z, 0.5, 0.0, 0.1, w["x_link"], w["y_link"],
-                                 False, False, False, ratio=w.get("ratio", 1.0), pert=0.2)
+            nnm = w.get("nn_mask", 0)
+            O.newton_update_step(X, Y, U, V, Z, 0.5, w.get("l1", 0.0), w.get("l2", 0.1), w["x_link"], w["y_link"],
+                                 bool(nnm & 1), bool(nnm & 2), bool(nnm & 4), ratio=w.get("ratio", 1.0), pert=0.2)
         warm, timed = 1, None
     for _ in range(warm):
         step()
@@ -207,30 +218,16 @@ def main():
 
     import numpy as np
     from pycmf_amd import _lib
-    from pycmf_amd.sharded import (block_bounds, make_torch_sharded_mu, make_torch_sharded_newton,
-                                   make_torch_sharded_newton_rows, shard_bounds)
+    from pycmf_amd.sharded import (block_bounds, make_sharded_mu, make_sharded_newton, make_sharded_newton_rows,
+                                   nnz_balanced_bounds, shard_bounds)
 
-    # Test hooks (not used by the driver): CMF_BENCH_SAME_DEVICE=1 puts every rank on GPU 0, CMF_BENCH_BACKEND=gloo
-    # swaps RCCL for gloo (RCCL refuses two ranks on one device), so the N>1 code path runs on a 1-GPU box;
-    # CMF_BENCH_FORCE_DIST=1 takes the torch.distributed path at N = 1 too (RCCL with a single rank).
+    # No PyTorch anywhere: the collectives are RCCL calls inside libcmfhip on the context's stream (pycmf_amd/comm.py).
+    # Test hooks (not used by the driver): CMF_BENCH_SAME_DEVICE=1 puts every rank on GPU 0 and CMF_COMM_BACKEND=host swaps
+    # RCCL (which refuses two ranks on one device) for the host-staged test double, so the N>1 code path runs on a 1-GPU box;
+    # CMF_BENCH_FORCE_DIST=1 takes the sharded drivers at N = 1 too (RCCL with a single rank).
     if os.environ.get("CMF_BENCH_SAME_DEVICE") == "1":
         local_rank = 0
-    backend = os.environ.get("CMF_BENCH_BACKEND", "nccl")
     use_dist = world > 1 or os.environ.get("CMF_BENCH_FORCE_DIST") == "1"
-    # PyTorch is plumbing for the collectives only: a single-rank run never imports it (on a cold box that import
-    # alone can take minutes, which has no place in or around a timed run)
-    torch = dist = device = None
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
 
     w = WORKLOADS[args.workload]
     m, d, p, k = w["m"], w["d"], w["p"], w["k"]
@@ -241,12 +238,14 @@ def main():
     bounds_fn = block_bounds if rows_mode else shard_bounds   # the row-sharded Newton all-gathers equal blocks
     r0, r1 = bounds_fn(m, world, rank)
     c0, c1 = bounds_fn(p, world, rank)
+    if "nnz_per_row" in w and not rows_mode and world > 1:
+        # CSR X in nnz-balanced row blocks (the synthetic rows all hold nnz_per_row entries, so this coincides
+        # with the balanced row count; real inputs take the same call in pycmf_amd/multi_gpu.py)
+        off = nnz_balanced_bounds(np.arange(0, m + 1, dtype=np.int64) * w["nnz_per_row"], world)
+        r0, r1 = int(off[rank]), int(off[rank + 1])
 
-    # every context of a rank launches on ONE stream; the collectives are ordered on it explicitly (TorchCollectives)
-    stream = torch.cuda.Stream(device=device) if use_dist else None
-    stream_handle = stream.cuda_stream if use_dist else None
-    force = world if world > 1 else (2 if use_dist else 1)  # FORCE_DIST: drivers built as if sharded, collectives of 1 rank
-    ctx = _lib.Context(local_rank, stream_handle)
+    # every context of a rank launches on ONE stream (the first context's own); the collectives are enqueued on it
+    ctx = _lib.Context(local_rank)
     for kv in args.option:
         name, _, val = kv.partition("=")
         ctx.set_option(name, int(val))
@@ -267,58 +266,61 @@ def main():
     else:
         ctx.fill_data_synthetic(0, 42, r0, 0)   # X rows [r0,r1): values depend only on global coordinates
         scale = (0.7979 / k) ** 0.5             # 'random' init rule sqrt(mean / k), pycmf/cmf.py:111
-    ctx.fill_data_synthetic(1, 43, 0, c0)       # Y columns [c0,c1)
+    # Y columns [c0,c1): |N(0,1)|, or the targets of a logit side: sigmoid(N(0,1)) as in
+    # benchmarks/benchmark_cmf.py:78, {0,1} labels as in samples/toxic_comments.ipynb
+    ctx.fill_data_synthetic(1, 43, 0, c0, w.get("y_kind", 0), w.get("y_param", 0.0))
+    l1_reg, l2_reg, nn_mask = w.get("l1", 0.0), w.get("l2", 0.1), w.get("nn_mask", 0)
     ctx.fill_factor_synthetic(_lib.CMF_U, 101, r0, scale)
     ctx.fill_factor_synthetic(_lib.CMF_V, 102, 0, scale)
     ctx.fill_factor_synthetic(_lib.CMF_Z, 103, c0, scale)
     ctxs = [ctx]
     drv = None
+    coll = None
+    if use_dist:
+        from pycmf_amd.comm import init_collectives
+        coll = init_collectives(ctx, rank, world, timed=True)
 
     if not newton:
-        drv = make_torch_sharded_mu(ctx, force, device, timed=True)
+        drv = make_sharded_mu(ctx, coll)
 
         def do_step(it):
             drv.step(0.0, 0.0, 7)
     elif sharded_ok:
-        drv = make_torch_sharded_newton(ctx, force, device, alpha=0.5, nn_mask=0, pert=0.2, timed=True)
+        drv = make_sharded_newton(ctx, coll, alpha=0.5, nn_mask=nn_mask, pert=0.2,
+                                  single_collective="newton_single_collective=1" in args.option)
 
         def do_step(it):
-            drv.step(0.0, 0.1, 7)
+            drv.step(l1_reg, l2_reg, 7)
     elif use_dist:
         # per-row sweeps (logit link and / or sampling): a second context holds the rank's COLUMNS of X and rows
         # of Y with U and Z whole, and sweeps the rank's rows of V; factor rows are all-gathered in between
         q0, q1 = block_bounds(d, world, rank)
-        ctx_v = _lib.Context(local_rank, stream_handle)
+        ctx_v = _lib.Context(local_rank, ctx.stream_handle())
         for kv in args.option:
             name, _, val = kv.partition("=")
             ctx_v.set_option(name, int(val))
         ctx_v.set_problem(m, q1 - q0, p, k)
         ctx_v.fill_data_synthetic(0, 42, 0, q0)
-        ctx_v.fill_data_synthetic(1, 43, q0, 0)
+        ctx_v.fill_data_synthetic(1, 43, q0, 0, w.get("y_kind", 0), w.get("y_param", 0.0))
         ctx_v.fill_factor_synthetic(_lib.CMF_U, 101, 0, scale)
         ctx_v.fill_factor_synthetic(_lib.CMF_V, 102, q0, scale)
         ctx_v.fill_factor_synthetic(_lib.CMF_Z, 103, 0, scale)
         ctxs.append(ctx_v)
-        drv = make_torch_sharded_newton_rows(ctx, ctx_v, (r0, r1, q0, q1, c0, c1), (m, d, p), world, device, 0.5,
-                                             w["x_link"], w["y_link"], nn_mask=0, pert=0.2, ratio=w["ratio"],
-                                             rank=rank, timed=True)
+        drv = make_sharded_newton_rows(ctx, ctx_v, (r0, r1, q0, q1, c0, c1), (m, d, p), coll, 0.5,
+                                       w["x_link"], w["y_link"], nn_mask=nn_mask, pert=0.2, ratio=w["ratio"])
 
         def do_step(it):
-            drv.step(0.0, 0.1, 7, 1000 + it)
+            drv.step(l1_reg, l2_reg, 7, 1000 + it)
     else:
         def do_step(it):
-            ctx.newton_step_device_sampled(0.5, 0.0, 0.1, w["x_link"], w["y_link"], 0, 7, 0.2,
+            ctx.newton_step_device_sampled(0.5, l1_reg, l2_reg, w["x_link"], w["y_link"], nn_mask, 7, 0.2,
                                            w["ratio"], 1000 + it)
-    coll = getattr(drv, "collectives", None)
 
     def sync_all():
-        if not use_dist:
-            for c_ in ctxs:
-                c_.sync()          # hipStreamSynchronize of the launch stream
-            return
-        torch.cuda.synchronize(device)
-        dist.barrier()
-        torch.cuda.synchronize(device)
+        for c_ in ctxs:
+            c_.sync()              # hipStreamSynchronize of the launch stream
+        if coll:
+            coll.barrier()         # every rank's stream has drained
 
     for it in range(args.warmup):
         do_step(it)
@@ -326,7 +328,7 @@ def main():
         c_.kernel_timing(2)        # HIP events around the data-pass launches only (the class the roofline prices): an event pair per
         c_.kernel_timing_reset()   # launch serialises the stream for a few microseconds, 7 % of a C2 iteration when every launch has one
     if coll:
-        coll.stream.synchronize()
+        ctx.sync()
         coll.reset()
     sync_all()
     t0 = time.perf_counter()
@@ -336,10 +338,8 @@ def main():
         ctx.marker()               # one event per iteration on the launch stream: the auditable time series
     sync_all()
     elapsed = time.perf_counter() - t0
-    if use_dist:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    if coll:
+        elapsed = float(coll.all_reduce_host([elapsed], "max")[0])   # the slowest rank's clock
     marks = ctx.marker_times()
     series_ms = [b_ - a_ for a_, b_ in zip(marks, marks[1:])]
     coll_stats = coll.stats() if coll else None
@@ -362,9 +362,10 @@ def main():
     x2, y2 = ctx.data_sq()
     kp = ctx.geometry()[3]
 
+    if coll:
+        coll.barrier()
+        coll.close()
     if rank != 0:
-        if use_dist:
-            dist.destroy_process_group()
         return
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -469,7 +470,7 @@ def main():
         "cells_per_s": (float(m) * d + float(d) * p) * its,
         "algorithmic_tflops": algorithmic_flops(w) * its / 1e12,
         "config": {"workload": w["desc"], "m": m, "d": d, "p": p, "n_components": k, "solver": w["solver"],
-                   "parallelism": ("rows of U, V, Z sharded x%d (every sweep row-parallel; X and Y held by rows and by "
+                   "parallelism": "single GPU: X, Y and all three factors resident on one device, no collective" if not use_dist else ("rows of U, V, Z sharded x%d (every sweep row-parallel; X and Y held by rows and by "
                                    "columns), factor rows reassembled by 3 in-place RCCL all-gathers, (m+p+d)*k f32 in all "
                                    "per iteration" % world) if rows_mode else
                                   ("X/U row-sharded, Y/Z column-sharded x%d, V replicated, "
@@ -482,12 +483,12 @@ def main():
                         "note": "HIP events on the launch stream of rank 0, one per iteration inside the timed region"}
     if use_dist:
         calls, nbytes, cms = coll_stats if coll_stats else (0, 0, 0.0)
-        out["collective"] = {"backend": "rccl" if backend == "nccl" else backend, "ranks": world,
+        out["collective"] = {"backend": coll.backend, "ranks": world,
                              "calls_per_iteration": calls / args.steps, "payload_bytes_per_iteration": nbytes / args.steps,
                              "ms_per_iteration": cms / args.steps,
                              "note": "rank 0; ms = events on the launch stream around every collective (waiting for the "
                                      "slowest rank included)"}
-    for key in ("x_link", "y_link", "ratio"):
+    for key in ("x_link", "y_link", "ratio", "l1", "l2", "nn_mask"):
         if key in w:
             out["config"][key] = w[key]
     if args.option:
@@ -506,6 +507,9 @@ def main():
             "host_cpu_count": cb["cpu_count"],
             "blas": cb["blas"],
             "kind": "port",
+            "cores_note": ("all host cores" if cb["threads"] >= cb["cpu_count"] else
+                           "the BLAS under NumPy (%s) is built for at most %d threads: that is every thread this build can use on the "
+                           "%d-CPU host" % (cb["blas"], cb["threads"], cb["cpu_count"])),
             "sample": ("oracle/cmf_oracle %s update_step (NumPy float64, reference operation order) at m,d,p,k=%s%s: %d timed "
                        "iterations in %.1f s = %.3f it/s on %d BLAS threads; scaled to the bench shape by the %s ratio %.3g"
                        % (w["solver"], cb["shape"], " (BASELINE config C2 in full)" if full and cb["shape"][0] == 16384 else "",
@@ -513,8 +517,6 @@ def main():
                           "reference-order flop" if full else "algorithmic-work", cb["ratio"])),
         }
     print(json.dumps(out))
-    if use_dist:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

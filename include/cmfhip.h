@@ -38,7 +38,8 @@ enum {
     CMF_EHIP = 2,     /* a HIP runtime call failed                  */
     CMF_ENOMEM = 3,   /* device or host allocation failed           */
     CMF_ENODEV = 4,   /* no usable gfx950 device                    */
-    CMF_EUNSUPPORTED = 5
+    CMF_EUNSUPPORTED = 5,
+    CMF_ERCCL = 6     /* RCCL missing or a collective failed         */
 };
 
 enum { CMF_U = 0, CMF_V = 1, CMF_Z = 2 };           /* factor selector          */
@@ -114,8 +115,13 @@ int cmf_set_data_csr(cmf_ctx *ctx, int which, const int64_t *indptr, const int32
  * (gi,gj) depends only on seed and its GLOBAL coordinates, so a shard can be
  * generated in place): rows [row0,row0+rows) x cols [col0,col0+cols) of the
  * global matrix land in the local matrix.  Used by bench.py.                 */
+/* rows x cols block of the dense device image into a packed host array (parity tests at full BASELINE sizes) */
+int cmf_get_data_block_f32(cmf_ctx *ctx, int which, int64_t row0, int64_t nrows, int64_t col0, int64_t ncols, float *host_dst);
 int cmf_fill_data_synthetic(cmf_ctx *ctx, int which, uint64_t seed, int64_t row0, int64_t col0);
 int cmf_fill_factor_synthetic(cmf_ctx *ctx, int which, uint64_t seed, int64_t row0, double scale);
+/* the same generator with the target distributions of the logit workloads: kind 0 = |N(0,1)|,
+ * 1 = sigmoid(N(0,1)) (benchmarks/benchmark_cmf.py:78), 2 = Bernoulli(param) in {0, 1} (samples/toxic_comments.ipynb labels) */
+int cmf_fill_data_synthetic_kind(cmf_ctx *ctx, int which, uint64_t seed, int64_t row0, int64_t col0, int kind, double param);
 /* out (host, rows_out x ncols, row-major float64) = op(A) * B with A = X (which 0) or Y (which 1),
  * op = transpose when trans != 0, B host row-major float64 (b_rows x ncols).  The big products of the
  * initialisers' randomized SVD (sklearn randomized_svd called at pycmf/cmf.py:126,:149) run through
@@ -169,6 +175,10 @@ int cmf_newton_step(cmf_ctx *ctx, double alpha, double l1, double l2,
 int cmf_newton_step_device_sampled(cmf_ctx *ctx, double alpha, double l1, double l2,
                                    int x_link, int y_link, int nn_mask, int update_mask,
                                    double hessian_pertubation, double sg_ratio, uint64_t seed);
+
+/* the index lists that throughput mode draws for rows [row0, row0 + nrows) of one sweep (0: U, lists over d; 1: Z, over d;
+ * 2: V / X side, over m; 3: V / Y side, over p): int(n * sg_ratio) ascending indices per row into host memory        */
+int cmf_sample_lists(cmf_ctx *ctx, int sweep, uint64_t seed, double sg_ratio, int64_t row0, int64_t nrows, int32_t *host_out);
 
 /* sharded Newton, linear links and sg_ratio == 1 only (same buffer shape as
  * the MU pair: gradient partial | Gram partial).                            */
@@ -244,6 +254,37 @@ int cmf_scratch_free(cmf_ctx *ctx, void *dev_ptr);
  * (the reference keeps U, V, Z in one address space: cmf_solvers.py:510-522)                      */
 int cmf_export_factor_rows(cmf_ctx *ctx, int which, float *dev_dst);
 int cmf_import_factor_rows(cmf_ctx *ctx, int which, const float *dev_src);
+
+
+/* ---- collectives of the sharded solvers: RCCL over xGMI, one communicator per context -------------
+ * The reference is single-process; what is replaced here is the sum over row blocks hidden in its products
+ * (cmf_solvers.py:242-246: X^T U + Y Z and U^T U + Z^T Z are sums over the rows each rank owns).  librccl.so.1 is loaded on the
+ * first call (no link-time dependency).  Every collective is enqueued on the context's stream.  Bootstrap: one rank calls
+ * cmf_comm_unique_id and hands the 128 bytes to the others out of band (pycmf_amd/comm.py: a file next to the job), then every
+ * rank calls cmf_comm_init on its own context (one process per GPU).                                                        */
+#define CMF_COMM_ID_BYTES 128
+int cmf_comm_unique_id(char *id128);
+int cmf_comm_init(cmf_ctx *ctx, int rank, int world, const char *id128);
+int cmf_comm_destroy(cmf_ctx *ctx);                 /* also done by cmf_ctx_destroy */
+int cmf_comm_info(cmf_ctx *ctx, int *rank, int *world);
+/* in-place sum over the ranks (device memory): the (d + k) k partial buffer of cmf_mu_v_partials / cmf_newton_v_partials, the
+ * d k buffer of cmf_newton_v_products (float32); the k^2 Gram of cmf_newton_v_gram (float64)                                */
+int cmf_comm_allreduce_f32(cmf_ctx *ctx, float *dev_buf, int64_t n);
+int cmf_comm_allreduce_f64(cmf_ctx *ctx, double *dev_buf, int64_t n);
+/* in-place all-gather of equal chunks (factor rows of the row-sharded Newton): rank r's elems_per_rank floats already sit at
+ * dev_full + r * elems_per_rank                                                                                             */
+int cmf_comm_allgather_f32(cmf_ctx *ctx, float *dev_full, int64_t elems_per_rank);
+/* at most 16 host scalars, op 0 = sum, 1 = max; waits for the result (convergence test on the global error, the slowest
+ * rank's clock of bench.py); cmf_comm_barrier = one such reduction                                                          */
+int cmf_comm_allreduce_host_f64(cmf_ctx *ctx, double *vals, int n, int op);
+int cmf_comm_barrier(cmf_ctx *ctx);
+/* accounting: calls and payload bytes since the last reset; with cmf_comm_timing(1) also the milliseconds the collectives
+ * occupied the stream (events around each one, waiting for the slowest rank included)                                       */
+int cmf_comm_timing(cmf_ctx *ctx, int enable);
+int cmf_comm_stats(cmf_ctx *ctx, int64_t *calls, int64_t *bytes, double *ms, int reset);
+/* raw copies between caller-held device pointers (scratch, partial buffers) and host memory on the context's stream; both wait */
+int cmf_copy_to_host(cmf_ctx *ctx, const void *dev, void *host, int64_t bytes);
+int cmf_copy_from_host(cmf_ctx *ctx, void *dev, const void *host, int64_t bytes);
 
 #ifdef __cplusplus
 }

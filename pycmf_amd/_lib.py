@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcmfhip.so")
 
 CMF_U, CMF_V, CMF_Z = 0, 1, 2
+CMF_UPD_U, CMF_UPD_V, CMF_UPD_Z = 1, 2, 4   # update_mask bits (include/cmfhip.h)
+CMF_NN_U, CMF_NN_V, CMF_NN_Z = 1, 2, 4      # nn_mask bits
 LINKS = {"linear": 0, "logit": 1}
 UPD_U, UPD_V, UPD_Z = 1, 2, 4
 K_GEMM_NN, K_GEMM_TN, K_GEMM_NT, K_ELEMWISE, K_EIGEN = 0, 1, 2, 3, 4
@@ -38,7 +40,10 @@ PROTOTYPES = {
     "cmf_set_data_csr": [_vp, _i32, _pi64, _pi32, _pd, _i64],
     "cmf_fill_data_synthetic": [_vp, _i32, C.c_uint64, _i64, _i64],
     "cmf_fill_factor_synthetic": [_vp, _i32, C.c_uint64, _i64, _dbl],
+    "cmf_fill_data_synthetic_kind": [_vp, _i32, C.c_uint64, _i64, _i64, _i32, _dbl],
     "cmf_get_data_f32": [_vp, _i32, _pf, _i64, _i64],
+    "cmf_get_data_block_f32": [_vp, _i32, _i64, _i64, _i64, _i64, _pf],
+    "cmf_sample_lists": [_vp, _i32, C.c_uint64, _dbl, _i64, _i64, _pi32],
     "cmf_data_matmul_f64": [_vp, _i32, _i32, _pd, _i64, _i32, _pd],
     "cmf_rsvd": [_vp, _i32, _i32, _i32, _i32, _i32, _pd, _pd, _pd, _pd],
     "cmf_data_sum": [_vp, _pd, _pd],
@@ -76,6 +81,19 @@ PROTOTYPES = {
     "cmf_scratch_free": [_vp, _vp],
     "cmf_export_factor_rows": [_vp, _i32, _vp],
     "cmf_import_factor_rows": [_vp, _i32, _vp],
+    "cmf_comm_unique_id": [C.c_char_p],
+    "cmf_comm_init": [_vp, _i32, _i32, C.c_char_p],
+    "cmf_comm_destroy": [_vp],
+    "cmf_comm_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "cmf_comm_allreduce_f32": [_vp, _vp, _i64],
+    "cmf_comm_allreduce_f64": [_vp, _vp, _i64],
+    "cmf_comm_allgather_f32": [_vp, _vp, _i64],
+    "cmf_comm_allreduce_host_f64": [_vp, _pd, _i32, _i32],
+    "cmf_comm_barrier": [_vp],
+    "cmf_comm_timing": [_vp, _i32],
+    "cmf_comm_stats": [_vp, _pi64, _pi64, _pd, _i32],
+    "cmf_copy_to_host": [_vp, _vp, _vp, _i64],
+    "cmf_copy_from_host": [_vp, _vp, _vp, _i64],
 }
 
 _lib = None
@@ -155,6 +173,43 @@ class _Scratch:
         if self._ptr and self._ctx._h:
             check(self._ctx._lib.cmf_scratch_free(self._ctx._h, _vp(self._ptr)))
         self._ptr = None
+
+
+class DeviceArray:
+    """rows x cols float32 (or float64) matrix in context scratch, row-major: the staging / partial buffers of the sharded
+    drivers when no other device allocator is around.  Duck-types what pycmf_amd/sharded.py uses of a torch tensor:
+    ``data_ptr()``, ``shape``, ``numel()``, ``element_size()`` and row slicing (a view)."""
+
+    def __init__(self, ctx, rows, cols=1, itemsize=4, _ptr=None, _owner=None):
+        self.shape = (int(rows), int(cols))
+        self.itemsize = itemsize
+        if _ptr is None:
+            self._owner = ctx.scratch(max(self.numel() * itemsize, 16))
+            self._ptr = self._owner.data_ptr()
+        else:
+            self._owner, self._ptr = _owner, _ptr
+        self._ctx = ctx
+
+    def data_ptr(self):
+        return self._ptr
+
+    def numel(self):
+        return self.shape[0] * self.shape[1]
+
+    def element_size(self):
+        return self.itemsize
+
+    def __getitem__(self, sl):
+        if not isinstance(sl, slice) or sl.step not in (None, 1):
+            raise TypeError("DeviceArray supports contiguous row slices only")
+        lo, hi, _ = sl.indices(self.shape[0])
+        hi = max(hi, lo)
+        return DeviceArray(self._ctx, hi - lo, self.shape[1], self.itemsize,
+                           _ptr=self._ptr + lo * self.shape[1] * self.itemsize, _owner=self._owner)
+
+    def release(self):
+        if self._owner is not None and hasattr(self._owner, "release"):
+            self._owner.release()
 
 
 class Context:
@@ -239,8 +294,27 @@ class Context:
         check(self._lib.cmf_data_sum(self._h, C.byref(sx), C.byref(sy)))
         return sx.value, sy.value
 
-    def fill_data_synthetic(self, which, seed, row0=0, col0=0):
-        check(self._lib.cmf_fill_data_synthetic(self._h, which, seed, row0, col0))
+    def get_data_block(self, which, row0, nrows, col0, ncols):
+        """float32 block of the dense device image of X (0) / Y (1)."""
+        out = np.empty((nrows, ncols), dtype=np.float32)
+        check(self._lib.cmf_get_data_block_f32(self._h, which, row0, nrows, col0, ncols, out.ctypes.data_as(_pf)))
+        return out
+
+    def sample_lists(self, sweep, seed, ratio, row0, nrows):
+        """Index lists of the device sampler for rows [row0, row0 + nrows) of sweep 0 (U) / 1 (Z) / 2 (V, X side) / 3 (V, Y side)."""
+        m, d, p = self.shape[:3]
+        n = d if sweep <= 1 else (m if sweep == 2 else p)
+        per = int(n * ratio)
+        out = np.empty((nrows, per), dtype=np.int32)
+        check(self._lib.cmf_sample_lists(self._h, sweep, seed, ratio, row0, nrows, out.ctypes.data_as(_pi32)))
+        return out
+
+    def fill_data_synthetic(self, which, seed, row0=0, col0=0, kind=0, param=0.0):
+        """kind 0: |N(0,1)|; 1: sigmoid(N(0,1)); 2: Bernoulli(param) in {0, 1}"""
+        if kind == 0:
+            check(self._lib.cmf_fill_data_synthetic(self._h, which, seed, row0, col0))
+        else:
+            check(self._lib.cmf_fill_data_synthetic_kind(self._h, which, seed, row0, col0, kind, param))
 
     def fill_factor_synthetic(self, which, seed, row0=0, scale=1.0):
         check(self._lib.cmf_fill_factor_synthetic(self._h, which, seed, row0, scale))
@@ -349,6 +423,51 @@ class Context:
         p = _vp()
         check(self._lib.cmf_scratch_alloc(self._h, int(nbytes), C.byref(p)))
         return _Scratch(self, p.value, int(nbytes))
+
+    # ---- collectives (RCCL inside the C ABI: csrc/cmf_comm.hip.h)
+    def comm_init(self, rank, world, unique_id):
+        check(self._lib.cmf_comm_init(self._h, rank, world, bytes(unique_id)))
+
+    def comm_destroy(self):
+        check(self._lib.cmf_comm_destroy(self._h))
+
+    def comm_allreduce(self, buf):
+        """In-place sum over the ranks of a DeviceArray / scratch / tensor-like (float32, or float64 by element_size)."""
+        n = buf.numel()
+        if buf.element_size() == 8:
+            check(self._lib.cmf_comm_allreduce_f64(self._h, _vp(buf.data_ptr()), n))
+        else:
+            check(self._lib.cmf_comm_allreduce_f32(self._h, _vp(buf.data_ptr()), n))
+
+    def comm_allgather(self, full, elems_per_rank):
+        check(self._lib.cmf_comm_allgather_f32(self._h, _vp(full.data_ptr()), elems_per_rank))
+
+    def comm_allreduce_host(self, values, op="sum"):
+        a = np.ascontiguousarray(values, dtype=np.float64).copy()
+        check(self._lib.cmf_comm_allreduce_host_f64(self._h, a.ctypes.data_as(_pd), a.size, 0 if op == "sum" else 1))
+        return a
+
+    def comm_barrier(self):
+        check(self._lib.cmf_comm_barrier(self._h))
+
+    def comm_timing(self, enable=True):
+        check(self._lib.cmf_comm_timing(self._h, 1 if enable else 0))
+
+    def comm_stats(self, reset=False):
+        """(calls, payload bytes, ms on the stream) since the last reset; waits for the stream."""
+        calls, nbytes, ms = C.c_int64(0), C.c_int64(0), C.c_double(0)
+        check(self._lib.cmf_comm_stats(self._h, C.byref(calls), C.byref(nbytes), C.byref(ms), 1 if reset else 0))
+        return calls.value, nbytes.value, ms.value
+
+    def copy_to_host(self, buf, dtype=np.float32):
+        """numpy copy of a DeviceArray / scratch buffer (waits for the stream)."""
+        out = np.empty(buf.numel(), dtype=np.float64 if buf.element_size() == 8 else dtype)
+        check(self._lib.cmf_copy_to_host(self._h, _vp(buf.data_ptr()), out.ctypes.data_as(_vp), out.nbytes))
+        return out.reshape(buf.shape) if hasattr(buf, "shape") else out
+
+    def copy_from_host(self, buf, a):
+        a = np.ascontiguousarray(a)
+        check(self._lib.cmf_copy_from_host(self._h, _vp(buf.data_ptr()), a.ctypes.data_as(_vp), a.nbytes))
 
     def export_factor_rows(self, which, dev_ptr):
         """Device-to-device copy of all valid rows (k_pad floats each) to `dev_ptr`, on the context's stream."""

@@ -1,0 +1,220 @@
+"""Process-group plumbing of the sharded solvers WITHOUT PyTorch: one process per GPU, the collectives are RCCL calls inside
+libcmfhip.so (csrc/cmf_comm.hip.h) enqueued on the context's stream.
+
+SURVEY.md 8(e): the V update of pycmf/cmf_solvers.py:242-246 sums over the row blocks the ranks own -- one all-reduce of the
+(d + k) k partial buffer per iteration (MU), a k^2 float64 Gram + the d k partial (linear Newton, re-associated form), three
+in-place all-gathers of factor rows (per-row Newton).
+
+Bootstrap: RCCL needs one 128-byte unique id shared by all ranks.  Rank 0 creates it (``cmf_comm_unique_id``) and publishes it
+as a file; the others poll for it.  The file lives in ``CMF_COMM_DIR`` (default: the system temp directory) under a name built
+from ``CMF_COMM_KEY`` or, by default, the launcher's pid and ``MASTER_PORT`` -- the ranks of one job share their parent (bench.py's
+own launcher, ``python -m torch.distributed.run``, ``multi_gpu.fit_multi_gpu``) and nothing else does.
+
+``HostStagedCollectives`` is a test double for boxes with ONE GPU, where RCCL refuses two ranks on one device: the same interface,
+every collective staged through host memory and files in a shared directory.  ``CMF_COMM_BACKEND=host`` selects it; it is never
+used when every rank has its own GPU.
+"""
+import os
+import tempfile
+import time
+
+import numpy as np
+
+from . import _lib
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def _job_key():
+    key = os.environ.get("CMF_COMM_KEY")
+    if key:
+        return key
+    return "%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
+
+
+def _job_dir():
+    return os.environ.get("CMF_COMM_DIR") or tempfile.gettempdir()
+
+
+def _timeout():
+    return float(os.environ.get("CMF_COMM_TIMEOUT", "600"))
+
+
+def _wait_for(path, timeout, what):
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > timeout:
+            raise RuntimeError("pycmf_amd.comm: timed out after %.0f s waiting for %s (%s)" % (timeout, what, path))
+        time.sleep(0.01)
+
+
+def exchange_unique_id(rank, world, timeout=None):
+    """The job's RCCL unique id: created by rank 0, read by everybody else."""
+    path = os.path.join(_job_dir(), "cmf_comm_%s.id" % _job_key())
+    lib = _lib.load()
+    if rank == 0:
+        import ctypes as C
+        buf = C.create_string_buffer(128)
+        _lib.check(lib.cmf_comm_unique_id(buf))
+        tmp = path + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(buf.raw)
+        os.replace(tmp, path)           # atomic: a reader sees all 128 bytes or no file
+        return buf.raw, path
+    _wait_for(path, timeout or _timeout(), "rank 0's RCCL unique id")
+    with open(path, "rb") as f:
+        raw = f.read()
+    if len(raw) != 128:
+        raise RuntimeError("pycmf_amd.comm: %s holds %d bytes, expected 128" % (path, len(raw)))
+    return raw, path
+
+
+class RcclCollectives:
+    """The context's RCCL communicator behind the interface the sharded drivers use.  ``all_reduce`` / ``all_gather`` only enqueue
+    on the context's stream; ``all_reduce_host`` and ``barrier`` wait."""
+
+    backend = "rccl"
+
+    def __init__(self, ctx, rank, world, timed=False):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        uid, path = exchange_unique_id(rank, world)
+        ctx.comm_init(rank, world, uid)
+        ctx.comm_barrier()              # every rank has read the id file
+        if rank == 0:
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+        if timed:
+            ctx.comm_timing(True)
+
+    def all_reduce(self, buf):
+        self.ctx.comm_allreduce(buf)
+
+    def all_gather(self, full, chunk=None):
+        self.ctx.comm_allgather(full, full.numel() // self.world)
+
+    def all_reduce_host(self, values, op="sum"):
+        return self.ctx.comm_allreduce_host(values, op)
+
+    def barrier(self):
+        self.ctx.comm_barrier()
+
+    def reset(self):
+        self.ctx.comm_stats(reset=True)
+
+    def stats(self):
+        return self.ctx.comm_stats(reset=False)
+
+    def close(self):
+        self.ctx.comm_destroy()
+
+
+class HostStagedCollectives:
+    """TEST DOUBLE (one GPU shared by all ranks): the same interface, every collective staged through host memory.  A
+    collective number s of rank r is the file ``<dir>/<key>_s_r.npy``; a rank publishes its contribution, waits for all of
+    them, combines them in rank order (deterministic) and removes its file of collective s - 1 (every rank has read it by then:
+    nobody publishes s before finishing s - 1)."""
+
+    backend = "host-staged (test double)"
+
+    def __init__(self, ctx, rank, world, timed=False):
+        self.ctx, self.rank, self.world, self.timed = ctx, rank, world, timed
+        self.dir, self.key, self.seq = _job_dir(), _job_key(), 0
+        self.calls = self.bytes = 0
+        self.ms = 0.0
+        self.barrier()
+
+    def _path(self, seq, rank):
+        return os.path.join(self.dir, "cmf_host_%s_%d_%d.npy" % (self.key, seq, rank))
+
+    def _exchange(self, mine):
+        timeout = _timeout()
+        self.seq += 1
+        tmp = self._path(self.seq, self.rank) + ".tmp.npy"
+        np.save(tmp, mine)
+        os.replace(tmp, self._path(self.seq, self.rank))
+        parts = []
+        for r in range(self.world):
+            if r == self.rank:
+                parts.append(mine)
+                continue
+            _wait_for(self._path(self.seq, r), timeout, "rank %d in collective %d" % (r, self.seq))
+            parts.append(np.load(self._path(self.seq, r)))
+        if self.seq > 1:
+            try:
+                os.remove(self._path(self.seq - 1, self.rank))
+            except OSError:
+                pass
+        return parts
+
+    def _account(self, nbytes, t0):
+        self.calls += 1
+        self.bytes += nbytes
+        self.ms += (time.perf_counter() - t0) * 1e3
+
+    def all_reduce(self, buf):
+        t0 = time.perf_counter()
+        mine = self.ctx.copy_to_host(buf)
+        parts = self._exchange(mine)
+        total = parts[0].copy()
+        for q in parts[1:]:
+            total += q
+        self.ctx.copy_from_host(buf, total)
+        self._account(mine.nbytes, t0)
+
+    def all_gather(self, full, chunk=None):
+        t0 = time.perf_counter()
+        per = full.numel() // self.world
+        whole = self.ctx.copy_to_host(full).reshape(-1)
+        parts = self._exchange(whole[self.rank * per:(self.rank + 1) * per].copy())
+        self.ctx.copy_from_host(full, np.concatenate(parts))
+        self._account(whole.nbytes, t0)
+
+    def all_reduce_host(self, values, op="sum"):
+        parts = self._exchange(np.ascontiguousarray(values, dtype=np.float64))
+        return np.sum(parts, axis=0) if op == "sum" else np.max(parts, axis=0)
+
+    def barrier(self):
+        self.all_reduce_host(np.zeros(1))
+
+    def reset(self):
+        self.calls = self.bytes = 0
+        self.ms = 0.0
+
+    def stats(self):
+        self.ctx.sync()
+        return self.calls, self.bytes, self.ms
+
+    def close(self):
+        """Collective: a last barrier, then rank 0 -- once every other rank has signalled that it has read everything --
+        removes the job's files (nobody removes a file another rank may still have to read)."""
+        import glob
+        self.barrier()
+        done = lambda r: os.path.join(self.dir, "cmf_host_%s_done_%d" % (self.key, r))
+        if self.rank != 0:
+            open(done(self.rank), "wb").close()
+            return
+        for r in range(1, self.world):
+            _wait_for(done(r), _timeout(), "rank %d to finish" % r)
+        for f in glob.glob(os.path.join(self.dir, "cmf_host_%s_*" % self.key)):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+
+
+def init_collectives(ctx, rank=None, world=None, timed=False, backend=None):
+    """The collectives object of this rank: RCCL unless ``CMF_COMM_BACKEND=host`` (test double).  None for a single rank unless
+    ``force`` is requested through world > 1."""
+    r, w = env_rank_world()
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    backend = backend or os.environ.get("CMF_COMM_BACKEND", "rccl")
+    if backend == "host":
+        return HostStagedCollectives(ctx, rank, world, timed)
+    if backend != "rccl":
+        raise ValueError("CMF_COMM_BACKEND must be 'rccl' or 'host' (test double), got %r" % backend)
+    return RcclCollectives(ctx, rank, world, timed)

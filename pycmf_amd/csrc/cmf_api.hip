@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <set>
 #include <string>
@@ -86,8 +87,10 @@ struct EvPair {
     double flops;
 };
 
+struct CmfComm;
 struct cmf_ctx {
     int device = 0;
+    CmfComm *comm = nullptr;              // RCCL communicator of a sharded run (cmf_comm.hip.h), or none
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cu = 256;
@@ -649,9 +652,11 @@ static void release_problem(cmf_ctx *c) {
     }
 }
 
+extern "C" int cmf_comm_destroy(cmf_ctx *c);
 extern "C" int cmf_ctx_destroy(cmf_ctx *c) {
     if (!c) return CMF_OK;
     DeviceGuard dg(c->device);
+    (void)cmf_comm_destroy(c);
     release_problem(c);
     for (void *p : c->scratch) (void)hipFree(p);
     c->scratch.clear();
@@ -989,12 +994,28 @@ extern "C" int cmf_get_data_f32(cmf_ctx *c, int which, float *ptr, int64_t rs, i
     return download_strided<float>(c, *slot, cp, r, cc, ptr, rs, cs);
 }
 
-static int launch_fill(cmf_ctx *c, float *A, int64_t ld, int64_t rows, int64_t cols, uint64_t seed, int64_t row0, int64_t col0, float scale) {
+// a rows x cols block of the DENSE device image of X / Y into a packed host array (parity tests at sizes whose whole matrix
+// does not fit the host)
+extern "C" int cmf_get_data_block_f32(cmf_ctx *c, int which, int64_t row0, int64_t nrows, int64_t col0, int64_t ncols, float *dst) {
+    NEED_PROBLEM(c);
+    DeviceGuard dg(c->device);
+    int64_t r, cc, rp, cp; float **slot;
+    CHK(data_dims(c, which, &r, &cc, &rp, &cp, &slot));
+    if (!dst || row0 < 0 || col0 < 0 || nrows < 0 || ncols < 0 || row0 + nrows > r || col0 + ncols > cc) return fail(CMF_EINVAL, "block out of range");
+    if (!*slot) return fail(CMF_EINVAL, "%s has no dense device image (native sparse input or not set)", which == 0 ? "X" : "Y");
+    if (nrows == 0 || ncols == 0) return CMF_OK;
+    HIPCHK(hipMemcpy2DAsync(dst, (size_t)ncols * sizeof(float), *slot + row0 * cp + col0, (size_t)cp * sizeof(float), (size_t)ncols * sizeof(float),
+                            (size_t)nrows, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CMF_OK;
+}
+
+static int launch_fill(cmf_ctx *c, float *A, int64_t ld, int64_t rows, int64_t cols, uint64_t seed, int64_t row0, int64_t col0, float scale, int kind = 0) {
     Timed tm(c, CMF_K_ELEMWISE);
     const int64_t total = rows * ((cols + 3) / 4);
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
     if (total == 0) return CMF_OK;
-    hipLaunchKernelGGL(fill_absnormal_kernel, dim3(blocks), dim3(256), 0, c->stream, A, ld, rows, cols, seed, row0, col0, scale);
+    hipLaunchKernelGGL(fill_absnormal_kernel, dim3(blocks), dim3(256), 0, c->stream, A, ld, rows, cols, seed, row0, col0, scale, kind);
     HIPCHK(hipGetLastError());
     return CMF_OK;
 }
@@ -1007,6 +1028,17 @@ extern "C" int cmf_fill_data_synthetic(cmf_ctx *c, int which, uint64_t seed, int
     CHK(ensure_dense(c, which));
     HIPCHK(hipMemsetAsync(*slot, 0, (size_t)rp * cp * sizeof(float), c->stream));
     return launch_fill(c, *slot, cp, r, cc, seed, row0, col0, 1.0f);
+}
+
+extern "C" int cmf_fill_data_synthetic_kind(cmf_ctx *c, int which, uint64_t seed, int64_t row0, int64_t col0, int kind, double param) {
+    NEED_PROBLEM(c);
+    if (kind < 0 || kind > 2) return fail(CMF_EINVAL, "synthetic data kind: 0 |N(0,1)|, 1 sigmoid(N(0,1)), 2 Bernoulli(param)");
+    DeviceGuard dg(c->device);
+    int64_t r, cc, rp, cp; float **slot;
+    CHK(data_dims(c, which, &r, &cc, &rp, &cp, &slot));
+    CHK(ensure_dense(c, which));
+    HIPCHK(hipMemsetAsync(*slot, 0, (size_t)rp * cp * sizeof(float), c->stream));
+    return launch_fill(c, *slot, cp, r, cc, seed, row0, col0, kind == 0 ? 1.0f : (float)param, kind);
 }
 
 extern "C" int cmf_fill_factor_synthetic(cmf_ctx *c, int which, uint64_t seed, int64_t row0, double scale) {
@@ -1398,3 +1430,4 @@ extern "C" int cmf_rowhess_samples(cmf_ctx *c, double *credited, double *gathere
 
 #include "cmf_newton.hip.h"
 #include "cmf_init.hip.h"
+#include "cmf_comm.hip.h"

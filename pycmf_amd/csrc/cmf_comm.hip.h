@@ -1,0 +1,217 @@
+// cmf_comm.hip.h -- the collectives of the sharded solvers inside the C ABI (included by cmf_api.hip).
+//
+// "one stream + one RCCL communicator per device"; 8(e): one rank per GPU, the V update needs ONE all-reduce of the
+// (d + k) x k partial buffer per iteration (pycmf/cmf_solvers.py:242-246 summed over row blocks), the row-sharded Newton three
+// in-place all-gathers of factor rows.  RCCL is loaded at run time (dlopen of librccl.so.1, RTLD_LOCAL): libcmfhip.so has no
+// link-time dependency on it, a single-GPU process never touches it, and a process that also holds PyTorch's own copy of RCCL sees
+// no symbol clash.  Every collective is enqueued on the context's stream: ordered behind the kernels that produce its buffer and
+// in front of the ones that consume it, no host synchronisation.  The unique id travels out of band (the launcher's file / pipe:
+// pycmf_amd/comm.py).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+static RcclApi g_rccl;
+static std::mutex g_rccl_mu;
+
+static int rccl_load() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.handle) return CMF_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) return fail(CMF_ERCCL, "librccl.so.1 not found (%s): multi-GPU runs need RCCL", dlerror());
+    RcclApi a;
+    a.handle = h;
+#define CMF_RCCL_SYM(field, sym)                                                                    \
+    a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, sym));                                   \
+    if (!a.field) { dlclose(h); return fail(CMF_ERCCL, "librccl: missing symbol %s", sym); }
+    CMF_RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
+    CMF_RCCL_SYM(CommInitRank, "ncclCommInitRank")
+    CMF_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    CMF_RCCL_SYM(AllReduce, "ncclAllReduce")
+    CMF_RCCL_SYM(AllGather, "ncclAllGather")
+    CMF_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef CMF_RCCL_SYM
+    g_rccl = a;
+    return CMF_OK;
+}
+#define RCCLCHK(expr)                                                                                             \
+    do {                                                                                                          \
+        ncclResult_t r_ = (expr);                                                                                 \
+        if (r_ != ncclSuccess) return fail(CMF_ERCCL, "%s: %s", #expr, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
+    } while (0)
+
+struct CmfComm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    bool timed = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // around every collective while `timed`
+    int64_t calls = 0, bytes = 0;
+    double *dscratch = nullptr; // 16 doubles on the device for the host-value reductions
+};
+
+extern "C" int cmf_comm_unique_id(char *id128) {
+    if (!id128) return fail(CMF_EINVAL, "null id buffer");
+    CHK(rccl_load());
+    ncclUniqueId id;
+    RCCLCHK(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(id) == CMF_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    memcpy(id128, &id, sizeof id);
+    return CMF_OK;
+}
+
+extern "C" int cmf_comm_init(cmf_ctx *c, int rank, int world, const char *id128) {
+    if (!c || !id128) return fail(CMF_EINVAL, "null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(CMF_EINVAL, "rank %d out of range for %d ranks", rank, world);
+    if (c->comm) return fail(CMF_EINVAL, "the context already holds a communicator");
+    CHK(rccl_load());
+    DeviceGuard dg(c->device);
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    CmfComm *cm = new CmfComm();
+    cm->rank = rank; cm->world = world;
+    ncclResult_t r = g_rccl.CommInitRank(&cm->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        delete cm;
+        return fail(CMF_ERCCL, "ncclCommInitRank(rank %d of %d, device %d): %s", rank, world, c->device, g_rccl.GetErrorString(r));
+    }
+    if (hipMalloc((void **)&cm->dscratch, 16 * sizeof(double)) != hipSuccess) {
+        (void)g_rccl.CommDestroy(cm->comm);
+        delete cm;
+        return fail(CMF_ENOMEM, "out of device memory");
+    }
+    c->comm = cm;
+    return CMF_OK;
+}
+
+extern "C" int cmf_comm_destroy(cmf_ctx *c) {
+    if (!c || !c->comm) return CMF_OK;
+    DeviceGuard dg(c->device);
+    CmfComm *cm = c->comm;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &e : cm->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (cm->dscratch) (void)hipFree(cm->dscratch);
+    if (cm->comm) (void)g_rccl.CommDestroy(cm->comm);
+    delete cm;
+    c->comm = nullptr;
+    return CMF_OK;
+}
+
+struct CommTimed { // events on the launch stream around one collective (bench.py: bytes and ms per iteration)
+    cmf_ctx *c; CmfComm *cm; hipEvent_t a = nullptr, b = nullptr;
+    CommTimed(cmf_ctx *c_, CmfComm *cm_, int64_t nbytes) : c(c_), cm(cm_) {
+        cm->calls += 1; cm->bytes += nbytes;
+        if (cm->timed && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, c->stream);
+        else a = b = nullptr;
+    }
+    ~CommTimed() {
+        if (a && b) { (void)hipEventRecord(b, c->stream); cm->events.push_back({a, b}); }
+    }
+};
+#define NEED_COMM(c)                                                                                  \
+    do {                                                                                              \
+        if (!(c)) return fail(CMF_EINVAL, "null context");                                            \
+        if (!(c)->comm) return fail(CMF_EINVAL, "cmf_comm_init has not been called on this context"); \
+    } while (0)
+
+// in-place sum over the ranks of n float32 / float64 values in device memory, on the context's stream
+extern "C" int cmf_comm_allreduce_f32(cmf_ctx *c, float *dev_buf, int64_t n) {
+    NEED_COMM(c);
+    if (!dev_buf || n < 0) return fail(CMF_EINVAL, "bad buffer");
+    DeviceGuard dg(c->device);
+    CommTimed tm(c, c->comm, n * 4);
+    RCCLCHK(g_rccl.AllReduce(dev_buf, dev_buf, (size_t)n, ncclFloat32, ncclSum, c->comm->comm, c->stream));
+    return CMF_OK;
+}
+extern "C" int cmf_comm_allreduce_f64(cmf_ctx *c, double *dev_buf, int64_t n) {
+    NEED_COMM(c);
+    if (!dev_buf || n < 0) return fail(CMF_EINVAL, "bad buffer");
+    DeviceGuard dg(c->device);
+    CommTimed tm(c, c->comm, n * 8);
+    RCCLCHK(g_rccl.AllReduce(dev_buf, dev_buf, (size_t)n, ncclFloat64, ncclSum, c->comm->comm, c->stream));
+    return CMF_OK;
+}
+// in-place all-gather of equal chunks: rank r's `elems_per_rank` floats already sit at dev_full + r * elems_per_rank
+extern "C" int cmf_comm_allgather_f32(cmf_ctx *c, float *dev_full, int64_t elems_per_rank) {
+    NEED_COMM(c);
+    if (!dev_full || elems_per_rank < 0) return fail(CMF_EINVAL, "bad buffer");
+    DeviceGuard dg(c->device);
+    CommTimed tm(c, c->comm, elems_per_rank * 4 * c->comm->world);
+    RCCLCHK(g_rccl.AllGather(dev_full + (int64_t)c->comm->rank * elems_per_rank, dev_full, (size_t)elems_per_rank, ncclFloat32, c->comm->comm, c->stream));
+    return CMF_OK;
+}
+// a few host scalars (convergence test: two squared residuals; bench: the slowest rank's time): op 0 = sum, 1 = max.  Waits.
+extern "C" int cmf_comm_allreduce_host_f64(cmf_ctx *c, double *vals, int n, int op) {
+    NEED_COMM(c);
+    if (!vals || n < 0 || n > 16 || (op != 0 && op != 1)) return fail(CMF_EINVAL, "bad argument (at most 16 values; op 0 sum, 1 max)");
+    DeviceGuard dg(c->device);
+    CmfComm *cm = c->comm;
+    HIPCHK(hipMemcpyAsync(cm->dscratch, vals, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    RCCLCHK(g_rccl.AllReduce(cm->dscratch, cm->dscratch, (size_t)n, ncclFloat64, op == 0 ? ncclSum : ncclMax, cm->comm, c->stream));
+    HIPCHK(hipMemcpyAsync(vals, cm->dscratch, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CMF_OK;
+}
+extern "C" int cmf_comm_barrier(cmf_ctx *c) {
+    double one = 1.0;
+    return cmf_comm_allreduce_host_f64(c, &one, 1, 0);
+}
+extern "C" int cmf_comm_info(cmf_ctx *c, int *rank, int *world) {
+    NEED_COMM(c);
+    if (rank) *rank = c->comm->rank;
+    if (world) *world = c->comm->world;
+    return CMF_OK;
+}
+// collective accounting since the last reset: calls, payload bytes, milliseconds on the stream (only while timed)
+extern "C" int cmf_comm_timing(cmf_ctx *c, int enable) {
+    NEED_COMM(c);
+    c->comm->timed = enable != 0;
+    return CMF_OK;
+}
+extern "C" int cmf_comm_stats(cmf_ctx *c, int64_t *calls, int64_t *bytes, double *ms, int reset) {
+    NEED_COMM(c);
+    DeviceGuard dg(c->device);
+    CmfComm *cm = c->comm;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double total = 0.0;
+    for (auto &e : cm->events) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, e.first, e.second) == hipSuccess) total += t;
+    }
+    if (calls) *calls = cm->calls;
+    if (bytes) *bytes = cm->bytes;
+    if (ms) *ms = total;
+    if (reset) {
+        for (auto &e : cm->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        cm->events.clear();
+        cm->calls = 0; cm->bytes = 0;
+    }
+    return CMF_OK;
+}
+
+// raw copies between device memory the caller holds a pointer to (scratch, partial buffers) and host memory, ordered on the
+// context's stream; both wait.  Used by the host-staged test double of the collectives (pycmf_amd/comm.py) and by tests.
+extern "C" int cmf_copy_to_host(cmf_ctx *c, const void *dev, void *host, int64_t bytes) {
+    if (!c || !dev || !host || bytes < 0) return fail(CMF_EINVAL, "bad argument");
+    DeviceGuard dg(c->device);
+    HIPCHK(hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CMF_OK;
+}
+extern "C" int cmf_copy_from_host(cmf_ctx *c, void *dev, const void *host, int64_t bytes) {
+    if (!c || !dev || !host || bytes < 0) return fail(CMF_EINVAL, "bad argument");
+    DeviceGuard dg(c->device);
+    HIPCHK(hipMemcpyAsync(dev, host, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CMF_OK;
+}

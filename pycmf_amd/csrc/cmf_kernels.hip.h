@@ -1007,15 +1007,26 @@ __device__ __forceinline__ float absnormal_at(uint64_t seed, uint64_t gi, uint64
     const float r = sqrtf(-2.0f * __logf(u1));
     return fabsf(r * __cosf(6.28318530718f * u2));
 }
+// kind 0: scale |N(0,1)|   1: sigmoid(N(0,1)) (targets of a logit side, benchmarks/benchmark_cmf.py:78)   2: Bernoulli(scale) in {0, 1}
 __global__ void fill_absnormal_kernel(float *A, int64_t ld, int64_t rows, int64_t cols, uint64_t seed,
-                                      int64_t row0, int64_t col0, float scale) {
+                                      int64_t row0, int64_t col0, float scale, int kind) {
     const int64_t c4n = (cols + 3) / 4;
     const int64_t total = rows * c4n;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / c4n, c = (i % c4n) * 4;
-        for (int e = 0; e < 4 && c + e < cols; ++e)
-            A[r * ld + c + e] = scale * absnormal_at(seed, (uint64_t)(row0 + r), (uint64_t)(col0 + c + e));
+        for (int e = 0; e < 4 && c + e < cols; ++e) {
+            float v;
+            if (kind == 0) v = scale * absnormal_at(seed, (uint64_t)(row0 + r), (uint64_t)(col0 + c + e));
+            else {
+                const uint64_t h = mix64(mix64(seed ^ ((uint64_t)(row0 + r) * 0xD1342543DE82EF95ull)) ^ (uint64_t)(col0 + c + e));
+                const float u1 = ((float)((h >> 40) + 1)) * (1.0f / 16777217.0f);
+                const float u2 = ((float)((h >> 8) & 0xFFFFFF)) * (1.0f / 16777216.0f);
+                if (kind == 1) v = 1.0f / (1.0f + __expf(-sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530718f * u2)));
+                else v = (u2 < scale) ? 1.0f : 0.0f;
+            }
+            A[r * ld + c + e] = v;
+        }
     }
 }
 

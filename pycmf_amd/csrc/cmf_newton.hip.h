@@ -1423,6 +1423,30 @@ extern "C" int cmf_newton_step_device_sampled(cmf_ctx *c, double alpha, double l
     return cmf_newton_step(c, alpha, l1, l2, x_link, y_link, nn_mask, upd, pert, ratio, nullptr, nullptr, nullptr, nullptr);
 }
 
+// The index lists the device sampler draws for `nrows` consecutive rows of one sweep (sweep 0: U rows, lists over d; 1: Z rows,
+// over d; 2: V rows, X side, over m; 3: V rows, Y side, over p) under `seed` -- exactly what
+// cmf_newton_step_device_sampled(seed) uses for those rows, ascending inside a list.  For parity tests that recompute single
+// rows in float64 at sizes where the whole sweep cannot be (pycmf/cmf_solvers.py:328-344 is the sampler being replaced).
+extern "C" int cmf_sample_lists(cmf_ctx *c, int sweep, uint64_t seed, double ratio, int64_t row0, int64_t nrows, int32_t *out) {
+    NEED_PROBLEM(c);
+    if (sweep < 0 || sweep > 3 || !out || nrows < 0 || row0 < 0 || !(ratio > 0.0 && ratio < 1.0)) return fail(CMF_EINVAL, "bad argument");
+    DeviceGuard dg(c->device);
+    const int64_t n = (sweep <= 1) ? c->d : (sweep == 2 ? c->m : c->p);
+    const int64_t per = (int64_t)((double)n * ratio);
+    if (nrows * per == 0) return CMF_OK;
+    int32_t *dl = nullptr;
+    HIPCHK(hipMalloc((void **)&dl, (size_t)nrows * per * sizeof(int32_t)));
+    const int64_t off = c->sample_off[sweep == 0 ? CMF_U : (sweep == 1 ? CMF_Z : CMF_V)] + row0;
+    hipLaunchKernelGGL(sample_select_kernel, dim3((unsigned)nrows), dim3(256), 0, c->stream, (uint8_t *)nullptr, (int64_t)0, 1, dl, nrows, (int)n,
+                       (int)per, seed * 4 + (uint64_t)sweep, off);
+    int rc = CMF_OK;
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, dl, (size_t)nrows * per * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+        rc = fail(CMF_EHIP, "cmf_sample_lists failed");
+    (void)hipFree(dl);
+    return rc;
+}
+
 // ---- generic "data times a host matrix" product (initialisers: randomized range finder) --------------
 // out (host, float64, rows_out x ncols) = op(A) * B,  A = X (which 0) or Y (which 1), op = transpose if trans.
 extern "C" int cmf_data_matmul_f64(cmf_ctx *c, int which, int trans, const double *B, int64_t b_rows, int ncols, double *out) {

@@ -1,16 +1,20 @@
 """``CMF(n_gpus=N)``: the sharded solvers behind the scikit-learn front end.
 
 The parent process never touches a GPU: it validates, initialises the factors, writes the job (X, Y, factors, solver
-keywords) to a scratch directory and starts N worker processes -- one rank per GPU, ``torch.distributed`` with backend
-'nccl' (RCCL over xGMI), rendezvous on 127.0.0.1.  Rank g memory-maps the job, takes its row block of X / U and column
-block of Y / Z (CSR X is cut into nnz-balanced row blocks for the MU solver) and runs
-``fit_mu_sharded`` / ``fit_newton_sharded`` (pycmf_amd/sharded.py: the reference's outer loop, pycmf/cmf_solvers.py:132-195,
-with one all-reduce per iteration for V).  For large inputs with a non-custom init, rank 0 first computes the initial
-factors with the device-side initialisers on its GPU (whole X, Y resident once, released before the fit).  The parent
-reassembles U, V, Z in the caller's arrays.
+keywords) to a scratch directory and starts N worker processes -- one rank per GPU; the collectives are RCCL calls inside
+libcmfhip (pycmf_amd/comm.py), no PyTorch anywhere.  Rank g memory-maps the job, takes its block and runs
 
-Test hooks (a 1-GPU box): PYCMF_AMD_SAME_DEVICE=1 puts every rank on GPU 0 and PYCMF_AMD_DIST_BACKEND=gloo replaces RCCL,
-which refuses two ranks on one device.
+* ``fit_mu_sharded`` (MU) or ``fit_newton_linear_sharded`` (Newton, linear links, no sampling) on north_star's partition: row
+  block of X / U (CSR X: nnz-balanced), column block of Y / rows of Z, V replicated, ONE large all-reduce per iteration;
+* ``fit_newton_sharded`` (any other Newton configuration): rows of all three factors in equal blocks, X and Y held by rows and
+  by columns, three in-place all-gathers of factor rows per iteration
+
+(pycmf_amd/sharded.py: the reference's outer loop, pycmf/cmf_solvers.py:132-195).  For large inputs with a non-custom init,
+rank 0 first computes the initial factors with the device-side initialisers on its GPU (whole X, Y resident once, released
+before the fit).  The parent reassembles U, V, Z in the caller's arrays.
+
+Test hooks (a 1-GPU box): PYCMF_AMD_SAME_DEVICE=1 puts every rank on GPU 0 and CMF_COMM_BACKEND=host replaces RCCL -- which
+refuses two ranks on one device -- with the host-staged test double of pycmf_amd/comm.py.
 """
 import json
 import os
@@ -42,17 +46,59 @@ def _load(path):
     return np.load(path + ".npy", mmap_mode="r")
 
 
-def partition(X, Y, solver, world):
+def partition(X, Y, solver, world, params=None):
     """(row offsets of X / U, row offsets of V, column offsets of Y = row offsets of Z), world + 1 entries each."""
+    from ._worker import linear_newton
     m, d = X.shape
     p = Y.shape[1]
-    if solver == "newton":   # the row-sharded Newton all-gathers equal blocks
+    if solver == "newton" and not (params is not None and linear_newton(params)):
+        # the row-sharded Newton all-gathers equal blocks
         cut = lambda n: np.array([block_bounds(n, world, r)[0] for r in range(world)] + [n], dtype=np.int64)
         return cut(m), cut(d), cut(p)
+    # north_star's partition (MU, and Newton with linear links and no sampling): CSR X in nnz-balanced row blocks
     rows = nnz_balanced_bounds(X.indptr, world) if sp.issparse(X) and X.format == "csr" else \
         np.array([shard_bounds(m, world, r)[0] for r in range(world)] + [m], dtype=np.int64)
     cols = np.array([shard_bounds(p, world, r)[0] for r in range(world)] + [p], dtype=np.int64)
     return rows, None, cols
+
+
+def _plain(v):
+    """JSON-serialisable copy of a parameter value (NumPy scalars from user code included)."""
+    if isinstance(v, dict):
+        return {k: _plain(x) for k, x in v.items()}
+    if isinstance(v, (np.integer,)):
+        return int(v)
+    if isinstance(v, (np.floating,)):
+        return float(v)
+    if isinstance(v, (np.bool_,)):
+        return bool(v)
+    return v
+
+
+def _job_base(nbytes):
+    """/dev/shm when it is writable AND has room for the job (it is RAM), else the ordinary temp directory."""
+    shm = "/dev/shm"
+    if os.path.isdir(shm) and os.access(shm, os.W_OK):
+        try:
+            if shutil.disk_usage(shm).free > 1.25 * nbytes + (64 << 20):
+                return shm
+        except OSError:
+            pass
+    return None
+
+
+def _nbytes(A):
+    if sp.issparse(A):
+        return A.data.nbytes + A.indices.nbytes + A.indptr.nbytes
+    return np.asarray(A).nbytes
+
+
+def _linear(params):
+    from ._worker import linear_newton
+    return linear_newton(params)
+
+
+last_collective_calls = [None]   # rank 0's collective count of the most recent fit (tests: one large all-reduce per iteration)
 
 
 class MultiGpuResult:
@@ -74,20 +120,23 @@ def fit_multi_gpu(X, Y, U, V, Z, solver, n_gpus, params, timeout=None):
     if sp.issparse(X):
         X = X.tocsr()
     if sp.issparse(Y):
-        Y = Y.toarray() if solver == "newton" else Y.tocsc()   # column blocks of Y
-    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
-    job = tempfile.mkdtemp(prefix="pycmf_amd_job_", dir=base)
+        Y = Y.tocsc()   # column blocks of Y
+    params = _plain(params)
+    sparse_y = sp.issparse(Y)
+    if solver == "newton" and sparse_y and not _linear(params):
+        Y = Y.toarray()
+    job = tempfile.mkdtemp(prefix="pycmf_amd_job_", dir=_job_base(_nbytes(X) + _nbytes(Y) + U.nbytes + V.nbytes + Z.nbytes))
     try:
         _save(os.path.join(job, "X"), X)
         _save(os.path.join(job, "Y"), Y)
         if not params.get("init"):   # else rank 0 computes the start on its GPU and writes this file
             np.savez(os.path.join(job, "factors.npz"), U=U, V=V, Z=Z)
-        rows, vrows, cols = partition(X, Y, solver, n_gpus)
+        rows, vrows, cols = partition(X, Y, solver, n_gpus, params)
         meta = dict(solver=solver, params=params, rows=[int(v) for v in rows], cols=[int(v) for v in cols],
                     vrows=None if vrows is None else [int(v) for v in vrows])
         with open(os.path.join(job, "job.json"), "w") as f:
             json.dump(meta, f)
-        s = socket.socket()
+        s = socket.socket()          # MASTER_PORT only names the job (pycmf_amd/comm.py); nothing listens on it
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
         s.close()
@@ -97,6 +146,7 @@ def fit_multi_gpu(X, Y, U, V, Z, solver, n_gpus, params, timeout=None):
                        MASTER_PORT=str(port))
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+            env["CMF_COMM_DIR"], env["CMF_COMM_KEY"] = job, "job"
             log = open(os.path.join(job, "rank%d.log" % r), "wb")
             procs.append((subprocess.Popen([sys.executable, "-m", "pycmf_amd._worker", job], env=env, stdout=log,
                                            stderr=subprocess.STDOUT), log))
@@ -121,6 +171,7 @@ def fit_multi_gpu(X, Y, U, V, Z, solver, n_gpus, params, timeout=None):
             tail = open(os.path.join(job, "rank%d.log" % r), "rb").read().decode("utf-8", "replace")[-3000:]
             raise RuntimeError("multi-GPU fit: rank %d failed (exit code %s)\n%s" % (r, procs[r][0].returncode, tail))
         n_iter, ex2, ey2 = None, 0.0, 0.0
+        last_collective_calls[0] = None
         for r in range(n_gpus):
             o = np.load(os.path.join(job, "out%d.npz" % r))
             U[rows[r]:rows[r + 1]] = o["U"]
@@ -128,6 +179,7 @@ def fit_multi_gpu(X, Y, U, V, Z, solver, n_gpus, params, timeout=None):
             if r == 0:
                 V[...] = o["V"]
                 n_iter, ex2, ey2 = int(o["n_iter"]), float(o["ex2"]), float(o["ey2"])
+                last_collective_calls[0] = int(o["collective_calls"]) if "collective_calls" in o else None
         return n_iter, MultiGpuResult(np.sqrt(ex2), np.sqrt(ey2))
     finally:
         shutil.rmtree(job, ignore_errors=True)

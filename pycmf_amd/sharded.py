@@ -6,8 +6,8 @@ sums over all of m and p, so every rank forms its partial
 
     buf_g = [ X_g^T U_g + Y_g Z_g  (d x k) | U_g^T U_g + Z_g^T Z_g  (k x k) ]
 
-and a single ``all_reduce(sum)`` (RCCL over xGMI through torch.distributed)
-turns it into the global numerator/Gram of pycmf/cmf_solvers.py:244-245; every
+and a single ``all_reduce(sum)`` (RCCL over xGMI, issued from inside libcmfhip on the context's stream:
+pycmf_amd/comm.py) turns it into the global numerator/Gram of pycmf/cmf_solvers.py:244-245; every
 rank then applies the identical V epilogue and updates its own U_g, Z_g locally.
 
 The local compute is a *backend* object with three methods so that the host
@@ -88,14 +88,16 @@ class ShardedMU:
     def step(self, l1=0.0, l2=0.0, mask=7):
         if mask & 2:
             self.backend.partials(self.buf)
-            if self.world > 1:
+            if self.all_reduce is not None:
                 self.all_reduce(self.buf)  # the single collective of the iteration
             self.backend.apply_v(self.buf, l1, l2)
         self.backend.update_uz(l1, l2, mask)
 
 
 class HipNewtonShardBackend:
-    """Linear-link, unsampled Newton step on one shard (cmf_newton_uz_update / _v_partials / _v_apply)."""
+    """Linear-link, unsampled Newton step on one shard: cmf_newton_uz_update, then the V sweep either in its re-associated
+    three-stage form (cmf_newton_v_gram / _products / _finish: two buffers to sum over the ranks) or in the gradient form
+    (cmf_newton_v_partials / _v_apply: one buffer)."""
 
     def __init__(self, ctx, alpha, nn_mask=0, pert=0.2):
         self.ctx, self.alpha, self.nn_mask, self.pert = ctx, alpha, nn_mask, pert
@@ -112,20 +114,43 @@ class HipNewtonShardBackend:
     def apply_v(self, buf, l1, l2):
         self.ctx.newton_v_apply(buf.data_ptr(), l1, l2, self.nn_mask, self.pert)
 
+    def gram(self, gbuf):
+        self.ctx.newton_v_gram(self.alpha, gbuf.data_ptr())
+
+    def products(self, gbuf, pbuf, l2):
+        self.ctx.newton_v_products(self.alpha, l2, self.pert, gbuf.data_ptr(), pbuf.data_ptr())
+
+    def finish(self, pbuf, l1):
+        self.ctx.newton_v_finish(pbuf.data_ptr(), l1, self.nn_mask)
+
 
 class ShardedNewtonLinear:
     """One Newton iteration (order U -> Z -> V, cmf_solvers.py:510-522) across ranks for linear links and
-    sg_sample_ratio == 1: U and Z sweeps are local, the V sweep needs one all-reduce of
-    [alpha X^T U + (1-alpha) Y Z | alpha U^T U + (1-alpha) Z^T Z]."""
+    sg_sample_ratio == 1: U and Z sweeps are local.  The V sweep sums over the ranks
 
-    def __init__(self, backend, buf, world=1, all_reduce=None):
-        self.backend, self.buf, self.world, self.all_reduce = backend, buf, world, all_reduce
+    * with ``gbuf`` (default of the product path, the re-associated form F E + T (O Hinv), csrc/cmf_newton.hip.h): first the
+      k_pad^2 float64 Gram  alpha U^T U + (1 - alpha) Z^T Z  (512 KB at k = 256: the inverse must be known BEFORE the data
+      pass), then the d x k float32 partial  X^T (alpha U Hinv) + Y ((1 - alpha) Z Hinv)  -- the one large all-reduce;
+    * without it (gradient form): one all-reduce of [alpha X^T U + (1 - alpha) Y Z | alpha U^T U + (1 - alpha) Z^T Z]."""
+
+    def __init__(self, backend, buf, world=1, all_reduce=None, gbuf=None):
+        self.backend, self.buf, self.world, self.all_reduce, self.gbuf = backend, buf, world, all_reduce, gbuf
 
     def step(self, l1=0.0, l2=0.0, mask=7):
         self.backend.update_uz(l1, l2, mask)
-        if mask & 2:
+        if not mask & 2:
+            return
+        if self.gbuf is not None:
+            self.backend.gram(self.gbuf)
+            if self.all_reduce is not None:
+                self.all_reduce(self.gbuf)
+            self.backend.products(self.gbuf, self.buf, l2)
+            if self.all_reduce is not None:
+                self.all_reduce(self.buf)
+            self.backend.finish(self.buf, l1)
+        else:
             self.backend.partials(self.buf)
-            if self.world > 1:
+            if self.all_reduce is not None:
                 self.all_reduce(self.buf)
             self.backend.apply_v(self.buf, l1, l2)
 
@@ -200,7 +225,7 @@ class ShardedNewtonRows:
     def _gather(self, which):
         full = self.staging[which]
         self.backend.export_rows(which, full)      # the rank's rows land at rows [lo, hi) = [rank * c, ...)
-        if self.world > 1:
+        if self.all_gather is not None:
             c = full.shape[0] // self.world
             self.all_gather(full, full[self.rank * c:(self.rank + 1) * c])
         self.backend.import_rows(which, full)      # reads the first n rows
@@ -225,99 +250,81 @@ class SingleGpuStep:
         self._fn(l1, l2, mask)
 
 
-class TorchCollectives:
-    """torch.distributed collectives (backend 'nccl' = RCCL over xGMI) ordered EXPLICITLY on the stream the context
-    launches on: every call runs under ``torch.cuda.stream(ExternalStream(ctx stream))``, so a driver's ``step()``
-    is correct whatever PyTorch's current stream is at the call site.  Optionally brackets every collective with
-    events on that stream (bench.py reports bytes and ms per iteration)."""
-
-    def __init__(self, ctx, device, timed=False):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=device)
-        self.timed, self.events, self.bytes, self.calls = timed, [], 0, 0
-
-    def _run(self, fn, nbytes):
-        torch = self.torch
-        with torch.cuda.stream(self.stream):
-            if self.timed:
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-            fn()
-            if self.timed:
-                b.record()
-                self.events.append((a, b))
-        self.bytes += nbytes
-        self.calls += 1
-
-    def all_reduce(self, t):
-        self._run(lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM), t.numel() * t.element_size())
-
-    def all_gather(self, full, chunk):
-        self._run(lambda: self.dist.all_gather_into_tensor(full, chunk), full.numel() * full.element_size())
-
-    def reset(self):
-        self.events, self.bytes, self.calls = [], 0, 0
-
-    def stats(self):
-        """(calls, payload bytes, ms on the stream) since the last reset; waits for the stream."""
-        self.stream.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b in self.events)
-        return self.calls, self.bytes, ms
-
-
-def make_torch_sharded_newton_rows(ctx_uz, ctx_v, bounds, shape, world, device, alpha, x_link, y_link, nn_mask=0,
-                                   pert=0.2, ratio=1.0, rank=0, timed=False):
+def make_sharded_newton_rows(ctx_uz, ctx_v, bounds, shape, coll, alpha, x_link, y_link, nn_mask=0, pert=0.2, ratio=1.0):
     """bounds = block_bounds of (m, d, p) for this rank.  Both contexts must launch on ONE stream (pass the same handle
-    to both constructors): sweeps, row copies and collectives are then ordered by the stream alone, no host syncs."""
-    import torch
+    to both constructors): sweeps, row copies and collectives are then ordered by the stream alone, no host syncs.
+    ``coll``: the rank's collectives (pycmf_amd/comm.py), created on ``ctx_uz``; None for a single rank."""
+    from . import _lib
+    world, rank = (coll.world, coll.rank) if coll else (1, 0)
     if ctx_uz.stream_handle() != ctx_v.stream_handle():
         raise ValueError("the U/Z-sweep and V-sweep contexts must share one stream")
     backend = HipNewtonRowsBackend(ctx_uz, ctx_v, bounds, shape, alpha, x_link, y_link, nn_mask, pert, ratio)
     for n, (lo, hi) in zip(shape, (bounds[0:2], bounds[2:4], bounds[4:6])):
         if (lo, hi) != block_bounds(n, world, rank):
             raise ValueError("row-sharded Newton needs block_bounds partitions (got rows [%d, %d) of %d)" % (lo, hi, n))
-    staging = [torch.zeros((max(world * -(-n // world), 1), backend.k_pad), dtype=torch.float32, device=device)
-               for n in shape]
-    torch.cuda.synchronize(device)   # the fills ran on PyTorch's stream; everything after this runs on the contexts' stream
-    coll = TorchCollectives(ctx_uz, device, timed) if world > 1 else None
+    staging = [_lib.DeviceArray(ctx_uz, max(world * -(-n // world), 1), backend.k_pad) for n in shape]
     drv = ShardedNewtonRows(backend, staging, world, rank, coll.all_gather if coll else None)
     drv.collectives = coll
     return drv
 
 
-def make_torch_sharded_mu(ctx, world, device, timed=False):
-    """Wire a HIP context to torch.distributed (backend 'nccl' = RCCL).  With world == 1 nothing of PyTorch is touched:
-    the partial buffer is context scratch."""
+def make_sharded_mu(ctx, coll):
+    """MU driver of one rank: with ``coll`` None the context's own fused step, else partials -> ONE all-reduce -> apply."""
+    from . import _lib
     backend = HipShardBackend(ctx)
-    if world == 1:
+    if coll is None:
         return SingleGpuStep(lambda l1, l2, mask: ctx.mu_step(l1, l2, mask))
-    import torch
-    buf = torch.zeros(backend.buf_elems(), dtype=torch.float32, device=device)
-    torch.cuda.synchronize(device)   # the fill ran on PyTorch's stream; the context launches on its own
-    coll = TorchCollectives(ctx, device, timed)
-    drv = ShardedMU(backend, buf, world, coll.all_reduce)
+    buf = _lib.DeviceArray(ctx, backend.buf_elems(), 1)
+    drv = ShardedMU(backend, buf, coll.world, coll.all_reduce)
     drv.collectives = coll
     return drv
 
 
-def make_torch_sharded_newton(ctx, world, device, alpha, nn_mask=0, pert=0.2, timed=False):
+def make_sharded_newton(ctx, coll, alpha, nn_mask=0, pert=0.2, single_collective=False):
+    """Linear-link Newton driver of one rank.  ``single_collective``: the gradient form with ONE all-reduce of (d + k) k floats
+    (round-2 protocol) instead of the re-associated form's k^2 float64 Gram + d k partial."""
+    from . import _lib
     backend = HipNewtonShardBackend(ctx, alpha, nn_mask, pert)
-    if world == 1:
+    if coll is None:
         return SingleGpuStep(lambda l1, l2, mask: ctx.newton_step(alpha, l1, l2, "linear", "linear", nn_mask, mask, pert, 1.0))
-    import torch
-    buf = torch.zeros(backend.buf_elems(), dtype=torch.float32, device=device)
-    torch.cuda.synchronize(device)
-    coll = TorchCollectives(ctx, device, timed)
-    drv = ShardedNewtonLinear(backend, buf, world, coll.all_reduce)
+    _, dp, _, kp = ctx.geometry()
+    if single_collective:
+        drv = ShardedNewtonLinear(backend, _lib.DeviceArray(ctx, backend.buf_elems(), 1), coll.world, coll.all_reduce)
+    else:
+        drv = ShardedNewtonLinear(backend, _lib.DeviceArray(ctx, dp, kp), coll.world, coll.all_reduce,
+                                  gbuf=_lib.DeviceArray(ctx, kp, kp, itemsize=8))
     drv.collectives = coll
     return drv
+
+
+def _outer_loop(step, global_error, max_iter, tol, verbose):
+    """The reference's outer loop (pycmf/cmf_solvers.py:132-195): error at init, one step per iteration, the convergence test
+    every 10th iteration on the GLOBAL error."""
+    previous = at_init = global_error()
+    n_iter = 0
+    for n_iter in range(1, max_iter + 1):
+        step(n_iter)
+        if tol > 0 and n_iter % 10 == 0:
+            err = global_error()
+            if verbose:
+                print("Epoch %02d, error: %f" % (n_iter, err))
+            if (previous - err) / at_init < tol:
+                break
+            previous = err
+    return n_iter
+
+
+def _collectives_for(ctx, rank, world):
+    from .comm import env_rank_world, init_collectives
+    r, w = env_rank_world()
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    return (init_collectives(ctx, rank, world) if world > 1 else None), rank, world
 
 
 def fit_mu_sharded(X_rows, Y_cols, U_rows, V, Z_rows, l1_reg=0.0, l2_reg=0.0, max_iter=200, tol=1e-4,
-                   device=0, verbose=0, stats=None):
-    """Data-parallel MU fit: call from every rank of an initialised ``torch.distributed`` group.
+                   device=0, verbose=0, stats=None, rank=None, world=None):
+    """Data-parallel MU fit: call from every rank (one process per GPU; RANK / WORLD_SIZE from the environment unless given).
 
     Rank g passes its row block of X (and the matching rows of U), the matching column block of Y (and rows
     of Z) and the full V (identical on every rank).  Runs the reference's outer loop
@@ -325,58 +332,84 @@ def fit_mu_sharded(X_rows, Y_cols, U_rows, V, Z_rows, l1_reg=0.0, l2_reg=0.0, ma
     0.5||X-UV^T|| + 0.5||Y-VZ^T||) with one all-reduce per iteration for V and one 2-float all-reduce per
     convergence check.  U_rows, V, Z_rows are updated in place; returns (U_rows, V, Z_rows, n_iter).
     """
-    import torch
-    import torch.distributed as dist
     from . import _lib
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    dev = torch.device("cuda", device)
-    torch.cuda.set_device(dev)
-    stream = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(stream):
-        ctx = _lib.Context(device, stream.cuda_stream)
-        ctx.set_problem(X_rows.shape[0], X_rows.shape[1], Y_cols.shape[1], V.shape[1])
-        ctx.set_data(0, X_rows)
-        ctx.set_data(1, Y_cols)
-        for which, F in ((_lib.CMF_U, U_rows), (_lib.CMF_V, V), (_lib.CMF_Z, Z_rows)):
-            ctx.set_factor(which, F)
-        drv = make_torch_sharded_mu(ctx, world, dev)
+    ctx = _lib.Context(device)
+    ctx.set_problem(X_rows.shape[0], X_rows.shape[1], Y_cols.shape[1], V.shape[1])
+    ctx.set_data(0, X_rows)
+    ctx.set_data(1, Y_cols)
+    for which, F in ((_lib.CMF_U, U_rows), (_lib.CMF_V, V), (_lib.CMF_Z, Z_rows)):
+        ctx.set_factor(which, F)
+    coll, rank, world = _collectives_for(ctx, rank, world)
+    drv = make_sharded_mu(ctx, coll)
 
-        def global_sq():
-            ex2, ey2 = ctx.residual_sq("linear", "linear")
-            t = torch.tensor([ex2, ey2], dtype=torch.float64, device=dev)
-            if world > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            return tuple(float(v) for v in t.tolist())
+    def global_sq():
+        sq = np.array(ctx.residual_sq("linear", "linear"))
+        return tuple(coll.all_reduce_host(sq)) if coll else tuple(sq)
 
-        def global_error():
-            ex2, ey2 = global_sq()
-            return 0.5 * np.sqrt(ex2) + 0.5 * np.sqrt(ey2)
+    def global_error():
+        ex2, ey2 = global_sq()
+        return 0.5 * np.sqrt(ex2) + 0.5 * np.sqrt(ey2)
 
-        previous = at_init = global_error()
-        n_iter = 0
-        for n_iter in range(1, max_iter + 1):
-            drv.step(l1_reg, l2_reg, 7)
-            if tol > 0 and n_iter % 10 == 0:
-                err = global_error()
-                if verbose:
-                    print("Epoch %02d, error: %f" % (n_iter, err))
-                if (previous - err) / at_init < tol:
-                    break
-                previous = err
-        torch.cuda.synchronize(dev)
-        if stats is not None:   # squared global residuals of the final factors (reconstruction_err_ of the front end)
-            stats["ex2"], stats["ey2"] = global_sq()
-        for which, F in ((_lib.CMF_U, U_rows), (_lib.CMF_V, V), (_lib.CMF_Z, Z_rows)):
-            ctx.get_factor_into(which, F)
-        ctx.close()
+    n_iter = _outer_loop(lambda it: drv.step(l1_reg, l2_reg, 7), global_error, max_iter, tol, verbose)
+    ctx.sync()
+    if stats is not None:   # squared global residuals of the final factors (reconstruction_err_ of the front end)
+        stats["ex2"], stats["ey2"] = global_sq()
+    for which, F in ((_lib.CMF_U, U_rows), (_lib.CMF_V, V), (_lib.CMF_Z, Z_rows)):
+        ctx.get_factor_into(which, F)
+    if coll:
+        coll.barrier()
+        coll.close()
+    ctx.close()
+    return U_rows, V, Z_rows, n_iter
+
+
+def fit_newton_linear_sharded(X_rows, Y_cols, U_rows, V, Z_rows, alpha=0.5, l1_reg=0.0, l2_reg=0.0, U_non_negative=True,
+                              V_non_negative=True, Z_non_negative=True, hessian_pertubation=0.2, max_iter=200, tol=1e-4,
+                              device=0, verbose=0, stats=None, rank=None, world=None, single_collective=False):
+    """Newton fit with linear links and sg_sample_ratio == 1 on north_star's partition -- the same one as MU: rank g holds its row
+    block of X / U (CSR X: nnz-balanced blocks) and column block of Y / rows of Z, V replicated, X and Y resident ONCE.  The U
+    and Z sweeps are local; the V sweep sums the k^2 Gram and then the d x k partial over the ranks (ShardedNewtonLinear).
+    Outer loop and convergence test as in the reference (pycmf/cmf_solvers.py:132-195) on the global error
+    alpha ||X - U V^T|| + (1 - alpha) ||Y - V Z^T||."""
+    from . import _lib
+    ctx = _lib.Context(device)
+    ctx.set_problem(X_rows.shape[0], X_rows.shape[1], Y_cols.shape[1], V.shape[1])
+    ctx.set_data(0, X_rows)
+    ctx.set_data(1, Y_cols)
+    for which, F in ((_lib.CMF_U, U_rows), (_lib.CMF_V, V), (_lib.CMF_Z, Z_rows)):
+        ctx.set_factor(which, F)
+    coll, rank, world = _collectives_for(ctx, rank, world)
+    nn_mask = (1 if U_non_negative else 0) | (2 if V_non_negative else 0) | (4 if Z_non_negative else 0)
+    drv = make_sharded_newton(ctx, coll, alpha, nn_mask, hessian_pertubation, single_collective)
+
+    def global_sq():
+        sq = np.array(ctx.residual_sq("linear", "linear"))
+        return tuple(coll.all_reduce_host(sq)) if coll else tuple(sq)
+
+    def global_error():
+        ex2, ey2 = global_sq()
+        return alpha * np.sqrt(ex2) + (1 - alpha) * np.sqrt(ey2)
+
+    n_iter = _outer_loop(lambda it: drv.step(l1_reg, l2_reg, 7), global_error, max_iter, tol, verbose)
+    ctx.sync()
+    if stats is not None:
+        stats["ex2"], stats["ey2"] = global_sq()
+        if coll:
+            stats["collective_calls"] = coll.stats()[0]
+    for which, F in ((_lib.CMF_U, U_rows), (_lib.CMF_V, V), (_lib.CMF_Z, Z_rows)):
+        ctx.get_factor_into(which, F)
+    if coll:
+        coll.barrier()
+        coll.close()
+    ctx.close()
     return U_rows, V, Z_rows, n_iter
 
 
 def fit_newton_sharded(X_rows, X_cols, Y_cols, Y_rows, U_rows, V, Z_rows, alpha=0.5, l1_reg=0.0, l2_reg=0.0,
                        x_link="linear", y_link="linear", U_non_negative=True, V_non_negative=True, Z_non_negative=True,
                        hessian_pertubation=0.2, sg_sample_ratio=1.0, random_state=None, max_iter=200, tol=1e-4,
-                       device=0, verbose=0, stats=None):
-    """Row-sharded Newton fit: call from every rank of an initialised ``torch.distributed`` group.
+                       device=0, verbose=0, stats=None, rank=None, world=None):
+    """Row-sharded Newton fit for ANY link / sampling combination: call from every rank (one process per GPU).
 
     Rank g passes its row block of X and the SAME rows of U, the matching column block of Y with its rows of Z, and
     additionally its column block of X and row block of Y (rows ``block_bounds(d, world, rank)`` of V; all three
@@ -387,13 +420,11 @@ def fit_newton_sharded(X_rows, X_cols, Y_cols, Y_rows, U_rows, V, Z_rows, alpha=
     seed schedule of ``HipNewtonSolver(sg_sampler='device')``, so the iterates equal the single-GPU ones.
     U_rows, V, Z_rows are updated in place; returns (U_rows, V, Z_rows, n_iter).
     """
-    import torch
-    import torch.distributed as dist
     from . import _lib
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    dev = torch.device("cuda", device)
-    torch.cuda.set_device(dev)
+    from .comm import env_rank_world
+    r_, w_ = env_rank_world()
+    rank = r_ if rank is None else rank
+    world = w_ if world is None else world
     m_g, d = X_rows.shape
     m = X_cols.shape[0]
     p_g, p = Y_cols.shape[1], Y_rows.shape[1]
@@ -404,52 +435,40 @@ def fit_newton_sharded(X_rows, X_cols, Y_cols, Y_rows, U_rows, V, Z_rows, alpha=
     if (m_g, p_g, X_cols.shape[1], Y_rows.shape[0]) != (r1 - r0, c1 - c0, q1 - q0, q1 - q0):
         raise ValueError("blocks do not match block_bounds for rank %d of %d" % (rank, world))
     nn_mask = (1 if U_non_negative else 0) | (2 if V_non_negative else 0) | (4 if Z_non_negative else 0)
-    stream = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(stream):
-        ctx_uz = _lib.Context(device, stream.cuda_stream)
-        ctx_uz.set_problem(m_g, d, p_g, k)
-        ctx_uz.set_data(0, X_rows)
-        ctx_uz.set_data(1, Y_cols)
-        ctx_uz.set_factor(_lib.CMF_U, U_rows); ctx_uz.set_factor(_lib.CMF_V, V); ctx_uz.set_factor(_lib.CMF_Z, Z_rows)
-        ctx_v = _lib.Context(device, stream.cuda_stream)
-        ctx_v.set_problem(m, q1 - q0, p, k)
-        ctx_v.set_data(0, X_cols)
-        ctx_v.set_data(1, Y_rows)
-        ctx_v.set_factor(_lib.CMF_V, V[q0:q1])
-        drv = make_torch_sharded_newton_rows(ctx_uz, ctx_v, (r0, r1, q0, q1, c0, c1), (m, d, p), world, dev, alpha,
-                                             x_link, y_link, nn_mask, hessian_pertubation, sg_sample_ratio, rank=rank)
-        # the V-sweep context needs U and Z whole before its first sweep: the gathers of the first step provide them
+    ctx_uz = _lib.Context(device)
+    ctx_uz.set_problem(m_g, d, p_g, k)
+    ctx_uz.set_data(0, X_rows)
+    ctx_uz.set_data(1, Y_cols)
+    ctx_uz.set_factor(_lib.CMF_U, U_rows); ctx_uz.set_factor(_lib.CMF_V, V); ctx_uz.set_factor(_lib.CMF_Z, Z_rows)
+    ctx_v = _lib.Context(device, ctx_uz.stream_handle())     # both contexts launch on ONE stream
+    ctx_v.set_problem(m, q1 - q0, p, k)
+    ctx_v.set_data(0, X_cols)
+    ctx_v.set_data(1, Y_rows)
+    ctx_v.set_factor(_lib.CMF_V, V[q0:q1])
+    coll, rank, world = _collectives_for(ctx_uz, rank, world)
+    drv = make_sharded_newton_rows(ctx_uz, ctx_v, (r0, r1, q0, q1, c0, c1), (m, d, p), coll, alpha, x_link, y_link, nn_mask,
+                                   hessian_pertubation, sg_sample_ratio)
+    # the V-sweep context needs U and Z whole before its first sweep: the gathers of the first step provide them
 
-        def global_sq():
-            ex2, ey2 = ctx_uz.residual_sq(x_link, y_link)
-            t = torch.tensor([ex2, ey2], dtype=torch.float64, device=dev)
-            if world > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            return tuple(float(v) for v in t.tolist())
+    def global_sq():
+        sq = np.array(ctx_uz.residual_sq(x_link, y_link))
+        return tuple(coll.all_reduce_host(sq)) if coll else tuple(sq)
 
-        def global_error():
-            ex2, ey2 = global_sq()
-            return alpha * np.sqrt(ex2) + (1 - alpha) * np.sqrt(ey2)
+    def global_error():
+        ex2, ey2 = global_sq()
+        return alpha * np.sqrt(ex2) + (1 - alpha) * np.sqrt(ey2)
 
-        seed = (int(random_state) if isinstance(random_state, (int, np.integer)) else 0) << 20
-        previous = at_init = global_error()
-        n_iter = 0
-        for n_iter in range(1, max_iter + 1):
-            seed += 1
-            drv.step(l1_reg, l2_reg, 7, seed)
-            if tol > 0 and n_iter % 10 == 0:
-                err = global_error()
-                if verbose:
-                    print("Epoch %02d, error: %f" % (n_iter, err))
-                if (previous - err) / at_init < tol:
-                    break
-                previous = err
-        torch.cuda.synchronize(dev)
-        if stats is not None:
-            stats["ex2"], stats["ey2"] = global_sq()
-        ctx_uz.get_factor_into(_lib.CMF_U, U_rows)
-        ctx_uz.get_factor_into(_lib.CMF_V, V)
-        ctx_uz.get_factor_into(_lib.CMF_Z, Z_rows)
-        ctx_uz.close()
-        ctx_v.close()
+    seed0 = (int(random_state) if isinstance(random_state, (int, np.integer)) else 0) << 20
+    n_iter = _outer_loop(lambda it: drv.step(l1_reg, l2_reg, 7, seed0 + it), global_error, max_iter, tol, verbose)
+    ctx_uz.sync()
+    if stats is not None:
+        stats["ex2"], stats["ey2"] = global_sq()
+    ctx_uz.get_factor_into(_lib.CMF_U, U_rows)
+    ctx_uz.get_factor_into(_lib.CMF_V, V)
+    ctx_uz.get_factor_into(_lib.CMF_Z, Z_rows)
+    if coll:
+        coll.barrier()
+        coll.close()
+    ctx_v.close()
+    ctx_uz.close()
     return U_rows, V, Z_rows, n_iter

@@ -95,6 +95,12 @@ def test_single_rank_bench_never_imports_torch():
                           "--warmup", "1", "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "torch imported: False" in out.stdout, out.stdout
+    # ... and neither does a rank of an N > 1 run: the sharded drivers + the RCCL communicator inside libcmfhip (one rank here)
+    env = dict(os.environ, CMF_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_no_torch_check.py"), "--gpus", "1", "--workload", "tiny",
+                          "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "torch imported: False" in out.stdout, out.stdout
 
 
 def test_csr_input_is_validated_canonicalised_and_left_alone(lib):

@@ -236,3 +236,171 @@ def test_c4_full_size_bf16x6_matches_fp32_path(lib):
     for a, b in zip(out[0][0], out[1][0]):  # 65536-term fp32 sums accumulated in a different order
         np.testing.assert_allclose(b, a, rtol=1e-4, atol=0)
     assert out[1][2] < out[1][1] and abs(out[1][2] - out[0][2]) <= 1e-6 * out[0][2]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# float64 recomputation of SAMPLED ROWS at the full BASELINE sizes: the inputs of a sweep are read back from the device
+# (factors whole, the rows / columns of X and Y that the sampled factor rows touch), those rows are recomputed on the host
+# with the oracle's arithmetic, and compared with what the device wrote.  Unlike the property checks above this ties the
+# full-size kernels to the reference's formulas directly: an index wrap past 2^31 or a tile never visited shows up here.
+def _spread(n, count, rng):
+    """first, last and a few random rows"""
+    return sorted(set([0, n - 1] + [int(v) for v in rng.randint(0, n, size=count)]))
+
+
+def test_c4_full_size_mu_sampled_rows_vs_fp64(lib):
+    """BASELINE configs[3] (65536^2, k = 256, MU): rows of V, U, Z after one update against pycmf/cmf_solvers.py:230-263
+    evaluated in float64 on the device's own inputs."""
+    m = d = p = 65536
+    k = 256
+    eps = float(np.finfo(np.float32).eps)
+    rng = np.random.RandomState(0)
+    ctx = _synthetic(lib, m, d, p, k)
+    U0, V0, Z0 = (ctx.get_factor(w) for w in range(3))
+    ctx.mu_step(0.0, 0.0, lib.CMF_UPD_V)
+    V1 = ctx.get_factor(1)
+    G = U0.T @ U0 + Z0.T @ Z0                                    # :245
+    for j in _spread(d, 6, rng):
+        xcol = ctx.get_data_block(0, 0, m, j, 1)[:, 0].astype(np.float64)
+        yrow = ctx.get_data_block(1, j, 1, 0, p)[0].astype(np.float64)
+        num = xcol @ U0 + yrow @ Z0                              # :244
+        den = V0[j] @ G
+        den[den == 0] = eps                                      # :219
+        np.testing.assert_allclose(V1[j], V0[j] * num / den, rtol=2e-4, atol=0, err_msg="V row %d" % j)
+    ctx.mu_step(0.0, 0.0, lib.CMF_UPD_U | lib.CMF_UPD_Z)
+    U1, Z1 = ctx.get_factor(0), ctx.get_factor(2)
+    G2 = V1.T @ V1
+    for i in _spread(m, 6, rng):
+        xrow = ctx.get_data_block(0, i, 1, 0, d)[0].astype(np.float64)
+        den = U0[i] @ G2                                         # (U V^T) V, :233
+        den[den == 0] = eps
+        np.testing.assert_allclose(U1[i], U0[i] * (xrow @ V1) / den, rtol=2e-4, atol=0, err_msg="U row %d" % i)
+    for c in _spread(p, 6, rng):
+        ycol = ctx.get_data_block(1, 0, d, c, 1)[:, 0].astype(np.float64)
+        den = Z0[c] @ G2                                         # :239
+        den[den == 0] = eps
+        np.testing.assert_allclose(Z1[c], Z0[c] * (ycol @ V1) / den, rtol=2e-4, atol=0, err_msg="Z row %d" % c)
+    ctx.close()
+
+
+def _feed(monkeypatch, O, lists):
+    """make the oracle's sampler hand out the given index lists, in order (it draws one per row, U / Z sweeps, or two per
+    row, V sweep: X side then Y side -- pycmf/cmf_solvers.py:414, :494, :455-456)"""
+    it = iter(lists)
+    monkeypatch.setattr(O, "draw_sample", lambda n, ratio: next(it))
+
+
+def test_c3_full_size_newton_sampled_rows_vs_fp64(lib, monkeypatch):
+    """BASELINE configs[2] (32768 x 16384 / 16384 x 8192, k = 256, y logit, sg_sample_ratio 0.5, device sampler): rows of
+    U, Z and V after their sweeps against the oracle's per-row arithmetic (pycmf/cmf_solvers.py:394-508) on the index lists the
+    device drew for exactly those rows (cmf_sample_lists) -- which also ties the drawn lists to what the row kernels consumed."""
+    from oracle import cmf_oracle as O
+    m, d, p, k = 32768, 16384, 8192, 256
+    alpha, l1, l2, pert, ratio, seed = 0.5, 0.0, 0.1, 0.2, 0.5, 1000
+    rng = np.random.RandomState(1)
+    ctx = _synthetic(lib, m, d, p, k)
+    ctx.fill_data_synthetic(1, 43, 0, 0, 1)            # targets of the logit side: sigmoid(N(0,1)), as bench.py's c3
+    U0, V0, Z0 = (ctx.get_factor(w) for w in range(3))
+
+    def tol(ref):
+        return dict(rtol=0, atol=2e-3 * np.abs(ref).max())
+
+    ctx.newton_step_device_sampled(alpha, l1, l2, "linear", "logit", 0, lib.CMF_UPD_U, pert, ratio, seed)
+    U1 = ctx.get_factor(0)
+    rows = _spread(m, 3, rng)
+    lists = [ctx.sample_lists(0, seed, ratio, i, 1)[0] for i in rows]
+    assert all(len(s) == int(d * ratio) and len(np.unique(s)) == len(s) for s in lists)
+    Xs = np.vstack([ctx.get_data_block(0, i, 1, 0, d) for i in rows]).astype(np.float64)
+    Us = U0[rows].copy()
+    _feed(monkeypatch, O, lists)
+    O.newton_sweep_U(Us, V0, Xs, alpha, l1, l2, "linear", False, ratio, pert)
+    np.testing.assert_allclose(U1[rows], Us, **tol(Us))
+    assert np.abs(U1[rows] - U0[rows]).max() > 1e-3 * np.abs(U0).max()
+
+    ctx.newton_step_device_sampled(alpha, l1, l2, "linear", "logit", 0, lib.CMF_UPD_Z, pert, ratio, seed)
+    Z1 = ctx.get_factor(2)
+    cols = _spread(p, 3, rng)
+    lists = [ctx.sample_lists(1, seed, ratio, c, 1)[0] for c in cols]
+    Ys = np.hstack([ctx.get_data_block(1, 0, d, c, 1) for c in cols]).astype(np.float64)
+    Zs = Z0[cols].copy()
+    _feed(monkeypatch, O, lists)
+    O.newton_sweep_Z(Zs, V0, Ys, alpha, l1, l2, "logit", False, ratio, pert)
+    np.testing.assert_allclose(Z1[cols], Zs, **tol(Zs))
+
+    ctx.newton_step_device_sampled(alpha, l1, l2, "linear", "logit", 0, lib.CMF_UPD_V, pert, ratio, seed)
+    V1 = ctx.get_factor(1)
+    rows = _spread(d, 3, rng)
+    lists = []
+    for q in rows:
+        lists += [ctx.sample_lists(2, seed, ratio, q, 1)[0], ctx.sample_lists(3, seed, ratio, q, 1)[0]]
+    Xs = np.hstack([ctx.get_data_block(0, 0, m, q, 1) for q in rows]).astype(np.float64)
+    Ys = np.vstack([ctx.get_data_block(1, q, 1, 0, p) for q in rows]).astype(np.float64)
+    Vs = V0[rows].copy()
+    _feed(monkeypatch, O, lists)
+    O.newton_sweep_V(Vs, U1, Z1, Xs, Ys, alpha, l1, l2, "linear", "logit", False, ratio, pert)
+    np.testing.assert_allclose(V1[rows], Vs, **tol(Vs))
+    ctx.close()
+
+
+def _c5_problem(lib, y_kind=0, y_param=0.0):
+    import scipy.sparse as sp
+    m, d, p, k, npr = 1000000, 100000, 64, 256, 100
+    rng = np.random.default_rng(42)
+    indices = rng.integers(0, d, size=m * npr, dtype=np.int32)
+    indices.reshape(m, npr).sort(axis=1)
+    X = sp.csr_matrix((np.ones(m * npr), indices, np.arange(0, m * npr + 1, npr, dtype=np.int64)), shape=(m, d))
+    X.sum_duplicates()
+    ctx = lib.Context(0)
+    ctx.set_option("sparse_mode", 2)
+    ctx.set_problem(m, d, p, k)
+    ctx.set_data(0, X)
+    ctx.fill_data_synthetic(1, 43, 0, 0, y_kind, y_param)
+    scale = (npr / d / k) ** 0.5
+    ctx.fill_factor_synthetic(lib.CMF_U, 101, 0, scale)
+    ctx.fill_factor_synthetic(lib.CMF_V, 102, 0, scale)
+    ctx.fill_factor_synthetic(lib.CMF_Z, 103, 0, scale)
+    return ctx, X, (m, d, p, k)
+
+
+@pytest.mark.parametrize("y_link", ["linear", "logit"])
+def test_c5_full_size_native_csr_sampled_rows_vs_fp64(lib, y_link):
+    """BASELINE configs[4] (CSR X 1e6 x 1e5 with 1e8 non-zeros kept native, Y 1e5 x 64, k = 256, Newton).  'linear': the
+    bench's c5 workload.  'logit': the reference's own sparse Newton settings (samples/toxic_comments.ipynb:853-856:
+    y_link='logit', Y in {0,1}, l1 = 2, l2 = 5, U and V non-negative) -- a dense image of X (400 GB) cannot exist, so passing
+    at all shows that X stayed CSR.  Two iterations; after every sweep sampled rows are recomputed with the oracle's
+    arithmetic (pycmf/cmf_solvers.py:394-508) from the device's own inputs."""
+    from oracle import cmf_oracle as O
+    logit = y_link == "logit"
+    alpha, pert = 0.5, 0.2
+    l1, l2, nnm = (2.0, 5.0, 3) if logit else (0.0, 0.1, 0)
+    nn = [bool(nnm & 1), bool(nnm & 2), bool(nnm & 4)]
+    ctx, X, (m, d, p, k) = _c5_problem(lib, 2 if logit else 0, 0.1)
+    Y = ctx.get_data(1).astype(np.float64)
+    rng = np.random.RandomState(2)
+    F = [ctx.get_factor(w) for w in range(3)]
+    e_prev = None
+    for it in range(2):
+        # U sweep
+        ctx.newton_step(alpha, l1, l2, "linear", y_link, nnm, lib.CMF_UPD_U, pert, 1.0)
+        U1 = ctx.get_factor(0)
+        rows = _spread(m, 4, rng)
+        Us = F[0][rows].copy()
+        O.newton_sweep_U(Us, F[1], X[rows], alpha, l1, l2, "linear", nn[0], 1.0, pert)
+        np.testing.assert_allclose(U1[rows], Us, rtol=0, atol=2e-3 * max(np.abs(Us).max(), 1e-3 * np.abs(F[0]).max()), err_msg="U it %d" % it)
+        # Z sweep
+        ctx.newton_step(alpha, l1, l2, "linear", y_link, nnm, lib.CMF_UPD_Z, pert, 1.0)
+        Z1 = ctx.get_factor(2)
+        cols = _spread(p, 2, rng)
+        Zs = F[2][cols].copy()
+        O.newton_sweep_Z(Zs, F[1], Y[:, cols], alpha, l1, l2, y_link, nn[2], 1.0, pert)
+        np.testing.assert_allclose(Z1[cols], Zs, rtol=0, atol=2e-3 * np.abs(Zs).max(), err_msg="Z it %d" % it)
+        # V sweep
+        ctx.newton_step(alpha, l1, l2, "linear", y_link, nnm, lib.CMF_UPD_V, pert, 1.0)
+        V1 = ctx.get_factor(1)
+        rows = _spread(d, 1, rng)
+        Vs = F[1][rows].copy()
+        O.newton_sweep_V(Vs, U1, Z1, X[:, rows], Y[rows], alpha, l1, l2, "linear", y_link, nn[1], 1.0, pert)
+        np.testing.assert_allclose(V1[rows], Vs, rtol=0, atol=2e-3 * np.abs(Vs).max(), err_msg="V it %d" % it)
+        F = [U1, V1, Z1]
+        assert all(np.isfinite(A).all() for A in F)
+    ctx.close()

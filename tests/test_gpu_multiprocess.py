@@ -1,5 +1,7 @@
-"""Two real processes, one per rank, sharing the single GPU of the test box (gloo for the collectives, since
-RCCL refuses two ranks on one device): the sharded fit must reproduce the single-process fit."""
+"""Two real processes, one per rank, sharing the single GPU of the test box: the sharded fit must reproduce the
+single-process fit.  RCCL refuses two ranks on one device, so the ranks use the host-staged test double of the collectives
+(pycmf_amd/comm.py, CMF_COMM_BACKEND=host: the same interface, staged through host memory); the RCCL path itself runs
+with one rank (test_bench_rccl_single_rank, test_rccl_abi_single_rank).  No PyTorch in any rank."""
 import os
 import socket
 import subprocess
@@ -16,10 +18,8 @@ WORKER = r'''
 import os, sys
 import numpy as np
 sys.path.insert(0, %(root)r)
-import torch.distributed as dist
 from pycmf_amd.sharded import fit_mu_sharded, shard_bounds
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo", rank=rank, world_size=world)
 d = np.load(%(data)r)
 X, Y, U, V, Z = d["X"], d["Y"], d["U"].copy(), d["V"].copy(), d["Z"].copy()
 r0, r1 = shard_bounds(X.shape[0], world, rank)
@@ -27,8 +27,13 @@ c0, c1 = shard_bounds(Y.shape[1], world, rank)
 Ur, Zr = U[r0:r1].copy(), Z[c0:c1].copy()
 Ur, V, Zr, n_iter = fit_mu_sharded(X[r0:r1], Y[:, c0:c1], Ur, V, Zr, l1_reg=0.01, l2_reg=0.02, max_iter=40, tol=1e-4, device=0)
 np.savez(%(out)r + str(rank) + ".npz", U=Ur, V=V, Z=Zr, n_iter=n_iter, r=np.array([r0, r1, c0, c1]))
-dist.destroy_process_group()
+assert "torch" not in sys.modules
 '''
+
+
+def _rank_env(r, world, port, tmp_path):
+    return dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                CMF_COMM_BACKEND="host", CMF_COMM_DIR=str(tmp_path), CMF_COMM_KEY="t%d" % port, CMF_COMM_TIMEOUT="120")
 
 
 def _free_port():
@@ -53,7 +58,7 @@ def test_sharded_fit_two_processes(tmp_path, world):
     script.write_text(WORKER % {"root": ROOT, "data": data, "out": str(tmp_path / "out")})
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, str(script)],
-                              env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
+                              env=_rank_env(r, world, port, tmp_path),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = [q.communicate(timeout=1800)[0].decode() for q in procs]
     for r, (q, o) in enumerate(zip(procs, outs)):
@@ -76,10 +81,8 @@ NEWTON_WORKER = r'''
 import os, sys
 import numpy as np
 sys.path.insert(0, %(root)r)
-import torch.distributed as dist
 from pycmf_amd.sharded import fit_newton_sharded, block_bounds
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo", rank=rank, world_size=world)
 d_ = np.load(%(data)r)
 X, Y, U, V, Z = d_["X"], d_["Y"], d_["U"].copy(), d_["V"].copy(), d_["Z"].copy()
 r0, r1 = block_bounds(X.shape[0], world, rank)
@@ -91,12 +94,12 @@ Ur, V, Zr, n_iter = fit_newton_sharded(X[r0:r1], X[:, q0:q1], Y[:, c0:c1], Y[q0:
                                        V_non_negative=False, Z_non_negative=False, hessian_pertubation=0.2,
                                        sg_sample_ratio=0.6, random_state=3, max_iter=20, tol=1e-4, device=0)
 np.savez(%(out)r + str(rank) + ".npz", U=Ur, V=V, Z=Zr, n_iter=n_iter, r=np.array([r0, r1, c0, c1]))
-dist.destroy_process_group()
+assert "torch" not in sys.modules
 '''
 
 
 def test_row_sharded_newton_fit_two_processes(tmp_path):
-    """fit_newton_sharded on 2 real ranks (gloo, one GPU): y logit, sg_sample_ratio 0.6, device sampler -- the same
+    """fit_newton_sharded on 2 real ranks (host-staged collectives, one GPU): y logit, sg_sample_ratio 0.6, device sampler -- the same
     iterates as the single-process HipNewtonSolver(sg_sampler='device'), including the stopping iteration."""
     from pycmf_amd import _lib
     from pycmf_amd.solver_shell import HipNewtonSolver
@@ -113,7 +116,7 @@ def test_row_sharded_newton_fit_two_processes(tmp_path):
     script.write_text(NEWTON_WORKER % {"root": ROOT, "data": data, "out": str(tmp_path / "out")})
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, str(script)],
-                              env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
+                              env=_rank_env(r, world, port, tmp_path),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = [q.communicate(timeout=1800)[0].decode() for q in procs]
     for r, (q, o) in enumerate(zip(procs, outs)):
@@ -152,14 +155,16 @@ def _run_bench(args, env_extra, timeout=1800):
 def test_bench_launches_its_own_ranks(workload):
     """`python bench.py --gpus 2` as the driver calls it -- no launcher, no WORLD_SIZE in the environment: bench.py
     starts the two rank processes itself (before any GPU call in the parent) and prints rank 0's JSON line.  The test
-    box has one GPU, so both ranks share it and gloo stands in for RCCL (which refuses two ranks on one device)."""
+    box has one GPU, so both ranks share it and the host-staged test double stands in for RCCL (which refuses two ranks on
+    one device)."""
     out = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", workload, "--no-cpu-baseline"],
-                     {"CMF_BENCH_SAME_DEVICE": "1", "CMF_BENCH_BACKEND": "gloo"})
+                     {"CMF_BENCH_SAME_DEVICE": "1", "CMF_COMM_BACKEND": "host", "CMF_COMM_TIMEOUT": "120"})
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0
     assert len(out["series_ms"]["per_iteration"]) == 3
     coll = out["collective"]
     assert coll["ranks"] == 2 and coll["payload_bytes_per_iteration"] > 0 and coll["ms_per_iteration"] > 0
-    assert coll["calls_per_iteration"] == (3 if workload == "tiny3" else 1)   # 3 all-gathers of factor rows | ONE all-reduce
+    # MU: ONE all-reduce; per-row Newton: 3 all-gathers of factor rows; linear Newton: the k^2 float64 Gram + ONE d x k partial
+    assert coll["calls_per_iteration"] == {"tiny": 1, "tiny3": 3, "tiny5": 2}[workload]
     one = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", workload, "--no-cpu-baseline"], {})
     assert one["n_gpus"] == 1 and "collective" not in one
     # same synthetic problem, same iteration count: the sharded run ends at the same residuals (rank 0's shard of X / Y
@@ -169,25 +174,63 @@ def test_bench_launches_its_own_ranks(workload):
 
 
 def test_bench_rccl_single_rank():
-    """The torch.distributed / RCCL branch of bench.py with one rank (all a 1-GPU box can offer RCCL): process-group
-    init with device_id, the all-reduce of the (d + k) k partial buffer ordered on the context's stream, teardown."""
+    """The RCCL branch of bench.py with one rank (all a 1-GPU box can offer RCCL): unique id through the job file,
+    ncclCommInitRank inside libcmfhip, the all-reduce of the (d + k) k partial buffer on the context's stream, teardown."""
     out = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "tiny", "--no-cpu-baseline"],
                      {"CMF_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1"})
     assert out["collective"]["backend"] == "rccl" and out["collective"]["calls_per_iteration"] == 1
+    assert out["collective"]["payload_bytes_per_iteration"] == (1024 + 64) * 64 * 4
     ref = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "tiny", "--no-cpu-baseline"], {})
     assert out["rel_residual"] == ref["rel_residual"]      # a 1-rank all-reduce is the identity: bit-identical iterates
+    # linear Newton on native CSR: float64 Gram + float32 partial per iteration
+    out = _run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "tiny5", "--no-cpu-baseline"],
+                     {"CMF_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1"})
+    assert out["collective"]["backend"] == "rccl" and out["collective"]["calls_per_iteration"] == 2
+
+
+def test_rccl_abi_single_rank(tmp_path, monkeypatch):
+    """The collectives of the C ABI with a one-rank communicator: in-place all-reduce (float32, float64), all-gather, the
+    host-scalar reduction, the barrier, accounting -- and the errors of calling them without a communicator."""
+    from pycmf_amd import _lib
+    from pycmf_amd.comm import RcclCollectives
+    monkeypatch.setenv("CMF_COMM_DIR", str(tmp_path))
+    monkeypatch.setenv("CMF_COMM_KEY", "abi")
+    ctx = _lib.Context(0)
+    ctx.set_problem(8, 8, 8, 4)
+    a = _lib.DeviceArray(ctx, 6, 5)
+    with pytest.raises(ValueError, match="cmf_comm_init"):
+        ctx.comm_allreduce(a)
+    coll = RcclCollectives(ctx, 0, 1, timed=True)
+    assert not os.path.exists(os.path.join(str(tmp_path), "cmf_comm_abi.id"))   # rank 0 removed the id file after the barrier
+    ref = np.arange(30, dtype=np.float32).reshape(6, 5)
+    ctx.copy_from_host(a, ref)
+    coll.all_reduce(a)
+    np.testing.assert_array_equal(ctx.copy_to_host(a), ref)
+    g = _lib.DeviceArray(ctx, 3, 3, itemsize=8)
+    ctx.copy_from_host(g, np.arange(9, dtype=np.float64).reshape(3, 3) / 7.0)
+    coll.all_reduce(g)
+    np.testing.assert_array_equal(ctx.copy_to_host(g), np.arange(9, dtype=np.float64).reshape(3, 3) / 7.0)
+    coll.all_gather(a)
+    np.testing.assert_array_equal(ctx.copy_to_host(a), ref)
+    np.testing.assert_array_equal(coll.all_reduce_host([1.5, -2.0], "max"), [1.5, -2.0])
+    coll.barrier()
+    calls, nbytes, ms = coll.stats()
+    assert calls == 3 and nbytes == 120 + 72 + 120 and ms >= 0.0
+    coll.close()
+    ctx.close()
 
 
 @pytest.mark.parametrize("solver,kw", [("mu", {}), ("newton", dict(y_link="logit", U_non_negative=False, V_non_negative=False,
                                                                  Z_non_negative=False, l2_reg=0.05, alpha=0.4))])
 def test_cmf_n_gpus_through_the_drop_in_api(solver, kw, monkeypatch):
-    """``CMF(n_gpus=2).fit`` -- worker processes started by the front end, one rank per GPU (both on GPU 0 here, gloo
-    instead of RCCL) -- against ``CMF(n_gpus=1)`` from the same initial factors: same iteration count, same factors,
+    """``CMF(n_gpus=2).fit`` -- worker processes started by the front end, one rank per GPU (both on GPU 0 here, the
+    host-staged test double instead of RCCL) -- against ``CMF(n_gpus=1)`` from the same initial factors: same iteration count, same factors,
     same reconstruction_err_; sklearn's clone carries n_gpus."""
     from sklearn.base import clone
     from pycmf_amd import CMF
     monkeypatch.setenv("PYCMF_AMD_SAME_DEVICE", "1")
-    monkeypatch.setenv("PYCMF_AMD_DIST_BACKEND", "gloo")
+    monkeypatch.setenv("CMF_COMM_BACKEND", "host")
+    monkeypatch.setenv("CMF_COMM_TIMEOUT", "120")
     rng = np.random.RandomState(3)
     m, d, p, k = 260, 150, 90, 6
     X = np.abs(rng.randn(m, d))
@@ -208,7 +251,8 @@ def test_cmf_n_gpus_initialises_on_rank0_for_large_inputs(monkeypatch):
     start with the device-side ones (whole X, Y on its GPU once) -- the same start, hence the same fit, as n_gpus=1."""
     from pycmf_amd import CMF
     monkeypatch.setenv("PYCMF_AMD_SAME_DEVICE", "1")
-    monkeypatch.setenv("PYCMF_AMD_DIST_BACKEND", "gloo")
+    monkeypatch.setenv("CMF_COMM_BACKEND", "host")
+    monkeypatch.setenv("CMF_COMM_TIMEOUT", "120")
     rng = np.random.RandomState(5)
     U, V, Z = np.abs(rng.randn(2600, 6)), np.abs(rng.randn(1700, 6)), np.abs(rng.randn(60, 6))
     X, Y = U @ V.T + 0.01 * np.abs(rng.randn(2600, 1700)), V @ Z.T           # 4.4e6 cells
@@ -220,3 +264,33 @@ def test_cmf_n_gpus_initialises_on_rank0_for_large_inputs(monkeypatch):
     assert two.n_iter_ == one.n_iter_
     np.testing.assert_allclose(two.reconstruction_err_, one.reconstruction_err_, rtol=1e-3)
     np.testing.assert_allclose(two.components, one.components, rtol=0, atol=2e-3 * np.abs(one.components).max())
+
+
+def test_cmf_n_gpus_sparse_linear_newton_takes_north_stars_partition(monkeypatch):
+    """``CMF(solver='newton', n_gpus=2)`` with linear links on CSR X: the front end routes it to north_star's partition
+    (nnz-balanced row blocks of X / U, column blocks of Y / Z, V replicated, X resident once per rank) with, per iteration, the
+    k^2 float64 Gram all-reduce and ONE all-reduce of the d x k partial -- not to the three all-gathers of the row-sharded
+    form -- and reproduces the single-GPU fit."""
+    import scipy.sparse as sp
+    from pycmf_amd import CMF
+    from pycmf_amd import multi_gpu
+    monkeypatch.setenv("PYCMF_AMD_SAME_DEVICE", "1")
+    monkeypatch.setenv("CMF_COMM_BACKEND", "host")
+    monkeypatch.setenv("CMF_COMM_TIMEOUT", "120")
+    rng = np.random.RandomState(4)
+    m, d, p, k = 400, 220, 60, 5
+    dens = rng.rand(m, 1) * 0.3                                   # heavy-tailed rows: the nnz-balanced cut is not the middle row
+    X = sp.csr_matrix(np.abs(rng.randn(m, d)) * (rng.rand(m, d) < dens))
+    Y = np.abs(rng.randn(d, p))
+    off = multi_gpu.partition(X, Y, "newton", 2, dict(x_link="linear", y_link="linear", sg_sample_ratio=1.0))[0]
+    nnz = np.diff(X.indptr)
+    assert abs(nnz[:off[1]].sum() - nnz[off[1]:].sum()) <= nnz.max() and off[1] != m // 2
+    kw = dict(n_components=k, solver="newton", x_init="random", y_init="random", random_state=0, max_iter=20, l2_reg=0.3,
+              U_non_negative=False, V_non_negative=False, Z_non_negative=False)
+    two = CMF(n_gpus=2, **kw); U2, V2, Z2 = two.fit_transform(X, Y)
+    assert multi_gpu.last_collective_calls[0] == 2 * two.n_iter_
+    one = CMF(n_gpus=1, **kw); U1, V1, Z1 = one.fit_transform(X, Y)
+    assert two.n_iter_ == one.n_iter_
+    np.testing.assert_allclose(two.reconstruction_err_, one.reconstruction_err_, rtol=1e-4)
+    for a, b in ((U2, U1), (V2, V1), (Z2, Z1)):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-4 * np.abs(b).max())

@@ -1,0 +1,47 @@
+"""Prints the measured distance of the Newton paths to the golden fixtures (what the tolerances in tests/ are set from).
+GPU box:  python tools/measure_parity.py"""
+import sys, os, warnings
+import numpy as np
+import scipy.sparse as sp
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_golden
+from test_oracle_golden import NEWTON_CASES
+from pycmf_amd import CMF
+from pycmf_amd.solver_shell import HipNewtonSolver
+
+g = load_golden("g4_fit_level")
+for solver in ("mu", "newton"):
+    m = CMF(n_components=5, solver=solver, x_init="custom", y_init="custom", random_state=0, max_iter=1000)
+    U, V, Z = m.fit_transform(g["fc_X"], g["fc_Y"], U=g["fc_U0"].copy(), V=g["fc_V0"].copy(), Z=g["fc_Z0"].copy())
+    ref_err = float(g["fc_%s_err" % solver])
+    print("fit custom %s: n_iter %d/%d err rel %.2e  U maxabs %.2e" % (solver, m.n_iter_, int(g["fc_%s_n_iter" % solver]),
+          abs(m.reconstruction_err_ - ref_err) / ref_err, np.abs(U - g["fc_%s_U" % solver]).max()))
+    m = CMF(n_components=5, solver=solver, x_init="nndsvdar", y_init="nndsvdar", random_state=0, max_iter=1000)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.fit(g["fc_X"], g["fc_Y"])
+    ref_err = float(g["fc_%s_nndsvdar_err" % solver])
+    print("fit nndsvdar %s: n_iter %d/%d err rel %.2e" % (solver, m.n_iter_, int(g["fc_%s_nndsvdar_n_iter" % solver]), abs(m.reconstruction_err_ - ref_err) / ref_err))
+
+g = load_golden("g3_newton_steps")
+for name in sorted(NEWTON_CASES):
+    xl, yl, nn, ratio, seed, l1, l2, signed = NEWTON_CASES[name]
+    for fmt in ("dense", "csr"):
+        X = g["Xlog"] if xl == "logit" else g["X"]
+        Y = g["Ylog"] if yl == "logit" else g["Y"]
+        if fmt == "csr":
+            X = sp.csr_matrix(X)
+        sfx = "s" if signed else "p"
+        U, V, Z = g["U0" + sfx].copy(), g["V0" + sfx].copy(), g["Z0" + sfx].copy()
+        s = HipNewtonSolver(alpha=0.3, l1_reg=l1, l2_reg=l2, x_link=xl, y_link=yl, U_non_negative=nn, V_non_negative=nn,
+                            Z_non_negative=nn, hessian_pertubation=0.2, sg_sample_ratio=ratio, random_state=seed)
+        out = []
+        for it in range(1, 4):
+            s.update_step(X, Y, U, V, Z, l1, l2, 0.3)
+            if it in (1, 3):
+                e = max(np.abs(a - g["%s_%s_%s%d" % (name, fmt, n, it)]).max() / max(1.0, np.abs(g["%s_%s_%s%d" % (name, fmt, n, it)]).max())
+                        for n, a in (("U", U), ("V", V), ("Z", Z)))
+                out.append(e)
+        s.release()
+        print("golden step %-22s %-5s it1 %.2e it3 %.2e" % (name, fmt, out[0], out[1]))
