@@ -115,6 +115,8 @@ int cmf_set_data_csr(cmf_ctx *ctx, int which, const int64_t *indptr, const int32
  * (gi,gj) depends only on seed and its GLOBAL coordinates, so a shard can be
  * generated in place): rows [row0,row0+rows) x cols [col0,col0+cols) of the
  * global matrix land in the local matrix.  Used by bench.py.                 */
+/* representation of X / Y on the device: *dense = a dense float32 image exists, *native = the CSR pair (A, A^T) is resident */
+int cmf_data_layout(cmf_ctx *ctx, int which, int *dense, int *native);
 /* rows x cols block of the dense device image into a packed host array (parity tests at full BASELINE sizes) */
 int cmf_get_data_block_f32(cmf_ctx *ctx, int which, int64_t row0, int64_t nrows, int64_t col0, int64_t ncols, float *host_dst);
 int cmf_fill_data_synthetic(cmf_ctx *ctx, int which, uint64_t seed, int64_t row0, int64_t col0);

@@ -42,6 +42,7 @@ PROTOTYPES = {
     "cmf_fill_factor_synthetic": [_vp, _i32, C.c_uint64, _i64, _dbl],
     "cmf_fill_data_synthetic_kind": [_vp, _i32, C.c_uint64, _i64, _i64, _i32, _dbl],
     "cmf_get_data_f32": [_vp, _i32, _pf, _i64, _i64],
+    "cmf_data_layout": [_vp, _i32, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "cmf_get_data_block_f32": [_vp, _i32, _i64, _i64, _i64, _i64, _pf],
     "cmf_sample_lists": [_vp, _i32, C.c_uint64, _dbl, _i64, _i64, _pi32],
     "cmf_data_matmul_f64": [_vp, _i32, _i32, _pd, _i64, _i32, _pd],
@@ -293,6 +294,12 @@ class Context:
         sx, sy = C.c_double(0), C.c_double(0)
         check(self._lib.cmf_data_sum(self._h, C.byref(sx), C.byref(sy)))
         return sx.value, sy.value
+
+    def data_layout(self, which):
+        """(dense image exists, native CSR pair resident) of X (0) / Y (1)."""
+        a, b = C.c_int(0), C.c_int(0)
+        check(self._lib.cmf_data_layout(self._h, which, C.byref(a), C.byref(b)))
+        return bool(a.value), bool(b.value)
 
     def get_data_block(self, which, row0, nrows, col0, ncols):
         """float32 block of the dense device image of X (0) / Y (1)."""

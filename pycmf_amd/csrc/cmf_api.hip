@@ -155,6 +155,7 @@ struct cmf_ctx {
     DevBuf hrows;                         // chunk of per-row Hessians / inverses
     DevBuf mask1, mask2;                  // stochastic sample masks (bytes)
     DevBuf lists1, lists2;                // device copies of the per-row sample index lists
+    DevBuf lists1s, lists2s, zerobuf;     // ascending copies of host-drawn lists (sparse target term); a few zero floats (zero targets)
     DevBuf cls_idx[2], cls_off[2], cls_cnt[2], cls_pat[2], hclass; // shared partial sums of linear sampled sides: class lists, pattern bytes, class images
     DevBuf certimg, certflag;             // per half group: the part of the Hessians common to its rows, and whether it alone passes the threshold test
     int opt_direct_step = 1;              // linear shared-Hessian sweeps with l1 = 0 and an unclamped inverse: F <- clamp(s (T O) H^-1) in one product
@@ -631,7 +632,7 @@ static void release_problem(cmf_ctx *c) {
     c->num = c->den = c->G = c->G2 = c->Hm = c->Hinv = c->Eye = c->vbuf = nullptr;
     c->slabs = DevBuf(); c->slabs_b = DevBuf(); c->slab_sel = 0; c->tickets = DevBuf(); c->resid = DevBuf(); c->resid2 = DevBuf(); c->resid3 = DevBuf(); c->dpart = DevBuf();
     c->kr1 = DevBuf(); c->kr2 = DevBuf(); c->hrows = DevBuf(); c->mask1 = DevBuf(); c->mask2 = DevBuf();
-    c->lists1 = DevBuf(); c->lists2 = DevBuf();
+    c->lists1 = DevBuf(); c->lists2 = DevBuf(); c->lists1s = DevBuf(); c->lists2s = DevBuf(); c->zerobuf = DevBuf();
     for (int q = 0; q < 2; ++q) { c->cls_idx[q] = DevBuf(); c->cls_off[q] = DevBuf(); c->cls_cnt[q] = DevBuf(); c->cls_pat[q] = DevBuf(); }
     c->hclass = DevBuf(); c->certimg = DevBuf(); c->certflag = DevBuf();
     c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf();
@@ -992,6 +993,16 @@ extern "C" int cmf_get_data_f32(cmf_ctx *c, int which, float *ptr, int64_t rs, i
     if (!*slot && c->sparse[which]) CHK(need_dense(c, which));
     if (!*slot) return fail(CMF_EINVAL, "data %d not set", which);
     return download_strided<float>(c, *slot, cp, r, cc, ptr, rs, cs);
+}
+
+// which image of X / Y lives on the device: *dense = 1 when a dense float32 image exists (dense input, small sparse input, or a
+// sparse input that some sweep had to expand), *native = 1 when the CSR pair (A, A^T) is resident
+extern "C" int cmf_data_layout(cmf_ctx *c, int which, int *dense, int *native) {
+    NEED_PROBLEM(c);
+    if (which != 0 && which != 1) return fail(CMF_EINVAL, "which must be 0 (X) or 1 (Y)");
+    if (dense) *dense = (which == 0 ? c->X : c->Y) != nullptr ? 1 : 0;
+    if (native) *native = c->sparse[which] ? 1 : 0;
+    return CMF_OK;
 }
 
 // a rows x cols block of the DENSE device image of X / Y into a packed host array (parity tests at sizes whose whole matrix

@@ -251,9 +251,12 @@ static int safe_solve_rows(cmf_ctx *c, float *Hc, const float *grad, float *step
     {
         Timed tm(c, CMF_K_EIGEN);
         const dim3 grid((unsigned)nr), block(256);
-        if (n <= 32) hipLaunchKernelGGL((chol_solve_kernel<2>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag);
-        else if (n <= 64) hipLaunchKernelGGL((chol_solve_kernel<4>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag);
-        else if (n <= 128) hipLaunchKernelGGL((chol_solve_kernel<8>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag);
+        if (n <= 32) hipLaunchKernelGGL((chol_solve_kernel<2>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag,
+                                         (const int *)nullptr, 1, cert.flags, cert.rows, cert.split);
+        else if (n <= 64) hipLaunchKernelGGL((chol_solve_kernel<4>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag,
+                                              (const int *)nullptr, 1, cert.flags, cert.rows, cert.split);
+        else if (n <= 128) hipLaunchKernelGGL((chol_solve_kernel<8>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag,
+                                               (const int *)nullptr, 1, cert.flags, cert.rows, cert.split);
         else hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag,
                                 (const int *)nullptr, 1, cert.flags, cert.rows, cert.split);
         HIPCHK(hipGetLastError());
@@ -1016,8 +1019,9 @@ static int launch_row_hess(cmf_ctx *c, const RowHessArgs &a, int64_t nrows, doub
 
 // device index lists for one sweep side: from the host lists (parity mode) or from the device sampler
 static int sample_lists(cmf_ctx *c, DevBuf &lb, DevBuf &mb, const int32_t *host_idx, int64_t nlists, int64_t per, int64_t n,
-                        int salt, const int32_t **out) {
+                        int salt, const int32_t **out, DevBuf *sorted_buf = nullptr, const int32_t **sorted_out = nullptr) {
     *out = nullptr;
+    if (sorted_out) *sorted_out = nullptr;
     if (nlists * per == 0) return CMF_OK;
     CHK(ensure(c, lb, (size_t)nlists * per * sizeof(int32_t)));
     if (c->dev_sampling) {
@@ -1031,8 +1035,18 @@ static int sample_lists(cmf_ctx *c, DevBuf &lb, DevBuf &mb, const int32_t *host_
     } else {
         HIPCHK(hipMemcpyAsync(lb.p, host_idx, (size_t)nlists * per * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         CHK(check_index_lists(c, (const int32_t *)lb.p, nlists * per, n)); // also waits: host_idx is caller memory
+        if (sorted_buf) { // the sparse target term looks samples up by binary search: an ascending copy of every list (NumPy's
+                          // permutation order stays what the row kernel sums in)
+            std::vector<int32_t> srt(host_idx, host_idx + nlists * per);
+            for (int64_t l = 0; l < nlists; ++l) std::sort(srt.begin() + l * per, srt.begin() + (l + 1) * per);
+            CHK(ensure(c, *sorted_buf, (size_t)nlists * per * sizeof(int32_t)));
+            HIPCHK(hipMemcpyAsync(sorted_buf->p, srt.data(), (size_t)nlists * per * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream)); // srt is a local
+            *sorted_out = (const int32_t *)sorted_buf->p;
+        }
     }
     *out = (const int32_t *)lb.p;
+    if (sorted_out && !*sorted_out) *sorted_out = *out; // the device sampler emits ascending lists
     return CMF_OK;
 }
 
@@ -1048,7 +1062,43 @@ struct RowSide {
     int cls = 0;                // > 0: shared partial sums over groups of `cls` rows (linear link, sampled; cmf_rowhess.hip.h)
     int64_t n = 0;              // candidates the lists draw from
     int slot = 0;               // which of the two class-list buffers
+    // natively sparse data on this side: the row kernel runs with zero targets and the stored values of data row i that lie in
+    // its sample enter the gradient afterwards (sparse_target_term); `sp` = CSR image whose row i belongs to factor row i
+    const CsrDev *sp = nullptr;
+    const int32_t *sorted = nullptr; // ascending copies of the lists (null: not sampled)
 };
+
+// zero targets for a native sparse side: one float of zeros read with strides 0
+static int zero_targets(cmf_ctx *c, RowSide &sd, const CsrDev *sp) {
+    CHK(ensure(c, c->zerobuf, 256));
+    HIPCHK(hipMemsetAsync(c->zerobuf.p, 0, 256, c->stream));
+    sd.T = (const float *)c->zerobuf.p; sd.t_row = 0; sd.t_col = 0; sd.sp = sp; sd.cls = 0;
+    return CMF_OK;
+}
+// grad[r0 .. r0 + nr) -= s * sum over the stored values t_ij of data row i with j in S_i of t_ij o_j   (see csr_sampled_sub_kernel)
+static int sparse_target_term(cmf_ctx *c, const RowSide &sd, float *grad_rows, int64_t r0, int64_t nr) {
+    const CsrDev &A = *sd.sp;
+    CsrView v{A.indptr, A.idx, A.val, A.rows};
+    const int64_t nrows = std::min(nr, A.rows - r0);
+    if (nrows <= 0) return CMF_OK;
+    Timed tm(c, CMF_K_SPMM, 2.0 * (double)A.nnz * (double)c->kp * (double)nrows / (double)std::max<int64_t>(1, A.rows));
+#define CMF_SUBK(GL_, CH_)                                                                                                     \
+    do {                                                                                                                        \
+        const int64_t waves = (nrows + (64 / GL_) - 1) / (64 / GL_);                                                            \
+        hipLaunchKernelGGL((csr_sampled_sub_kernel<GL_, CH_>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, c->stream, v, sd.O, c->kp, \
+                           grad_rows, (float)sd.scale, r0, nrows, sd.sorted, sd.per);                                          \
+    } while (0)
+    switch (c->kp) {
+    case 32: CMF_SUBK(8, 1); break;
+    case 64: CMF_SUBK(16, 1); break;
+    case 128: CMF_SUBK(32, 1); break;
+    case 256: CMF_SUBK(64, 1); break;
+    default: return fail(CMF_EUNSUPPORTED, "native sparse per-row sweeps support k_pad <= 256");
+    }
+#undef CMF_SUBK
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
 
 // Rows per group for the shared-partial-sum form of a linear, sampled side, or 0: worth it when the distinct samples of a
 // group, n (1 - (1 - rho)^R), are well below the R rho n of the row-by-row form.
@@ -1149,10 +1199,20 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
     CHK(ensure(c, c->hrows, (size_t)chunk * kk * sizeof(float)));
     float *Hc = (float *)c->hrows.p;
     float *grad = c->num, *step = c->den;
+    // global certificate: every H_i of this sweep is  (sums of w o o^T, w >= 0) + (positive semi-definite shared part) + diag I,
+    // so diag >= pert alone puts lambda_min(H_i) at or above the threshold of _safe_invert (cmf_solvers.py:346-356): the safe
+    // inverse is the plain inverse for EVERY row and nobody runs the Cholesky test of H_i - pert I (half of the solve kernel).
+    // The reference's own sparse Newton settings (l2_reg = 5, hessian_pertubation = 0.2) are such a case.
+    const bool global_cert = c->hess_psd && c->opt_rowcert && !c->opt_choldiag && diag >= pert && c->k <= 256;
+    if (global_cert) {
+        CHK(ensure(c, c->certflag, 2 * sizeof(int)));
+        HIPCHK(hipMemsetAsync(c->certflag.p, 0, 2 * sizeof(int), c->stream));
+    }
     for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
         const int64_t nr = std::min(chunk, rows - r0);
         bool have_h = false, have_g = grad_preloaded;
         RowCert cert;
+        if (global_cert) { cert.flags = (const int *)c->certflag.p; cert.rows = 0x7fffffff; cert.split = 0; }
         for (const RowSide *sd : {&s1, &s2}) {
             if (!sd->active) continue;
             RowHessArgs a;
@@ -1217,9 +1277,11 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
             have_h = have_g = true;
         }
         if (!have_h) CHK(launch_ew(c, hessian_finalize_kernel, nr * kk, Hc, S, (float)diag, nr, c->kp, c->k, 0));
+        for (const RowSide *sd : {&s1, &s2})
+            if (sd->active && sd->sp) CHK(sparse_target_term(c, *sd, grad + r0 * c->kp, r0, nr));
         CHK(launch_ew(c, newton_grad_kernel, nr * c->kp, grad + r0 * c->kp, (const float *)(grad + r0 * c->kp), 1.0f, (const float *)nullptr, 0.f,
                       (const float *)(c->F[which] + r0 * c->kp), (float)l1, (float)l2, nr * c->kp));
-        if (cert.flags) { // test the certificates (threshold test only): part + diag I - pert I positive definite?
+        if (cert.flags && !global_cert) { // test the certificates (threshold test only): part + diag I - pert I positive definite?
             Timed tm(c, CMF_K_EIGEN);
             const int64_t ncert = 2 * ((nr + cert.rows - 1) / cert.rows);
             hipLaunchKernelGGL((chol_solve_kernel<16>), dim3((unsigned)ncert), dim3(256), 0, c->stream, (const float *)c->certimg.p, (const float *)nullptr,
@@ -1239,11 +1301,16 @@ static int sweep_side_fused(cmf_ctx *c, bool is_u, int link, double scale, doubl
     sd.active = true;
     sd.O = c->F[CMF_V];
     sd.per = sampled ? per : c->d;
-    if (sampled) CHK(sample_lists(c, c->lists1, c->mask1, idx, c->frows[which], per, c->d, is_u ? 0 : 1, &sd.lists));
+    const int dw = is_u ? 0 : 1;
+    const bool native = (dw == 0 ? c->X : c->Y) == nullptr && c->sparse[dw]; // the data of this sweep stays CSR
+    if (sampled) CHK(sample_lists(c, c->lists1, c->mask1, idx, c->frows[which], per, c->d, is_u ? 0 : 1, &sd.lists,
+                                  native ? &c->lists1s : nullptr, native ? &sd.sorted : nullptr));
     if (is_u) { sd.T = c->X; sd.t_row = c->dp; sd.t_col = 1; }
     else { sd.T = c->Y; sd.t_row = 1; sd.t_col = c->pp; }
     sd.scale = scale; sd.link = link;
     sd.n = c->d; sd.cls = class_group_rows(c, link, sampled, per, c->d);
+    // U rows pair with rows of X, Z rows with rows of Y^T
+    if (native) CHK(zero_targets(c, sd, &c->sp[dw][is_u ? 0 : 1]));
     if (sd.cls) {
         CHK(build_class_lists(c, sd, c->frows[which]));
         CHK(class_side_gradient(c, is_u, is_u, sd, c->frows[which], scale, which, false));
@@ -1280,9 +1347,12 @@ static int sweep_v_fused(cmf_ctx *c, double alpha, double l1, double l2, int x_l
     if (!x_shared) {
         sx.active = true; sx.O = c->F[CMF_U];
         sx.per = sampled ? per_x : c->m;
-        if (sampled) CHK(sample_lists(c, c->lists1, c->mask1, vx_idx, c->d, per_x, c->m, 2, &sx.lists));
+        const bool native = c->X == nullptr && c->sparse[0];
+        if (sampled) CHK(sample_lists(c, c->lists1, c->mask1, vx_idx, c->d, per_x, c->m, 2, &sx.lists, native ? &c->lists1s : nullptr,
+                                      native ? &sx.sorted : nullptr));
         sx.T = c->X; sx.t_row = 1; sx.t_col = c->dp; sx.scale = alpha; sx.link = x_link;
         sx.n = c->m; sx.slot = 0; sx.cls = class_group_rows(c, x_link, sampled, per_x, c->m);
+        if (native) CHK(zero_targets(c, sx, &c->sp[0][1])); // V row i pairs with column i of X = row i of X^T
         if (sx.cls) {
             CHK(build_class_lists(c, sx, c->d));
             CHK(class_side_gradient(c, true, false, sx, c->d, alpha, CMF_V, preloaded));
@@ -1292,9 +1362,12 @@ static int sweep_v_fused(cmf_ctx *c, double alpha, double l1, double l2, int x_l
     if (!y_shared) {
         sy.active = true; sy.O = c->F[CMF_Z];
         sy.per = sampled ? per_y : c->p;
-        if (sampled) CHK(sample_lists(c, c->lists2, c->mask2, vy_idx, c->d, per_y, c->p, 3, &sy.lists));
+        const bool native = c->Y == nullptr && c->sparse[1];
+        if (sampled) CHK(sample_lists(c, c->lists2, c->mask2, vy_idx, c->d, per_y, c->p, 3, &sy.lists, native ? &c->lists2s : nullptr,
+                                      native ? &sy.sorted : nullptr));
         sy.T = c->Y; sy.t_row = c->pp; sy.t_col = 1; sy.scale = 1.0 - alpha; sy.link = y_link;
         sy.n = c->p; sy.slot = 1; sy.cls = class_group_rows(c, y_link, sampled, per_y, c->p);
+        if (native) CHK(zero_targets(c, sy, &c->sp[1][0])); // V row i pairs with row i of Y
         if (sy.cls) {
             CHK(build_class_lists(c, sy, c->d));
             CHK(class_side_gradient(c, false, true, sy, c->d, 1.0 - alpha, CMF_V, preloaded));
@@ -1353,7 +1426,8 @@ static int newton_step_impl(cmf_ctx *c, double alpha, double l1, double l2, int 
     bool vgram = false; // V^T V (float64) left behind by a shared U sweep for the Z sweep that follows (V unchanged)
     if (upd & CMF_UPD_U) {
         if (!have_data(c, 0)) return fail(CMF_EINVAL, "X must be set before a U update");
-        if (!(x_link == CMF_LINK_LINEAR && !sampled)) CHK(need_dense(c, 0));
+        // the fused per-row sweeps keep a natively sparse side sparse (zero-target row kernel + sparse target term)
+        if (!(x_link == CMF_LINK_LINEAR && !sampled) && !fused) CHK(need_dense(c, 0));
         if (x_link == CMF_LINK_LINEAR && !sampled) {
             CHK(sweep_side_shared(c, true, alpha, l1, l2, pert, (nn_mask & CMF_NN_U) != 0));
             vgram = use_shared64(c);
@@ -1368,7 +1442,7 @@ static int newton_step_impl(cmf_ctx *c, double alpha, double l1, double l2, int 
     }
     if (upd & CMF_UPD_Z) {
         if (!have_data(c, 1)) return fail(CMF_EINVAL, "Y must be set before a Z update");
-        if (!(y_link == CMF_LINK_LINEAR && !sampled)) CHK(need_dense(c, 1));
+        if (!(y_link == CMF_LINK_LINEAR && !sampled) && !fused) CHK(need_dense(c, 1));
         if (y_link == CMF_LINK_LINEAR && !sampled)
             CHK(sweep_side_shared(c, false, 1.0 - alpha, l1, l2, pert, (nn_mask & CMF_NN_Z) != 0, vgram));
         else if (fused) {
@@ -1382,14 +1456,15 @@ static int newton_step_impl(cmf_ctx *c, double alpha, double l1, double l2, int 
     }
     if (upd & CMF_UPD_V) {
         if (!have_data(c, 0) || !have_data(c, 1)) return fail(CMF_EINVAL, "X and Y must be set before a V update");
-        // a natively sparse side stays sparse while ITS part of the sweep is shared (linear link, no sampling): the fused V
-        // sweep serves it from the SpMM gradient + the shared Gram (sweep_v_fused) and never reads a dense image -- the
-        // reference's own sparse-X / logit-Y Newton workload (samples/toxic_comments.ipynb:853-856; cmf_solvers.py:432-486)
+        // a natively sparse side stays sparse in the fused sweeps: a shared part (linear link, no sampling) is served from the
+        // SpMM gradient + the shared Gram, a per-row part by the zero-target row kernel + the sparse target term -- the
+        // reference's own sparse Newton workloads (samples/toxic_comments.ipynb:853-856, benchmarks/benchmark_cmf.py:72-82;
+        // cmf_solvers.py:328-344, :432-486)
         {
             const bool xs = (x_link == CMF_LINK_LINEAR && !sampled), ys = (y_link == CMF_LINK_LINEAR && !sampled);
-            if (!(xs && ys)) {
-                if (!xs || !fused) CHK(need_dense(c, 0));
-                if (!ys || !fused) CHK(need_dense(c, 1));
+            if (!(xs && ys) && !fused) {
+                CHK(need_dense(c, 0));
+                CHK(need_dense(c, 1));
             }
         }
         if (x_link == CMF_LINK_LINEAR && y_link == CMF_LINK_LINEAR && !sampled && use_reassoc(c)) {

@@ -61,6 +61,48 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(CsrView A, const float *F
     }
 }
 
+// Target term of a per-row Newton gradient on a NATIVE sparse side (cmf_newton.hip.h): the row kernel ran with zero targets, i.e.
+// it accumulated  s sum_{j in S_i} f(f_i . o_j) o_j;  the reference's residual is f(.) - t_ij (pycmf/cmf_solvers.py:419-420,
+// :459-461, :495-497), so what is missing is  - s sum_{j in S_i, t_ij != 0} t_ij o_j  -- a row-gather SpMM over the stored values
+// of data row i that lie in its sample S_i (all of them when the sweep is not sampled).  `lists`: the rows' ASCENDING index
+// lists (per entries each) or null; membership by binary search.  grad rows are relative to row0.
+template <int GL, int CH>
+__global__ __launch_bounds__(256) void csr_sampled_sub_kernel(CsrView A, const float *F, int kp, float *grad, float scale, int64_t row0,
+                                                              int64_t nrows, const int32_t *lists, int64_t per) {
+    constexpr int RPW = 64 / GL;
+    const int lane = threadIdx.x & 63;
+    const int gl = lane % GL, gsub = lane / GL;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t lr = wave * RPW + gsub;
+    if (lr >= nrows) return;
+    const int64_t row = row0 + lr;
+    const int64_t beg = A.indptr[row], end = A.indptr[row + 1];
+    const int32_t *L = lists ? lists + row * per : nullptr;
+    f32x4 acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t q = beg; q < end; ++q) {
+        const int32_t j = A.idx[q];
+        if (L) { // j in S_i ?
+            int64_t lo = 0, hi = per;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (L[mid] < j) lo = mid + 1;
+                else hi = mid;
+            }
+            if (lo >= per || L[lo] != j) continue;
+        }
+        const float v = A.val[q];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[c] += v * *reinterpret_cast<const f32x4 *>(F + (int64_t)j * kp + 4 * (gl + GL * c));
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        f32x4 *dst = reinterpret_cast<f32x4 *>(grad + lr * kp + 4 * (gl + GL * c));
+        *dst = *dst - scale * acc[c];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Output-stationary, column-blocked SpMM for matrices whose gathered operand does not fit the XCD's 4 MB L2
 // (C5: X V gathers 1 KB rows of a 102 MB V, X^T U of a 1 GB U; one gather per non-zero served by the Infinity Cache /

@@ -292,6 +292,36 @@ def test_group_certificates_do_not_change_the_step(lib, l2, rank):
     assert np.abs(got[1] - U0).max() > 0
 
 
+@pytest.mark.parametrize("k", [24, 200])
+def test_global_certificate_when_l2_reaches_the_perturbation(lib, k):
+    """l2 >= hessian_pertubation with non-negative weights: every per-row Hessian is (positive semi-definite) + l2 I, so
+    _safe_invert (pycmf/cmf_solvers.py:346-356) never clamps and no row needs its threshold test -- the reference's own sparse
+    Newton settings (l2_reg = 5).  Same step with the certificate (default) and with every row testing itself, bit for bit,
+    on the Z sweep (logit, row by row) and the V sweep (shared linear X side + per-row logit Y side); and the oracle's step."""
+    from oracle import cmf_oracle as O
+    m, d, p = 90, 700, 30
+    rng = np.random.RandomState(k)
+    X, Y = np.abs(rng.randn(m, d)), (rng.rand(d, p) < 0.2).astype(np.float64)
+    sc = (0.8 / k) ** 0.5
+    U0, V0, Z0 = sc * np.abs(rng.randn(m, k)), sc * np.abs(rng.randn(d, k)), sc * rng.randn(p, k)
+    got = {}
+    for certs in (1, 0):
+        ctx = lib.Context(0)
+        ctx.set_option("row_certificates", certs)
+        ctx.set_problem(m, d, p, k)
+        ctx.set_data(0, X); ctx.set_data(1, Y)
+        for w, F in enumerate((U0, V0, Z0)):
+            ctx.set_factor(w, F)
+        ctx.newton_step(0.5, 0.05, 0.6, "linear", "logit", 3, 7, 0.2, 1.0)
+        got[certs] = [ctx.get_factor(w) for w in range(3)]
+        ctx.close()
+    U, V, Z = U0.copy(), V0.copy(), Z0.copy()
+    O.newton_update_step(X, Y, U, V, Z, 0.5, 0.05, 0.6, "linear", "logit", True, True, False, 1.0, 0.2)
+    for a, b, o in zip(got[1], got[0], (U, V, Z)):
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_allclose(a, o, rtol=0, atol=5e-4 * np.abs(o).max())
+
+
 @pytest.mark.parametrize("name", ["lin_log_nn", "log_log_free", "lin_log_free_sg"])
 def test_cython_variant_matches_compiled_reference(lib, name):
     """HipNewtonSolver(cython_variant=True) reproduces the reference's Cython twin (g7 fixture)."""

@@ -457,3 +457,17 @@ def test_comm_without_a_gpu_fails_loudly(tmp_path, monkeypatch):
     monkeypatch.setenv("CMF_COMM_KEY", "nogpu")
     with pytest.raises(RuntimeError, match="libcmfhip"):
         comm.exchange_unique_id(0, 1)
+
+
+def test_integration_md_stub_parses_and_binds_declared_symbols():
+    """INTEGRATION.md section 1 (the reference-side ctypes stub): valid Python, and every entry point it calls is declared in
+    include/cmfhip.h (its execution against the golden MU steps is the -m gpu test tests/test_gpu_integration_doc.py)."""
+    import ast
+    import re
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## 1."):text.index("## 2.")]
+    (block,) = re.findall(r"```python\n(.*?)```", sec, re.S)
+    ast.parse(block)
+    header = open(os.path.join(ROOT, "include", "cmfhip.h")).read()
+    called = set(re.findall(r"_lib\.(cmf_\w+)", block))
+    assert called and all(re.search(r"\b%s\s*\(" % name, header) for name in called), called
