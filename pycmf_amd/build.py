@@ -1,6 +1,6 @@
 """Build libcmfhip.so (gfx950 only) in-tree with hipcc.
 
-    python -m pycmf_amd.build [--force] [--verbose]
+    python -m pycmf_amd.build [--force] [--verbose] [--diag]
 
 hipcc cross-compiles without a GPU, so this also runs in the CPU-only build
 container.  The .so stays next to this file (git-ignored) so that it travels
@@ -37,11 +37,15 @@ def needs_build():
     return False
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, diag=False):
+    """diag: also compile the timing-only diagnostic kernel variants (row_diag / chol_diag / cmf_debug_clock: wrong results,
+    tools/archive/probe_*.py); the default product build does not carry them."""
+    if not force and not diag and not needs_build():
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
            "-I", os.path.join(ROOT, "include"), "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if diag:
+        cmd.append("-DCMF_DIAG_BUILD")
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))
@@ -50,5 +54,5 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
+    build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, diag="--diag" in sys.argv)
     print(LIB)

@@ -155,6 +155,8 @@ struct cmf_ctx {
     DevBuf hrows;                         // chunk of per-row Hessians / inverses
     DevBuf mask1, mask2;                  // stochastic sample masks (bytes)
     DevBuf lists1, lists2;                // device copies of the per-row sample index lists
+    DevBuf lr_small, lr_rows;             // low-rank per-row side (sweep_v_lowrank): B / Z^T / K images; per-row p x p systems
+    int opt_lowrank = 1;                  // Woodbury form of the V sweep when the per-row side has fewer samples than components
     DevBuf lists1s, lists2s, zerobuf;     // ascending copies of host-drawn lists (sparse target term); a few zero floats (zero targets)
     DevBuf cls_idx[2], cls_off[2], cls_cnt[2], cls_pat[2], hclass; // shared partial sums of linear sampled sides: class lists, pattern bytes, class images
     DevBuf certimg, certflag;             // per half group: the part of the Hessians common to its rows, and whether it alone passes the threshold test
@@ -632,7 +634,7 @@ static void release_problem(cmf_ctx *c) {
     c->num = c->den = c->G = c->G2 = c->Hm = c->Hinv = c->Eye = c->vbuf = nullptr;
     c->slabs = DevBuf(); c->slabs_b = DevBuf(); c->slab_sel = 0; c->tickets = DevBuf(); c->resid = DevBuf(); c->resid2 = DevBuf(); c->resid3 = DevBuf(); c->dpart = DevBuf();
     c->kr1 = DevBuf(); c->kr2 = DevBuf(); c->hrows = DevBuf(); c->mask1 = DevBuf(); c->mask2 = DevBuf();
-    c->lists1 = DevBuf(); c->lists2 = DevBuf(); c->lists1s = DevBuf(); c->lists2s = DevBuf(); c->zerobuf = DevBuf();
+    c->lists1 = DevBuf(); c->lists2 = DevBuf(); c->lists1s = DevBuf(); c->lists2s = DevBuf(); c->zerobuf = DevBuf(); c->lr_small = DevBuf(); c->lr_rows = DevBuf();
     for (int q = 0; q < 2; ++q) { c->cls_idx[q] = DevBuf(); c->cls_off[q] = DevBuf(); c->cls_cnt[q] = DevBuf(); c->cls_pat[q] = DevBuf(); }
     c->hclass = DevBuf(); c->certimg = DevBuf(); c->certflag = DevBuf();
     c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf();
@@ -695,6 +697,10 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "z_logit_hessian_l2")) {
         c->opt_zlogit_l2 = value != 0;
     } else if (!strcmp(name, "row_diag")) {
+#ifndef CMF_DIAG_BUILD
+        if (value != 0) return fail(CMF_EINVAL, "row_diag is a timing-only diagnostic (wrong results) that the default build does not carry: "
+                                                "build with `python -m pycmf_amd.build --diag` and set CMF_DIAG=1");
+#endif
         if (value != 0 && !c->diag_ok) return fail(CMF_EINVAL, "row_diag is a timing-only diagnostic (wrong results): set CMF_DIAG=1 in the environment to allow it");
         c->opt_rowdiag = (int)value;
     } else if (!strcmp(name, "row_stagger")) {
@@ -726,6 +732,10 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "newton_schulz")) {
         c->opt_ns = value != 0;
     } else if (!strcmp(name, "chol_diag")) {
+#ifndef CMF_DIAG_BUILD
+        if (value != 0) return fail(CMF_EINVAL, "chol_diag is a timing-only diagnostic (wrong results) that the default build does not carry: "
+                                                "build with `python -m pycmf_amd.build --diag` and set CMF_DIAG=1");
+#endif
         if (value != 0 && !c->diag_ok) return fail(CMF_EINVAL, "chol_diag is a timing-only diagnostic (wrong results): set CMF_DIAG=1 in the environment to allow it");
         c->opt_choldiag = (int)value;
     } else if (!strcmp(name, "safe_inverse_cholesky")) {
@@ -738,6 +748,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_fused_mu = value != 0;
     } else if (!strcmp(name, "shared_hessian_f64")) {
         c->opt_shared64 = value != 0;
+    } else if (!strcmp(name, "lowrank_rows")) {
+        c->opt_lowrank = value != 0;
     } else if (!strcmp(name, "newton_reassoc")) {
         c->opt_reassoc = value != 0;
     } else if (!strcmp(name, "spmm_blocked")) {
@@ -1343,6 +1355,10 @@ extern "C" int cmf_data_sq(cmf_ctx *c, double *x2, double *y2) {
 // Diagnostic: launch the NN data pass X*V once with clock stamps; returns the median over workgroups of
 // (shader cycles / elapsed time) in GHz and of the main-loop duration in microseconds.
 extern "C" int cmf_debug_clock(cmf_ctx *c, double *ghz, double *loop_us) {
+#ifndef CMF_DIAG_BUILD
+    (void)c; (void)ghz; (void)loop_us;
+    return fail(CMF_EUNSUPPORTED, "cmf_debug_clock: diagnostic builds only (python -m pycmf_amd.build --diag)");
+#else
     NEED_PROBLEM(c);
     if (!c->X) return fail(CMF_EINVAL, "dense X required");
     DeviceGuard dg(c->device);
@@ -1370,10 +1386,9 @@ extern "C" int cmf_debug_clock(cmf_ctx *c, double *ghz, double *loop_us) {
     if (ghz) *ghz = f[f.size() / 2];
     if (loop_us) *loop_us = us[us.size() / 2];
     return CMF_OK;
+#endif
 }
 
-// stream markers: one event per call on the launch stream; cmf_marker_times returns the elapsed ms of every marker
-// since the first one and clears the list (bench.py's per-iteration time series)
 extern "C" int cmf_marker(cmf_ctx *c) {
     if (!c) return fail(CMF_EINVAL, "null context");
     DeviceGuard dg(c->device);

@@ -563,6 +563,58 @@ __global__ __launch_bounds__(256) void rowvec_mat_flagged_kernel(float *step, co
     }
 }
 
+// ---- low-rank per-row side (cmf_newton.hip.h, sweep_v_lowrank) --------------------------------------------------------------------
+// A V row whose per-row Hessian part has FEWER samples than components -- p label columns of Y, p <= 64 < k -- has
+//   H_i = S + Z^T C_i Z,   S = shared part (alpha U^T U + l2 I, one k x k matrix),  C_i = diag(c_ij) >= 0  (p x p),
+// and when the safe inverse is the plain inverse (lambda_min >= pert: certified by l2 >= pert) the Woodbury identity gives
+//   g H_i^-1 = a - (sqrt(C) y)^T B,   a = g S^-1,  B = Z S^-1 (p x k),  K = B Z^T (p x p),
+//   (I + sqrt(C) K sqrt(C)) y = sqrt(C) (B g^T)                      -- a p x p positive definite system per row
+// instead of forming and factoring a k x k matrix per row (reference: cmf_solvers.py:463-486 builds H_i and eigen-decomposes it).
+// K = B Z^T for p <= 64 valid rows (pitch kp in, pitch pk out); one workgroup
+__global__ __launch_bounds__(256) void lowrank_k_kernel(const float *B, const float *Z, float *K, int p, int pk, int kp) {
+    for (int idx = threadIdx.x; idx < pk * pk; idx += 256) {
+        const int j = idx / pk, l = idx % pk;
+        float acc = 0.f;
+        if (j < p && l < p)
+            for (int c = 0; c < kp; ++c) acc += B[(int64_t)j * kp + c] * Z[(int64_t)l * kp + c];
+        K[idx] = acc;
+    }
+}
+// per row i (one workgroup of 256 threads per 4 rows): M_i = I + sqrt(c_i) K sqrt(c_i)^T (pk x pk, row-major), rhs_i = sqrt(c_i) o b_i
+__global__ __launch_bounds__(256) void lowrank_build_kernel(const float *W, const float *Bv, int64_t ldw, const float *K, float *M, float *rhs,
+                                                           int64_t nrows, int p, int pk) {
+    __shared__ float sq[4][64];
+    const int sub = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + sub;
+    const bool live = i < nrows;
+    float s = 0.f;
+    if (live && lane < p) s = __builtin_amdgcn_sqrtf(fmaxf(W[i * ldw + lane], 0.f));
+    sq[sub][lane] = s;
+    __syncthreads();
+    if (!live) return;
+    if (lane < pk) rhs[i * pk + lane] = (lane < p) ? s * Bv[i * ldw + lane] : 0.f;
+    float *Mi = M + i * (int64_t)pk * pk;
+    for (int idx = lane; idx < pk * pk; idx += 64) {
+        const int j = idx / pk, l = idx % pk;
+        Mi[idx] = (j == l ? 1.f : 0.f) + sq[sub][j] * K[idx] * sq[sub][l];
+    }
+}
+// Q (nrows x ldw, zero outside the p valid columns) = sqrt(c_i) o y_i
+__global__ __launch_bounds__(256) void lowrank_scale_kernel(const float *W, const float *y, float *Q, int64_t ldw, int64_t nrows, int p, int pk) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nrows * ldw; idx += (int64_t)gridDim.x * 256) {
+        const int64_t i = idx / ldw;
+        const int j = (int)(idx % ldw);
+        Q[idx] = (j < p) ? __builtin_amdgcn_sqrtf(fmaxf(W[idx], 0.f)) * y[i * pk + j] : 0.f;
+    }
+}
+// out (cols x ld_out) = in (rows x ld_in)^T over the padded extents (small factor images)
+__global__ __launch_bounds__(256) void transpose_small_kernel(const float *in, float *out, int rows, int cols, int ld_in, int ld_out) {
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < rows * cols; idx += gridDim.x * 256) {
+        const int r = idx / cols, c = idx % cols;
+        out[(int64_t)c * ld_out + r] = in[(int64_t)r * ld_in + c];
+    }
+}
+
 // KR[j][a*kp + b] = F[j][a] * F[j][b]     (row-wise Khatri-Rao square of a factor)
 __global__ void khatri_rao_kernel(float *KR, const float *F, int64_t rows, int kp) {
     const int64_t total4 = rows * kp * (kp / 4);

@@ -945,6 +945,7 @@ static int sweep_v_rows(cmf_ctx *c, double alpha, double l1, double l2, int x_li
 template <int KP>
 static int launch_row_hess_kp(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
     using Cfg = RowHessCfg<KP>;
+#ifdef CMF_DIAG_BUILD // timing-only instantiations of the k_pad = 256 kernel (wrong results): python -m pycmf_amd.build --diag
     if (KP == 256 && c->opt_rowdiag > 0) { // DIAGNOSTIC builds of the k_pad = 256 kernel (wrong results)
 #define CMF_ROWDIAG(D_, S_)                                                                                          \
     do {                                                                                                           \
@@ -963,7 +964,9 @@ static int launch_row_hess_kp(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
             else CMF_ROWDIAG(3, 0);
         }
 #undef CMF_ROWDIAG
-    } else if (KP == 256 && c->opt_rowsym == 3 && a.scale >= 0.f && a.cls_cnt && a.cls_upper) { // class launch, upper blocks only
+    } else
+#endif
+    if (KP == 256 && c->opt_rowsym == 3 && a.scale >= 0.f && a.cls_cnt && a.cls_upper) { // class launch, upper blocks only
         constexpr int KS = KP == 256 ? 256 : 0;
         if constexpr (KS == 256) {
             constexpr size_t lds = Cfg::LDS_BYTES / 2; // one image per stage: two workgroups per CU
@@ -1377,6 +1380,84 @@ static int sweep_v_fused(cmf_ctx *c, double alpha, double l1, double l2, int x_l
     return fused_rows_finish(c, CMF_V, sx, sy, S, l2, preloaded, l1, l2, pert, nn);
 }
 
+// V sweep with a shared X side (linear link, no sampling) and a per-row Y side of FEWER samples than components (p <= 64 < k),
+// every H_i certified above the threshold by l2 >= pert: the Woodbury form of cmf_eigen.hip.h ("low-rank per-row side") -- five
+// d x k x k-sized products and one p x p solve per row instead of a k x k Hessian and factorisation per row.  Same step as
+// sweep_v_fused up to float32 rounding (pycmf/cmf_solvers.py:432-486; the reference's own sparse Newton shape: 6 label columns,
+// samples/toxic_comments.ipynb).  *done = false: a precondition failed at run time (the shared part dipped under the threshold),
+// the caller takes the general path.
+static int sweep_v_lowrank(cmf_ctx *c, double alpha, double l1, double l2, int y_link, double pert, bool nn, const int32_t *vy_idx,
+                           int64_t per_y, bool sampled, bool *done) {
+    *done = false;
+    const int kp = c->kp;
+    const int64_t dp = c->dp, pp = c->pp, d = c->d;
+    const int p = (int)c->p, pk = p <= 32 ? 32 : 64;
+    float *V = c->F[CMF_V], *U = c->F[CMF_U], *Z = c->F[CMF_Z];
+    // S = alpha U^T U + l2 I in float64, S^-1 (plain inverse expected)
+    CHK(ensure_shared64(c));
+    CHK(gram64(c, U, c->mp, (double *)c->g64a.p, c->G));                         // U^T U: float64 + float32 copy (c->G)
+    CHK(launch_hess64(c, (const double *)c->g64a.p, alpha, nullptr, 0.0, l2));
+    bool plain = false;
+    CHK(shared_inverse(c, pert, &plain));
+    if (!plain && c->k > 64) return CMF_OK;                                        // clamped shared part: general path
+    if (c->k <= 64) return CMF_OK;                                                 // p < k <= 64: nothing to gain, and `plain` is unknown on the host
+    // workspaces: B (pp x kp), Zt (kp x pp), K (pk^2), M (d x pk^2), rhs / y (d x pk), images R, W, b, Q (dp x pp)
+    const size_t img = (size_t)dp * pp * sizeof(float);
+    CHK(ensure(c, c->lr_small, ((size_t)pp * kp * 2 + (size_t)pk * pk) * sizeof(float)));
+    float *B = (float *)c->lr_small.p, *Zt = B + pp * kp, *K = Zt + pp * kp;
+    CHK(ensure(c, c->lr_rows, (size_t)d * pk * (pk + 2) * sizeof(float)));
+    float *M = (float *)c->lr_rows.p, *rhs = M + (size_t)d * pk * pk, *y = rhs + (size_t)d * pk;
+    CHK(ensure(c, c->resid, img));
+    CHK(ensure(c, c->resid2, img));
+    CHK(ensure(c, c->resid3, img));
+    float *R = (float *)c->resid.p, *W = (float *)c->resid2.p, *bq = (float *)c->resid3.p;
+    CHK(factor_times_hinv(c, Z, pp, 1.0, B));                                     // B = Z S^-1
+    {
+        Timed tm(c, CMF_K_ELEMWISE);
+        hipLaunchKernelGGL(lowrank_k_kernel, dim3(1), dim3(256), 0, c->stream, (const float *)B, (const float *)Z, K, p, pk, kp);
+        hipLaunchKernelGGL(transpose_small_kernel, dim3(64), dim3(256), 0, c->stream, (const float *)Z, Zt, (int)pp, kp, kp, (int)pp);
+        HIPCHK(hipGetLastError());
+    }
+    // gradient: shared X part alpha (V G_U - X^T U), per-row Y part R Z with R = (1 - alpha) m o (f(V Z^T) - Y), regularisation
+    CHK(data_times(c, 0, true, U, c->num));                                         // X^T U
+    CHK(gemm(c, MODE_NN, V, kp, c->G, kp, c->den, dp, kp, kp));                     // V G_U
+    CHK(launch_ew(c, axpby_kernel, dp * kp, c->num, (const float *)c->den, (float)alpha, (const float *)c->num, (float)-alpha, dp * kp));
+    const uint8_t *my = nullptr;
+    if (sampled) { // list i = columns (over p) of Y row i
+        CHK(build_mask(c, c->mask2, dp, pp, vy_idx, d, per_y, true, c->p, 3));
+        my = (const uint8_t *)c->mask2.p;
+    }
+    CHK(residual_images(c, false, y_link, 1.0 - alpha, my, R, W, y_link == CMF_LINK_LOGIT));
+    CHK(gemm(c, MODE_NN, R, pp, Z, kp, c->num, dp, kp, pp, true));                  // += R Z
+    CHK(launch_ew(c, newton_grad_kernel, dp * kp, c->num, (const float *)c->num, 1.0f, (const float *)nullptr, 0.f, (const float *)V,
+                  (float)l1, (float)l2, dp * kp));
+    CHK(gemm(c, MODE_NN, c->num, kp, c->Hinv, kp, c->den, dp, kp, kp));             // a = g S^-1
+    CHK(gemm(c, MODE_NN, c->den, kp, Zt, pp, bq, dp, pp, kp));                      // b = a Z^T
+    {
+        Timed tm(c, CMF_K_EIGEN);
+        hipLaunchKernelGGL(lowrank_build_kernel, dim3((unsigned)((d + 3) / 4)), dim3(256), 0, c->stream, (const float *)W, (const float *)bq, pp,
+                           (const float *)K, M, rhs, d, p, pk);
+        CHK(ensure(c, c->eigflag, (size_t)d * sizeof(int)));
+        CHK(ensure(c, c->certflag, 2 * sizeof(int)));
+        HIPCHK(hipMemsetAsync(c->certflag.p, 0, 2 * sizeof(int), c->stream));
+        // I + sqrt(C) K sqrt(C) is positive definite with lambda_min >= 1: certified, one factorisation + solve per row
+        const dim3 grid((unsigned)d), block(256);
+        if (pk == 32) hipLaunchKernelGGL((chol_solve_kernel<2>), grid, block, 0, c->stream, (const float *)M, (const float *)rhs, y, (int *)c->eigflag.p, p, pk,
+                                         (int64_t)pk * pk, 0.0f, (int)d, 0, (const int *)nullptr, 1, (const int *)c->certflag.p, 0x7fffffff, 0);
+        else hipLaunchKernelGGL((chol_solve_kernel<4>), grid, block, 0, c->stream, (const float *)M, (const float *)rhs, y, (int *)c->eigflag.p, p, pk,
+                                (int64_t)pk * pk, 0.0f, (int)d, 0, (const int *)nullptr, 1, (const int *)c->certflag.p, 0x7fffffff, 0);
+        hipLaunchKernelGGL(lowrank_scale_kernel, dim3((unsigned)std::min<int64_t>((dp * pp + 255) / 256, (int64_t)c->num_cu * 32)), dim3(256), 0, c->stream,
+                           (const float *)W, (const float *)y, bq, pp, d, p, pk);
+        HIPCHK(hipGetLastError());
+        if (dp > d) HIPCHK(hipMemsetAsync(bq + d * pp, 0, (size_t)(dp - d) * pp * sizeof(float), c->stream));
+    }
+    CHK(gemm(c, MODE_NN, bq, pp, B, kp, c->num, dp, kp, pp));                        // (sqrt(C) y)^T B
+    CHK(launch_ew(c, axpby_kernel, dp * kp, c->den, (const float *)c->den, 1.0f, (const float *)c->num, -1.0f, dp * kp)); // step
+    CHK(launch_ew(c, newton_apply_kernel, dp * kp, V, (const float *)c->den, d, kp, c->k, dp * kp, nn ? 1 : 0));
+    *done = true;
+    return CMF_OK;
+}
+
 static int newton_step_impl(cmf_ctx *c, double alpha, double l1, double l2, int x_link, int y_link, int nn_mask, int upd,
                             double pert, double ratio, const int32_t *u_idx, const int32_t *z_idx, const int32_t *vx_idx,
                             const int32_t *vy_idx);
@@ -1477,6 +1558,12 @@ static int newton_step_impl(cmf_ctx *c, double alpha, double l1, double l2, int 
             c->gmix64_valid = use_shared64(c); // no collective between the two halves: keep the float64 Gram mix
             CHK(cmf_newton_v_apply(c, c->vbuf, l1, l2, nn_mask, pert));
         } else if (fused) {
+            bool done = false;
+            // shared X side + per-row Y side of fewer samples than components, all H_i certified (l2 >= pert): Woodbury form
+            if (c->opt_lowrank && x_link == CMF_LINK_LINEAR && !sampled && c->p <= 64 && c->p < c->k && c->k > 64 && c->Y && c->hess_psd &&
+                c->opt_rowcert && l2 >= pert && use_shared64(c))
+                CHK(sweep_v_lowrank(c, alpha, l1, l2, y_link, pert, (nn_mask & CMF_NN_V) != 0, vy_idx, sp, sampled, &done));
+            if (!done)
             CHK(sweep_v_fused(c, alpha, l1, l2, x_link, y_link, pert, (nn_mask & CMF_NN_V) != 0, vx_idx, sm, vy_idx, sp, sampled));
         } else {
             c->flop_scale = sampled ? ratio : 1.0;

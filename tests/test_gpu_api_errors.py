@@ -157,10 +157,12 @@ def test_scratch_survives_set_problem_and_diagnostics_are_gated(lib):
     ctx.mu_v_apply(buf.data_ptr(), 0.0, 0.0)
     assert np.isfinite(ctx.get_factor(1)).all()
     buf.release()                                                   # and it is still known to the context
-    with pytest.raises(ValueError, match="CMF_DIAG=1"):
+    with pytest.raises(ValueError, match="CMF_DIAG=1"):      # ... and are not even compiled into the default build
         ctx.set_option("row_diag", 1)
     with pytest.raises(ValueError, match="CMF_DIAG=1"):
         ctx.set_option("chol_diag", 2)
+    with pytest.raises(NotImplementedError, match="diagnostic builds only"):
+        ctx.debug_clock()
     ctx.set_option("row_diag", 0)
     ctx.close()
 

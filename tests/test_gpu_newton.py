@@ -627,3 +627,39 @@ def test_two_class_sides_with_different_group_sizes_across_chunks(lib):
     assert np.abs(ref - V0).max() > 0
     for key in ((-1, 256), (-1, 0)):
         np.testing.assert_allclose(got[key], ref, rtol=0, atol=2e-4 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("p,k", [(40, 100), (64, 200), (20, 256), (6, 80)])
+def test_lowrank_per_row_side_woodbury_form(lib, p, k):
+    """V sweep with a shared (linear, unsampled) X side and a logit Y side of p < k label columns, l2 >= hessian_pertubation:
+    H_i = (alpha U^T U + l2 I) + Z^T C_i Z is a rank-p update of ONE shared matrix, so g H_i^-1 comes from a p x p system per
+    row (Woodbury) instead of a k x k factorisation per row.  Same iterates as the general per-row path (option off) and as the
+    float64 oracle (pycmf/cmf_solvers.py:432-486); the reference's own sparse Newton shape (samples/toxic_comments.ipynb:
+    6 label columns, l2_reg = 5)."""
+    from oracle import cmf_oracle as O
+    m, d = 300, 500
+    rng = np.random.RandomState(p + k)
+    X = np.abs(rng.randn(m, d)) * (rng.rand(m, d) < 0.2)
+    Y = (rng.rand(d, p) < 0.15).astype(np.float64)
+    sc = (0.5 / k) ** 0.5
+    U0, V0, Z0 = sc * np.abs(rng.randn(m, k)), sc * np.abs(rng.randn(d, k)), sc * rng.randn(p, k)
+    args = (0.4, 0.05, 0.7, "linear", "logit", 3, 7, 0.2, 1.0)
+    got = {}
+    for low in (1, 0):
+        ctx = lib.Context(0)
+        ctx.set_option("lowrank_rows", low)
+        ctx.set_problem(m, d, p, k)
+        ctx.set_data(0, X); ctx.set_data(1, Y)
+        for w, F in enumerate((U0, V0, Z0)):
+            ctx.set_factor(w, F)
+        for _ in range(2):
+            ctx.newton_step(*args)
+        got[low] = [ctx.get_factor(w) for w in range(3)]
+        ctx.close()
+    U, V, Z = U0.copy(), V0.copy(), Z0.copy()
+    for _ in range(2):
+        O.newton_update_step(X, Y, U, V, Z, 0.4, 0.05, 0.7, "linear", "logit", True, True, False, 1.0, 0.2)
+    for a, b, o in zip(got[1], got[0], (U, V, Z)):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-4 * np.abs(b).max())
+        np.testing.assert_allclose(a, o, rtol=0, atol=5e-4 * np.abs(o).max())
+    assert np.abs(got[1][1] - got[0][1]).max() > 0 or k <= 64      # the two paths really are different code
