@@ -155,6 +155,8 @@ struct cmf_ctx {
     DevBuf hrows;                         // chunk of per-row Hessians / inverses
     DevBuf mask1, mask2;                  // stochastic sample masks (bytes)
     DevBuf lists1, lists2;                // device copies of the per-row sample index lists
+    DevBuf hpart;                         // partial Hessians / gradients of the split row launches (few rows, long lists)
+    int opt_rowsplit = 1;                 // split the samples of a row over several workgroups when a sweep has fewer rows than CUs
     DevBuf lr_small, lr_rows;             // low-rank per-row side (sweep_v_lowrank): B / Z^T / K images; per-row p x p systems
     int opt_lowrank = 1;                  // Woodbury form of the V sweep when the per-row side has fewer samples than components
     DevBuf lists1s, lists2s, zerobuf;     // ascending copies of host-drawn lists (sparse target term); a few zero floats (zero targets)
@@ -634,7 +636,7 @@ static void release_problem(cmf_ctx *c) {
     c->num = c->den = c->G = c->G2 = c->Hm = c->Hinv = c->Eye = c->vbuf = nullptr;
     c->slabs = DevBuf(); c->slabs_b = DevBuf(); c->slab_sel = 0; c->tickets = DevBuf(); c->resid = DevBuf(); c->resid2 = DevBuf(); c->resid3 = DevBuf(); c->dpart = DevBuf();
     c->kr1 = DevBuf(); c->kr2 = DevBuf(); c->hrows = DevBuf(); c->mask1 = DevBuf(); c->mask2 = DevBuf();
-    c->lists1 = DevBuf(); c->lists2 = DevBuf(); c->lists1s = DevBuf(); c->lists2s = DevBuf(); c->zerobuf = DevBuf(); c->lr_small = DevBuf(); c->lr_rows = DevBuf();
+    c->lists1 = DevBuf(); c->lists2 = DevBuf(); c->lists1s = DevBuf(); c->lists2s = DevBuf(); c->zerobuf = DevBuf(); c->lr_small = DevBuf(); c->lr_rows = DevBuf(); c->hpart = DevBuf();
     for (int q = 0; q < 2; ++q) { c->cls_idx[q] = DevBuf(); c->cls_off[q] = DevBuf(); c->cls_cnt[q] = DevBuf(); c->cls_pat[q] = DevBuf(); }
     c->hclass = DevBuf(); c->certimg = DevBuf(); c->certflag = DevBuf();
     c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf();
@@ -748,6 +750,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_fused_mu = value != 0;
     } else if (!strcmp(name, "shared_hessian_f64")) {
         c->opt_shared64 = value != 0;
+    } else if (!strcmp(name, "row_split")) {
+        c->opt_rowsplit = value != 0;
     } else if (!strcmp(name, "lowrank_rows")) {
         c->opt_lowrank = value != 0;
     } else if (!strcmp(name, "newton_reassoc")) {

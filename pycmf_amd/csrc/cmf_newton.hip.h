@@ -1005,7 +1005,7 @@ static int launch_row_hess(cmf_ctx *c, const RowHessArgs &a, int64_t nrows, doub
     // symmetric half may be credited as half"), plus the dot product and the gradient accumulation (2 k_pad each).
     // A class launch is credited with the sample rows of the factor rows it serves (Hessian part only: their gradient
     // is a pair of GEMMs); what it gathers is counted on the device (cmf_rowhess_samples).
-    const double samples = class_samples >= 0.0 ? class_samples : (double)nrows * (double)a.s;
+    const double samples = class_samples >= 0.0 ? class_samples : (double)(a.nsplit > 1 ? nrows / a.nsplit : nrows) * (double)a.s;
     if (c->timing) {
         c->rh_credited += samples;
         if (class_samples < 0.0) c->rh_gathered += samples;
@@ -1273,9 +1273,29 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
             a.idx = sd->lists; a.idx_stride = sd->per; a.s = (int)sd->per;
             a.T = sd->T; a.t_row = sd->t_row; a.t_col = sd->t_col;
             a.H = Hc; a.G = grad; a.accumulate = 0; a.row0 = r0; a.nrows = nr;
+            a.kvalid = c->k;
+            // few rows with long lists (the Z sweep of a 64-column Y over 1e5 rows of V: 64 workgroups on 256 CUs): split every
+            // row's samples over several workgroups that write partial sums, added up in chunk order afterwards
+            int nsplit = 1;
+            if (nr < c->num_cu && sd->per >= 4096 && !(c->opt_arith == 1 && c->kp == 256) && c->opt_rowsplit)
+                nsplit = (int)std::min<int64_t>((2 * c->num_cu + nr - 1) / nr, sd->per / 1024);
+            if (nsplit > 1) {
+                const int split_len = (int)rup((sd->per + nsplit - 1) / nsplit, 32);
+                nsplit = (int)((sd->per + split_len - 1) / split_len);
+                CHK(ensure(c, c->hpart, ((size_t)nsplit * nr * kk + (size_t)nsplit * rows_pad * c->kp) * sizeof(float)));
+                float *Hp = (float *)c->hpart.p, *Gp = Hp + (size_t)nsplit * nr * kk;
+                a.H = Hp; a.G = Gp; a.accumulate = 0; a.S = nullptr; a.diag = 0.f;
+                a.nsplit = nsplit; a.split_len = split_len; a.g_split_stride = rows_pad * c->kp;
+                CHK(launch_row_hess(c, a, nr * nsplit));
+                CHK(sum_slabs(c, Hc, Hp, nr * kk, nsplit, nr * kk, have_h));
+                if (!have_h) CHK(launch_ew(c, hessian_finalize_kernel, nr * kk, Hc, S, (float)diag, nr, c->kp, c->k, 1));
+                CHK(sum_slabs(c, grad + r0 * c->kp, Gp + r0 * c->kp, nr * c->kp, nsplit, rows_pad * c->kp, have_g));
+                have_h = have_g = true;
+                continue;
+            }
             // H and G accumulate independently: encode as two flags in one int (bit0: H, bit1: G)
             a.accumulate = (have_h ? 1 : 0) | (have_g ? 2 : 0);
-            a.S = S; a.diag = (float)diag; a.kvalid = c->k; // folded into the epilogue of the launch that starts H_i
+            a.S = S; a.diag = (float)diag; // folded into the epilogue of the launch that starts H_i
             CHK(launch_row_hess(c, a, nr));
             have_h = have_g = true;
         }

@@ -41,6 +41,12 @@ struct RowHessArgs {
     const int64_t *cls_off;
     const int32_t *cls_cnt;
     int cls_upper;        // class launch of the k_pad = 256 symmetric kernel: store the 36 upper blocks only
+    // SPLIT mode (nsplit > 1; few rows with long sample lists, e.g. the Z sweep of a 64-column Y over 1e5 rows of V): workgroup
+    // b serves chunk b / nrows of row b % nrows -- samples [chunk * split_len, ...) of its list -- and writes PARTIAL sums:
+    // H to slot b (so the partials of chunk c form slab c of nrows images), G to G + chunk * g_split_stride.  The caller launches
+    // with accumulate = 0, S = null, diag = 0 and adds the slabs up afterwards (deterministic, in chunk order).
+    int nsplit, split_len;
+    int64_t g_split_stride;
 };
 
 template <int KP>
@@ -95,14 +101,17 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const bool cls = g.cls_cnt != nullptr;
-    const int64_t i = cls ? 0 : g.row0 + blockIdx.x;
-    const int ns = cls ? g.cls_cnt[blockIdx.x] : g.s;        // samples of this row
+    const bool split = !cls && g.nsplit > 1;
+    const int chunk = split ? (int)(blockIdx.x / g.nrows) : 0;
+    const int s0 = chunk * g.split_len;                      // first sample of this workgroup's share of the list
+    const int64_t i = cls ? 0 : g.row0 + (split ? (int64_t)(blockIdx.x % g.nrows) : (int64_t)blockIdx.x);
+    const int ns = cls ? g.cls_cnt[blockIdx.x] : (split ? (g.s - s0 < g.split_len ? g.s - s0 : g.split_len) : g.s); // samples of this row
     const int trow = t / C::LPR, tl16 = t % C::LPR;          // this thread's tile row and lane within the row
     const bool loader = t < 32 * C::LPR;                      // k_pad = 32: half of the threads cover the tile
     f32x4 u4[C::CPT];
 #pragma unroll
     for (int q = 0; q < C::CPT; ++q) u4[q] = *reinterpret_cast<const f32x4 *>(g.F + i * KP + 4 * (q * C::LPR + tl16));
-    const int32_t *list = cls ? g.idx + g.cls_off[blockIdx.x] : (g.idx ? g.idx + i * g.idx_stride : nullptr);
+    const int32_t *list = cls ? g.idx + g.cls_off[blockIdx.x] : (g.idx ? g.idx + i * g.idx_stride + s0 : nullptr);
     const float *Ti = g.T + i * g.t_row;
     const int nt = (ns + 31) / 32;
 
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
     auto load_idx = [&](int tl) {
         const int q = 32 * tl + trow;
         const int qc = q < ns ? q : ns - 1;
-        jn = list ? list[qc] : qc;
+        jn = list ? list[qc] : qc + s0;
     };
     auto gather = [&](int tl) {
         vv = 32 * tl + trow < ns;
@@ -428,7 +437,7 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
     if (t < KP) {
         float sacc = 0.f;
         for (int rep = 0; rep < NREP; ++rep) sacc += gr[rep * KP + t];
-        float *dst = g.G + i * KP + t;
+        float *dst = g.G + (int64_t)chunk * g.g_split_stride + i * KP + t;
         *dst = sacc + ((g.accumulate & 2) ? *dst : 0.f);
     }
 }

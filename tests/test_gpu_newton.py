@@ -308,6 +308,7 @@ def test_global_certificate_when_l2_reaches_the_perturbation(lib, k):
     for certs in (1, 0):
         ctx = lib.Context(0)
         ctx.set_option("row_certificates", certs)
+        ctx.set_option("lowrank_rows", 0)      # the general per-row path on both sides of the comparison (p < k here)
         ctx.set_problem(m, d, p, k)
         ctx.set_data(0, X); ctx.set_data(1, Y)
         for w, F in enumerate((U0, V0, Z0)):
@@ -663,3 +664,39 @@ def test_lowrank_per_row_side_woodbury_form(lib, p, k):
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-4 * np.abs(b).max())
         np.testing.assert_allclose(a, o, rtol=0, atol=5e-4 * np.abs(o).max())
     assert np.abs(got[1][1] - got[0][1]).max() > 0 or k <= 64      # the two paths really are different code
+
+
+@pytest.mark.parametrize("k,link", [(24, "logit"), (200, "logit"), (200, "linear"), (100, "logit")])
+def test_split_row_launches_for_few_rows_with_long_lists(lib, k, link):
+    """A Z sweep with fewer rows than CUs and thousands of samples per row (BASELINE configs[4]: 64 label columns over 1e5 rows
+    of V): every row's samples are split over several workgroups that write partial Hessians / gradients, summed in chunk order
+    (option row_split).  Same step as one workgroup per row (float32 sums in another order) and as the oracle
+    (pycmf/cmf_solvers.py:488-508)."""
+    from oracle import cmf_oracle as O
+    m, d, p = 40, 9000, 12
+    rng = np.random.RandomState(k)
+    X = np.abs(rng.randn(m, d)).astype(np.float32)
+    Y = (rng.rand(d, p) < 0.3).astype(np.float64) if link == "logit" else np.abs(rng.randn(d, p))
+    sc = (0.5 / k) ** 0.5
+    U0, V0, Z0 = sc * rng.randn(m, k), sc * rng.randn(d, k), sc * rng.randn(p, k)
+    got = {}
+    for split in (1, 0):
+        ctx = lib.Context(0)
+        ctx.set_option("row_split", split)
+        ctx.set_problem(m, d, p, k)
+        ctx.set_data(0, X); ctx.set_data(1, Y)
+        for w, F in enumerate((U0, V0, Z0)):
+            ctx.set_factor(w, F)
+        if link == "logit":
+            ctx.newton_step(0.5, 0.01, 0.3, "linear", "logit", 0, 4, 0.2, 1.0)                 # Z sweep, all d samples per row
+        else:
+            ctx.newton_step_device_sampled(0.5, 0.01, 0.3, "linear", "linear", 0, 4, 0.2, 0.6, 5)   # sampled: explicit lists
+        got[split] = ctx.get_factor(2)
+        ctx.close()
+    np.testing.assert_allclose(got[1], got[0], rtol=0, atol=2e-4 * np.abs(got[0]).max())
+    assert np.abs(got[1] - Z0).max() > 0
+    if link == "logit":
+        U, V, Z = U0.copy(), V0.copy(), Z0.copy()
+        O.newton_update_step(X.astype(np.float64), Y, U, V, Z, 0.5, 0.01, 0.3, "linear", "logit", False, False, False, 1.0, 0.2,
+                             update_U=False, update_V=False)
+        np.testing.assert_allclose(got[1], Z, rtol=0, atol=1e-3 * np.abs(Z).max())
