@@ -164,7 +164,9 @@ int cmf_mu_uz_update(cmf_ctx *ctx, double l1, double l2, int update_mask);
 /* sample index lists (parity mode): for sg_ratio < 1 the caller passes the
  * indices the reference would have drawn (cmf_solvers.py:328-344), row after
  * row, as int32: u_idx[m][su] over d, z_idx[p][su] over d,
- * vx_idx[d][sm] over m, vy_idx[d][sp] over p.  NULL when sg_ratio == 1.     */
+ * vx_idx[d][sm] over m, vy_idx[d][sp] over p.  NULL when sg_ratio == 1.
+ * Every list must hold DISTINCT indices (the reference's permutation()[:s] never repeats one): the shared-partial-sum form of
+ * linear sampled sides counts a repeated index once, the row-by-row form once per occurrence.                              */
 int cmf_newton_step(cmf_ctx *ctx, double alpha, double l1, double l2,
                     int x_link, int y_link, int nn_mask, int update_mask,
                     double hessian_pertubation, double sg_ratio,

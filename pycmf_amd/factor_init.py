@@ -55,11 +55,10 @@ def randomized_svd_device(op, n_components, random_state=None, n_oversamples=10)
     rng = check_random_state(random_state)
     omega = rng.normal(size=(cols, n_components + n_oversamples))[:, :size]
     U, s, Vt = op.rsvd(transpose, n_components, size, n_iter, omega)
-    # svd_flip (u-based decision when not transposed, v-based when transposed), as sklearn does
-    if not transpose:
-        signs = np.sign(U[np.argmax(np.abs(U), axis=0), range(U.shape[1])])
-    else:
-        signs = np.sign(Vt[range(Vt.shape[0]), np.argmax(np.abs(Vt), axis=1)])
+    # svd_flip as sklearn does it: u-based when not transposed; when transposed sklearn flips the TRANSPOSED problem v-based
+    # ("to actually flip based on u and not v"), and that problem's V is M's U.  cmf_rsvd hands U and Vt back in M's
+    # orientation either way, so the decision always reads M's U: the largest |entry| of every column becomes positive
+    signs = np.sign(U[np.argmax(np.abs(U), axis=0), range(U.shape[1])])
     signs[signs == 0] = 1.0
     U *= signs
     Vt *= signs[:, None]

@@ -116,7 +116,10 @@ class MultiGpuResult:
 
 def fit_multi_gpu(X, Y, U, V, Z, solver, n_gpus, params, timeout=None):
     """Run the sharded fit on ``n_gpus`` worker processes; U, V, Z are updated in place.
-    Returns (n_iter, MultiGpuResult)."""
+    Returns (n_iter, MultiGpuResult).  ``timeout`` (seconds; default: the environment's PYCMF_AMD_FIT_TIMEOUT, else none) bounds
+    the whole fit; a rank that waits longer than CMF_COMM_TIMEOUT (default 600 s) for the job's RCCL id fails on its own."""
+    if timeout is None and os.environ.get("PYCMF_AMD_FIT_TIMEOUT"):
+        timeout = float(os.environ["PYCMF_AMD_FIT_TIMEOUT"])
     if sp.issparse(X):
         X = X.tocsr()
     if sp.issparse(Y):

@@ -327,6 +327,10 @@ def test_device_assisted_randomized_svd_matches_sklearn():
         U0, s0, V0 = randomized_svd(M, 8, random_state=3)
         np.testing.assert_allclose(s1, s0, rtol=1e-4)
         np.testing.assert_allclose(U1 * s1 @ V1, U0 * s0 @ V0, rtol=0, atol=2e-3 * np.abs(M).max())
+        # component signs (svd_flip): sklearn's decision reads M's U in both orientations -- the leading, well
+        # separated components must come out with sklearn's sign, not just the product
+        for comp in range(3):
+            assert np.dot(U1[:, comp], U0[:, comp]) > 0.99 and np.dot(V1[comp], V0[comp]) > 0.99, (shape, comp)
         A1, B1 = initialize_mf(M, 8, init="nndsvd", random_state=3, non_negative=True, operand=op)
         A0, B0 = initialize_mf(M, 8, init="nndsvd", random_state=3, non_negative=True)
         np.testing.assert_allclose(A1 @ B1.T, A0 @ B0.T, rtol=0, atol=5e-3 * np.abs(M).max())
