@@ -470,6 +470,7 @@ static bool use_reassoc(const cmf_ctx *c) { return c->opt_reassoc && c->opt_shar
 static int factor_times_hinv(cmf_ctx *c, const float *O, int64_t rows_pad, double scale, float *out) {
     Timed tm(c, CMF_K_GEMM_SMALL, 2.0 * (double)rows_pad * c->kp * c->kp);
     if (c->kp == 32) hipLaunchKernelGGL((factor_times64_kernel<32>), dim3(1, (unsigned)(rows_pad / 64)), dim3(256), 0, c->stream, O, (const double *)c->hinv64.p, out, c->kp, scale);
+    else if (c->kp >= 128 && c->opt_ft_tile == 128) hipLaunchKernelGGL((factor_times64_kernel<128>), dim3((unsigned)(c->kp / 128), (unsigned)(rows_pad / 64)), dim3(256), 0, c->stream, O, (const double *)c->hinv64.p, out, c->kp, scale);
     else hipLaunchKernelGGL((factor_times64_kernel<64>), dim3((unsigned)(c->kp / 64), (unsigned)(rows_pad / 64)), dim3(256), 0, c->stream, O, (const double *)c->hinv64.p, out, c->kp, scale);
     HIPCHK(hipGetLastError());
     return CMF_OK;
@@ -563,6 +564,13 @@ static int sweep_side_shared(cmf_ctx *c, bool is_u, double scale, double l1, dou
         CHK(ensure(c, c->opr, (size_t)std::max(c->dp, c->mp + c->pp) * c->kp * sizeof(float)));
         float *Op = (float *)c->opr.p;
         CHK(factor_times_hinv(c, V, c->dp, scale, Op));
+        {
+            // unclamped inverse, no l1 term, data kept as blocked CSR: the product IS the new factor -- written (clamped) by the SpMM
+            const int dw = is_u ? 0 : 1;
+            const CsrDev &A = c->sp[dw][is_u ? 0 : 1];
+            if (plain && l1 == 0.0 && c->sparse[dw] && !(dw == 0 ? c->X : c->Y) && spmm_can_update(c, A) && c->opt_arith == 0)
+                return spmm(c, A, Op, F, rows, false, 0, nn ? 2 : 1);
+        }
         if (is_u) CHK(data_times(c, 0, false, Op, c->num)); // X (s V Hinv)
         else CHK(data_times(c, 1, true, Op, c->num));       // Y^T (s V Hinv)
         return reassoc_finish(c, which, c->num, l1, plain, nn);

@@ -635,12 +635,13 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const double *A, const doub
 // Hinv of the ONE shared Hessian the reference's  F - grad Hinv,  grad = s (F G - T O) + l2 F  (pycmf/cmf_solvers.py:399-410,
 // :436-450, :321-326)  equals  F (I - H Hinv) + s T (O Hinv):  O Hinv is formed here in float64, so the float32 rounding of the
 // data contraction is no longer multiplied by cond(H).
-// Workgroup = 4 waves, output tile 64 x 64 (wave tile 32 x 32 = 2 x 2 MFMA blocks), the reduction in steps of 32 through LDS:
+// Workgroup = 4 waves, output tile 64 x NW (NW = 128: wave tile 32 x 64 = 2 x 4 MFMA blocks, six fragment reads per eight MFMAs),
+// the reduction in steps of 32 through LDS:
 // A tile [64][36] floats (k contiguous; 16 rows x 4 k of a ds_read_b32 group fall on 64 distinct banks), B tile [32][80] doubles
 // (the two 16-lane halves of a ds_read_b64 group read rows k and k + 1, 128 bytes apart mod 256).
 template <int NW>
 __global__ __launch_bounds__(256) void factor_times64_kernel(const float *A, const double *B, float *O, int kp, double scale) {
-    static_assert(NW == 64 || NW == 32, "column tile 64 (k_pad >= 64) or 32 (k_pad = 32)");
+    static_assert(NW == 128 || NW == 64 || NW == 32, "column tile 128 (k_pad >= 128), 64 (k_pad = 64) or 32 (k_pad = 32)");
     // wave (wi, wj) owns rows wi * 32 .. + 31 and columns wj * NW / 2 .. : 2 x JB MFMA blocks
     constexpr int LA = 36, LB = NW + 16, WN = NW / 2, JB = WN / 16, BL = NW / 16; // BL: double2 loads of the B tile per thread
     __shared__ __attribute__((aligned(16))) float As[64 * LA];

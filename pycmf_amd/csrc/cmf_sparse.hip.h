@@ -134,7 +134,9 @@ struct BcsrView {
 
 constexpr int BCSR_NW = 8;  // waves per workgroup (host layout and kernel agree on it)
 template <int VEC> // floats per lane; k_pad = 64 * VEC
-__global__ __launch_bounds__(64 * BCSR_NW) void spmm_blocked_kernel(BcsrView A, const float *F, float *out, int accumulate, unsigned *bar) {
+// `accumulate`: bit 0 out += ; bit 1: the output IS a Newton factor update (re-associated sweep, cmf_newton.hip.h): negatives
+// clamp to 0; kvalid > 0: columns >= kvalid are written as 0.
+__global__ __launch_bounds__(64 * BCSR_NW) void spmm_blocked_kernel(BcsrView A, const float *F, float *out, int accumulate, unsigned *bar, int kvalid) {
     typedef float vec __attribute__((ext_vector_type(VEC)));
     constexpr int KP = 64 * VEC;
     constexpr int CH = BCSR_NW == 8 ? 16 : 8; // gathers issued together; two chunks are in flight (32 KB per wave at k_pad = 256)
@@ -227,7 +229,14 @@ __global__ __launch_bounds__(64 * BCSR_NW) void spmm_blocked_kernel(BcsrView A, 
         for (int r = w; r < nrows; r += BCSR_NW) {
             vec v = *reinterpret_cast<const vec *>(lacc + r * KP + lane * VEC);
             vec *dst = reinterpret_cast<vec *>(out + (int64_t)(r0 + r) * KP + lane * VEC);
-            if (accumulate) v += *dst;
+            if (accumulate & 1) v += *dst;
+            if (kvalid > 0 || (accumulate & 2)) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    if (kvalid > 0 && lane * VEC + e >= kvalid) v[e] = 0.f;
+                    else if ((accumulate & 2) && v[e] < 0.f) v[e] = 0.f;
+                }
+            }
             *dst = v;
         }
     }

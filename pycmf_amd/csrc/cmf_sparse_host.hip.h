@@ -167,8 +167,12 @@ static void launch_spmm(cmf_ctx *c, const CsrView &v, const float *F, float *out
 }
 
 // out[rows x width] (+)= A F for a device CSR matrix A (width = k_pad unless stated)
-static int spmm(cmf_ctx *c, const CsrDev &A, const float *F, float *out, int64_t rows_pad, bool accumulate, int width = 0) {
+// `update`: 0 plain product; 1 / 2 (blocked form only): the output is a Newton factor update -- columns >= k are zeroed and, for 2,
+// negatives clamp to 0 (see spmm_blocked_kernel)
+static bool spmm_can_update(const cmf_ctx *c, const CsrDev &A) { return A.b_ent != nullptr; }
+static int spmm(cmf_ctx *c, const CsrDev &A, const float *F, float *out, int64_t rows_pad, bool accumulate, int width = 0, int update = 0) {
     if (width <= 0) width = c->kp;
+    if (update && !(A.b_ent && width == c->kp)) return fail(CMF_EINVAL, "spmm: the update epilogue exists in the blocked form only");
     if (!accumulate && rows_pad > A.rows)
         HIPCHK(hipMemsetAsync(out + A.rows * width, 0, (size_t)(rows_pad - A.rows) * width * sizeof(float), c->stream));
     CsrView v{A.indptr, A.idx, A.val, A.rows};
@@ -182,8 +186,8 @@ static int spmm(cmf_ctx *c, const CsrDev &A, const float *F, float *out, int64_t
 #define CMF_SPMMB(V_)                                                                                                     \
     do {                                                                                                                  \
         CHK(allow_big_lds(c, reinterpret_cast<const void *>(&spmm_blocked_kernel<V_>), 156 * 1024));                      \
-        hipLaunchKernelGGL((spmm_blocked_kernel<V_>), dim3(grid), dim3(64 * cmfk::BCSR_NW), lds, c->stream, bv, F, out, accumulate ? 1 : 0, \
-                           (unsigned *)c->spmm_bar.p);                                                                   \
+        hipLaunchKernelGGL((spmm_blocked_kernel<V_>), dim3(grid), dim3(64 * cmfk::BCSR_NW), lds, c->stream, bv, F, out,                   \
+                           (accumulate ? 1 : 0) | (update == 2 ? 2 : 0), (unsigned *)c->spmm_bar.p, update ? c->k : 0);                \
     } while (0)
         if (width == 256) CMF_SPMMB(4);
         else if (width == 128) CMF_SPMMB(2);

@@ -225,3 +225,35 @@ def test_native_csr_per_row_sweeps_never_expand(lib, xl, yl, ratio, sampler):
     ctx.close()
     for a, b in zip(got, want):
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-4 * np.abs(b).max())
+
+
+@pytest.mark.parametrize("nn", [False, True])
+@pytest.mark.parametrize("k", [40, 200])
+def test_blocked_spmm_writes_the_newton_update_itself(lib, k, nn):
+    """Re-associated shared sweep on blocked CSR data with an unclamped inverse and l1 = 0: F <- clamp(T (s O Hinv)) is the
+    epilogue of the SpMM (no product buffer, no combine pass).  Same factors as the one-wave-per-row SpMM + combine kernel and
+    as the oracle (pycmf/cmf_solvers.py:396-410, :321-326)."""
+    from oracle import cmf_oracle as O
+    X, Y, U0, V0, Z0 = _sparse_problem(k, 900, 700, 200, k, 0.03)
+    if not nn:
+        U0, V0, Z0 = U0 - U0.mean(), V0 - V0.mean(), Z0 - Z0.mean()
+    got = {}
+    for blocked in (2, 0):
+        ctx = lib.Context(0)
+        ctx.set_option("sparse_mode", 2)
+        ctx.set_option("spmm_blocked", blocked)
+        ctx.set_option("spmm_block_cols", 64)
+        ctx.set_problem(900, 700, 200, k)
+        ctx.set_data(0, X); ctx.set_data(1, Y)
+        for w, F in enumerate((U0, V0, Z0)):
+            ctx.set_factor(w, F)
+        for _ in range(2):
+            ctx.newton_step(0.4, 0.0, 0.6, "linear", "linear", 7 if nn else 0, 7, 0.2, 1.0)
+        got[blocked] = [ctx.get_factor(w) for w in range(3)]
+        ctx.close()
+    U, V, Z = U0.copy(), V0.copy(), Z0.copy()
+    for _ in range(2):
+        O.newton_update_step(X, Y, U, V, Z, 0.4, 0.0, 0.6, "linear", "linear", nn, nn, nn, 1.0, 0.2)
+    for a, b, o in zip(got[2], got[0], (U, V, Z)):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-5 * np.abs(b).max())
+        np.testing.assert_allclose(a, o, rtol=0, atol=5e-5 * np.abs(o).max())
