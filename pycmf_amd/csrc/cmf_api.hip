@@ -156,7 +156,7 @@ struct cmf_ctx {
     DevBuf mask1, mask2;                  // stochastic sample masks (bytes)
     DevBuf lists1, lists2;                // device copies of the per-row sample index lists
     DevBuf hpart;                         // partial Hessians / gradients of the split row launches (few rows, long lists)
-    int opt_ft_tile = 128;                // column tile of factor_times64_kernel at k_pad >= 128 (A/B: 64)
+    int opt_ft_tile = 64;                 // column tile of factor_times64_kernel at k_pad >= 128: 64 (2.40 ms per 1e6 x 256 x 256 product at C5) | 128 (2.8 ms: measured slower)
     int opt_rowsplit = 1;                 // split the samples of a row over several workgroups when a sweep has fewer rows than CUs
     DevBuf lr_small, lr_rows;             // low-rank per-row side (sweep_v_lowrank): B / Z^T / K images; per-row p x p systems
     int opt_lowrank = 1;                  // Woodbury form of the V sweep when the per-row side has fewer samples than components
@@ -658,6 +658,7 @@ static void release_problem(cmf_ctx *c) {
     }
 }
 
+static void pin_give(void *p);
 extern "C" int cmf_comm_destroy(cmf_ctx *c);
 extern "C" int cmf_ctx_destroy(cmf_ctx *c) {
     if (!c) return CMF_OK;
@@ -671,7 +672,7 @@ extern "C" int cmf_ctx_destroy(cmf_ctx *c) {
     for (auto e : c->evpool) (void)hipEventDestroy(e);
     for (auto e : c->markers) (void)hipEventDestroy(e);
     for (int b = 0; b < 2; ++b) {
-        if (c->pin[b]) (void)hipHostFree(c->pin[b]);
+        pin_give(c->pin[b]);
         if (c->pin_ev[b]) (void)hipEventDestroy(c->pin_ev[b]);
     }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -846,9 +847,30 @@ static int ensure_dense(cmf_ctx *c, int which) {
 }
 
 static constexpr size_t PIN_BYTES = (size_t)64 << 20;
+// The two pinned 64 MB staging buffers of a context come from a small process-wide pool: allocating and freeing 128 MB of pinned
+// memory costs ~5 ms each way, which was two thirds of a whole `CMF.fit` at the reference's own benchmark shape (2000 x 150:
+// 17 ms, of which 1 ms solver loop).  A context borrows a pair on its first transfer and hands it back when it is destroyed.
+static std::mutex g_pin_mu;
+static std::vector<void *> g_pin_pool;
+static int pin_take(void **p) {
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        if (!g_pin_pool.empty()) { *p = g_pin_pool.back(); g_pin_pool.pop_back(); return CMF_OK; }
+    }
+    HIPCHK(hipHostMalloc(p, PIN_BYTES, hipHostMallocPortable));
+    return CMF_OK;
+}
+static void pin_give(void *p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        if (g_pin_pool.size() < 4) { g_pin_pool.push_back(p); return; }
+    }
+    (void)hipHostFree(p);
+}
 static int pin_buffers(cmf_ctx *c) {
     for (int b = 0; b < 2; ++b) {
-        if (!c->pin[b]) HIPCHK(hipHostMalloc(&c->pin[b], PIN_BYTES, hipHostMallocDefault));
+        if (!c->pin[b]) CHK(pin_take(&c->pin[b]));
         if (!c->pin_ev[b]) HIPCHK(hipEventCreateWithFlags(&c->pin_ev[b], hipEventDisableTiming));
     }
     return CMF_OK;
