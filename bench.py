@@ -205,6 +205,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap-chunks", type=int, default=1,
+                    help="N > 1 GPUs, MU on dense data: reduce the (d + k) k buffer in this many row blocks on a side stream while the "
+                         "next block's partial is computed (default 1: one serial all-reduce)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="cmf_set_option knob for A/B runs (e.g. row_symmetric=0); recorded in config")
     args = ap.parse_args()
@@ -281,7 +284,7 @@ def main():
         coll = init_collectives(ctx, rank, world, timed=True)
 
     if not newton:
-        drv = make_sharded_mu(ctx, coll)
+        drv = make_sharded_mu(ctx, coll, chunks=args.overlap_chunks if "nnz_per_row" not in w and not bf16x6 else 1)
 
         def do_step(it):
             drv.step(0.0, 0.0, 7)
@@ -343,6 +346,7 @@ def main():
     marks = ctx.marker_times()
     series_ms = [b_ - a_ for a_, b_ in zip(marks, marks[1:])]
     coll_stats = coll.stats() if coll else None
+    coll_exposed = coll.exposed_ms() if coll and hasattr(coll, "exposed_ms") else None
 
     names = ("gemm_nn", "gemm_tn", "gemm_small", "gemm_nt", "spmm", "rowhess", "eigen", "elementwise")
     classes = {c: tuple(sum(v) for v in zip(*(c_.kernel_time(c) for c_ in ctxs))) for c in names}
@@ -490,6 +494,9 @@ def main():
         out["collective"] = {"backend": coll.backend, "ranks": world,
                              "calls_per_iteration": calls / args.steps, "payload_bytes_per_iteration": nbytes / args.steps,
                              "ms_per_iteration": cms / args.steps,
+                             "overlap_chunks": args.overlap_chunks,
+                             "exposed_ms_per_iteration": (cms if args.overlap_chunks <= 1 else coll_exposed) / args.steps,
+                             "hidden_ms_per_iteration": (0.0 if args.overlap_chunks <= 1 else max(0.0, cms - coll_exposed)) / args.steps,
                              "note": "rank 0; ms = events on the launch stream around every collective (waiting for the "
                                      "slowest rank included)"}
     for key in ("x_link", "y_link", "ratio", "l1", "l2", "nn_mask"):

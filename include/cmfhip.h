@@ -157,6 +157,9 @@ int cmf_mu_step(cmf_ctx *ctx, double l1, double l2, int update_mask);
  * cmf_solvers.py:242-246 (V numerator/denominator).                        */
 int cmf_v_buf_elems(cmf_ctx *ctx, int64_t *n);
 int cmf_mu_v_partials(cmf_ctx *ctx, float *dev_buf);
+/* the partial of cmf_mu_v_partials for a 256-aligned block of V rows only (dense X, Y), the Gram part when with_gram: lets a
+ * sharded driver compute block c + 1 while block c is all-reduced in the background (cmf_comm_allreduce_f32_bg)              */
+int cmf_mu_v_partials_rows(cmf_ctx *ctx, float *dev_buf, int64_t row0, int64_t nrows, int with_gram);
 int cmf_mu_v_apply(cmf_ctx *ctx, const float *dev_buf, double l1, double l2);
 int cmf_mu_uz_update(cmf_ctx *ctx, double l1, double l2, int update_mask);
 
@@ -275,6 +278,13 @@ int cmf_comm_info(cmf_ctx *ctx, int *rank, int *world);
  * d k buffer of cmf_newton_v_products (float32); the k^2 Gram of cmf_newton_v_gram (float64)                                */
 int cmf_comm_allreduce_f32(cmf_ctx *ctx, float *dev_buf, int64_t n);
 int cmf_comm_allreduce_f64(cmf_ctx *ctx, double *dev_buf, int64_t n);
+/* the float32 all-reduce in the background: on a side stream, behind what the context's stream holds at the call; kernels
+ * launched on the context's stream afterwards overlap with it.  cmf_comm_join: the context's stream waits for all of them.
+ * cmf_comm_exposed_ms: time that stream spent waiting in joins (while cmf_comm_timing) -- the exposed part; the rest of the
+ * collectives' duration (cmf_comm_stats) was hidden under compute                                                              */
+int cmf_comm_allreduce_f32_bg(cmf_ctx *ctx, float *dev_buf, int64_t n);
+int cmf_comm_join(cmf_ctx *ctx);
+int cmf_comm_exposed_ms(cmf_ctx *ctx, double *ms, int reset);
 /* in-place all-gather of equal chunks (factor rows of the row-sharded Newton): rank r's elems_per_rank floats already sit at
  * dev_full + r * elems_per_rank                                                                                             */
 int cmf_comm_allgather_f32(cmf_ctx *ctx, float *dev_full, int64_t elems_per_rank);

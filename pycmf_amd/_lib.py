@@ -54,6 +54,7 @@ PROTOTYPES = {
     "cmf_v_buf_elems": [_vp, _pi64],
     "cmf_mu_v_partials": [_vp, _vp],
     "cmf_mu_v_apply": [_vp, _vp, _dbl, _dbl],
+    "cmf_mu_v_partials_rows": [_vp, _vp, _i64, _i64, _i32],
     "cmf_mu_uz_update": [_vp, _dbl, _dbl, _i32],
     "cmf_newton_step": [_vp, _dbl, _dbl, _dbl, _i32, _i32, _i32, _i32, _dbl, _dbl,
                         _pi32, _pi32, _pi32, _pi32],
@@ -88,6 +89,9 @@ PROTOTYPES = {
     "cmf_comm_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "cmf_comm_allreduce_f32": [_vp, _vp, _i64],
     "cmf_comm_allreduce_f64": [_vp, _vp, _i64],
+    "cmf_comm_allreduce_f32_bg": [_vp, _vp, _i64],
+    "cmf_comm_join": [_vp],
+    "cmf_comm_exposed_ms": [_vp, _pd, _i32],
     "cmf_comm_allgather_f32": [_vp, _vp, _i64],
     "cmf_comm_allreduce_host_f64": [_vp, _pd, _i32, _i32],
     "cmf_comm_barrier": [_vp],
@@ -357,6 +361,9 @@ class Context:
     def mu_v_partials(self, dev_ptr):
         check(self._lib.cmf_mu_v_partials(self._h, _vp(dev_ptr)))
 
+    def mu_v_partials_rows(self, dev_ptr, row0, nrows, with_gram):
+        check(self._lib.cmf_mu_v_partials_rows(self._h, _vp(dev_ptr), row0, nrows, 1 if with_gram else 0))
+
     def mu_v_apply(self, dev_ptr, l1, l2):
         check(self._lib.cmf_mu_v_apply(self._h, _vp(dev_ptr), l1, l2))
 
@@ -445,6 +452,17 @@ class Context:
             check(self._lib.cmf_comm_allreduce_f64(self._h, _vp(buf.data_ptr()), n))
         else:
             check(self._lib.cmf_comm_allreduce_f32(self._h, _vp(buf.data_ptr()), n))
+
+    def comm_allreduce_bg(self, buf):
+        check(self._lib.cmf_comm_allreduce_f32_bg(self._h, _vp(buf.data_ptr()), buf.numel()))
+
+    def comm_join(self):
+        check(self._lib.cmf_comm_join(self._h))
+
+    def comm_exposed_ms(self, reset=False):
+        ms = C.c_double(0)
+        check(self._lib.cmf_comm_exposed_ms(self._h, C.byref(ms), 1 if reset else 0))
+        return ms.value
 
     def comm_allgather(self, full, elems_per_rank):
         check(self._lib.cmf_comm_allgather_f32(self._h, _vp(full.data_ptr()), elems_per_rank))

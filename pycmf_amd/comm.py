@@ -93,6 +93,16 @@ class RcclCollectives:
     def all_reduce(self, buf):
         self.ctx.comm_allreduce(buf)
 
+    def all_reduce_bg(self, buf):
+        """float32 all-reduce on the communicator's side stream: kernels launched afterwards overlap with it (until join)."""
+        self.ctx.comm_allreduce_bg(buf)
+
+    def join(self):
+        self.ctx.comm_join()
+
+    def exposed_ms(self):
+        return self.ctx.comm_exposed_ms()
+
     def all_gather(self, full, chunk=None):
         self.ctx.comm_allgather(full, full.numel() // self.world)
 
@@ -104,6 +114,7 @@ class RcclCollectives:
 
     def reset(self):
         self.ctx.comm_stats(reset=True)
+        self.ctx.comm_exposed_ms(reset=True)
 
     def stats(self):
         return self.ctx.comm_stats(reset=False)
@@ -165,6 +176,14 @@ class HostStagedCollectives:
         self.ctx.copy_from_host(buf, total)
         self._account(mine.nbytes, t0)
 
+    all_reduce_bg = all_reduce          # the double has no streams: the background form is the blocking one
+
+    def join(self):
+        pass
+
+    def exposed_ms(self):
+        return self.ms
+
     def all_gather(self, full, chunk=None):
         t0 = time.perf_counter()
         per = full.numel() // self.world
@@ -206,6 +225,47 @@ class HostStagedCollectives:
                 pass
 
 
+class NullCollectives:
+    """MEASUREMENT HOOK (``CMF_COMM_BACKEND=null``): rank r of N with no peers -- every collective returns at once and changes
+    nothing, so a single GPU can time the per-rank COMPUTE of a sharded run (the shard's GEMM shapes, split-K choices, row-block
+    launches of --overlap-chunks) with the collective excluded.  The iterates are those of a rank whose peers contribute zero."""
+
+    backend = "null (per-rank compute only, measurement hook)"
+
+    def __init__(self, ctx, rank, world, timed=False):
+        self.ctx, self.rank, self.world = ctx, rank, world
+
+    def all_reduce(self, buf):
+        pass
+
+    all_reduce_bg = all_reduce
+
+    def join(self):
+        pass
+
+    def all_gather(self, full, chunk=None):
+        pass
+
+    def all_reduce_host(self, values, op="sum"):
+        return np.ascontiguousarray(values, dtype=np.float64)
+
+    def barrier(self):
+        pass
+
+    def reset(self):
+        pass
+
+    def stats(self):
+        self.ctx.sync()
+        return 0, 0, 0.0
+
+    def exposed_ms(self):
+        return 0.0
+
+    def close(self):
+        pass
+
+
 def init_collectives(ctx, rank=None, world=None, timed=False, backend=None):
     """The collectives object of this rank: RCCL unless ``CMF_COMM_BACKEND=host`` (test double).  None for a single rank unless
     ``force`` is requested through world > 1."""
@@ -215,6 +275,8 @@ def init_collectives(ctx, rank=None, world=None, timed=False, backend=None):
     backend = backend or os.environ.get("CMF_COMM_BACKEND", "rccl")
     if backend == "host":
         return HostStagedCollectives(ctx, rank, world, timed)
+    if backend == "null":
+        return NullCollectives(ctx, rank, world, timed)
     if backend != "rccl":
-        raise ValueError("CMF_COMM_BACKEND must be 'rccl' or 'host' (test double), got %r" % backend)
+        raise ValueError("CMF_COMM_BACKEND must be 'rccl', 'host' (test double) or 'null' (measurement hook), got %r" % backend)
     return RcclCollectives(ctx, rank, world, timed)

@@ -1196,6 +1196,25 @@ extern "C" int cmf_mu_v_partials(cmf_ctx *c, float *buf) {
     return CMF_OK;
 }
 
+// The same partial for a block of V rows only: P[row0 .. row0 + nrows) = X[:, rows]^T U + Y[rows, :] Z (dense X and Y), plus the
+// Gram part when with_gram.  A sharded driver computes block c + 1 while block c is being all-reduced on the communicator's side
+// stream (cmf_comm_allreduce_f32_bg): the only way to overlap the one collective of an MU iteration with compute, since everything
+// after it needs the new V (pycmf/cmf_solvers.py:248-263).
+extern "C" int cmf_mu_v_partials_rows(cmf_ctx *c, float *buf, int64_t row0, int64_t nrows, int with_gram) {
+    NEED_PROBLEM(c);
+    if (!buf) return fail(CMF_EINVAL, "null buffer");
+    if (!c->X || !c->Y) return fail(CMF_EUNSUPPORTED, "cmf_mu_v_partials_rows needs dense images of X and Y");
+    if (c->opt_arith != 0) return fail(CMF_EUNSUPPORTED, "cmf_mu_v_partials_rows: fp32 MFMA arithmetic only");
+    if (row0 < 0 || nrows <= 0 || row0 % 256 || nrows % 256 || row0 + nrows > c->dp) return fail(CMF_EINVAL, "row block must be 256-aligned inside [0, d_pad)");
+    DeviceGuard dg(c->device);
+    float *P = buf + row0 * c->kp;
+    CHK(gemm(c, MODE_TN, c->X + row0, c->dp, c->F[CMF_U], c->kp, P, nrows, c->kp, c->mp));                       // X[:, rows]^T U
+    CHK(gemm(c, MODE_NN, c->Y + row0 * c->pp, c->pp, c->F[CMF_Z], c->kp, P, nrows, c->kp, c->pp, true));        // + Y[rows, :] Z
+    if (with_gram)
+        CHK(gemm(c, MODE_TN, c->F[CMF_U], c->kp, c->F[CMF_U], c->kp, buf + c->dp * c->kp, c->kp, c->kp, c->mp + c->pp));
+    return CMF_OK;
+}
+
 // V *= P / reg(V G): cmf_solvers.py:245, :212-228, :253-255
 extern "C" int cmf_mu_v_apply(cmf_ctx *c, const float *buf, double l1, double l2) {
     NEED_PROBLEM(c);

@@ -58,6 +58,12 @@ struct CmfComm {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // around every collective while `timed`
     int64_t calls = 0, bytes = 0;
     double *dscratch = nullptr; // 16 doubles on the device for the host-value reductions
+    // background collectives (cmf_comm_allreduce_f32_bg): a side stream ordered behind / in front of the context's stream by events
+    hipStream_t side = nullptr;
+    hipEvent_t ev_ready[8] = {nullptr}, ev_done = nullptr;
+    int ev_next = 0;
+    bool bg_pending = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> joins; // on the context's stream around every join: the EXPOSED wait
 };
 
 extern "C" int cmf_comm_unique_id(char *id128) {
@@ -99,7 +105,12 @@ extern "C" int cmf_comm_destroy(cmf_ctx *c) {
     DeviceGuard dg(c->device);
     CmfComm *cm = c->comm;
     (void)hipStreamSynchronize(c->stream);
+    if (cm->side) (void)hipStreamSynchronize(cm->side);
     for (auto &e : cm->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : cm->joins) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : cm->ev_ready) if (e) (void)hipEventDestroy(e);
+    if (cm->ev_done) (void)hipEventDestroy(cm->ev_done);
+    if (cm->side) (void)hipStreamDestroy(cm->side);
     if (cm->dscratch) (void)hipFree(cm->dscratch);
     if (cm->comm) (void)g_rccl.CommDestroy(cm->comm);
     delete cm;
@@ -107,15 +118,15 @@ extern "C" int cmf_comm_destroy(cmf_ctx *c) {
     return CMF_OK;
 }
 
-struct CommTimed { // events on the launch stream around one collective (bench.py: bytes and ms per iteration)
-    cmf_ctx *c; CmfComm *cm; hipEvent_t a = nullptr, b = nullptr;
-    CommTimed(cmf_ctx *c_, CmfComm *cm_, int64_t nbytes) : c(c_), cm(cm_) {
+struct CommTimed { // events on the collective's stream around it (bench.py: bytes and ms per iteration)
+    cmf_ctx *c; CmfComm *cm; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    CommTimed(cmf_ctx *c_, CmfComm *cm_, int64_t nbytes, hipStream_t st_ = nullptr) : c(c_), cm(cm_), st(st_ ? st_ : c_->stream) {
         cm->calls += 1; cm->bytes += nbytes;
-        if (cm->timed && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, c->stream);
+        if (cm->timed && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, st);
         else a = b = nullptr;
     }
     ~CommTimed() {
-        if (a && b) { (void)hipEventRecord(b, c->stream); cm->events.push_back({a, b}); }
+        if (a && b) { (void)hipEventRecord(b, st); cm->events.push_back({a, b}); }
     }
 };
 #define NEED_COMM(c)                                                                                  \
@@ -141,6 +152,63 @@ extern "C" int cmf_comm_allreduce_f64(cmf_ctx *c, double *dev_buf, int64_t n) {
     RCCLCHK(g_rccl.AllReduce(dev_buf, dev_buf, (size_t)n, ncclFloat64, ncclSum, c->comm->comm, c->stream));
     return CMF_OK;
 }
+// The same all-reduce in the BACKGROUND: enqueued on the communicator's side stream behind everything the context's stream holds
+// now, so that kernels launched on the context's stream afterwards overlap with it.  cmf_comm_join makes the context's stream
+// wait for every background collective issued so far (call it before anything reads the reduced buffers).
+extern "C" int cmf_comm_allreduce_f32_bg(cmf_ctx *c, float *dev_buf, int64_t n) {
+    NEED_COMM(c);
+    if (!dev_buf || n < 0) return fail(CMF_EINVAL, "bad buffer");
+    DeviceGuard dg(c->device);
+    CmfComm *cm = c->comm;
+    if (!cm->side) {
+        HIPCHK(hipStreamCreateWithFlags(&cm->side, hipStreamNonBlocking));
+        for (auto &e : cm->ev_ready) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&cm->ev_done, hipEventDisableTiming));
+    }
+    hipEvent_t ready = cm->ev_ready[cm->ev_next++ & 7];
+    HIPCHK(hipEventRecord(ready, c->stream));
+    HIPCHK(hipStreamWaitEvent(cm->side, ready, 0));
+    {
+        CommTimed tm(c, cm, n * 4, cm->side);
+        RCCLCHK(g_rccl.AllReduce(dev_buf, dev_buf, (size_t)n, ncclFloat32, ncclSum, cm->comm, cm->side));
+    }
+    HIPCHK(hipEventRecord(cm->ev_done, cm->side));
+    cm->bg_pending = true;
+    return CMF_OK;
+}
+extern "C" int cmf_comm_join(cmf_ctx *c) {
+    NEED_COMM(c);
+    CmfComm *cm = c->comm;
+    if (!cm->bg_pending) return CMF_OK;
+    DeviceGuard dg(c->device);
+    hipEvent_t a = nullptr, b = nullptr;
+    if (cm->timed && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, c->stream);
+    else a = b = nullptr;
+    HIPCHK(hipStreamWaitEvent(c->stream, cm->ev_done, 0));
+    if (a && b) { (void)hipEventRecord(b, c->stream); cm->joins.push_back({a, b}); }
+    cm->bg_pending = false;
+    return CMF_OK;
+}
+// milliseconds the context's stream spent WAITING in cmf_comm_join since the last reset (while timed): the exposed part of the
+// background collectives; cmf_comm_stats' ms is their total duration, the difference was hidden under compute
+extern "C" int cmf_comm_exposed_ms(cmf_ctx *c, double *ms, int reset) {
+    NEED_COMM(c);
+    DeviceGuard dg(c->device);
+    CmfComm *cm = c->comm;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double total = 0.0;
+    for (auto &e : cm->joins) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, e.first, e.second) == hipSuccess) total += t;
+    }
+    if (ms) *ms = total;
+    if (reset) {
+        for (auto &e : cm->joins) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        cm->joins.clear();
+    }
+    return CMF_OK;
+}
+
 // in-place all-gather of equal chunks: rank r's `elems_per_rank` floats already sit at dev_full + r * elems_per_rank
 extern "C" int cmf_comm_allgather_f32(cmf_ctx *c, float *dev_full, int64_t elems_per_rank) {
     NEED_COMM(c);
@@ -183,6 +251,7 @@ extern "C" int cmf_comm_stats(cmf_ctx *c, int64_t *calls, int64_t *bytes, double
     DeviceGuard dg(c->device);
     CmfComm *cm = c->comm;
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (cm->side) HIPCHK(hipStreamSynchronize(cm->side));
     double total = 0.0;
     for (auto &e : cm->events) {
         float t = 0.f;

@@ -75,21 +75,51 @@ class HipShardBackend:
     def update_uz(self, l1, l2, mask):
         self.ctx.mu_uz_update(l1, l2, mask)
 
+    def partials_rows(self, buf, row0, nrows, with_gram):
+        self.ctx.mu_v_partials_rows(buf.data_ptr(), row0, nrows, with_gram)
+
+    def row_blocks(self, chunks):
+        """256-aligned blocks of the d_pad rows of the partial, at most `chunks` of them."""
+        _, dp, _, kp = self.ctx.geometry()
+        tiles = dp // 256
+        chunks = max(1, min(chunks, tiles))
+        cuts = [256 * (tiles * c // chunks) for c in range(chunks + 1)]
+        return [(a, b - a) for a, b in zip(cuts, cuts[1:]) if b > a], dp, kp
+
 
 class ShardedMU:
-    """One MU iteration across ``world`` ranks (order V -> U -> Z, cmf_solvers.py:248-263)."""
+    """One MU iteration across ``world`` ranks (order V -> U -> Z, cmf_solvers.py:248-263).
 
-    def __init__(self, backend, buf, world=1, all_reduce=None):
+    ``chunks > 1`` (opt-in; needs ``coll`` with background collectives and dense X, Y): the partial is formed in row blocks of
+    V, and block c is all-reduced on the communicator's side stream while block c + 1 is computed -- the same single buffer,
+    summed in `chunks` pieces.  Nothing else in the iteration is independent of the reduced buffer, so this is the only overlap
+    there is; it trades GEMM launches with fewer output tiles for a hidden collective (priced as a wash at
+    N = 8, unmeasured)."""
+
+    def __init__(self, backend, buf, world=1, all_reduce=None, chunks=1, coll=None):
         self.backend = backend
         self.buf = buf
         self.world = world
         self.all_reduce = all_reduce
+        self.chunks, self.coll = chunks, coll
+        self.blocks = None
+        if chunks > 1 and coll is not None:
+            self.blocks, self.dp, self.kp = backend.row_blocks(chunks)
 
     def step(self, l1=0.0, l2=0.0, mask=7):
         if mask & 2:
-            self.backend.partials(self.buf)
-            if self.all_reduce is not None:
-                self.all_reduce(self.buf)  # the single collective of the iteration
+            if self.blocks and len(self.blocks) > 1:
+                last = len(self.blocks) - 1
+                for c, (r0, nr) in enumerate(self.blocks):
+                    self.backend.partials_rows(self.buf, r0, nr, c == last)
+                    # the last block travels with the Gram part, which sits right behind it in the buffer
+                    piece = self.buf[r0 * self.kp:(r0 + nr) * self.kp] if c < last else self.buf[r0 * self.kp:self.buf.shape[0]]
+                    self.coll.all_reduce_bg(piece)
+                self.coll.join()
+            else:
+                self.backend.partials(self.buf)
+                if self.all_reduce is not None:
+                    self.all_reduce(self.buf)  # the single collective of the iteration
             self.backend.apply_v(self.buf, l1, l2)
         self.backend.update_uz(l1, l2, mask)
 
@@ -268,14 +298,15 @@ def make_sharded_newton_rows(ctx_uz, ctx_v, bounds, shape, coll, alpha, x_link, 
     return drv
 
 
-def make_sharded_mu(ctx, coll):
-    """MU driver of one rank: with ``coll`` None the context's own fused step, else partials -> ONE all-reduce -> apply."""
+def make_sharded_mu(ctx, coll, chunks=1):
+    """MU driver of one rank: with ``coll`` None the context's own fused step, else partials -> ONE all-reduce -> apply
+    (``chunks`` > 1: the buffer reduced in that many row blocks, overlapped with the partials of the next block)."""
     from . import _lib
     backend = HipShardBackend(ctx)
     if coll is None:
         return SingleGpuStep(lambda l1, l2, mask: ctx.mu_step(l1, l2, mask))
     buf = _lib.DeviceArray(ctx, backend.buf_elems(), 1)
-    drv = ShardedMU(backend, buf, coll.world, coll.all_reduce)
+    drv = ShardedMU(backend, buf, coll.world, coll.all_reduce, chunks=chunks, coll=coll)
     drv.collectives = coll
     return drv
 

@@ -188,6 +188,29 @@ def test_bench_rccl_single_rank():
     assert out["collective"]["backend"] == "rccl" and out["collective"]["calls_per_iteration"] == 2
 
 
+def test_bench_overlapped_all_reduce_in_row_blocks():
+    """--overlap-chunks 4 (opt-in): the (d + k) k buffer of the MU step is formed and all-reduced in four row blocks of V, every
+    block's collective on the communicator's side stream under the next block's GEMMs (cmf_mu_v_partials_rows,
+    cmf_comm_allreduce_f32_bg, cmf_comm_join).  Same payload, four calls, the same iterates up to the split-K partition of
+    the smaller GEMMs; exposed + hidden time add up to the collectives' duration.  RCCL with one rank, and two ranks on the
+    host-staged double."""
+    base = ["--steps", "3", "--warmup", "1", "--workload", "tiny", "--no-cpu-baseline"]
+    env = {"CMF_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1"}
+    serial = _run_bench(["--gpus", "1"] + base, env)
+    over = _run_bench(["--gpus", "1", "--overlap-chunks", "4"] + base, env)
+    cs, co = serial["collective"], over["collective"]
+    assert cs["calls_per_iteration"] == 1 and co["calls_per_iteration"] == 4 and co["overlap_chunks"] == 4
+    assert co["payload_bytes_per_iteration"] == cs["payload_bytes_per_iteration"] == (1024 + 64) * 64 * 4
+    assert abs(co["exposed_ms_per_iteration"] + co["hidden_ms_per_iteration"] - co["ms_per_iteration"]) < 1e-6 + 0.5 * co["ms_per_iteration"]
+    for key in ("x", "y"):
+        assert abs(over["rel_residual"][key] - serial["rel_residual"][key]) <= 1e-5 * serial["rel_residual"][key]
+    two = _run_bench(["--gpus", "2", "--overlap-chunks", "2"] + base,
+                     {"CMF_BENCH_SAME_DEVICE": "1", "CMF_COMM_BACKEND": "host", "CMF_COMM_TIMEOUT": "120"})
+    assert two["collective"]["calls_per_iteration"] == 2
+    for key in ("x", "y"):
+        assert abs(two["rel_residual"][key] - serial["rel_residual"][key]) < 0.05 * serial["rel_residual"][key]
+
+
 def test_rccl_abi_single_rank(tmp_path, monkeypatch):
     """The collectives of the C ABI with a one-rank communicator: in-place all-reduce (float32, float64), all-gather, the
     host-scalar reduction, the barrier, accounting -- and the errors of calling them without a communicator."""
