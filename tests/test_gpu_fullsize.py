@@ -404,3 +404,51 @@ def test_c5_full_size_native_csr_sampled_rows_vs_fp64(lib, y_link):
         F = [U1, V1, Z1]
         assert all(np.isfinite(A).all() for A in F)
     ctx.close()
+
+
+def test_c5_shape_native_csr_mu_sampled_rows_vs_fp64(lib):
+    """The C5 shape under the MU solver (native CSR X 1e6 x 1e5, 1e8 non-zeros: SpMM numerators, SDDMM error): rows of V, U and Z
+    after one update recomputed in float64 (pycmf/cmf_solvers.py:230-263), and the sparse error expansion of sklearn
+    (cmf_solvers.py:40) against the float64 value on the same factors."""
+    eps = float(np.finfo(np.float32).eps)
+    ctx, X, (m, d, p, k) = _c5_problem(lib)
+    Y = ctx.get_data(1).astype(np.float64)
+    rng = np.random.RandomState(3)
+    U0, V0, Z0 = (ctx.get_factor(w) for w in range(3))
+    ctx.mu_step(0.0, 0.0, lib.CMF_UPD_V)
+    V1 = ctx.get_factor(1)
+    G = U0.T @ U0 + Z0.T @ Z0
+    rows = _spread(d, 4, rng)
+    num = np.asarray((X[:, rows].T @ U0)) + Y[rows] @ Z0
+    den = V0[rows] @ G
+    den[den == 0] = eps
+    np.testing.assert_allclose(V1[rows], V0[rows] * num / den, rtol=2e-4, atol=0)
+    ctx.mu_step(0.0, 0.0, lib.CMF_UPD_U | lib.CMF_UPD_Z)
+    U1, Z1 = ctx.get_factor(0), ctx.get_factor(2)
+    G2 = V1.T @ V1
+    rows = _spread(m, 6, rng)
+    den = U0[rows] @ G2
+    den[den == 0] = eps
+    np.testing.assert_allclose(U1[rows], U0[rows] * np.asarray(X[rows] @ V1) / den, rtol=2e-4, atol=0)
+    den = Z0 @ G2
+    den[den == 0] = eps
+    np.testing.assert_allclose(Z1, Z0 * (Y.T @ V1) / den, rtol=2e-4, atol=0)
+    ex2, ey2 = ctx.residual_sq("linear", "linear")
+    # sklearn's expansion ||X||^2 - 2 sum_nnz x_ij (u_i . v_j) + <U^T U, V^T V> (cmf_solvers.py:40) on a row block of 20000 rows in
+    # float64 (the whole sum costs a minute of host time; the SDDMM kernel is the same for every row, and
+    # test_gpu_sparse.py checks the total at mid size): device value of the block = total of a second context holding that block
+    blk = slice(400000, 420000)
+    sub = lib.Context(0)
+    sub.set_option("sparse_mode", 2)
+    sub.set_problem(20000, d, p, k)
+    sub.set_data(0, X[blk]); sub.set_data(1, Y)
+    sub.set_factor(0, U1[blk]); sub.set_factor(1, V1); sub.set_factor(2, Z1)
+    bx2, _ = sub.residual_sq("linear", "linear")
+    sub.close()
+    coo = X[blk].tocoo()
+    cross = float(np.einsum("ij,ij->i", U1[blk][coo.row], V1[coo.col]) @ coo.data)
+    want = float(coo.data @ coo.data) - 2.0 * cross + float(np.sum((U1[blk].T @ U1[blk]) * (V1.T @ V1)))
+    np.testing.assert_allclose(bx2, want, rtol=1e-4)
+    assert 0.0 < ex2 < float(X.data @ X.data)
+    np.testing.assert_allclose(ey2, float(np.sum((Y - V1 @ Z1.T) ** 2)), rtol=1e-4)
+    ctx.close()
