@@ -238,6 +238,9 @@ def main():
     newton = w["solver"] == "newton"
     sharded_ok = (not newton) or (w["x_link"] == "linear" and w["y_link"] == "linear" and w["ratio"] == 1.0)
     rows_mode = newton and not sharded_ok and use_dist
+    if rows_mode and "nnz_per_row" in w:
+        raise SystemExit("bench.py: --workload %s is a single-GPU bench line (the row-sharded Newton of a CSR X needs its column "
+                         "blocks as well: use CMF(n_gpus=N), pycmf_amd/multi_gpu.py)" % args.workload)
     bounds_fn = block_bounds if rows_mode else shard_bounds   # the row-sharded Newton all-gathers equal blocks
     r0, r1 = bounds_fn(m, world, rank)
     c0, c1 = bounds_fn(p, world, rank)

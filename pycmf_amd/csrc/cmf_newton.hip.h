@@ -1433,8 +1433,9 @@ static int sweep_v_lowrank(cmf_ctx *c, double alpha, double l1, double l2, int y
     const size_t img = (size_t)dp * pp * sizeof(float);
     CHK(ensure(c, c->lr_small, ((size_t)pp * kp * 2 + (size_t)pk * pk) * sizeof(float)));
     float *B = (float *)c->lr_small.p, *Zt = B + pp * kp, *K = Zt + pp * kp;
-    CHK(ensure(c, c->lr_rows, (size_t)d * pk * (pk + 2) * sizeof(float)));
-    float *M = (float *)c->lr_rows.p, *rhs = M + (size_t)d * pk * pk, *y = rhs + (size_t)d * pk;
+    const int64_t lr_chunk = std::min<int64_t>(d, c->opt_rowchunk > 0 ? rup(c->opt_rowchunk, 4) : 262144);                         // rows per batch of p x p systems (4.3 GB at pk = 64)
+    CHK(ensure(c, c->lr_rows, (size_t)lr_chunk * pk * (pk + 2) * sizeof(float)));
+    float *M = (float *)c->lr_rows.p, *rhs = M + (size_t)lr_chunk * pk * pk, *y = rhs + (size_t)lr_chunk * pk;
     CHK(ensure(c, c->resid, img));
     CHK(ensure(c, c->resid2, img));
     CHK(ensure(c, c->resid3, img));
@@ -1463,20 +1464,24 @@ static int sweep_v_lowrank(cmf_ctx *c, double alpha, double l1, double l2, int y
     CHK(gemm(c, MODE_NN, c->den, kp, Zt, pp, bq, dp, pp, kp));                      // b = a Z^T
     {
         Timed tm(c, CMF_K_EIGEN);
-        hipLaunchKernelGGL(lowrank_build_kernel, dim3((unsigned)((d + 3) / 4)), dim3(256), 0, c->stream, (const float *)W, (const float *)bq, pp,
-                           (const float *)K, M, rhs, d, p, pk);
-        CHK(ensure(c, c->eigflag, (size_t)d * sizeof(int)));
+        CHK(ensure(c, c->eigflag, (size_t)lr_chunk * sizeof(int)));
         CHK(ensure(c, c->certflag, 2 * sizeof(int)));
         HIPCHK(hipMemsetAsync(c->certflag.p, 0, 2 * sizeof(int), c->stream));
-        // I + sqrt(C) K sqrt(C) is positive definite with lambda_min >= 1: certified, one factorisation + solve per row
-        const dim3 grid((unsigned)d), block(256);
-        if (pk == 32) hipLaunchKernelGGL((chol_solve_kernel<2>), grid, block, 0, c->stream, (const float *)M, (const float *)rhs, y, (int *)c->eigflag.p, p, pk,
-                                         (int64_t)pk * pk, 0.0f, (int)d, 0, (const int *)nullptr, 1, (const int *)c->certflag.p, 0x7fffffff, 0);
-        else hipLaunchKernelGGL((chol_solve_kernel<4>), grid, block, 0, c->stream, (const float *)M, (const float *)rhs, y, (int *)c->eigflag.p, p, pk,
-                                (int64_t)pk * pk, 0.0f, (int)d, 0, (const int *)nullptr, 1, (const int *)c->certflag.p, 0x7fffffff, 0);
-        hipLaunchKernelGGL(lowrank_scale_kernel, dim3((unsigned)std::min<int64_t>((dp * pp + 255) / 256, (int64_t)c->num_cu * 32)), dim3(256), 0, c->stream,
-                           (const float *)W, (const float *)y, bq, pp, d, p, pk);
-        HIPCHK(hipGetLastError());
+        for (int64_t r0 = 0; r0 < d; r0 += lr_chunk) {
+            const int64_t nr = std::min(lr_chunk, d - r0);
+            hipLaunchKernelGGL(lowrank_build_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, c->stream, (const float *)(W + r0 * pp),
+                               (const float *)(bq + r0 * pp), pp, (const float *)K, M, rhs, nr, p, pk);
+            // I + sqrt(C) K sqrt(C) is positive definite with lambda_min >= 1: certified, one factorisation + solve per row
+            const dim3 grid((unsigned)nr), block(256);
+            if (pk == 32) hipLaunchKernelGGL((chol_solve_kernel<2>), grid, block, 0, c->stream, (const float *)M, (const float *)rhs, y, (int *)c->eigflag.p, p, pk,
+                                             (int64_t)pk * pk, 0.0f, (int)nr, 0, (const int *)nullptr, 1, (const int *)c->certflag.p, 0x7fffffff, 0);
+            else hipLaunchKernelGGL((chol_solve_kernel<4>), grid, block, 0, c->stream, (const float *)M, (const float *)rhs, y, (int *)c->eigflag.p, p, pk,
+                                    (int64_t)pk * pk, 0.0f, (int)nr, 0, (const int *)nullptr, 1, (const int *)c->certflag.p, 0x7fffffff, 0);
+            // the b image is consumed row block by row block: its rows become sqrt(C) y in place
+            hipLaunchKernelGGL(lowrank_scale_kernel, dim3((unsigned)std::min<int64_t>((nr * pp + 255) / 256, (int64_t)c->num_cu * 32)), dim3(256), 0, c->stream,
+                               (const float *)(W + r0 * pp), (const float *)y, bq + r0 * pp, pp, nr, p, pk);
+            HIPCHK(hipGetLastError());
+        }
         if (dp > d) HIPCHK(hipMemsetAsync(bq + d * pp, 0, (size_t)(dp - d) * pp * sizeof(float), c->stream));
     }
     CHK(gemm(c, MODE_NN, bq, pp, B, kp, c->num, dp, kp, pp));                        // (sqrt(C) y)^T B

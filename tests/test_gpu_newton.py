@@ -649,6 +649,8 @@ def test_lowrank_per_row_side_woodbury_form(lib, p, k):
     for low in (1, 0):
         ctx = lib.Context(0)
         ctx.set_option("lowrank_rows", low)
+        if p == 40:
+            ctx.set_option("row_chunk", 100)       # several batches of p x p systems
         ctx.set_problem(m, d, p, k)
         ctx.set_data(0, X); ctx.set_data(1, Y)
         for w, F in enumerate((U0, V0, Z0)):
