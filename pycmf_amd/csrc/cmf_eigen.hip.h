@@ -607,6 +607,66 @@ __global__ __launch_bounds__(256) void lowrank_scale_kernel(const float *W, cons
         Q[idx] = (j < p) ? __builtin_amdgcn_sqrtf(fmaxf(W[idx], 0.f)) * y[i * pk + j] : 0.f;
     }
 }
+// The p x p system of one row solved by ONE WAVE entirely in registers: lane j holds row j of M = I + sqrt(c) K sqrt(c)^T (register
+// c = column c), a right-looking Cholesky whose column t is scaled by every lane at once and whose rank-1 update takes L[c][t]
+// from lane c with v_readlane (compile-time lane index: the loops are fully unrolled), then the two triangular solves (forward
+// by lane broadcasts, backward by a wave sum per unknown).  M never exists in memory: the kernel reads c_i, b_i (p floats each)
+// and K, and overwrites b_i with q_i = sqrt(c_i) o y_i.  Instantiated for P = 32 only (p <= 32: the reference's own workload has 6
+// label columns): hipcc compiles the fully unrolled P = 32 body in 4 s and does not finish P >= 40 in 10 minutes, so 32 < p <= 64
+// (BASELINE configs[4]: 64 columns) takes the systems through memory and chol_solve_kernel<4> (4.5 ms per C5L iteration).
+template <int P>
+__global__ __launch_bounds__(256) void lowrank_solve_kernel(const float *W, float *Bq, int64_t ldw, const float *K, int64_t nrows, int p) {
+    static_assert(P == 32, "padded order 32 (see above)");
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nrows) return;
+    const int j = lane < P ? lane : P - 1;          // lanes >= P (P = 32) mirror lane P - 1 and write nothing
+    const bool live = lane < p;
+    const float s = live ? __builtin_amdgcn_sqrtf(fmaxf(W[i * ldw + lane], 0.f)) : 0.f;
+    float rhs = live ? s * Bq[i * ldw + lane] : 0.f;
+    float M[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+        const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), c));
+        M[c] = (j == c ? 1.f : 0.f) + s * K[j * P + c] * sc;
+    }
+    // Cholesky, M = L L^T (lower triangle of the register image becomes L)
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+        const float piv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, M[t]), t));
+        const float inv = __builtin_amdgcn_rsqf(piv);
+        const float Ljt = j >= t ? M[t] * inv : 0.f;
+        M[t] = Ljt;
+#pragma unroll
+        for (int c = t + 1; c < P; ++c) {
+            const float Lct = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Ljt), c));
+            M[c] -= Ljt * Lct;
+        }
+    }
+    // forward  L y = rhs
+    float y = 0.f;
+#pragma unroll
+    for (int t = 0; t < P; ++t) {
+        const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, M[t]), t));
+        const float yt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rhs), t)) * __builtin_amdgcn_rcpf(d);
+        if (j == t) y = yt;
+        if (j > t) rhs -= M[t] * yt;
+    }
+    // backward  L^T x = y
+    float x = 0.f;
+#pragma unroll
+    for (int t = P - 1; t >= 0; --t) {
+        float part = (j > t && lane < P) ? M[t] * x : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, M[t]), t));
+        const float yt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), t));
+        const float xt = (yt - part) * __builtin_amdgcn_rcpf(d);
+        if (j == t) x = xt;
+    }
+    if (lane < P) Bq[i * ldw + lane] = live ? s * x : 0.f;
+}
+
 // out (cols x ld_out) = in (rows x ld_in)^T over the padded extents (small factor images)
 __global__ __launch_bounds__(256) void transpose_small_kernel(const float *in, float *out, int rows, int cols, int ld_in, int ld_out) {
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < rows * cols; idx += gridDim.x * 256) {

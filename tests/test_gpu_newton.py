@@ -646,7 +646,7 @@ def test_lowrank_per_row_side_woodbury_form(lib, p, k):
     U0, V0, Z0 = sc * np.abs(rng.randn(m, k)), sc * np.abs(rng.randn(d, k)), sc * rng.randn(p, k)
     args = (0.4, 0.05, 0.7, "linear", "logit", 3, 7, 0.2, 1.0)
     got = {}
-    for low in (1, 0):
+    for low in (1, 2, 0):
         ctx = lib.Context(0)
         ctx.set_option("lowrank_rows", low)
         if p == 40:
@@ -662,8 +662,9 @@ def test_lowrank_per_row_side_woodbury_form(lib, p, k):
     U, V, Z = U0.copy(), V0.copy(), Z0.copy()
     for _ in range(2):
         O.newton_update_step(X, Y, U, V, Z, 0.4, 0.05, 0.7, "linear", "logit", True, True, False, 1.0, 0.2)
-    for a, b, o in zip(got[1], got[0], (U, V, Z)):
+    for a, a2, b, o in zip(got[1], got[2], got[0], (U, V, Z)):
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-4 * np.abs(b).max())
+        np.testing.assert_allclose(a2, a, rtol=0, atol=2e-5 * np.abs(a).max())   # the p x p systems in registers / through memory
         np.testing.assert_allclose(a, o, rtol=0, atol=5e-4 * np.abs(o).max())
     assert np.abs(got[1][1] - got[0][1]).max() > 0 or k <= 64      # the two paths really are different code
 

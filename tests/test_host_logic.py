@@ -471,3 +471,55 @@ def test_integration_md_stub_parses_and_binds_declared_symbols():
     header = open(os.path.join(ROOT, "include", "cmfhip.h")).read()
     called = set(re.findall(r"_lib\.(cmf_\w+)", block))
     assert called and all(re.search(r"\b%s\s*\(" % name, header) for name in called), called
+
+
+HOST_STAGED_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from pycmf_amd.comm import HostStagedCollectives, env_rank_world
+
+class Buf:
+    """numpy stand-in for a DeviceArray"""
+    def __init__(self, a): self.a = a; self.shape = a.shape
+    def numel(self): return self.a.size
+    def element_size(self): return self.a.itemsize
+
+class FakeCtx:
+    """what HostStagedCollectives needs of a Context: copies between "device" buffers and host arrays, sync"""
+    def copy_to_host(self, buf): return buf.a.copy()
+    def copy_from_host(self, buf, a): buf.a[...] = np.asarray(a).reshape(buf.a.shape)
+    def sync(self): pass
+
+rank, world = env_rank_world()
+coll = HostStagedCollectives(FakeCtx(), rank, world)
+x = Buf(np.full((3, 4), float(rank + 1), dtype=np.float32))
+for it in range(5):
+    coll.all_reduce(x)                                   # 1+2 = 3, then 6, 12, ...
+assert np.all(x.a == 3.0 * 2 ** 4), x.a
+full = Buf(np.full((2 * world, 5), -1.0, dtype=np.float32))
+full.a[2 * rank:2 * rank + 2] = rank
+coll.all_gather(full)
+assert all(np.all(full.a[2 * r:2 * r + 2] == r) for r in range(world)), full.a
+assert list(coll.all_reduce_host([rank, 10.0], "max")) == [world - 1, 10.0]
+assert coll.stats()[0] == 6
+coll.close()
+print("rank", rank, "ok")
+'''
+
+
+def test_host_staged_collectives_world2(tmp_path):
+    """The test double of the collectives (pycmf_amd/comm.py, CMF_COMM_BACKEND=host) with two processes on CPU: sums in rank
+    order, in-place all-gather of equal chunks, host-scalar reduction, and the job's files are gone after close()."""
+    script = tmp_path / "hs_worker.py"
+    script.write_text(HOST_STAGED_WORKER % {"root": ROOT})
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", CMF_COMM_DIR=str(tmp_path), CMF_COMM_KEY="hs", CMF_COMM_TIMEOUT="60")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
+        assert "rank %d ok" % r in o
+    left = [f for f in os.listdir(str(tmp_path)) if f.startswith("cmf_host_hs_") and "done" not in f]
+    assert left == [], left
