@@ -757,7 +757,7 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "row_split")) {
         c->opt_rowsplit = value != 0;
     } else if (!strcmp(name, "lowrank_rows")) {
-        if (value < 0 || value > 2) return fail(CMF_EINVAL, "lowrank_rows: 0 off, 1 on (one wave per p x p system), 2 on (systems through chol_solve_kernel)");
+        if (value < 0 || value > 2) return fail(CMF_EINVAL, "lowrank_rows: 0 off, 1 on (p x p systems through chol_solve_kernel), 2 on (one wave per system in registers: A/B, slower)");
         c->opt_lowrank = (int)value;
     } else if (!strcmp(name, "newton_reassoc")) {
         c->opt_reassoc = value != 0;

@@ -570,15 +570,15 @@ __global__ __launch_bounds__(256) void rowvec_mat_flagged_kernel(float *step, co
 //   g H_i^-1 = a - (sqrt(C) y)^T B,   a = g S^-1,  B = Z S^-1 (p x k),  K = B Z^T (p x p),
 //   (I + sqrt(C) K sqrt(C)) y = sqrt(C) (B g^T)                      -- a p x p positive definite system per row
 // instead of forming and factoring a k x k matrix per row (reference: cmf_solvers.py:463-486 builds H_i and eigen-decomposes it).
-// K = B Z^T for p <= 64 valid rows (pitch kp in, pitch pk out); one workgroup
+// K = B Z^T for p <= 64 valid rows (pitch kp in, pitch pk out); workgroup j forms row j, four lanes share a dot product
 __global__ __launch_bounds__(256) void lowrank_k_kernel(const float *B, const float *Z, float *K, int p, int pk, int kp) {
-    for (int idx = threadIdx.x; idx < pk * pk; idx += 256) {
-        const int j = idx / pk, l = idx % pk;
-        float acc = 0.f;
-        if (j < p && l < p)
-            for (int c = 0; c < kp; ++c) acc += B[(int64_t)j * kp + c] * Z[(int64_t)l * kp + c];
-        K[idx] = acc;
-    }
+    const int j = blockIdx.x, l = threadIdx.x >> 2, q = threadIdx.x & 3;   // l = 0 .. 63
+    float acc = 0.f;
+    if (j < p && l < p)
+        for (int c = q; c < kp; c += 4) acc += B[(int64_t)j * kp + c] * Z[(int64_t)l * kp + c];
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (q == 0 && l < pk) K[j * pk + l] = acc;
 }
 // per row i (one workgroup of 256 threads per 4 rows): M_i = I + sqrt(c_i) K sqrt(c_i)^T (pk x pk, row-major), rhs_i = sqrt(c_i) o b_i
 __global__ __launch_bounds__(256) void lowrank_build_kernel(const float *W, const float *Bv, int64_t ldw, const float *K, float *M, float *rhs,
@@ -607,20 +607,25 @@ __global__ __launch_bounds__(256) void lowrank_scale_kernel(const float *W, cons
         Q[idx] = (j < p) ? __builtin_amdgcn_sqrtf(fmaxf(W[idx], 0.f)) * y[i * pk + j] : 0.f;
     }
 }
-// The p x p system of one row solved by ONE WAVE entirely in registers: lane j holds row j of M = I + sqrt(c) K sqrt(c)^T (register
-// c = column c), a right-looking Cholesky whose column t is scaled by every lane at once and whose rank-1 update takes L[c][t]
-// from lane c with v_readlane (compile-time lane index: the loops are fully unrolled), then the two triangular solves (forward
-// by lane broadcasts, backward by a wave sum per unknown).  M never exists in memory: the kernel reads c_i, b_i (p floats each)
-// and K, and overwrites b_i with q_i = sqrt(c_i) o y_i.  Instantiated for P = 32 only (p <= 32: the reference's own workload has 6
-// label columns): hipcc compiles the fully unrolled P = 32 body in 4 s and does not finish P >= 40 in 10 minutes, so 32 < p <= 64
-// (BASELINE configs[4]: 64 columns) takes the systems through memory and chol_solve_kernel<4> (4.5 ms per C5L iteration).
+// The p x p system of one row solved by ONE WAVE: lane j holds row j of M = I + sqrt(c) K sqrt(c)^T in registers.  Right-looking
+// Cholesky with a ROTATING register image: at step t the live columns t .. P - 1 sit in registers 0 .. P - 1 - t, so the pivot
+// column is always register 0, every lane scales its entry at once, and the rank-1 update of column t + c takes L[t + c][t] from
+// lane t + c with v_readlane and lands one register to the left (M[c - 1] = M[c] - L[j][t] L[t + c][t]: the shift is free).  The
+// loop over t is a runtime loop with one compact body (a body unrolled over t needs compile-time register indices; hipcc does
+// not finish that form for P >= 40).  The forward solve rides along (y_t is final as soon as column t is); column t of L goes
+// to LDS for the backward solve (one wave sum per unknown).  M never exists in memory: the kernel reads c_i, b_i (p floats
+// each) and K, and overwrites b_i with q_i = sqrt(c_i) o y_i.  MEASURED SLOWER than the route through memory and is therefore an
+// A/B option only (lowrank_rows = 2): C5L, 1e5 rows, P = 64: 3.06 ms per launch against ~1.7 ms for build + chol_solve_kernel<4> +
+// scale -- the v_readlane with a run-time lane index costs an SALU add + select and SGPR hazard slots per multiply-add, and
+// 64 KB of LDS per workgroup leaves two waves per SIMD to hide them.
 template <int P>
 __global__ __launch_bounds__(256) void lowrank_solve_kernel(const float *W, float *Bq, int64_t ldw, const float *K, int64_t nrows, int p) {
-    static_assert(P == 32, "padded order 32 (see above)");
-    const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= nrows) return;
-    const int j = lane < P ? lane : P - 1;          // lanes >= P (P = 32) mirror lane P - 1 and write nothing
+    static_assert(P == 32 || P == 64, "padded order 32 or 64");
+    __shared__ float Ls[4][P][64];                  // [wave][column t][lane j] = L[j][t]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wv;
+    if (i >= nrows) return;                         // whole waves leave: no workgroup barrier below
+    const int j = lane < P ? lane : P - 1;          // P = 32: lanes 32 .. 63 mirror lane 31 and write nothing
     const bool live = lane < p;
     const float s = live ? __builtin_amdgcn_sqrtf(fmaxf(W[i * ldw + lane], 0.f)) : 0.f;
     float rhs = live ? s * Bq[i * ldw + lane] : 0.f;
@@ -630,36 +635,31 @@ __global__ __launch_bounds__(256) void lowrank_solve_kernel(const float *W, floa
         const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), c));
         M[c] = (j == c ? 1.f : 0.f) + s * K[j * P + c] * sc;
     }
-    // Cholesky, M = L L^T (lower triangle of the register image becomes L)
-#pragma unroll
-    for (int t = 0; t < P; ++t) {
-        const float piv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, M[t]), t));
+    float y = 0.f;
+    for (int t = 0; t < P; ++t) {                   // runtime loop: register 0 = column t
+        const float piv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, M[0]), t));
         const float inv = __builtin_amdgcn_rsqf(piv);
-        const float Ljt = j >= t ? M[t] * inv : 0.f;
-        M[t] = Ljt;
+        const float Ljt = j >= t ? M[0] * inv : 0.f;                          // L[j][t]; L[t][t] = sqrt(piv) in lane t
+        Ls[wv][t][lane] = Ljt;
+        // forward substitution with the finished column: y_t = rhs_t / L[t][t], rhs_j -= L[j][t] y_t
+        const float yt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rhs), t)) * inv;
+        if (j == t) y = yt;
+        if (j > t) rhs -= Ljt * yt;
 #pragma unroll
-        for (int c = t + 1; c < P; ++c) {
-            const float Lct = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Ljt), c));
-            M[c] -= Ljt * Lct;
+        for (int c = 1; c < P; ++c) {
+            const int src = t + c < P ? t + c : P - 1;                          // dead columns: any lane will do
+            const float Lct = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Ljt), src));
+            M[c - 1] = M[c] - Ljt * Lct;
         }
     }
-    // forward  L y = rhs
-    float y = 0.f;
-#pragma unroll
-    for (int t = 0; t < P; ++t) {
-        const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, M[t]), t));
-        const float yt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rhs), t)) * __builtin_amdgcn_rcpf(d);
-        if (j == t) y = yt;
-        if (j > t) rhs -= M[t] * yt;
-    }
-    // backward  L^T x = y
+    // backward  L^T x = y:  x_t = (y_t - sum_{j > t} L[j][t] x_j) / L[t][t]
     float x = 0.f;
-#pragma unroll
     for (int t = P - 1; t >= 0; --t) {
-        float part = (j > t && lane < P) ? M[t] * x : 0.f;
+        const float Ljt = Ls[wv][t][lane];
+        float part = (j > t && lane < P) ? Ljt * x : 0.f;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-        const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, M[t]), t));
+        const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Ljt), t));
         const float yt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), t));
         const float xt = (yt - part) * __builtin_amdgcn_rcpf(d);
         if (j == t) x = xt;

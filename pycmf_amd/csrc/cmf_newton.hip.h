@@ -1434,7 +1434,7 @@ static int sweep_v_lowrank(cmf_ctx *c, double alpha, double l1, double l2, int y
     CHK(ensure(c, c->lr_small, ((size_t)pp * kp * 2 + (size_t)pk * pk) * sizeof(float)));
     float *B = (float *)c->lr_small.p, *Zt = B + pp * kp, *K = Zt + pp * kp;
     const int64_t lr_chunk = std::min<int64_t>(d, c->opt_rowchunk > 0 ? rup(c->opt_rowchunk, 4) : 262144);                         // rows per batch of p x p systems (4.3 GB at pk = 64)
-    const bool in_regs = c->opt_lowrank == 1 && pk == 32;
+    const bool in_regs = c->opt_lowrank == 2;   // A/B: one wave per system in registers (measured slower: cmf_eigen.hip.h)
     CHK(ensure(c, c->lr_rows, in_regs ? (size_t)256 : (size_t)lr_chunk * pk * (pk + 2) * sizeof(float)));
     float *M = (float *)c->lr_rows.p, *rhs = M + (size_t)lr_chunk * pk * pk, *y = rhs + (size_t)lr_chunk * pk;
     CHK(ensure(c, c->resid, img));
@@ -1444,7 +1444,7 @@ static int sweep_v_lowrank(cmf_ctx *c, double alpha, double l1, double l2, int y
     CHK(factor_times_hinv(c, Z, pp, 1.0, B));                                     // B = Z S^-1
     {
         Timed tm(c, CMF_K_ELEMWISE);
-        hipLaunchKernelGGL(lowrank_k_kernel, dim3(1), dim3(256), 0, c->stream, (const float *)B, (const float *)Z, K, p, pk, kp);
+        hipLaunchKernelGGL(lowrank_k_kernel, dim3((unsigned)pk), dim3(256), 0, c->stream, (const float *)B, (const float *)Z, K, p, pk, kp);
         hipLaunchKernelGGL(transpose_small_kernel, dim3(64), dim3(256), 0, c->stream, (const float *)Z, Zt, (int)pp, kp, kp, (int)pp);
         HIPCHK(hipGetLastError());
     }
@@ -1468,10 +1468,11 @@ static int sweep_v_lowrank(cmf_ctx *c, double alpha, double l1, double l2, int y
         CHK(ensure(c, c->eigflag, (size_t)lr_chunk * sizeof(int)));
         CHK(ensure(c, c->certflag, 2 * sizeof(int)));
         HIPCHK(hipMemsetAsync(c->certflag.p, 0, 2 * sizeof(int), c->stream));
-        if (in_regs) { // p <= 32: one wave per row, the p x p system in registers
-            hipLaunchKernelGGL((lowrank_solve_kernel<32>), dim3((unsigned)((d + 3) / 4)), dim3(256), 0, c->stream, (const float *)W, bq, pp, (const float *)K, d, p);
+        if (in_regs) { // one wave per row, the p x p system in registers
+            if (pk == 32) hipLaunchKernelGGL((lowrank_solve_kernel<32>), dim3((unsigned)((d + 3) / 4)), dim3(256), 0, c->stream, (const float *)W, bq, pp, (const float *)K, d, p);
+            else hipLaunchKernelGGL((lowrank_solve_kernel<64>), dim3((unsigned)((d + 3) / 4)), dim3(256), 0, c->stream, (const float *)W, bq, pp, (const float *)K, d, p);
             HIPCHK(hipGetLastError());
-        } else // 32 < p <= 64 (or lowrank_rows = 2): the systems through memory and chol_solve_kernel
+        } else // default: the systems through memory and chol_solve_kernel
         for (int64_t r0 = 0; r0 < d; r0 += lr_chunk) {
             const int64_t nr = std::min(lr_chunk, d - r0);
             hipLaunchKernelGGL(lowrank_build_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, c->stream, (const float *)(W + r0 * pp),
