@@ -1347,8 +1347,8 @@ extern "C" int cmf_residual_sq(cmf_ctx *c, int x_link, int y_link, double *ex2, 
     double host[2] = {0, 0};
     HIPCHK(hipMemsetAsync(c->dscalar, 0, 2 * sizeof(double), c->stream));
     if (ex2 && have_data(c, 0)) {
-        if (!c->X && x_link == CMF_LINK_LINEAR) {
-            CHK(sparse_residual_sq(c, 0, c->dscalar));
+        if (!c->X && c->sparse[0]) {
+            CHK(sparse_residual_sq(c, 0, c->dscalar, x_link));
         } else {
             CHK(need_dense(c, 0));
             NtOut o; o.T = c->X; o.ldt = c->dp; o.sq = c->dscalar; o.link = x_link;
@@ -1356,8 +1356,8 @@ extern "C" int cmf_residual_sq(cmf_ctx *c, int x_link, int y_link, double *ex2, 
         }
     }
     if (ey2 && have_data(c, 1)) {
-        if (!c->Y && y_link == CMF_LINK_LINEAR) {
-            CHK(sparse_residual_sq(c, 1, c->dscalar + 1));
+        if (!c->Y && c->sparse[1]) {
+            CHK(sparse_residual_sq(c, 1, c->dscalar + 1, y_link));
         } else {
             CHK(need_dense(c, 1));
             NtOut o; o.T = c->Y; o.ldt = c->pp; o.sq = c->dscalar + 1; o.link = y_link;

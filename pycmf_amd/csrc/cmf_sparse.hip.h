@@ -245,8 +245,10 @@ __global__ __launch_bounds__(64 * BCSR_NW) void spmm_blocked_kernel(BcsrView A, 
 // cross[wg] = sum over the nonzeros of this workgroup's rows of  a_ij * (L_i . R_j)
 // (the 2 tr((A R)^T L) term of the expanded Frobenius error, sklearn _beta_divergence
 // sparse branch used at pycmf/cmf_solvers.py:40)
+// logit != 0: a_ij * sigmoid(L_i . R_j) instead -- the cross term of ||A - sigmoid(L R^T)||^2 = sum_all sigmoid^2 + sum_nnz
+// (a^2 - 2 a sigmoid), whose first part is a dense pass with zero targets (pycmf/cmf_solvers.py:42 on a sparse target)
 template <int GL, int CH>
-__global__ __launch_bounds__(256) void sddmm_cross_kernel(CsrView A, const float *L, const float *R, int kp, double *partials) {
+__global__ __launch_bounds__(256) void sddmm_cross_kernel(CsrView A, const float *L, const float *R, int kp, double *partials, int logit) {
     constexpr int RPW = 64 / GL;
     const int lane = threadIdx.x & 63;
     const int gl = lane % GL, gsub = lane / GL;
@@ -267,6 +269,11 @@ __global__ __launch_bounds__(256) void sddmm_cross_kernel(CsrView A, const float
                 const f32x4 r = *reinterpret_cast<const f32x4 *>(R + (int64_t)j * kp + 4 * (gl + GL * c));
                 dot += l[c][0] * r[0] + l[c][1] * r[1] + l[c][2] * r[2] + l[c][3] * r[3];
             }
+            if (logit) { // the lanes of a row group hold partial dot products: finish the sum before the sigmoid
+                float full = dot;
+                for (int off = GL / 2; off > 0; off >>= 1) full += __shfl_xor(full, off, 64);
+                acc += (gl == 0) ? v * (1.0f / (1.0f + __expf(-full))) : 0.f;
+            } else
             acc += v * dot;
         }
     }

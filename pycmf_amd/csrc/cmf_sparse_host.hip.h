@@ -306,18 +306,27 @@ static int data_times(cmf_ctx *c, int which, bool trans, const float *B, float *
 static bool have_data(const cmf_ctx *c, int which) { return (which == 0 ? c->X : c->Y) != nullptr || c->sparse[which]; }
 
 template <int GL, int CH>
-static void launch_sddmm(cmf_ctx *c, const CsrView &v, const float *L, const float *R, double *partials, unsigned blocks) {
-    hipLaunchKernelGGL((sddmm_cross_kernel<GL, CH>), dim3(blocks), dim3(256), 0, c->stream, v, L, R, c->kp, partials);
+static void launch_sddmm(cmf_ctx *c, const CsrView &v, const float *L, const float *R, double *partials, unsigned blocks, int logit) {
+    hipLaunchKernelGGL((sddmm_cross_kernel<GL, CH>), dim3(blocks), dim3(256), 0, c->stream, v, L, R, c->kp, partials, logit);
 }
 
-// ||A - L R^T||^2 = ||A||^2 - 2 sum_nnz a_ij (l_i . r_j) + <L^T L, R^T R>   (linear link, native CSR)
-static int sparse_residual_sq(cmf_ctx *c, int which, double *dev_out) {
+// native CSR target:
+//   linear  ||A - L R^T||^2          = ||A||^2 - 2 sum_nnz a_ij (l_i . r_j) + <L^T L, R^T R>       (sklearn's expansion, cmf_solvers.py:40)
+//   logit   ||A - sigmoid(L R^T)||^2 = ||A||^2 - 2 sum_nnz a_ij sigmoid(l_i . r_j) + sum_all sigmoid(l_i . r_j)^2   (:42)
+// the last term of the logit form is the dense NT pass with zero targets: compute without any m x d image
+static int sparse_residual_sq(cmf_ctx *c, int which, double *dev_out, int link) {
     const CsrDev &A = c->sp[which][0];
     const float *L = which == 0 ? c->F[CMF_U] : c->F[CMF_V];
     const float *R = which == 0 ? c->F[CMF_V] : c->F[CMF_Z];
     const int64_t lrows = which == 0 ? c->mp : c->dp, rrows = which == 0 ? c->dp : c->pp;
-    CHK(gemm(c, MODE_TN, L, c->kp, L, c->kp, c->G, c->kp, c->kp, lrows));
-    CHK(gemm(c, MODE_TN, R, c->kp, R, c->kp, c->G2, c->kp, c->kp, rrows));
+    const bool logit = link == CMF_LINK_LOGIT;
+    if (logit) {
+        NtOut o; o.T = nullptr; o.ldt = 0; o.sq = c->dscalar + 5; o.link = link;
+        CHK(gemm_nt(c, L, lrows, which == 0 ? c->m : c->d, R, rrows, which == 0 ? c->d : c->p, o));
+    } else {
+        CHK(gemm(c, MODE_TN, L, c->kp, L, c->kp, c->G, c->kp, c->kp, lrows));
+        CHK(gemm(c, MODE_TN, R, c->kp, R, c->kp, c->G2, c->kp, c->kp, rrows));
+    }
     const int gl = std::min(64, c->kp / 4);
     const int rpw = 64 / gl;
     const unsigned blocks = (unsigned)std::max<int64_t>(1, ((A.rows + rpw - 1) / rpw + 3) / 4);
@@ -326,20 +335,20 @@ static int sparse_residual_sq(cmf_ctx *c, int which, double *dev_out) {
     {
         Timed tm(c, CMF_K_SPMM, 2.0 * (double)A.nnz * (double)c->kp);
         switch (c->kp) {
-        case 32: launch_sddmm<8, 1>(c, v, L, R, (double *)c->dpart.p, blocks); break;
-        case 64: launch_sddmm<16, 1>(c, v, L, R, (double *)c->dpart.p, blocks); break;
-        case 128: launch_sddmm<32, 1>(c, v, L, R, (double *)c->dpart.p, blocks); break;
-        case 256: launch_sddmm<64, 1>(c, v, L, R, (double *)c->dpart.p, blocks); break;
-        case 512: launch_sddmm<64, 2>(c, v, L, R, (double *)c->dpart.p, blocks); break;
-        case 768: launch_sddmm<64, 3>(c, v, L, R, (double *)c->dpart.p, blocks); break;
-        case 1024: launch_sddmm<64, 4>(c, v, L, R, (double *)c->dpart.p, blocks); break;
+        case 32: launch_sddmm<8, 1>(c, v, L, R, (double *)c->dpart.p, blocks, logit ? 1 : 0); break;
+        case 64: launch_sddmm<16, 1>(c, v, L, R, (double *)c->dpart.p, blocks, logit ? 1 : 0); break;
+        case 128: launch_sddmm<32, 1>(c, v, L, R, (double *)c->dpart.p, blocks, logit ? 1 : 0); break;
+        case 256: launch_sddmm<64, 1>(c, v, L, R, (double *)c->dpart.p, blocks, logit ? 1 : 0); break;
+        case 512: launch_sddmm<64, 2>(c, v, L, R, (double *)c->dpart.p, blocks, logit ? 1 : 0); break;
+        case 768: launch_sddmm<64, 3>(c, v, L, R, (double *)c->dpart.p, blocks, logit ? 1 : 0); break;
+        case 1024: launch_sddmm<64, 4>(c, v, L, R, (double *)c->dpart.p, blocks, logit ? 1 : 0); break;
         default: return fail(CMF_EUNSUPPORTED, "native CSR path supports n_components <= 1024");
         }
         HIPCHK(hipGetLastError());
     }
     Timed tm(c, CMF_K_ELEMWISE);
     hipLaunchKernelGGL(sum_doubles_kernel, dim3(1), dim3(256), 0, c->stream, (const double *)c->dpart.p, (int64_t)blocks, c->dscalar + 4);
-    hipLaunchKernelGGL(frob_inner_kernel, dim3(1), dim3(256), 0, c->stream, (const float *)c->G, (const float *)c->G2, c->kp * c->kp, c->dscalar + 5);
+    if (!logit) hipLaunchKernelGGL(frob_inner_kernel, dim3(1), dim3(256), 0, c->stream, (const float *)c->G, (const float *)c->G2, c->kp * c->kp, c->dscalar + 5);
     HIPCHK(hipGetLastError());
     double h[2];
     HIPCHK(hipMemcpyAsync(h, c->dscalar + 4, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));

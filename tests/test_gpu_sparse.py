@@ -221,10 +221,15 @@ def test_native_csr_per_row_sweeps_never_expand(lib, xl, yl, ratio, sampler):
         want = [ref.get_factor(w) for w in range(3)]
         ref.close()
     got = [ctx.get_factor(w) for w in range(3)]
+    # the error metric of either link on the native CSR targets (pycmf/cmf_solvers.py:36-42): linear by sklearn's expansion,
+    # logit as sum_all sigmoid^2 + sum_nnz (a^2 - 2 a sigmoid) -- still no dense image afterwards
+    ex2, ey2 = ctx.residual_sq(xl, yl)
     assert ctx.data_layout(0) == (False, True) and ctx.data_layout(1) == (False, True)
     ctx.close()
     for a, b in zip(got, want):
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-4 * np.abs(b).max())
+    np.testing.assert_allclose(np.sqrt(ex2), O.factorization_error(X, got[0], got[1].T, xl), rtol=1e-4)
+    np.testing.assert_allclose(np.sqrt(ey2), O.factorization_error(Y, got[1], got[2].T, yl), rtol=1e-4)
 
 
 @pytest.mark.parametrize("nn", [False, True])
