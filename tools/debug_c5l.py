@@ -9,6 +9,7 @@ from pycmf_amd import _lib
 def make(m, d, p, k, npr, seed=42):
     rng = np.random.default_rng(seed)
     X = sp.csr_matrix((np.ones(m * npr), rng.integers(0, d, size=m * npr, dtype=np.int32), np.arange(0, m * npr + 1, npr, dtype=np.int64)), shape=(m, d))
+    X.sum_duplicates()      # the upload merges repeated (row, column) pairs; the oracle's error formula must see the same matrix
     return X
 
 def trace(m, d, p, k, npr, iters, oracle=False, l1=2.0, l2=5.0):
