@@ -84,3 +84,29 @@ def test_newton_random_shapes(lib, seed):
     for w, ref in enumerate((Ur, Vr, Zr)):
         np.testing.assert_allclose(ctx.get_factor(w), ref, rtol=3e-3, atol=3e-3 * max(1e-3, np.abs(ref).max()))
     ctx.close()
+
+
+@pytest.mark.parametrize("alpha", [0.0, 1.0, 0.3])
+@pytest.mark.parametrize("l1,l2", [(0.0, 0.0), (0.1, 0.0), (0.0, 0.5), (0.05, 0.1)])
+@pytest.mark.parametrize("k", [5, 70])
+def test_linear_newton_edge_weights(lib, alpha, l1, l2, k):
+    """The shared (re-associated) sweeps at the edges of their parameter range: alpha = 0 / 1 remove one matrix from a sweep
+    altogether (H = l2 I, or exactly zero when l2 = 0 too: every eigenvalue clamps to the perturbation), l2 = 0 leaves
+    rank-deficient Grams, l1 adds the sign term.  Two iterations against the float64 oracle (pycmf/cmf_solvers.py:394-522)."""
+    from oracle import cmf_oracle as O
+    rng = np.random.RandomState(int(100 * alpha) + k)
+    m, d, p = 90, 75, 40
+    X, Y = np.abs(rng.randn(m, d)), np.abs(rng.randn(d, p))
+    U0, V0, Z0 = 0.3 * rng.randn(m, k), 0.3 * rng.randn(d, k), 0.3 * rng.randn(p, k)
+    U, V, Z = U0.copy(), V0.copy(), Z0.copy()
+    ctx = lib.Context(0)
+    ctx.set_problem(m, d, p, k)
+    ctx.set_data(0, X); ctx.set_data(1, Y)
+    for w, F in enumerate((U0, V0, Z0)):
+        ctx.set_factor(w, F)
+    for _ in range(2):
+        O.newton_update_step(X, Y, U, V, Z, alpha, l1, l2, "linear", "linear", False, False, False, 1.0, 0.2)
+        ctx.newton_step(alpha, l1, l2, "linear", "linear", 0, 7, 0.2, 1.0)
+    for w, ref in enumerate((U, V, Z)):
+        np.testing.assert_allclose(ctx.get_factor(w), ref, rtol=0, atol=2e-4 * max(1e-3, np.abs(ref).max()))
+    ctx.close()
