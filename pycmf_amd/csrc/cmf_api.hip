@@ -108,6 +108,7 @@ struct cmf_ctx {
     int opt_pipe_small = 4; // staging schedule of the factor-side products (0 or 4; 4 measured +5..15 %, tools/ab_small.py)
     int opt_pipe = 4;      // GEMM staging schedule (see gemm_kernel PIPE); 4 measured best (tools/ab_gemm.py)
     int opt_split = -1;    // force split-K factor (<=0: heuristic)
+    int opt_tile512 = 0;   // A/B: k_pad = 128 data passes on a 512 x 128 x 16 tile (GemmCfg TILE 1) instead of 256 x 128 x 32
     int opt_rounds = 1;    // split-K heuristic of the data passes: aim at this many workgroups per CU (A/B option: 2 measured within noise of 1 at C2)
     int opt_arith_min_tiles = 8;   // ... only for operands of at least this many 256-row tiles
     int opt_arith = 0;     // data passes at k_pad = 256: 0 fp32 MFMA | 1 bf16x6 (three bf16 planes per operand, fp32-equivalent)
@@ -312,13 +313,15 @@ struct GemmPlan {
     int64_t tiles_m;
     int nsplit;
     int64_t klen;
+    int tile = 0; // 1: the 512 x 128 x 16 tile (GemmCfg TILE 1)
 };
 
 static GemmPlan plan_gemm(const cmf_ctx *c, int64_t mout, int64_t n, int64_t kred, bool allow_split, bool data_pass = false) {
     GemmPlan pl;
     pl.bn = n >= 256 ? 256 : (int)n; // n in {32,64,128} or a multiple of 256
     pl.ntiles_n = (int)(n / pl.bn);
-    pl.tiles_m = (mout + 255) / 256;
+    pl.tile = (c->opt_tile512 && data_pass && allow_split && pl.bn == 128 && mout % 512 == 0 && c->opt_pipe == 4) ? 1 : 0;
+    pl.tiles_m = pl.tile ? mout / 512 : (mout + 255) / 256;
     const int64_t tiles = pl.tiles_m * pl.ntiles_n;
     int64_t s = 1;
     if (allow_split && c->opt_split > 0) {
@@ -350,6 +353,15 @@ static int launch_gemm_pipe(cmf_ctx *c, const GemmArgs &a, const GemmPlan &pl) {
         if (pl.bn != 128) return fail(CMF_EINVAL, "NT tile width must be 128");
         CMF_LAUNCH(128);
     } else {
+        if constexpr (ROLE == 0 && PIPE == 4) {
+            if (pl.tile == 1 && pl.bn == 128) { // A/B: 512 x 128 x 16 tile
+                using Cfg = GemmCfg<MODE, 128, 1>;
+                CHK(allow_big_lds(c, reinterpret_cast<const void *>(&gemm_kernel<MODE, 128, ROLE, PIPE, 1>), (int)Cfg::LDS_BYTES));
+                hipLaunchKernelGGL((gemm_kernel<MODE, 128, ROLE, PIPE, 1>), grid, block, Cfg::LDS_BYTES, c->stream, a);
+                HIPCHK(hipGetLastError());
+                return CMF_OK;
+            }
+        }
         switch (pl.bn) {
         case 256: CMF_LAUNCH(256); break;
         case 128: CMF_LAUNCH(128); break;
@@ -696,6 +708,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_pipe_small = (int)value;
     } else if (!strcmp(name, "gemm_split")) {
         c->opt_split = (int)value;
+    } else if (!strcmp(name, "gemm_tile512")) {
+        c->opt_tile512 = value != 0;
     } else if (!strcmp(name, "gemm_rounds")) {
         c->opt_rounds = (int)std::max<int64_t>(1, value);
     } else if (!strcmp(name, "z_logit_hessian_l2")) {

@@ -85,9 +85,13 @@ typedef float f32x1 __attribute__((ext_vector_type(1)));
 __device__ __forceinline__ void store_wt(float *p, f32x1 v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v[0]) : "memory"); }
 __device__ __forceinline__ void store_wt(float *p, float v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
 
-template <int MODE, int BN>
+// TILE 0: 256 x BN output tile, 32-deep K-step (everything).  TILE 1 (BN = 128 data passes, A/B option gemm_tile512): 512 x 128
+// output tile, 16-deep K-step -- wave tile 128 x 64 like the 256 x 256 kernel's 64 x 128 (six fragment reads per eight MFMAs
+// instead of four per four, half the B-tile fill per flop), the same MFMA work per barrier as the 256 x 128 x 32 step, and
+// 98 KB of LDS double-buffered (a 32-deep step of this tile would need 180 KB).
+template <int MODE, int BN, int TILE = 0>
 struct GemmCfg {
-    static constexpr int BM = 256, BK = 32, PADK = 36, NT = 512;
+    static constexpr int BM = TILE ? 512 : 256, BK = TILE ? 16 : 32, PADK = BK + 4, NT = 512;
     static constexpr bool A_KC = (MODE != MODE_TN);
     static constexpr bool B_KC = (MODE == MODE_NT);
     static constexpr int A_ELEMS = A_KC ? BM * PADK : BK * BM;
@@ -177,9 +181,13 @@ struct VecLoad<4> {
 //  loader wave per SIMD doing all the staging and the 8 MFMA waves only reading fragments: 131/121 TF/s NN/TN
 //  with direct-to-LDS loads, 131/136 with register staging, against 142.5/141.7 for schedule 4 - a third wave
 //  per SIMD costs more than the staging instructions it takes off the MFMA waves)
-template <int MODE, int BN, int ROLE = 0, int PIPE = 0>
+template <int MODE, int BN, int ROLE = 0, int PIPE = 0, int TILE = 0>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
-    using C = GemmCfg<MODE, BN>;
+    using C = GemmCfg<MODE, BN, TILE>;
+    static_assert(TILE == 0 || (BN == 128 && MODE != MODE_NT && ROLE == 0 && PIPE == 4), "the 512 x 128 x 16 tile: k_pad = 128 data passes only");
+    constexpr int F4K = C::BK / 4;   // 16-byte chunks per row of a k-contiguous tile
+    constexpr int F4M = C::BM / 4;   // ... per row of the [k][rows] tile of the TN form
+    constexpr int NGRP = C::BK / 2;  // MFMA groups (k pairs) per K-step
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int t = threadIdx.x;
@@ -217,13 +225,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
         for (int p = 0; p < C::A_LD; ++p) {
             const int idx = t + C::NT * p;
             if constexpr (C::A_KC) {
-                const int r = idx >> 3, c4 = idx & 7;
+                const int r = idx / F4K, c4 = idx % F4K;
                 ra[p] = *reinterpret_cast<const f32x4 *>(g.A + (row0 + r) * g.lda + k0 + 4 * c4);
             } else {
                 // branch-free: a conditional load makes hipcc wait for the loads it has just
                 // issued (it must assume the skipped path); out-of-range columns are clamped
                 // here and zeroed when the tile is written to LDS
-                const int r = idx >> 6, c4 = idx & 63;
+                const int r = idx / F4M, c4 = idx % F4M;
                 int64_t col = row0 + 4 * c4;
                 if (ROLE == 1 && col > g.Mout - 4) col = g.Mout - 4;
                 ra[p] = *reinterpret_cast<const f32x4 *>(g.A + (k0 + r) * g.lda + col);
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
             const int idx = t + C::NT * p;
             if (C::B_F4 >= C::NT || idx < C::B_F4) {
                 if constexpr (C::B_KC) {
-                    const int r = idx >> 3, c4 = idx & 7;
+                    const int r = idx / F4K, c4 = idx % F4K;
                     rb[p] = *reinterpret_cast<const f32x4 *>(Bbase + (n0 + r) * g.ldb + k0 + 4 * c4);
                 } else {
                     constexpr int F4R = BN / 4;
@@ -249,10 +257,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
         if (p < C::A_LD) {
             const int idx = t + C::NT * p;
             if constexpr (C::A_KC) {
-                const int r = idx >> 3, c4 = idx & 7;
+                const int r = idx / F4K, c4 = idx % F4K;
                 *reinterpret_cast<f32x4 *>(As + r * C::PADK + 4 * c4) = ra[p];
             } else {
-                const int r = idx >> 6, c4 = idx & 63;
+                const int r = idx / F4M, c4 = idx % F4M;
                 f32x4 v = ra[p];
                 if (ROLE == 1 && row0 + 4 * c4 >= g.Mout) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f32x4 *>(As + r * C::BM + 4 * c4) = v;
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
             const int idx = t + C::NT * pb;
             if (C::B_F4 >= C::NT || idx < C::B_F4) {
                 if constexpr (C::B_KC) {
-                    const int r = idx >> 3, c4 = idx & 7;
+                    const int r = idx / F4K, c4 = idx % F4K;
                     *reinterpret_cast<f32x4 *>(Bs + r * C::PADK + 4 * c4) = rb[pb];
                 } else {
                     constexpr int F4R = BN / 4;
@@ -291,6 +299,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
     // XOR-swizzled instead (16-byte chunk c of row r lives at chunk c ^ (r & 7)); the permutation is applied to
     // the per-lane SOURCE address and again on the fragment read.
     constexpr bool GLDS = (PIPE == 10);
+    static_assert(!GLDS || TILE == 0, "direct-to-LDS staging is laid out for the 256-row tile");
     constexpr int APK = GLDS ? C::BK : C::PADK; // floats per row of a k-contiguous A tile
     auto glds_tile = [&](float *As, float *Bs, int64_t k0) {
         typedef __attribute__((address_space(3))) float lds_f;
@@ -395,11 +404,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
                 lda_frag(0, a[0]);
                 ldb_frag(0, b[0]);
 #pragma unroll
-                for (int sidx = 0; sidx < 16; ++sidx) {
+                for (int sidx = 0; sidx < NGRP; ++sidx) {
                     const int q = sidx >> 2, e = sidx & 3;
-                    if (sidx + 1 < 16) {
+                    if (sidx + 1 < NGRP) {
                         ldb_frag(sidx + 1, b[(sidx + 1) & 1]);
-                        if (e == 0 && q + 1 < 4) lda_frag(q + 1, a[(q + 1) & 1]);
+                        if (e == 0 && q + 1 < NGRP / 4) lda_frag(q + 1, a[(q + 1) & 1]);
                     }
                     side(sidx);
                     __builtin_amdgcn_sched_barrier(0);
@@ -420,8 +429,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
             };
             ld_frag(0, a[0], b[0]);
 #pragma unroll
-            for (int sidx = 0; sidx < 16; ++sidx) {
-                if (sidx + 1 < 16) ld_frag(sidx + 1, a[(sidx + 1) & 1], b[(sidx + 1) & 1]);
+            for (int sidx = 0; sidx < NGRP; ++sidx) {
+                if (sidx + 1 < NGRP) ld_frag(sidx + 1, a[(sidx + 1) & 1], b[(sidx + 1) & 1]);
                 side(sidx);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
