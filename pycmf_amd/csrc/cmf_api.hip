@@ -143,6 +143,9 @@ struct cmf_ctx {
     float *num = nullptr, *den = nullptr; // max(mp,dp,pp) x kp
     float *G = nullptr, *G2 = nullptr, *Hm = nullptr, *Hinv = nullptr, *Eye = nullptr; // kp x kp
     float *vbuf = nullptr;                // dp*kp + kp*kp
+    DevBuf gslab32;                       // partial tiles of the small-Gram kernels
+    int opt_gram32_shares = 64;           // row shares (= partial slabs) of a small Gram
+    int opt_gram32 = 1;                   // k_pad 64 / 128 Grams on gram32_partial_kernel (0: one-tile TN GEMM, split + slab sum)
     DevBuf slabs, slabs_b;                // split-K partial tiles (grow-only); second set for a product whose slabs must outlive the next one
     int slab_sel = 0;                     // which set gemm() writes
     DevBuf tickets;                       // one arrival counter per output tile of a split-K GEMM (zero between launches)
@@ -490,6 +493,24 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
     return CMF_OK;
 }
 
+// G (k_pad x k_pad) = F^T F over rows_pad rows of a factor-sized operand: the dedicated small-Gram kernels at k_pad 64 / 128
+// (cmf_kernels.hip.h), else the TN GEMM
+static int gram32(cmf_ctx *c, const float *F, int64_t rows_pad, float *G) {
+    if (!(c->opt_gram32 && (c->kp == 64 || c->kp == 128) && rows_pad >= 1024))
+        return gemm(c, MODE_TN, F, c->kp, F, c->kp, G, c->kp, c->kp, rows_pad);
+    const int T = c->kp / 64, ntile = T * (T + 1) / 2;
+    int64_t nsplit = std::min<int64_t>(c->opt_gram32_shares, rows_pad / 32);
+    const int64_t chunk = rup((rows_pad + nsplit - 1) / nsplit, 32);
+    nsplit = (rows_pad + chunk - 1) / chunk;
+    CHK(ensure(c, c->gslab32, (size_t)nsplit * ntile * 64 * 64 * sizeof(float)));
+    Timed tm(c, CMF_K_GEMM_SMALL, 2.0 * (double)rows_pad * c->kp * c->kp);
+    hipLaunchKernelGGL(gram32_partial_kernel, dim3((unsigned)ntile, (unsigned)nsplit), dim3(256), 0, c->stream, F, c->kp, rows_pad, chunk, (float *)c->gslab32.p);
+    hipLaunchKernelGGL(gram32_reduce_kernel, dim3((unsigned)std::min(64, (c->kp * c->kp + 255) / 256)), dim3(256), 0, c->stream, (const float *)c->gslab32.p,
+                       c->kp, (int)nsplit, G);
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
 // rows x k_pad x k_pad product with a fused factor update on 64-row tiles (k_pad 64 / 128): see factor_update_kernel
 static bool small_tile_ok(const cmf_ctx *c, int64_t rows_pad) {
     return c->opt_fused_mu && c->opt_small_tile && (c->kp == 64 || c->kp == 128) && rows_pad * c->kp <= ((int64_t)1 << 27);
@@ -647,7 +668,7 @@ static void release_problem(cmf_ctx *c) {
     c->X = c->Y = nullptr;
     c->F[0] = c->F[1] = c->F[2] = nullptr;
     c->num = c->den = c->G = c->G2 = c->Hm = c->Hinv = c->Eye = c->vbuf = nullptr;
-    c->slabs = DevBuf(); c->slabs_b = DevBuf(); c->slab_sel = 0; c->tickets = DevBuf(); c->resid = DevBuf(); c->resid2 = DevBuf(); c->resid3 = DevBuf(); c->dpart = DevBuf();
+    c->slabs = DevBuf(); c->slabs_b = DevBuf(); c->gslab32 = DevBuf(); c->slab_sel = 0; c->tickets = DevBuf(); c->resid = DevBuf(); c->resid2 = DevBuf(); c->resid3 = DevBuf(); c->dpart = DevBuf();
     c->kr1 = DevBuf(); c->kr2 = DevBuf(); c->hrows = DevBuf(); c->mask1 = DevBuf(); c->mask2 = DevBuf();
     c->lists1 = DevBuf(); c->lists2 = DevBuf(); c->lists1s = DevBuf(); c->lists2s = DevBuf(); c->zerobuf = DevBuf(); c->lr_small = DevBuf(); c->lr_rows = DevBuf(); c->hpart = DevBuf();
     for (int q = 0; q < 2; ++q) { c->cls_idx[q] = DevBuf(); c->cls_off[q] = DevBuf(); c->cls_cnt[q] = DevBuf(); c->cls_pat[q] = DevBuf(); }
@@ -708,6 +729,10 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_pipe_small = (int)value;
     } else if (!strcmp(name, "gemm_split")) {
         c->opt_split = (int)value;
+    } else if (!strcmp(name, "small_gram_shares")) {
+        c->opt_gram32_shares = (int)std::max<int64_t>(1, std::min<int64_t>(value, 1024));
+    } else if (!strcmp(name, "small_gram")) {
+        c->opt_gram32 = value != 0;
     } else if (!strcmp(name, "gemm_tile512")) {
         c->opt_tile512 = value != 0;
     } else if (!strcmp(name, "gemm_rounds")) {
@@ -1207,7 +1232,7 @@ extern "C" int cmf_mu_v_partials(cmf_ctx *c, float *buf) {
     CHK(data_times(c, 0, true, c->F[CMF_U], P));
     CHK(data_times(c, 1, false, c->F[CMF_Z], P, true));
     // G = U^T U + Z^T Z: Gram of the stacked [U; Z]
-    CHK(gemm(c, MODE_TN, c->F[CMF_U], c->kp, c->F[CMF_U], c->kp, Gs, c->kp, c->kp, c->mp + c->pp));
+    CHK(gram32(c, c->F[CMF_U], c->mp + c->pp, Gs));
     return CMF_OK;
 }
 
@@ -1226,7 +1251,7 @@ extern "C" int cmf_mu_v_partials_rows(cmf_ctx *c, float *buf, int64_t row0, int6
     CHK(gemm(c, MODE_TN, c->X + row0, c->dp, c->F[CMF_U], c->kp, P, nrows, c->kp, c->mp));                       // X[:, rows]^T U
     CHK(gemm(c, MODE_NN, c->Y + row0 * c->pp, c->pp, c->F[CMF_Z], c->kp, P, nrows, c->kp, c->pp, true));        // + Y[rows, :] Z
     if (with_gram)
-        CHK(gemm(c, MODE_TN, c->F[CMF_U], c->kp, c->F[CMF_U], c->kp, buf + c->dp * c->kp, c->kp, c->kp, c->mp + c->pp));
+        CHK(gram32(c, c->F[CMF_U], c->mp + c->pp, buf + c->dp * c->kp));
     return CMF_OK;
 }
 
@@ -1245,7 +1270,7 @@ extern "C" int cmf_mu_uz_update(cmf_ctx *c, double l1, double l2, int mask) {
     NEED_PROBLEM(c);
     DeviceGuard dg(c->device);
     if (!(mask & (CMF_UPD_U | CMF_UPD_Z))) return CMF_OK;
-    CHK(gemm(c, MODE_TN, c->F[CMF_V], c->kp, c->F[CMF_V], c->kp, c->G2, c->kp, c->kp, c->dp));
+    CHK(gram32(c, c->F[CMF_V], c->dp, c->G2));
     if (mask & CMF_UPD_U) {
         if (!have_data(c, 0)) return fail(CMF_EINVAL, "X must be set before a U update");
         SlabRef sl;
@@ -1317,7 +1342,7 @@ static int mu_v_fused(cmf_ctx *c, double l1, double l2) {
     float *P = c->vbuf, *Gs = c->vbuf + c->dp * c->kp;
     SlabRef s1, s2;
     // the Gram first: its own split goes through slab set 0, which the deferred products below must own until the update
-    CHK(gemm(c, MODE_TN, c->F[CMF_U], c->kp, c->F[CMF_U], c->kp, Gs, c->kp, c->kp, c->mp + c->pp));
+    CHK(gram32(c, c->F[CMF_U], c->mp + c->pp, Gs));
     CHK(data_times(c, 0, true, c->F[CMF_U], P, false, &s1));           // X^T U: slabs (set 0) or, unsplit, P itself
     const float *direct = s1.nslab > 0 ? nullptr : P;
     if (s1.nslab > 0) {

@@ -866,6 +866,67 @@ __global__ __launch_bounds__(256) void factor_update_kernel(FactorUpdArgs g) {
     }
 }
 
+// ------------------------------------------------------------------ small Grams (k_pad 64 / 128)
+// G = F^T F for a factor of a few thousand rows (MU at C2: V^T V over 8192 rows, U^T U + Z^T Z over the stacked 20480) costs
+// next to nothing in flops but was 12 % of the C2 iteration as a one-tile TN GEMM split 160 ways plus the sum of its 10 MB of
+// slabs.  Here every workgroup forms ONE upper 64 x 64 tile over its share of the rows (four waves, one 32 x 32 MFMA block each,
+// both operands from the same 32-row LDS image: pitch 96 floats puts the two 32-lane halves of a fragment read 32 banks apart)
+// and there are at most 64 row shares, so the partial sums are 64 slabs of the upper tiles (0.75 MB at k_pad = 128), added up in
+// share order by gram32_reduce_kernel (deterministic).  F: rows_pad x kp, zero padding rows.
+__global__ __launch_bounds__(256) void gram32_partial_kernel(const float *F, int kp, int64_t rows_pad, int64_t chunk, float *slab) {
+    constexpr int TS = 64, LD = TS + 32;
+    __shared__ __attribute__((aligned(16))) float sA[32 * LD];
+    __shared__ __attribute__((aligned(16))) float sB[32 * LD];
+    const int T = kp / TS;
+    int b = blockIdx.x, ti = 0;
+    while (b >= T - ti) { b -= T - ti; ++ti; }
+    const int tj = ti + b;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wi = w >> 1, wj = w & 1, l31 = lane & 31, lh = lane >> 5;
+    const int64_t r0 = (int64_t)blockIdx.y * chunk;
+    const int64_t r1 = r0 + chunk < rows_pad ? r0 + chunk : rows_pad;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int64_t r = r0; r < r1; r += 32) {
+        __syncthreads();
+        for (int idx = t; idx < 8 * TS; idx += 256) { // 32 rows x 16 float4 per operand
+            const int row = idx / (TS / 4), c4 = idx % (TS / 4);
+            const float *src = F + (r + row) * kp + 4 * c4;
+            *reinterpret_cast<f32x4 *>(sA + row * LD + 4 * c4) = *reinterpret_cast<const f32x4 *>(src + ti * TS);
+            *reinterpret_cast<f32x4 *>(sB + row * LD + 4 * c4) = *reinterpret_cast<const f32x4 *>(src + tj * TS);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float a = sA[(2 * s + lh) * LD + wi * 32 + l31];
+            const float bb = sB[(2 * s + lh) * LD + wj * 32 + l31];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
+        }
+    }
+    float *out = slab + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (TS * TS);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        out[(wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TS + wj * 32 + l31] = acc[r];
+}
+// G[r][c] (kp x kp, symmetric) = sum over the shares, in share order
+__global__ __launch_bounds__(256) void gram32_reduce_kernel(const float *slab, int kp, int nsplit, float *G) {
+    constexpr int ts = 64;
+    const int T = kp / ts, ntile = T * (T + 1) / 2;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < kp * kp; idx += gridDim.x * 256) {
+        const int r = idx / kp, c = idx % kp;
+        const int rr = r < c ? r : c, cc = r < c ? c : r; // upper-triangle representative (tile row <= tile column)
+        const int ti = rr / ts, tj = cc / ts;
+        int ir = rr % ts, ic = cc % ts;
+        if (ti == tj) { ir = r % ts; ic = c % ts; }       // diagonal tiles are stored whole
+        const int tile = ti * T - ti * (ti - 1) / 2 + (tj - ti);
+        const float *p = slab + (int64_t)tile * ts * ts + ir * ts + ic;
+        float s = 0.f;
+        for (int q = 0; q < nsplit; ++q) s += p[(int64_t)q * ntile * ts * ts];
+        G[idx] = s;
+    }
+}
+
 // ------------------------------------------------------------------ elementwise
 // dst[i] = (accumulate ? dst[i] : 0) + sum_s src[s*stride + i]      (float4 lanes)
 __global__ void sum_slabs_kernel(float *dst, const float *src, int64_t n4, int nslab,
