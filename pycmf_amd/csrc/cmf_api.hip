@@ -144,7 +144,7 @@ struct cmf_ctx {
     float *G = nullptr, *G2 = nullptr, *Hm = nullptr, *Hinv = nullptr, *Eye = nullptr; // kp x kp
     float *vbuf = nullptr;                // dp*kp + kp*kp
     DevBuf gslab32;                       // partial tiles of the small-Gram kernels
-    int opt_gram32_shares = 64;           // row shares (= partial slabs) of a small Gram
+    int opt_gram32_shares = 32;           // row shares (= partial slabs) of a small Gram (C2: 8 -> 1127, 16 -> 1163, 24 -> 1166, 32 -> 1170-1177, 64 -> 1160, 128 -> 1099 it/s)
     int opt_gram32 = 1;                   // k_pad 64 / 128 Grams on gram32_partial_kernel (0: one-tile TN GEMM, split + slab sum)
     DevBuf slabs, slabs_b;                // split-K partial tiles (grow-only); second set for a product whose slabs must outlive the next one
     int slab_sel = 0;                     // which set gemm() writes

@@ -888,15 +888,28 @@ __global__ __launch_bounds__(256) void gram32_partial_kernel(const float *F, int
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // 32 rows x 16 float4 per operand = two float4 per thread and operand; the next 32 rows wait in registers under the MFMAs
+    f32x4 na[2], nb[2];
+    auto fetch = [&](int64_t r) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = t + 256 * q, row = idx / (TS / 4), c4 = idx % (TS / 4);
+            const float *src = F + (r + row) * kp + 4 * c4;
+            na[q] = *reinterpret_cast<const f32x4 *>(src + ti * TS);
+            nb[q] = *reinterpret_cast<const f32x4 *>(src + tj * TS);
+        }
+    };
+    if (r0 < r1) fetch(r0);
     for (int64_t r = r0; r < r1; r += 32) {
         __syncthreads();
-        for (int idx = t; idx < 8 * TS; idx += 256) { // 32 rows x 16 float4 per operand
-            const int row = idx / (TS / 4), c4 = idx % (TS / 4);
-            const float *src = F + (r + row) * kp + 4 * c4;
-            *reinterpret_cast<f32x4 *>(sA + row * LD + 4 * c4) = *reinterpret_cast<const f32x4 *>(src + ti * TS);
-            *reinterpret_cast<f32x4 *>(sB + row * LD + 4 * c4) = *reinterpret_cast<const f32x4 *>(src + tj * TS);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = t + 256 * q, row = idx / (TS / 4), c4 = idx % (TS / 4);
+            *reinterpret_cast<f32x4 *>(sA + row * LD + 4 * c4) = na[q];
+            *reinterpret_cast<f32x4 *>(sB + row * LD + 4 * c4) = nb[q];
         }
         __syncthreads();
+        if (r + 32 < r1) fetch(r + 32);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const float a = sA[(2 * s + lh) * LD + wi * 32 + l31];
