@@ -496,10 +496,12 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
 // G (k_pad x k_pad) = F^T F over rows_pad rows of a factor-sized operand: the dedicated small-Gram kernels at k_pad 64 / 128
 // (cmf_kernels.hip.h), else the TN GEMM
 static int gram32(cmf_ctx *c, const float *F, int64_t rows_pad, float *G) {
+    // (k_pad = 256, C4: measured equal to the TN GEMM + slab sum, 0.70 against 0.53 + 0.13 ms per iteration -- not used there)
     if (!(c->opt_gram32 && (c->kp == 64 || c->kp == 128) && rows_pad >= 1024))
         return gemm(c, MODE_TN, F, c->kp, F, c->kp, G, c->kp, c->kp, rows_pad);
     const int T = c->kp / 64, ntile = T * (T + 1) / 2;
-    int64_t nsplit = std::min<int64_t>(c->opt_gram32_shares, rows_pad / 32);
+    // row shares: 32 for a few thousand rows (C2); long factors (C4: 131072 stacked rows) take one share per 1024 rows
+    int64_t nsplit = std::min<int64_t>(std::max<int64_t>(c->opt_gram32_shares, std::min<int64_t>(256, rows_pad / 1024)), rows_pad / 32);
     const int64_t chunk = rup((rows_pad + nsplit - 1) / nsplit, 32);
     nsplit = (rows_pad + chunk - 1) / chunk;
     CHK(ensure(c, c->gslab32, (size_t)nsplit * ntile * 64 * 64 * sizeof(float)));
