@@ -160,7 +160,7 @@ struct cmf_ctx {
     DevBuf mask1, mask2;                  // stochastic sample masks (bytes)
     DevBuf lists1, lists2;                // device copies of the per-row sample index lists
     DevBuf hpart;                         // partial Hessians / gradients of the split row launches (few rows, long lists)
-    int opt_ft_tile = 64;                 // column tile of factor_times64_kernel at k_pad >= 128: 64 (2.40 ms per 1e6 x 256 x 256 product at C5) | 128 (2.8 ms: measured slower)
+    int opt_ft_tile = 256;                // tile of factor_times64_kernel: 256 = 128 rows x 64 columns, eight waves (default; C5: 2.2 ms per 1e6 x 256 x 256 product) | 64 = 64 x 64 (2.4 ms) | 128 = 64 x 128 (2.8 ms)
     int opt_rowsplit = 1;                 // split the samples of a row over several workgroups when a sweep has fewer rows than CUs
     DevBuf lr_small, lr_rows;             // low-rank per-row side (sweep_v_lowrank): B / Z^T / K images; per-row p x p systems
     int opt_lowrank = 1;                  // Woodbury form of the V sweep when the per-row side has fewer samples than components
@@ -794,7 +794,7 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "shared_hessian_f64")) {
         c->opt_shared64 = value != 0;
     } else if (!strcmp(name, "factor_times_tile")) {
-        c->opt_ft_tile = value == 64 ? 64 : 128;
+        c->opt_ft_tile = (value == 64 || value == 256) ? (int)value : 128;   // 64: 64 x 64 tile | 128: 64 x 128 | 256: 128 rows x 64 columns, eight waves
     } else if (!strcmp(name, "row_split")) {
         c->opt_rowsplit = value != 0;
     } else if (!strcmp(name, "lowrank_rows")) {

@@ -470,6 +470,7 @@ static bool use_reassoc(const cmf_ctx *c) { return c->opt_reassoc && c->opt_shar
 static int factor_times_hinv(cmf_ctx *c, const float *O, int64_t rows_pad, double scale, float *out) {
     Timed tm(c, CMF_K_GEMM_SMALL, 2.0 * (double)rows_pad * c->kp * c->kp);
     if (c->kp == 32) hipLaunchKernelGGL((factor_times64_kernel<32>), dim3(1, (unsigned)(rows_pad / 64)), dim3(256), 0, c->stream, O, (const double *)c->hinv64.p, out, c->kp, scale);
+    else if (c->kp >= 64 && c->opt_ft_tile == 256 && rows_pad % 128 == 0) hipLaunchKernelGGL((factor_times64_kernel<64, 128>), dim3((unsigned)(c->kp / 64), (unsigned)(rows_pad / 128)), dim3(512), 0, c->stream, O, (const double *)c->hinv64.p, out, c->kp, scale);
     else if (c->kp >= 128 && c->opt_ft_tile == 128) hipLaunchKernelGGL((factor_times64_kernel<128>), dim3((unsigned)(c->kp / 128), (unsigned)(rows_pad / 64)), dim3(256), 0, c->stream, O, (const double *)c->hinv64.p, out, c->kp, scale);
     else hipLaunchKernelGGL((factor_times64_kernel<64>), dim3((unsigned)(c->kp / 64), (unsigned)(rows_pad / 64)), dim3(256), 0, c->stream, O, (const double *)c->hinv64.p, out, c->kp, scale);
     HIPCHK(hipGetLastError());

@@ -639,17 +639,19 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const double *A, const doub
 // the reduction in steps of 32 through LDS:
 // A tile [64][36] floats (k contiguous; 16 rows x 4 k of a ds_read_b32 group fall on 64 distinct banks), B tile [32][80] doubles
 // (the two 16-lane halves of a ds_read_b64 group read rows k and k + 1, 128 bytes apart mod 256).
-template <int NW>
-__global__ __launch_bounds__(256) void factor_times64_kernel(const float *A, const double *B, float *O, int kp, double scale) {
+template <int NW, int RW = 64>
+__global__ __launch_bounds__(4 * RW) void factor_times64_kernel(const float *A, const double *B, float *O, int kp, double scale) {
     static_assert(NW == 128 || NW == 64 || NW == 32, "column tile 128 (k_pad >= 128), 64 (k_pad = 64) or 32 (k_pad = 32)");
+    static_assert(RW == 64 || RW == 128, "row tile 64 (four waves) or 128 (eight waves: half the B traffic per flop)");
     // wave (wi, wj) owns rows wi * 32 .. + 31 and columns wj * NW / 2 .. : 2 x JB MFMA blocks
-    constexpr int LA = 36, LB = NW + 16, WN = NW / 2, JB = WN / 16, BL = NW / 16; // BL: double2 loads of the B tile per thread
-    __shared__ __attribute__((aligned(16))) float As[64 * LA];
+    constexpr int NT = 4 * RW, LA = 36, LB = NW + 16, WN = NW / 2, JB = WN / 16;
+    constexpr int AL = RW * 8 / NT, BL = 32 * (NW / 2) / NT; // float4 loads of the A tile / double2 loads of the B tile per thread
+    __shared__ __attribute__((aligned(16))) float As[RW * LA];
     __shared__ __attribute__((aligned(16))) double Bs[32 * LB];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wi = w >> 1, wj = w & 1;
     const int l15 = lane & 15, lk = lane >> 4;
-    const int64_t m0 = (int64_t)blockIdx.y * 64;
+    const int64_t m0 = (int64_t)blockIdx.y * RW;
     const int n0 = blockIdx.x * NW;
     f64x4 acc[2][JB];
 #pragma unroll
@@ -657,27 +659,27 @@ __global__ __launch_bounds__(256) void factor_times64_kernel(const float *A, con
 #pragma unroll
         for (int j = 0; j < JB; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
     for (int k0 = 0; k0 < kp; k0 += 32) {
-        f32x4 av[2];
+        f32x4 av[AL];
         f64x2 bv[BL];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) { // 64 rows x 8 float4
-            const int idx = t + 256 * q, r = idx >> 3, c4 = idx & 7;
+        for (int q = 0; q < AL; ++q) { // RW rows x 8 float4
+            const int idx = t + NT * q, r = idx >> 3, c4 = idx & 7;
             av[q] = *reinterpret_cast<const f32x4 *>(A + (m0 + r) * kp + k0 + 4 * c4);
         }
 #pragma unroll
         for (int q = 0; q < BL; ++q) { // 32 rows x NW / 2 double2
-            const int idx = t + 256 * q, r = idx / (NW / 2), c2 = idx % (NW / 2);
+            const int idx = t + NT * q, r = idx / (NW / 2), c2 = idx % (NW / 2);
             bv[q] = *reinterpret_cast<const f64x2 *>(B + (int64_t)(k0 + r) * kp + n0 + 2 * c2);
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int idx = t + 256 * q, r = idx >> 3, c4 = idx & 7;
+        for (int q = 0; q < AL; ++q) {
+            const int idx = t + NT * q, r = idx >> 3, c4 = idx & 7;
             *reinterpret_cast<f32x4 *>(As + r * LA + 4 * c4) = av[q];
         }
 #pragma unroll
         for (int q = 0; q < BL; ++q) {
-            const int idx = t + 256 * q, r = idx / (NW / 2), c2 = idx % (NW / 2);
+            const int idx = t + NT * q, r = idx / (NW / 2), c2 = idx % (NW / 2);
             *reinterpret_cast<f64x2 *>(Bs + r * LB + 2 * c2) = bv[q];
         }
         __syncthreads();
