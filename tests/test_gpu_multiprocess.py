@@ -201,7 +201,11 @@ def test_bench_overlapped_all_reduce_in_row_blocks():
     cs, co = serial["collective"], over["collective"]
     assert cs["calls_per_iteration"] == 1 and co["calls_per_iteration"] == 4 and co["overlap_chunks"] == 4
     assert co["payload_bytes_per_iteration"] == cs["payload_bytes_per_iteration"] == (1024 + 64) * 64 * 4
-    assert abs(co["exposed_ms_per_iteration"] + co["hidden_ms_per_iteration"] - co["ms_per_iteration"]) < 1e-6 + 0.5 * co["ms_per_iteration"]
+    # exposed = stream time spent waiting in the joins, hidden = max(0, collectives - exposed).  With one rank a collective
+    # lasts ~5 us, the same order as the event pair around a join, so the two clocks agree only up to that granularity:
+    # 0.05 ms absolute slack per iteration (four joins)
+    assert co["exposed_ms_per_iteration"] >= 0 and co["hidden_ms_per_iteration"] >= 0
+    assert abs(co["exposed_ms_per_iteration"] + co["hidden_ms_per_iteration"] - co["ms_per_iteration"]) < 0.05 + 0.5 * co["ms_per_iteration"]
     for key in ("x", "y"):
         assert abs(over["rel_residual"][key] - serial["rel_residual"][key]) <= 1e-5 * serial["rel_residual"][key]
     two = _run_bench(["--gpus", "2", "--overlap-chunks", "2"] + base,
