@@ -216,6 +216,15 @@ int cmf_data_sq(cmf_ctx *ctx, double *x2, double *y2);  /* ||X||^2, ||Y||^2 */
 /* H: n symmetric k x k float64 matrices (host), out: Q diag(1/max(|l|,pert)) Q^T */
 int cmf_safe_invert_batch(cmf_ctx *ctx, const double *H, double *out, int n, int k, double pert);
 
+/* Conditioning record of the per-row Newton sweeps.  The spectral clamp of _safe_invert (pycmf/cmf_solvers.py:346-356) acts on a
+ * row's Hessian only when its smallest eigenvalue is below `pert`; on the device that Hessian is a float32 matrix, whose
+ * eigenvalues are resolved to about eps32 * ||H||, so the clamped directions of the inverse carry a relative error of the order
+ * eps32 * ||H|| / pert (the reference works in float64).  rows = matrices the float32 clamp acted on since the last reset,
+ * max_ratio = the largest ||H||_F / pert among them (0 when there were none).  The stated tolerances hold
+ * for max_ratio up to ~1e4; the estimator warns above that.  The shared Hessians of the linear unsampled sweeps are formed and
+ * clamped in float64 and never appear here. */
+int cmf_newton_clamp_stats(cmf_ctx *ctx, int64_t *rows, double *max_ratio, int reset);
+
 /* float64 path of the ONE shared Hessian of a linear-link sweep (cmf_solvers.py:407-410, :448-450): H is k x k
  * float64 on the host, k = the problem's n_components; out = Q diag(1/max(|l|,pert)) Q^T computed in float64 on
  * the device (positive semi-definite H), returned after its rounding to float32 (the form the step product uses) */

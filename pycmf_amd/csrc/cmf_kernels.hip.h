@@ -1120,6 +1120,30 @@ __global__ __launch_bounds__(256) void compact_flags_kernel(const int *flags, in
         if (flags[i]) idx[atomicAdd(count, 1)] = i;
 }
 
+// Record of the spectral clamp in float32 (cmf_newton_clamp_stats): for every matrix the clamp acts on (flags[b] != 0, or all when
+// flags is null) count it and keep the largest ||H_b||_F / pert.  The clamp max(|lambda|, pert) of a float32 Hessian resolves
+// eigenvalues only to about eps32 * ||H||, i.e. to a RELATIVE error of eps32 * ||H|| / pert in the clamped directions of the
+// inverse: the ratio says when that leaves the stated tolerance.  One wave per matrix, H is not modified.
+__global__ __launch_bounds__(64) void clamp_stats_kernel(const float *H, const int *flags, int n, int kp, int64_t stride, float pert,
+                                                         unsigned long long *count, unsigned *maxratio) {
+    const int b = blockIdx.x;
+    if (flags && !flags[b]) return;
+    const float *src = H + (int64_t)b * stride;
+    float fro = 0.f;
+    for (int r = 0; r < n; ++r)
+        for (int q = threadIdx.x; q < n; q += 64) {
+            const float v = src[r * kp + q];
+            fro += v * v;
+        }
+    for (int off = 32; off > 0; off >>= 1) fro += __shfl_xor(fro, off, 64);
+    if (threadIdx.x == 0) {
+        const float ratio = sqrtf(fro) / pert;
+        if (ratio == ratio) atomicMax(maxratio, __float_as_uint(fminf(ratio, 3.0e38f)));
+        atomicAdd(count, 1ull);
+    }
+}
+
+
 // B = H - pert I for flagged matrix b (valid n x n block; padding: c on the diagonal, 0 elsewhere),
 // c = min(||B||_F, ||B||_inf) >= rho(B), X0 = B / c.  One workgroup per matrix; thread t owns column t
 // (H is symmetric, so column sums are row sums and the reads are coalesced).  cmax collects max c (float bits).

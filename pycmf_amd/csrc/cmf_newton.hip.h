@@ -52,6 +52,38 @@ static int jacobi_chipwide(cmf_ctx *c, const float *Hin, float *Hout, int *flags
     return CMF_OK;
 }
 
+// note the matrices the float32 spectral clamp is about to act on (see clamp_stats_kernel)
+static int clamp_stats(cmf_ctx *c, const float *Hc, const int *flags, int64_t nmat, int n, int kp, int64_t stride, double pert) {
+    if (nmat <= 0) return CMF_OK;
+    if (!c->clampstat.p) {
+        CHK(ensure(c, c->clampstat, 16));
+        HIPCHK(hipMemsetAsync(c->clampstat.p, 0, 16, c->stream));
+    }
+    hipLaunchKernelGGL(clamp_stats_kernel, dim3((unsigned)nmat), dim3(64), 0, c->stream, Hc, flags, n, kp, stride, (float)pert,
+                       (unsigned long long *)c->clampstat.p, (unsigned *)((char *)c->clampstat.p + 8));
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
+// Rows whose Hessian went through the float32 spectral clamp since the last reset, and the largest ||H||_F / pert among them.
+extern "C" int cmf_newton_clamp_stats(cmf_ctx *c, int64_t *rows, double *max_ratio, int reset) {
+    if (!c) return fail(CMF_EINVAL, "null context");
+    DeviceGuard dg(c->device);
+    unsigned long long cnt = 0;
+    float ratio = 0.f;
+    if (c->clampstat.p) {
+        unsigned char host[16];
+        HIPCHK(hipMemcpyAsync(host, c->clampstat.p, 16, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        memcpy(&cnt, host, 8);
+        memcpy(&ratio, host + 8, 4);
+        if (reset) HIPCHK(hipMemsetAsync(c->clampstat.p, 0, 16, c->stream));
+    }
+    if (rows) *rows = (int64_t)cnt;
+    if (max_ratio) *max_ratio = (double)ratio;
+    return CMF_OK;
+}
+
 static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat, int n, int kp, double pert, bool psd = false) {
     if (nmat <= 0) return CMF_OK;
     const int64_t stride = (int64_t)kp * kp;
@@ -119,6 +151,7 @@ static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat,
         need = (const int *)c->eigflag.p;
         Hin = src;
     }
+    CHK(clamp_stats(c, Hin, need, nmat, n, kp, stride, pert));
     const size_t lds_need = (size_t)(2 * n * n + n) * sizeof(float);
     if (lds_need <= 150 * 1024) {
         CHK(allow_big_lds(c, reinterpret_cast<const void *>(&jacobi_safe_inverse_kernel<true>), 150 * 1024));
@@ -260,6 +293,7 @@ static int safe_solve_rows(cmf_ctx *c, float *Hc, const float *grad, float *step
         else hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag,
                                 (const int *)nullptr, 1, cert.flags, cert.rows, cert.split);
         HIPCHK(hipGetLastError());
+        CHK(clamp_stats(c, Hc, flags, nr, n, kp, stride, pert));
         // flagged matrices, k_pad = 128 / 256, Hessians positive semi-definite by construction (weights >= 0):
         // spectral clamp by Newton-Schulz (MFMA) + a second Cholesky solve; clears the flags it serves
         if ((kp == 256 || kp == 128) && c->opt_ns && c->hess_psd) CHK(ns_clamp_solve_rows(c, Hc, grad, step, flags, nr, n, kp, pert));

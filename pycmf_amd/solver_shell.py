@@ -182,6 +182,7 @@ class _HipIterativeSolver:
         start_time = time.time()
         self._bind(X, Y, U, V, Z)
         self._push_factors(U, V, Z)
+        self._fit_begin()
         ex, ey = self._device_error()
         previous_error = error_at_init = self.alpha * ex + (1 - self.alpha) * ey
 
@@ -202,8 +203,15 @@ class _HipIterativeSolver:
             self._ctx.sync()
             print("Epoch %02d reached after %.3f seconds." % (n_iter, time.time() - start_time))
 
+        self._fit_end()
         self._pull_factors(U, V, Z)
         return U, V, Z, n_iter
+
+    def _fit_begin(self):
+        pass
+
+    def _fit_end(self):
+        pass
 
 
 class HipMUSolver(_HipIterativeSolver):
@@ -224,6 +232,24 @@ class HipNewtonSolver(_HipIterativeSolver):
     candidates per row) is drawn on the GPU from a counter-based generator: no
     host RNG time, no index upload, but not NumPy's stream.
     """
+
+    #: ||H||_F / hessian_pertubation above which the float32 spectral clamp of a row's Hessian leaves the stated tolerance
+    #: (tools/fuzz_campaign.py: every case within 3e-3 of the float64 reference below it; DESIGN.md section 7)
+    CLAMP_RATIO_WARN = 1.0e4
+
+    def _fit_begin(self):
+        self._ctx.newton_clamp_stats(reset=True)
+
+    def _fit_end(self):
+        self.clamped_rows_, self.clamp_ratio_ = self._ctx.newton_clamp_stats()
+        if self.clamp_ratio_ > self.CLAMP_RATIO_WARN:
+            import warnings
+            warnings.warn("pycmf_amd: %d row Hessians had eigenvalues below hessian_pertubation=%g while ||H||_F / pertubation reached "
+                          "%.1e: the device forms per-row Hessians in float32 and resolves the clamped directions only to about "
+                          "1e-7 * that ratio, so the factors may differ from the float64 reference by more than the stated "
+                          "tolerance.  A positive l2_reg at least as large as the perturbation, or fewer components than samples "
+                          "per row, keeps the Hessians well conditioned." % (self.clamped_rows_, self.hessian_pertubation, self.clamp_ratio_),
+                          RuntimeWarning, stacklevel=3)
 
     def _draw(self, rows, n, ratio):
         size = int(n * ratio)

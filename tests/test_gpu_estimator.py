@@ -299,6 +299,20 @@ def test_transform_after_fit(solver):  # :374-408
     assert clone(m).get_params()["solver"] == solver
 
 
+@pytest.mark.parametrize("solver", ["mu", "newton"])
+def test_transform_after_fit_no_labels(solver):  # :395-408
+    rng = np.random.mtrand.RandomState(36)
+    X = rng.randn(7, 5)
+    Y = rng.randn(5, 3)
+    X_new = rng.randn(15, 5)
+    m = CMF(n_components=2, solver=solver, x_init="svd", y_init="svd", U_non_negative=False, V_non_negative=False,
+            Z_non_negative=False, random_state=0, max_iter=100)
+    U_ft, V_ft, Z_ft = m.fit_transform(X, Y)
+    U_t, V_t, Z_t = m.transform(X_new, None)
+    np.testing.assert_array_equal(V_t, V_ft)
+    assert U_t.shape == (15, 2) and np.isfinite(U_t).all()
+
+
 def test_missing_library_is_loud(monkeypatch):
     from pycmf_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
