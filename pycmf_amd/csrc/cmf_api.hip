@@ -175,6 +175,12 @@ struct cmf_ctx {
     DevBuf eigws;                         // Jacobi workspace when k_pad > 128
     DevBuf eigflag, eigcopy;              // Cholesky fast path: per-matrix fallback flags, input copy
     DevBuf clampstat;                     // [count (u64), max ||H||_F / pert (float bits)] of the float32 spectral clamp (cmf_newton_clamp_stats)
+    DevBuf badbuf, rw64, rh64;            // float64 refinement of ill-conditioned rows: [count, list], sample weights, one Hessian
+    std::vector<int> bad_host;            // rows of the current chunk to redo in float64 (relative to the chunk)
+    int opt_refine = 1;                   // redo clamped rows with ||H||_F / pert > refine_ratio in float64 (0: float32 only, recorded)
+    double opt_refine_ratio = 1.0e4;
+    int64_t opt_refine_max = 16384;       // at most this many rows per sweep (a float64 clamp is ~170 small launches); beyond: float32, recorded
+    int64_t refined_sweep = 0, refined_total = 0;
     DevBuf bfp[2][2], bff;                // gemm_arith = 1: bf16 planes of X / Y (normal, transposed) and of the factor operand
     bool bfp_valid[2][2] = {{false, false}, {false, false}};
     DevBuf nsidx, nsws;                   // Newton-Schulz clamp: flagged-row list + counters, matrix workspaces
@@ -676,7 +682,7 @@ static void release_problem(cmf_ctx *c) {
     c->lists1 = DevBuf(); c->lists2 = DevBuf(); c->lists1s = DevBuf(); c->lists2s = DevBuf(); c->zerobuf = DevBuf(); c->lr_small = DevBuf(); c->lr_rows = DevBuf(); c->hpart = DevBuf();
     for (int q = 0; q < 2; ++q) { c->cls_idx[q] = DevBuf(); c->cls_off[q] = DevBuf(); c->cls_cnt[q] = DevBuf(); c->cls_pat[q] = DevBuf(); }
     c->hclass = DevBuf(); c->certimg = DevBuf(); c->certflag = DevBuf();
-    c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf(); c->clampstat = DevBuf();
+    c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf(); c->clampstat = DevBuf(); c->badbuf = DevBuf(); c->rw64 = DevBuf(); c->rh64 = DevBuf(); c->bad_host.clear();
     c->nsidx = DevBuf(); c->nsws = DevBuf();
     c->spmm_bar = DevBuf();
     c->g64a = DevBuf(); c->g64b = DevBuf(); c->gmix64 = DevBuf(); c->h64 = DevBuf();
@@ -796,6 +802,12 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_shared64 = value != 0;
     } else if (!strcmp(name, "factor_times_tile")) {
         c->opt_ft_tile = (value == 64 || value == 256) ? (int)value : 128;   // 64: 64 x 64 tile | 128: 64 x 128 | 256: 128 rows x 64 columns, eight waves
+    } else if (!strcmp(name, "refine_rows")) {
+        c->opt_refine = value != 0;
+    } else if (!strcmp(name, "refine_rows_ratio")) {
+        c->opt_refine_ratio = (double)std::max<int64_t>(1, value);
+    } else if (!strcmp(name, "refine_rows_max")) {
+        c->opt_refine_max = std::max<int64_t>(0, value);
     } else if (!strcmp(name, "row_split")) {
         c->opt_rowsplit = value != 0;
     } else if (!strcmp(name, "lowrank_rows")) {

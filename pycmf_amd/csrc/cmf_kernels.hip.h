@@ -1125,7 +1125,10 @@ __global__ __launch_bounds__(256) void compact_flags_kernel(const int *flags, in
 // eigenvalues only to about eps32 * ||H||, i.e. to a RELATIVE error of eps32 * ||H|| / pert in the clamped directions of the
 // inverse: the ratio says when that leaves the stated tolerance.  One wave per matrix, H is not modified.
 __global__ __launch_bounds__(64) void clamp_stats_kernel(const float *H, const int *flags, int n, int kp, int64_t stride, float pert,
-                                                         unsigned long long *count, unsigned *maxratio) {
+                                                         unsigned long long *count, unsigned *maxratio, float thr, int mode, int *bad) {
+    // mode 0: record every clamped matrix.  mode 1 (float64 refinement on): matrices with ratio > thr are LISTED in bad[1 ..]
+    // (bad[0] = how many; they will be redone in float64) and only the others recorded.  mode 2: record only those above thr
+    // (a chunk whose list the host declined to refine).
     const int b = blockIdx.x;
     if (flags && !flags[b]) return;
     const float *src = H + (int64_t)b * stride;
@@ -1137,8 +1140,16 @@ __global__ __launch_bounds__(64) void clamp_stats_kernel(const float *H, const i
         }
     for (int off = 32; off > 0; off >>= 1) fro += __shfl_xor(fro, off, 64);
     if (threadIdx.x == 0) {
-        const float ratio = sqrtf(fro) / pert;
-        if (ratio == ratio) atomicMax(maxratio, __float_as_uint(fminf(ratio, 3.0e38f)));
+        float ratio = sqrtf(fro) / pert;
+        if (!(ratio == ratio)) ratio = 3.0e38f;
+        ratio = fminf(ratio, 3.0e38f);
+        const bool above = ratio > thr;
+        if (mode == 1 && above) {
+            bad[1 + atomicAdd(bad, 1)] = b;
+            return;
+        }
+        if (mode == 2 && !above) return;
+        atomicMax(maxratio, __float_as_uint(ratio));
         atomicAdd(count, 1ull);
     }
 }

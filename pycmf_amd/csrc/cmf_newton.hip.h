@@ -52,21 +52,54 @@ static int jacobi_chipwide(cmf_ctx *c, const float *Hin, float *Hout, int *flags
     return CMF_OK;
 }
 
-// note the matrices the float32 spectral clamp is about to act on (see clamp_stats_kernel)
-static int clamp_stats(cmf_ctx *c, const float *Hc, const int *flags, int64_t nmat, int n, int kp, int64_t stride, double pert) {
+// note the matrices the float32 spectral clamp is about to act on (see clamp_stats_kernel).  refine: those with ||H||_F / pert above
+// the refinement ratio are not recorded but collected (chunk-relative, ascending) in c->bad_host for refine_rows64 -- one 4-byte
+// read-back per call; a list that would take the sweep over opt_refine_max is declined and recorded instead.
+static int clamp_stats(cmf_ctx *c, const float *Hc, const int *flags, int64_t nmat, int n, int kp, int64_t stride, double pert,
+                       bool refine = false) {
+    c->bad_host.clear();
     if (nmat <= 0) return CMF_OK;
     if (!c->clampstat.p) {
         CHK(ensure(c, c->clampstat, 16));
         HIPCHK(hipMemsetAsync(c->clampstat.p, 0, 16, c->stream));
     }
-    hipLaunchKernelGGL(clamp_stats_kernel, dim3((unsigned)nmat), dim3(64), 0, c->stream, Hc, flags, n, kp, stride, (float)pert,
-                       (unsigned long long *)c->clampstat.p, (unsigned *)((char *)c->clampstat.p + 8));
+    unsigned long long *cnt = (unsigned long long *)c->clampstat.p;
+    unsigned *mx = (unsigned *)((char *)c->clampstat.p + 8);
+    const float thr = (float)c->opt_refine_ratio;
+    const bool want = refine && c->opt_refine && c->hess_psd && c->refined_sweep < c->opt_refine_max;
+    if (!want) {
+        hipLaunchKernelGGL(clamp_stats_kernel, dim3((unsigned)nmat), dim3(64), 0, c->stream, Hc, flags, n, kp, stride, (float)pert, cnt, mx, thr, 0,
+                           (int *)nullptr);
+        HIPCHK(hipGetLastError());
+        return CMF_OK;
+    }
+    CHK(ensure(c, c->badbuf, (size_t)(nmat + 1) * sizeof(int)));
+    int *bad = (int *)c->badbuf.p;
+    HIPCHK(hipMemsetAsync(bad, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(clamp_stats_kernel, dim3((unsigned)nmat), dim3(64), 0, c->stream, Hc, flags, n, kp, stride, (float)pert, cnt, mx, thr, 1, bad);
     HIPCHK(hipGetLastError());
+    int nb = 0;
+    HIPCHK(hipMemcpyAsync(&nb, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (nb <= 0) return CMF_OK;
+    if (c->refined_sweep + nb > c->opt_refine_max) { // too many for this sweep: they stay float32 and are recorded as such
+        hipLaunchKernelGGL(clamp_stats_kernel, dim3((unsigned)nmat), dim3(64), 0, c->stream, Hc, flags, n, kp, stride, (float)pert, cnt, mx, thr, 2,
+                           (int *)nullptr);
+        HIPCHK(hipGetLastError());
+        c->refined_sweep = c->opt_refine_max;
+        return CMF_OK;
+    }
+    c->bad_host.resize((size_t)nb);
+    HIPCHK(hipMemcpyAsync(c->bad_host.data(), bad + 1, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::sort(c->bad_host.begin(), c->bad_host.end());
+    c->refined_sweep += nb;
     return CMF_OK;
 }
 
-// Rows whose Hessian went through the float32 spectral clamp since the last reset, and the largest ||H||_F / pert among them.
-extern "C" int cmf_newton_clamp_stats(cmf_ctx *c, int64_t *rows, double *max_ratio, int reset) {
+// Rows whose Hessian went through the float32 spectral clamp since the last reset (and were not redone in float64), the largest
+// ||H||_F / pert among them, and the rows redone in float64.
+extern "C" int cmf_newton_clamp_stats(cmf_ctx *c, int64_t *rows, double *max_ratio, int64_t *refined, int reset) {
     if (!c) return fail(CMF_EINVAL, "null context");
     DeviceGuard dg(c->device);
     unsigned long long cnt = 0;
@@ -81,6 +114,8 @@ extern "C" int cmf_newton_clamp_stats(cmf_ctx *c, int64_t *rows, double *max_rat
     }
     if (rows) *rows = (int64_t)cnt;
     if (max_ratio) *max_ratio = (double)ratio;
+    if (refined) *refined = c->refined_total;
+    if (reset) c->refined_total = 0;
     return CMF_OK;
 }
 
@@ -269,7 +304,7 @@ struct RowCert { // per-group positive-definiteness certificates of a chunk (fus
     int rows = 1, split = 0;    // rows per group, rows in its first half
 };
 static int safe_solve_rows(cmf_ctx *c, float *Hc, const float *grad, float *step, int64_t nr, int n, int kp, double pert,
-                           const RowCert &cert = RowCert()) {
+                           const RowCert &cert = RowCert(), bool refine = false) {
     if (nr <= 0) return CMF_OK;
     const int64_t stride = (int64_t)kp * kp;
     if (!c->opt_chol || n > 256) { // general path only
@@ -293,7 +328,7 @@ static int safe_solve_rows(cmf_ctx *c, float *Hc, const float *grad, float *step
         else hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag,
                                 (const int *)nullptr, 1, cert.flags, cert.rows, cert.split);
         HIPCHK(hipGetLastError());
-        CHK(clamp_stats(c, Hc, flags, nr, n, kp, stride, pert));
+        CHK(clamp_stats(c, Hc, flags, nr, n, kp, stride, pert, refine));
         // flagged matrices, k_pad = 128 / 256, Hessians positive semi-definite by construction (weights >= 0):
         // spectral clamp by Newton-Schulz (MFMA) + a second Cholesky solve; clears the flags it serves
         if ((kp == 256 || kp == 128) && c->opt_ns && c->hess_psd) CHK(ns_clamp_solve_rows(c, Hc, grad, step, flags, nr, n, kp, pert));
@@ -1223,8 +1258,81 @@ static int class_side_gradient(cmf_ctx *c, bool x_side, bool by_row, const RowSi
 
 // finish a sweep of factor `which` whose per-row parts come from up to two fused sides;
 // c->num must already hold any shared-side gradient part if `grad_preloaded`
+// the shared part of a sweep's Hessians as the refinement needs it: scale * F^T F, re-formed in float64
+struct SharedPart {
+    const float *F = nullptr;
+    int64_t rows_pad = 0;
+    double scale = 0.0;
+};
+
+// Float64 refinement of the rows clamp_stats listed for this chunk (c->bad_host): per sample z = o_j . f_i, residual and Hessian
+// weight in float64 (exact products of the float32 factor rows and data values, float64 sums); H_i = diag I + shared part + the
+// per-row sums; g_i from the same residuals (stored values of natively sparse sides subtracted separately; the shared side of a
+// V sweep enters the gradient as one more, unsampled, side); safe inverse by the float64 routine of the shared sweeps (Cholesky
+// test, spectral clamp by float64 matrix polynomials; Jacobi for k <= 64); step = g_i H_i^-1 rounded once to float32.  One row
+// at a time (~200 small launches for a clamped k = 256 row): the exception path of ill-conditioned problems, not a throughput
+// path.  Reference: pycmf/cmf_solvers.py:394-508 with :346-356 on float64 Hessians.
+static int refine_rows64(cmf_ctx *c, int which, const RowSide &s1, const RowSide &s2, const SharedPart &sh, const RowSide *shside,
+                         double diag, double l1, double l2, int64_t r0, float *step, double pert) {
+    if (c->bad_host.empty()) return CMF_OK;
+    const int kp = c->kp, n = c->k;
+    const size_t kk = (size_t)kp * kp;
+    const RowSide *sides[3] = {&s1, &s2, shside};
+    int64_t smax = 1;
+    for (const RowSide *sd : sides)
+        if (sd && sd->active) smax = std::max(smax, sd->per);
+    CHK(ensure(c, c->rw64, (size_t)(2 * smax + kp) * sizeof(double)));
+    CHK(ensure(c, c->rh64, 2 * kk * sizeof(double)));
+    double *H64 = (double *)c->rh64.p, *S64 = nullptr, *w = (double *)c->rw64.p, *r = w + smax, *g = r + smax;
+    if (sh.F) {
+        S64 = H64 + kk;
+        CHK(gram64(c, sh.F, sh.rows_pad, S64, nullptr));
+    }
+    const std::vector<int> bad = c->bad_host;
+    c->bad_host.clear();
+    for (int b : bad) {
+        const int64_t i = r0 + b;
+        const float *f = c->F[which] + i * kp;
+        bool first_h = true, first_g = true;
+        for (int q = 0; q < 3; ++q) {
+            const RowSide *sd = sides[q];
+            if (!sd || !sd->active) continue;
+            const int32_t *list = sd->lists ? sd->lists + i * sd->per : nullptr;
+            const int s = (int)sd->per;
+            if (s > 0)
+                hipLaunchKernelGGL(row_terms64_kernel, dim3((unsigned)((s + 3) / 4)), dim3(256), 0, c->stream, sd->O, kp, f, list, s,
+                                   sd->link == CMF_LINK_LOGIT ? 1 : 0, sd->T, i * sd->t_row, sd->t_col, r, w);
+            hipLaunchKernelGGL(row_grad64_kernel, dim3((unsigned)(kp / 32)), dim3(256), 0, c->stream, sd->O, kp, list, s, (const double *)r, sd->scale,
+                               g, first_g ? 1 : 0);
+            first_g = false;
+            if (sd->sp)
+                hipLaunchKernelGGL(row_sparse_grad64_kernel, dim3((unsigned)((kp + 255) / 256)), dim3(256), 0, c->stream, (const int64_t *)sd->sp->indptr,
+                                   (const int32_t *)sd->sp->idx, (const float *)sd->sp->val, i, sd->O, kp,
+                                   sd->sorted ? sd->sorted + i * sd->per : (const int32_t *)nullptr, sd->per, sd->scale, g);
+            if (q < 2) { // the shared side's Hessian part is S64
+                hipLaunchKernelGGL(weighted_gram64_kernel, dim3((unsigned)(kp / 32), (unsigned)(kp / 32)), dim3(256), 0, c->stream, sd->O, kp, n, list, s,
+                                   (const double *)w, sd->scale, H64, first_h ? 1 : 0, diag, (const double *)S64, sh.scale);
+                first_h = false;
+            }
+            HIPCHK(hipGetLastError());
+        }
+        if (first_h) continue; // no per-row side: nothing to redo
+        hipLaunchKernelGGL(row_grad_finish64_kernel, dim3((unsigned)((kp + 255) / 256)), dim3(256), 0, c->stream, g, f, l1, l2, n, kp);
+        const int rc = shared_inverse64(c, H64, n, pert, true);
+        if (rc == CMF_EUNSUPPORTED) continue; // (not reached for positive semi-definite Hessians) the float32 step stands
+        CHK(rc);
+        hipLaunchKernelGGL(rowvec_mat64_kernel, dim3((unsigned)((kp + 255) / 256)), dim3(256), 0, c->stream, (const double *)g,
+                           (const double *)c->hinv64.p, step + (int64_t)b * kp, n, kp);
+        HIPCHK(hipGetLastError());
+        ++c->refined_total;
+    }
+    return CMF_OK;
+}
+
 static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const RowSide &s2, const float *S, double diag, bool grad_preloaded,
-                             double l1, double l2, double pert, bool nn) {
+                             double l1, double l2, double pert, bool nn, const SharedPart &shared = SharedPart(),
+                             const RowSide *shside = nullptr) {
+    c->refined_sweep = 0;
     const int64_t rows_pad = c->frows_pad[which], rows = c->frows[which];
     const int64_t kk = (int64_t)c->kp * c->kp;
     int64_t chunk = hessian_chunk_rows(c, rows_pad);
@@ -1354,7 +1462,8 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
                                (float *)nullptr, (int *)c->certflag.p, c->k, c->kp, kk, (float)(pert - diag), (int)ncert, 1);
             HIPCHK(hipGetLastError());
         }
-        CHK(safe_solve_rows(c, Hc, grad + r0 * c->kp, step + r0 * c->kp, nr, c->k, c->kp, pert, cert));
+        CHK(safe_solve_rows(c, Hc, grad + r0 * c->kp, step + r0 * c->kp, nr, c->k, c->kp, pert, cert, !global_cert)); // certified sweeps never clamp
+        CHK(refine_rows64(c, which, s1, s2, shared, shside, diag, l1, l2, r0, step + r0 * c->kp, pert));
     }
     return launch_ew(c, newton_apply_kernel, rows_pad * c->kp, c->F[which], (const float *)step, rows, c->kp, c->k, rows_pad * c->kp,
                      nn ? 1 : 0);
@@ -1390,7 +1499,8 @@ static int sweep_v_fused(cmf_ctx *c, double alpha, double l1, double l2, int x_l
                          const int32_t *vx_idx, int64_t per_x, const int32_t *vy_idx, int64_t per_y, bool sampled) {
     const bool x_shared = (x_link == CMF_LINK_LINEAR && !sampled);
     const bool y_shared = (y_link == CMF_LINK_LINEAR && !sampled);
-    RowSide sx, sy;
+    RowSide sx, sy, shs;
+    SharedPart shp;
     const float *S = nullptr;
     bool preloaded = false;
     float *V = c->F[CMF_V];
@@ -1408,6 +1518,12 @@ static int sweep_v_fused(cmf_ctx *c, double alpha, double l1, double l2, int x_l
         CHK(launch_ew(c, axpby_kernel, (int64_t)c->kp * c->kp, c->Hm, (const float *)c->G, (float)sc, (const float *)nullptr, 0.f,
                       (int64_t)c->kp * c->kp));
         S = c->Hm;
+        shp.F = Fo; shp.rows_pad = orow; shp.scale = sc;
+        // the same side as the float64 refinement sees it: an unsampled linear per-row side (gradient only)
+        shs.active = true; shs.O = Fo; shs.per = xs ? c->m : c->p; shs.scale = sc; shs.link = CMF_LINK_LINEAR;
+        if (xs) { shs.T = c->X; shs.t_row = 1; shs.t_col = c->dp; }
+        else { shs.T = c->Y; shs.t_row = c->pp; shs.t_col = 1; }
+        if ((xs ? c->X : c->Y) == nullptr && c->sparse[xs ? 0 : 1]) CHK(zero_targets(c, shs, xs ? &c->sp[0][1] : &c->sp[1][0]));
         preloaded = true;
     }
     if (!x_shared) {
@@ -1440,7 +1556,7 @@ static int sweep_v_fused(cmf_ctx *c, double alpha, double l1, double l2, int x_l
             preloaded = true;
         }
     }
-    return fused_rows_finish(c, CMF_V, sx, sy, S, l2, preloaded, l1, l2, pert, nn);
+    return fused_rows_finish(c, CMF_V, sx, sy, S, l2, preloaded, l1, l2, pert, nn, shp, shs.active ? &shs : nullptr);
 }
 
 // V sweep with a shared X side (linear link, no sampling) and a per-row Y side of FEWER samples than components (p <= 64 < k),

@@ -753,4 +753,160 @@ __global__ __launch_bounds__(1024) void ns64_prepare_kernel(const double *H, dou
     }
 }
 
+// ------------------------------------------------------------------ float64 refinement of single rows (cmf_newton.hip.h: refine_rows64)
+// A row whose float32 Hessian went through the spectral clamp with ||H||_F / pert beyond what float32 resolves is redone here
+// in float64, one row at a time: weights, Hessian, safe inverse (shared_inverse64), step.  The factor rows themselves are the
+// float32 values both sides of the comparison start from, so every product below is exact and only float64 sums round.
+
+// Per sample j of one row (list position q): z = o_j . f in float64, residual r[q] = link(z) - t_ij, Hessian weight w[q] = 1 (linear)
+// or sigma'(z) (logit); one wave per sample.  t_ij = T[t_off + j * t_col] (a zero buffer with stride 0 on natively sparse sides,
+// whose stored values enter through row_sparse_grad64_kernel).                                (:419-428, :459-484, :495-506)
+__global__ __launch_bounds__(256) void row_terms64_kernel(const float *O, int kp, const float *f, const int32_t *list, int s, int link,
+                                                          const float *T, int64_t t_off, int64_t t_col, double *r, double *w) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= s) return;
+    const int64_t j = list ? list[q] : q;
+    const float *o = O + j * kp;
+    double z = 0.0;
+    for (int e = lane; e < kp; e += 64) z += (double)o[e] * (double)f[e];
+    for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
+    if (lane == 0) {
+        const double t = (double)T[t_off + j * t_col];
+        if (link) {
+            const double sg = 1.0 / (1.0 + exp(-z));
+            r[q] = sg - t;
+            w[q] = sg * (1.0 - sg);
+        } else {
+            r[q] = z - t;
+            w[q] = 1.0;
+        }
+    }
+}
+
+// g[col] (+)= scale * sum_q r[q] o_{j(q)}[col]: 32 columns per workgroup, 64 samples per LDS stage, eight partial sums per column
+// (sample position mod 8) added in a fixed order -- deterministic.
+__global__ __launch_bounds__(256) void row_grad64_kernel(const float *O, int kp, const int32_t *list, int s, const double *r, double scale,
+                                                         double *g, int first) {
+    __shared__ float so[64][33];
+    __shared__ double sr[64];
+    __shared__ double part[8][32];
+    const int t = threadIdx.x, c0 = blockIdx.x * 32, col = t & 31, ph = t >> 5;
+    double acc = 0.0;
+    for (int j0 = 0; j0 < s; j0 += 64) {
+        __syncthreads();
+        for (int e = t; e < 64 * 32; e += 256) {
+            const int jj = e >> 5, q = e & 31;
+            so[jj][q] = (j0 + jj < s) ? O[(int64_t)(list ? list[j0 + jj] : j0 + jj) * kp + c0 + q] : 0.f;
+        }
+        if (t < 64) sr[t] = (j0 + t < s) ? r[j0 + t] : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += sr[ph + 8 * u] * (double)so[ph + 8 * u][col];
+    }
+    part[ph][col] = acc;
+    __syncthreads();
+    if (t < 32) {
+        double v = 0.0;
+        for (int u = 0; u < 8; ++u) v += part[u][t];
+        v *= scale;
+        g[c0 + t] = first ? v : g[c0 + t] + v;
+    }
+}
+
+// natively sparse side: g[col] -= scale * sum over the stored values t_ij of data row `row` with j in S_i (ascending list L, or all)
+// of t_ij o_j[col]; one thread per column, entries in storage order (see csr_sampled_sub_kernel)
+__global__ __launch_bounds__(256) void row_sparse_grad64_kernel(const int64_t *indptr, const int32_t *idx, const float *val, int64_t row,
+                                                                const float *O, int kp, const int32_t *L, int64_t per, double scale,
+                                                                double *g) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= kp) return;
+    const int64_t beg = indptr[row], end = indptr[row + 1];
+    double acc = 0.0;
+    for (int64_t q = beg; q < end; ++q) {
+        const int32_t j = idx[q];
+        if (L) {
+            int64_t lo = 0, hi = per;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (L[mid] < j) lo = mid + 1;
+                else hi = mid;
+            }
+            if (lo >= per || L[lo] != j) continue;
+        }
+        acc += (double)val[q] * (double)O[(int64_t)j * kp + col];
+    }
+    g[col] -= scale * acc;
+}
+
+// g += l1 sign(f) + l2 f on the valid columns, zero on the padding                                        (:399-400, :420, :498)
+__global__ __launch_bounds__(256) void row_grad_finish64_kernel(double *g, const float *f, double l1, double l2, int n, int kp) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= kp) return;
+    if (col >= n) { g[col] = 0.0; return; }
+    const double fv = (double)f[col];
+    g[col] += l1 * (fv > 0.0 ? 1.0 : (fv < 0.0 ? -1.0 : 0.0)) + l2 * fv;
+}
+
+// H (kp x kp float64) (+)= scale * sum_j w[j] o_j o_j^T over the s samples of one row: one 32 x 32 tile per workgroup, samples
+// staged through LDS 64 at a time, every thread four entries; samples are added in list order (deterministic).
+// first != 0: the tile starts from diag on the diagonal of the valid block plus sscale * S (S: float64 shared part, nullable).
+__global__ __launch_bounds__(256) void weighted_gram64_kernel(const float *O, int kp, int n, const int32_t *list, int s, const double *w,
+                                                              double scale, double *H, int first, double diag, const double *S,
+                                                              double sscale) {
+    __shared__ float sa[64][33], sb[64][33];
+    __shared__ double sw[64];
+    const int t = threadIdx.x, a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+    const int ta = (t >> 4) * 2, tb = (t & 15) * 2;
+    double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    for (int j0 = 0; j0 < s; j0 += 64) {
+        __syncthreads();
+        for (int e = t; e < 64 * 32; e += 256) {
+            const int jj = e >> 5, q = e & 31;
+            float va = 0.f, vb = 0.f;
+            if (j0 + jj < s) {
+                const float *o = O + (int64_t)(list ? list[j0 + jj] : j0 + jj) * kp;
+                va = o[a0 + q];
+                vb = o[b0 + q];
+            }
+            sa[jj][q] = va;
+            sb[jj][q] = vb;
+        }
+        if (t < 64) sw[t] = (j0 + t < s) ? w[j0 + t] : 0.0;
+        __syncthreads();
+        for (int jj = 0; jj < 64; ++jj) {
+            const double wj = sw[jj];
+            const double x0 = wj * (double)sa[jj][ta], x1 = wj * (double)sa[jj][ta + 1];
+            const double y0 = (double)sb[jj][tb], y1 = (double)sb[jj][tb + 1];
+            acc[0][0] += x0 * y0; acc[0][1] += x0 * y1;
+            acc[1][0] += x1 * y0; acc[1][1] += x1 * y1;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jx = 0; jx < 2; ++jx) {
+            const int r = a0 + ta + i, cidx = b0 + tb + jx;
+            const int64_t at = (int64_t)r * kp + cidx;
+            double v = scale * acc[i][jx];
+            if (first) {
+                if (r < n && cidx < n) {
+                    if (r == cidx) v += diag;
+                    if (S) v += sscale * S[at];
+                } else v = 0.0;
+            } else v += H[at];
+            H[at] = v;
+        }
+}
+
+// step[q] = sum_r g[r] Hinv[r][q]   (row vector times matrix, :321-326) in float64, rounded once to float32
+__global__ __launch_bounds__(256) void rowvec_mat64_kernel(const double *g, const double *Hinv, float *step, int n, int kp) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= kp) return;
+    double a = 0.0;
+    if (q < n)
+        for (int r = 0; r < n; ++r) a += g[r] * Hinv[(int64_t)r * kp + q];
+    step[q] = (float)a;
+}
+
 } // namespace cmfk

@@ -114,6 +114,8 @@ class _HipIterativeSolver:
                 self._ctx.set_option("z_logit_hessian_l2", 0)
             if os.environ.get("PYCMF_AMD_GEMM_ARITH") == "bf16x6":  # opt-in arithmetic of the k_pad = 256 data passes
                 self._ctx.set_option("gemm_arith", 1)
+            if os.environ.get("PYCMF_AMD_REFINE_ROWS") == "0":  # A/B: leave ill-conditioned clamped rows in float32 (recorded, warned)
+                self._ctx.set_option("refine_rows", 0)
         if self._bound != key:
             self._ctx.set_problem(m, d, p, k)
             if X is not None:
@@ -241,14 +243,15 @@ class HipNewtonSolver(_HipIterativeSolver):
         self._ctx.newton_clamp_stats(reset=True)
 
     def _fit_end(self):
-        self.clamped_rows_, self.clamp_ratio_ = self._ctx.newton_clamp_stats()
+        self.clamped_rows_, self.clamp_ratio_, self.refined_rows_ = self._ctx.newton_clamp_stats()
         if self.clamp_ratio_ > self.CLAMP_RATIO_WARN:
             import warnings
             warnings.warn("pycmf_amd: %d row Hessians had eigenvalues below hessian_pertubation=%g while ||H||_F / pertubation reached "
-                          "%.1e: the device forms per-row Hessians in float32 and resolves the clamped directions only to about "
-                          "1e-7 * that ratio, so the factors may differ from the float64 reference by more than the stated "
-                          "tolerance.  A positive l2_reg at least as large as the perturbation, or fewer components than samples "
-                          "per row, keeps the Hessians well conditioned." % (self.clamped_rows_, self.hessian_pertubation, self.clamp_ratio_),
+                          "%.1e and were NOT redone in float64 (more than refine_rows_max rows in one sweep, n_components > 256, or "
+                          "refinement switched off): float32 Hessians resolve the clamped directions only to about 1e-7 * that ratio, "
+                          "so the factors may differ from the float64 reference by more than the stated tolerance.  A positive l2_reg "
+                          "at least as large as the perturbation, or fewer components than samples per row, keeps the Hessians well "
+                          "conditioned." % (self.clamped_rows_, self.hessian_pertubation, self.clamp_ratio_),
                           RuntimeWarning, stacklevel=3)
 
     def _draw(self, rows, n, ratio):

@@ -24,7 +24,7 @@ OPTIONS = {"row_classes": [-1, 0, 2, 3, 5], "row_certificates": [0, 1], "lowrank
            "row_chunk": [0, 256, 512], "small_gram": [0, 1], "gemm_split": [0, 1, 3], "row_symmetric": [0, 1, 3],
            "row_kernel": [0, 1], "direct_newton_step": [0, 1], "small_tile_update": [0, 1], "fused_mu_update": [0, 1],
            "split_reduce_in_kernel": [0, 1], "spmm_blocked": [0, 1], "newton_schulz": [0, 1], "safe_inverse_cholesky": [0, 1],
-           "factor_times_tile": [64, 128, 256], "graph": [0, 1]}
+           "factor_times_tile": [64, 128, 256], "graph": [0, 1], "refine_rows": [0, 1]}
 
 
 def log_int(rng, lo, hi):
@@ -113,7 +113,7 @@ def run_case(c, seed, info=None):
             else:
                 errs.append(float(np.abs(got[w] - ref).max() / max(1e-3, np.abs(ref).max())))
         if info is not None and newton:
-            info["clamp_rows"], info["clamp_ratio"] = ctx.newton_clamp_stats()
+            info["clamp_rows"], info["clamp_ratio"], info["refined_rows"] = ctx.newton_clamp_stats()
         if info is not None and np.isfinite(errs).all():
             a = c.get("alpha", 0.5)
             e_ref = O.weighted_error(X, Y, Ur, Vr, Zr, a, xl, yl)
