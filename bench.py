@@ -511,6 +511,13 @@ def main():
         out["note"] = ("fp32 MFMA arithmetic (the default).  Opt-in --option gemm_arith=1 (fp32 operands split exactly into three "
                        "bf16 planes, six products on the bf16 matrix pipe, fp32-equivalent to 4e-7): 23.3-24.0 it/s, "
                        "profiles/r01_c4_n1_bench_bf16x6.json, DESIGN.md section 4")
+    if newton:
+        st = ctx.newton_clamp_stats(full=True)
+        out["conditioning"] = {"clamped_rows_float32": st[0], "max_ratio_left_in_float32": st[1], "rows_refined_in_float64": st[2],
+                               "max_condition_estimate_plain_solves": st[3],
+                               "note": "per-row sweeps since the context was created (cmf_newton_clamp_stats): rows whose float32 Hessian "
+                                       "went through the spectral clamp, largest ||H||_F / pert left in float32, rows redone in float64, "
+                                       "largest max H_ii / min L_ii^2 over all plain Cholesky solves"}
     if world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline(w)
         full = w["solver"] == "mu"

@@ -224,8 +224,10 @@ int cmf_safe_invert_batch(cmf_ctx *ctx, const double *H, double *out, int n, int
  * for max_ratio up to ~1e4.  Rows above that ratio (option "refine_rows_ratio") are REDONE IN FLOAT64 (Hessian from float64 sums,
  * float64 clamp, float64 step; option "refine_rows", default on, at most "refine_rows_max" = 16384 rows per sweep, k <= 256) and
  * counted in `refined` instead; only rows left in float32 enter rows / max_ratio, and the estimator warns when max_ratio
- * exceeds 1e4.  The shared Hessians of the linear unsampled sweeps are formed and clamped in float64 and never appear here. */
-int cmf_newton_clamp_stats(cmf_ctx *ctx, int64_t *rows, double *max_ratio, int64_t *refined, int reset);
+ * exceeds 1e4.  The shared Hessians of the linear unsampled sweeps are formed and clamped in float64 and never appear here.
+ * plain_cond: the largest condition estimate max H_ii / min L_ii^2 (<= cond(H)) over ALL rows solved by plain Cholesky -- rows above
+ * the refinement ratio by that estimate are refined too; the ones left in float32 also enter max_ratio. */
+int cmf_newton_clamp_stats(cmf_ctx *ctx, int64_t *rows, double *max_ratio, int64_t *refined, double *plain_cond, int reset);
 
 /* float64 path of the ONE shared Hessian of a linear-link sweep (cmf_solvers.py:407-410, :448-450): H is k x k
  * float64 on the host, k = the problem's n_components; out = Q diag(1/max(|l|,pert)) Q^T computed in float64 on

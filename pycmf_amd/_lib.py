@@ -45,7 +45,7 @@ PROTOTYPES = {
     "cmf_data_layout": [_vp, _i32, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "cmf_get_data_block_f32": [_vp, _i32, _i64, _i64, _i64, _i64, _pf],
     "cmf_sample_lists": [_vp, _i32, C.c_uint64, _dbl, _i64, _i64, _pi32],
-    "cmf_newton_clamp_stats": [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64), _i32],
+    "cmf_newton_clamp_stats": [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), _i32],
     "cmf_data_matmul_f64": [_vp, _i32, _i32, _pd, _i64, _i32, _pd],
     "cmf_rsvd": [_vp, _i32, _i32, _i32, _i32, _i32, _pd, _pd, _pd, _pd],
     "cmf_data_sum": [_vp, _pd, _pd],
@@ -409,12 +409,13 @@ class Context:
         check(self._lib.cmf_newton_v_finish(self._h, _vp(dev_pbuf), l1, nn_mask))
 
     # ---- metrics
-    def newton_clamp_stats(self, reset=False):
-        """(rows whose float32 Hessian went through the spectral clamp and stayed float32, largest ||H||_F / pert among them,
-        rows redone in float64) since the last reset."""
-        rows, ratio, refined = C.c_int64(0), C.c_double(0), C.c_int64(0)
-        check(self._lib.cmf_newton_clamp_stats(self._h, C.byref(rows), C.byref(ratio), C.byref(refined), 1 if reset else 0))
-        return rows.value, ratio.value, refined.value
+    def newton_clamp_stats(self, reset=False, full=False):
+        """(rows whose float32 Hessian went through the spectral clamp and stayed float32, largest ||H||_F / pert (or condition
+        estimate of a plain solve) among the rows left in float32, rows redone in float64) since the last reset; ``full`` adds the
+        largest condition estimate over all plain float32 solves."""
+        rows, ratio, refined, plain = C.c_int64(0), C.c_double(0), C.c_int64(0), C.c_double(0)
+        check(self._lib.cmf_newton_clamp_stats(self._h, C.byref(rows), C.byref(ratio), C.byref(refined), C.byref(plain), 1 if reset else 0))
+        return (rows.value, ratio.value, refined.value, plain.value) if full else (rows.value, ratio.value, refined.value)
 
     def residual_sq(self, x_link="linear", y_link="linear"):
         ex, ey = C.c_double(0), C.c_double(0)

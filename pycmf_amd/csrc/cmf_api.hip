@@ -178,7 +178,8 @@ struct cmf_ctx {
     DevBuf badbuf, rw64, rh64;            // float64 refinement of ill-conditioned rows: [count, list], sample weights, one Hessian
     std::vector<int> bad_host;            // rows of the current chunk to redo in float64 (relative to the chunk)
     int opt_refine = 1;                   // redo clamped rows with ||H||_F / pert > refine_ratio in float64 (0: float32 only, recorded)
-    double opt_refine_ratio = 1.0e4;
+    double opt_refine_ratio = 1.0e4;       // clamped rows: ||H||_F / pert above this
+    double opt_refine_cond = 1.0e3;        // plain Cholesky solves: max H_ii / min L_ii^2 (a LOWER bound of cond H) above this
     int64_t opt_refine_max = 16384;       // at most this many rows per sweep (a float64 clamp is ~170 small launches); beyond: float32, recorded
     int64_t refined_sweep = 0, refined_total = 0;
     DevBuf bfp[2][2], bff;                // gemm_arith = 1: bf16 planes of X / Y (normal, transposed) and of the factor operand
@@ -806,6 +807,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_refine = value != 0;
     } else if (!strcmp(name, "refine_rows_ratio")) {
         c->opt_refine_ratio = (double)std::max<int64_t>(1, value);
+    } else if (!strcmp(name, "refine_rows_cond")) {
+        c->opt_refine_cond = (double)std::max<int64_t>(1, value);
     } else if (!strcmp(name, "refine_rows_max")) {
         c->opt_refine_max = std::max<int64_t>(0, value);
     } else if (!strcmp(name, "row_split")) {

@@ -460,7 +460,7 @@ template <int NB>
 __global__ __launch_bounds__(256, 2) void chol_solve_kernel(const float *Hin, const float *grad, float *step, int *need_jacobi,
                                                             int n, int kp, int64_t stride, float pert, int nmat, int diag = 0,
                                                             const int *rowidx = nullptr, int sub = 1, const int *cert = nullptr,
-                                                            int cert_rows = 1, int cert_split = 0) {
+                                                            int cert_rows = 1, int cert_split = 0, float *condest = nullptr) {
     __shared__ __attribute__((aligned(16))) float col[2 * (16 * NB + 4)]; // two buffers of (published column + pivot slot)
     __shared__ float vec[16 * NB];
     __shared__ float stage[16 * 17 + 16]; // diagonal block + block right-hand side of the back substitution
@@ -510,6 +510,19 @@ __global__ __launch_bounds__(256, 2) void chol_solve_kernel(const float *Hin, co
     chol_load<NB>(R, H, n, ldh, 0.f, t);
     __syncthreads(); // publish vec
     (void)chol_factor<NB>(R, n, 0.f, col, t); // H = L L^T
+    if (condest) { // max_i H_ii / min_i L_ii^2 <= cond(H): how far float32 can be trusted with this solve (cmf_newton.hip.h, clamp_stats)
+        float pmin = 3.0e38f;
+        if (ti == tc) {
+#pragma unroll
+            for (int a = 0; a < NB; ++a)
+                if (16 * a + ti < n) pmin = fminf(pmin, R.M[a][a]);
+        }
+        for (int off = 32; off > 0; off >>= 1) pmin = fminf(pmin, __shfl_xor(pmin, off, 64));
+        if ((t & 63) == 0) red[t >> 6] = pmin;
+        __syncthreads();
+        pmin = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+        if (t == 0) condest[orow] = dmax / fmaxf(pmin * pmin, 1.0e-37f);
+    }
     chol_forward<NB>(R, n, vec, stage, fpart, t); // L y = g
 
     if (diag == 2) return;

@@ -1125,32 +1125,42 @@ __global__ __launch_bounds__(256) void compact_flags_kernel(const int *flags, in
 // eigenvalues only to about eps32 * ||H||, i.e. to a RELATIVE error of eps32 * ||H|| / pert in the clamped directions of the
 // inverse: the ratio says when that leaves the stated tolerance.  One wave per matrix, H is not modified.
 __global__ __launch_bounds__(64) void clamp_stats_kernel(const float *H, const int *flags, int n, int kp, int64_t stride, float pert,
-                                                         unsigned long long *count, unsigned *maxratio, float thr, int mode, int *bad) {
+                                                         unsigned long long *count, unsigned *maxratio, float thr, int mode, int *bad,
+                                                         const float *condest, float thr_plain) {
     // mode 0: record every clamped matrix.  mode 1 (float64 refinement on): matrices with ratio > thr are LISTED in bad[1 ..]
     // (bad[0] = how many; they will be redone in float64) and only the others recorded.  mode 2: record only those above thr
     // (a chunk whose list the host declined to refine).
+    // condest (nullable): for the matrices the clamp does NOT act on (flags[b] == 0: solved by plain Cholesky), the solve
+    // kernel's condition estimate max H_ii / min L_ii^2 -- the same eps32 * ratio argument applies to a plain float32 solve;
+    // they enter the list / the maximum by that ratio but not the count of clamped matrices.
     const int b = blockIdx.x;
-    if (flags && !flags[b]) return;
-    const float *src = H + (int64_t)b * stride;
+    const bool clamped = !flags || flags[b];
+    if (!clamped && !condest) return;
     float fro = 0.f;
-    for (int r = 0; r < n; ++r)
-        for (int q = threadIdx.x; q < n; q += 64) {
-            const float v = src[r * kp + q];
-            fro += v * v;
-        }
-    for (int off = 32; off > 0; off >>= 1) fro += __shfl_xor(fro, off, 64);
+    if (clamped) {
+        const float *src = H + (int64_t)b * stride;
+        for (int r = 0; r < n; ++r)
+            for (int q = threadIdx.x; q < n; q += 64) {
+                const float v = src[r * kp + q];
+                fro += v * v;
+            }
+        for (int off = 32; off > 0; off >>= 1) fro += __shfl_xor(fro, off, 64);
+    }
     if (threadIdx.x == 0) {
-        float ratio = sqrtf(fro) / pert;
+        float ratio = clamped ? sqrtf(fro) / pert : condest[b];
         if (!(ratio == ratio)) ratio = 3.0e38f;
         ratio = fminf(ratio, 3.0e38f);
-        const bool above = ratio > thr;
-        if (mode == 1 && above) {
+        if (!clamped && mode != 2) atomicMax(maxratio + 1, __float_as_uint(ratio)); // largest estimate over ALL plain solves (diagnostic)
+        // an overflowed Hessian (inf / NaN: a diverged iteration) is recorded, never listed: float64 cannot repair it
+        const bool above = ratio > (clamped ? thr : thr_plain);
+        if (mode == 1 && above && ratio < 1.0e30f) {
             bad[1 + atomicAdd(bad, 1)] = b;
             return;
         }
         if (mode == 2 && !above) return;
+        if (!clamped && !above) return; // a well-conditioned plain solve: nothing to record
         atomicMax(maxratio, __float_as_uint(ratio));
-        atomicAdd(count, 1ull);
+        if (clamped) atomicAdd(count, 1ull);
     }
 }
 

@@ -56,7 +56,7 @@ static int jacobi_chipwide(cmf_ctx *c, const float *Hin, float *Hout, int *flags
 // the refinement ratio are not recorded but collected (chunk-relative, ascending) in c->bad_host for refine_rows64 -- one 4-byte
 // read-back per call; a list that would take the sweep over opt_refine_max is declined and recorded instead.
 static int clamp_stats(cmf_ctx *c, const float *Hc, const int *flags, int64_t nmat, int n, int kp, int64_t stride, double pert,
-                       bool refine = false) {
+                       bool refine = false, const float *condest = nullptr) {
     c->bad_host.clear();
     if (nmat <= 0) return CMF_OK;
     if (!c->clampstat.p) {
@@ -65,18 +65,18 @@ static int clamp_stats(cmf_ctx *c, const float *Hc, const int *flags, int64_t nm
     }
     unsigned long long *cnt = (unsigned long long *)c->clampstat.p;
     unsigned *mx = (unsigned *)((char *)c->clampstat.p + 8);
-    const float thr = (float)c->opt_refine_ratio;
+    const float thr = (float)c->opt_refine_ratio, thrp = (float)c->opt_refine_cond;
     const bool want = refine && c->opt_refine && c->hess_psd && c->refined_sweep < c->opt_refine_max;
     if (!want) {
         hipLaunchKernelGGL(clamp_stats_kernel, dim3((unsigned)nmat), dim3(64), 0, c->stream, Hc, flags, n, kp, stride, (float)pert, cnt, mx, thr, 0,
-                           (int *)nullptr);
+                           (int *)nullptr, condest, thrp);
         HIPCHK(hipGetLastError());
         return CMF_OK;
     }
     CHK(ensure(c, c->badbuf, (size_t)(nmat + 1) * sizeof(int)));
     int *bad = (int *)c->badbuf.p;
     HIPCHK(hipMemsetAsync(bad, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL(clamp_stats_kernel, dim3((unsigned)nmat), dim3(64), 0, c->stream, Hc, flags, n, kp, stride, (float)pert, cnt, mx, thr, 1, bad);
+    hipLaunchKernelGGL(clamp_stats_kernel, dim3((unsigned)nmat), dim3(64), 0, c->stream, Hc, flags, n, kp, stride, (float)pert, cnt, mx, thr, 1, bad, condest, thrp);
     HIPCHK(hipGetLastError());
     int nb = 0;
     HIPCHK(hipMemcpyAsync(&nb, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -84,7 +84,7 @@ static int clamp_stats(cmf_ctx *c, const float *Hc, const int *flags, int64_t nm
     if (nb <= 0) return CMF_OK;
     if (c->refined_sweep + nb > c->opt_refine_max) { // too many for this sweep: they stay float32 and are recorded as such
         hipLaunchKernelGGL(clamp_stats_kernel, dim3((unsigned)nmat), dim3(64), 0, c->stream, Hc, flags, n, kp, stride, (float)pert, cnt, mx, thr, 2,
-                           (int *)nullptr);
+                           (int *)nullptr, condest, thrp);
         HIPCHK(hipGetLastError());
         c->refined_sweep = c->opt_refine_max;
         return CMF_OK;
@@ -99,27 +99,30 @@ static int clamp_stats(cmf_ctx *c, const float *Hc, const int *flags, int64_t nm
 
 // Rows whose Hessian went through the float32 spectral clamp since the last reset (and were not redone in float64), the largest
 // ||H||_F / pert among them, and the rows redone in float64.
-extern "C" int cmf_newton_clamp_stats(cmf_ctx *c, int64_t *rows, double *max_ratio, int64_t *refined, int reset) {
+extern "C" int cmf_newton_clamp_stats(cmf_ctx *c, int64_t *rows, double *max_ratio, int64_t *refined, double *plain_cond, int reset) {
     if (!c) return fail(CMF_EINVAL, "null context");
     DeviceGuard dg(c->device);
     unsigned long long cnt = 0;
-    float ratio = 0.f;
+    float ratio = 0.f, plain = 0.f;
     if (c->clampstat.p) {
         unsigned char host[16];
         HIPCHK(hipMemcpyAsync(host, c->clampstat.p, 16, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         memcpy(&cnt, host, 8);
         memcpy(&ratio, host + 8, 4);
+        memcpy(&plain, host + 12, 4);
         if (reset) HIPCHK(hipMemsetAsync(c->clampstat.p, 0, 16, c->stream));
     }
     if (rows) *rows = (int64_t)cnt;
     if (max_ratio) *max_ratio = (double)ratio;
     if (refined) *refined = c->refined_total;
+    if (plain_cond) *plain_cond = (double)plain;
     if (reset) c->refined_total = 0;
     return CMF_OK;
 }
 
-static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat, int n, int kp, double pert, bool psd = false) {
+static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat, int n, int kp, double pert, bool psd = false,
+                            bool refine = false) {
     if (nmat <= 0) return CMF_OK;
     const int64_t stride = (int64_t)kp * kp;
     Timed tm(c, CMF_K_EIGEN);
@@ -186,7 +189,7 @@ static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat,
         need = (const int *)c->eigflag.p;
         Hin = src;
     }
-    CHK(clamp_stats(c, Hin, need, nmat, n, kp, stride, pert));
+    CHK(clamp_stats(c, Hin, need, nmat, n, kp, stride, pert, refine));
     const size_t lds_need = (size_t)(2 * n * n + n) * sizeof(float);
     if (lds_need <= 150 * 1024) {
         CHK(allow_big_lds(c, reinterpret_cast<const void *>(&jacobi_safe_inverse_kernel<true>), 150 * 1024));
@@ -308,27 +311,28 @@ static int safe_solve_rows(cmf_ctx *c, float *Hc, const float *grad, float *step
     if (nr <= 0) return CMF_OK;
     const int64_t stride = (int64_t)kp * kp;
     if (!c->opt_chol || n > 256) { // general path only
-        CHK(safe_inverse_dev(c, Hc, Hc, (int)nr, n, kp, pert));
+        CHK(safe_inverse_dev(c, Hc, Hc, (int)nr, n, kp, pert, false, refine));
         Timed tm(c, CMF_K_ELEMWISE);
         hipLaunchKernelGGL(rowvec_mat_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, c->stream, step, grad, (const float *)Hc, nr, kp, n);
         HIPCHK(hipGetLastError());
         return CMF_OK;
     }
-    CHK(ensure(c, c->eigflag, (size_t)nr * sizeof(int)));
+    CHK(ensure(c, c->eigflag, (size_t)nr * (sizeof(int) + sizeof(float))));
     int *flags = (int *)c->eigflag.p;
+    float *condest = (refine && c->opt_refine && c->hess_psd) ? (float *)(flags + nr) : nullptr; // per-row condition estimates of the plain solves
     {
         Timed tm(c, CMF_K_EIGEN);
         const dim3 grid((unsigned)nr), block(256);
         if (n <= 32) hipLaunchKernelGGL((chol_solve_kernel<2>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag,
-                                         (const int *)nullptr, 1, cert.flags, cert.rows, cert.split);
+                                         (const int *)nullptr, 1, cert.flags, cert.rows, cert.split, condest);
         else if (n <= 64) hipLaunchKernelGGL((chol_solve_kernel<4>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag,
-                                              (const int *)nullptr, 1, cert.flags, cert.rows, cert.split);
+                                              (const int *)nullptr, 1, cert.flags, cert.rows, cert.split, condest);
         else if (n <= 128) hipLaunchKernelGGL((chol_solve_kernel<8>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag,
-                                               (const int *)nullptr, 1, cert.flags, cert.rows, cert.split);
+                                               (const int *)nullptr, 1, cert.flags, cert.rows, cert.split, condest);
         else hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag,
-                                (const int *)nullptr, 1, cert.flags, cert.rows, cert.split);
+                                (const int *)nullptr, 1, cert.flags, cert.rows, cert.split, condest);
         HIPCHK(hipGetLastError());
-        CHK(clamp_stats(c, Hc, flags, nr, n, kp, stride, pert, refine));
+        CHK(clamp_stats(c, Hc, flags, nr, n, kp, stride, pert, refine, condest));
         // flagged matrices, k_pad = 128 / 256, Hessians positive semi-definite by construction (weights >= 0):
         // spectral clamp by Newton-Schulz (MFMA) + a second Cholesky solve; clears the flags it serves
         if ((kp == 256 || kp == 128) && c->opt_ns && c->hess_psd) CHK(ns_clamp_solve_rows(c, Hc, grad, step, flags, nr, n, kp, pert));
@@ -901,6 +905,43 @@ static int residual_images(cmf_ctx *c, bool x_side, int link, double scale, cons
     return gemm_nt(c, c->F[CMF_V], c->dp, c->d, c->F[CMF_Z], c->pp, c->p, o);
 }
 
+struct RowSide {
+    bool active = false;
+    const float *O = nullptr;   // other factor
+    const int32_t *lists = nullptr;
+    int64_t per = 0;            // samples per row
+    const float *T = nullptr;
+    int64_t t_row = 0, t_col = 0;
+    double scale = 1.0;
+    int link = 0;
+    int cls = 0;                // > 0: shared partial sums over groups of `cls` rows (linear link, sampled; cmf_rowhess.hip.h)
+    int64_t n = 0;              // candidates the lists draw from
+    int slot = 0;               // which of the two class-list buffers
+    // natively sparse data on this side: the row kernel runs with zero targets and the stored values of data row i that lie in
+    // its sample enter the gradient afterwards (sparse_target_term); `sp` = CSR image whose row i belongs to factor row i
+    const CsrDev *sp = nullptr;
+    const int32_t *sorted = nullptr; // ascending copies of the lists (null: not sampled)
+};
+
+// the shared part of a sweep's Hessians as the refinement needs it: scale * F^T F, re-formed in float64
+struct SharedPart {
+    const float *F = nullptr;
+    int64_t rows_pad = 0;
+    double scale = 0.0;
+};
+
+static int sample_lists(cmf_ctx *c, DevBuf &lb, DevBuf &mb, const int32_t *host_idx, int64_t nlists, int64_t per, int64_t n,
+                        int salt, const int32_t **out, DevBuf *sorted_buf = nullptr, const int32_t **sorted_out = nullptr);
+static int refine_rows64(cmf_ctx *c, int which, const RowSide &s1, const RowSide &s2, const SharedPart &sh, const RowSide *shside,
+                         double diag, double l1, double l2, int64_t r0, float *step, double pert);
+// what the float64 refinement needs to know about a masked-dense sweep (the same sides, as index lists)
+struct RefineSpec {
+    bool on = false;
+    RowSide s1, s2, shs;
+    SharedPart shared;
+    double l1 = 0.0, l2 = 0.0;
+};
+
 // finish a per-row sweep: for every chunk of rows build H_i, invert, step; then apply
 struct RowHess {
     // H_i = [tn ? A1^T : A1] KR1  (+ A2 KR2)  + S + diag I
@@ -910,9 +951,10 @@ struct RowHess {
     double diag = 0.0;
 };
 
-static int per_row_finish(cmf_ctx *c, int which, const RowHess &h, double pert, bool nn) {
+static int per_row_finish(cmf_ctx *c, int which, const RowHess &h, double pert, bool nn, const RefineSpec &rf = RefineSpec()) {
     const int64_t rows_pad = c->frows_pad[which], rows = c->frows[which];
     const int64_t kk = (int64_t)c->kp * c->kp;
+    c->refined_sweep = 0;
     const int64_t chunk = hessian_chunk_rows(c, rows_pad);
     CHK(ensure(c, c->hrows, (size_t)chunk * kk * sizeof(float)));
     float *Hc = (float *)c->hrows.p;
@@ -932,7 +974,8 @@ static int per_row_finish(cmf_ctx *c, int which, const RowHess &h, double pert, 
             have = true;
         }
         CHK(launch_ew(c, hessian_finalize_kernel, nr_pad * kk, Hc, h.S, (float)h.diag, nr_pad, c->kp, c->k, have ? 1 : 0));
-        CHK(safe_solve_rows(c, Hc, grad + r0 * c->kp, step + r0 * c->kp, nr, c->k, c->kp, pert));
+        CHK(safe_solve_rows(c, Hc, grad + r0 * c->kp, step + r0 * c->kp, nr, c->k, c->kp, pert, RowCert(), rf.on));
+        if (rf.on) CHK(refine_rows64(c, which, rf.s1, rf.s2, rf.shared, rf.shs.active ? &rf.shs : nullptr, h.diag, rf.l1, rf.l2, r0, step + r0 * c->kp, pert));
     }
     return launch_ew(c, newton_apply_kernel, rows_pad * c->kp, c->F[which], (const float *)step, rows, c->kp, c->k,
                      rows_pad * c->kp, nn ? 1 : 0);
@@ -964,7 +1007,17 @@ static int sweep_side_rows(cmf_ctx *c, bool is_u, int link, double scale, double
     h.A1 = W; h.lda1 = is_u ? c->dp : c->pp; h.a1_tn = !is_u; h.KR1 = (const float *)c->kr1.p; h.kred1 = c->dp;
     // the logit Hessian of U carries no l2 term (:427-428); Z always does (:501-506)
     h.diag = (link == CMF_LINK_LOGIT && (is_u || !c->opt_zlogit_l2)) ? 0.0 : l2;
-    return per_row_finish(c, which, h, pert, nn);
+    RefineSpec rf;
+    if (c->opt_refine && c->hess_psd && (is_u ? c->X : c->Y)) {
+        rf.on = true; rf.l1 = l1; rf.l2 = l2;
+        RowSide &sd = rf.s1;
+        sd.active = true; sd.O = V; sd.scale = scale; sd.link = link; sd.n = c->d;
+        sd.per = mask ? per : c->d;
+        if (mask) CHK(sample_lists(c, c->lists1, c->mask1, idx, c->frows[which], per, c->d, is_u ? 0 : 1, &sd.lists));
+        if (is_u) { sd.T = c->X; sd.t_row = c->dp; sd.t_col = 1; }
+        else { sd.T = c->Y; sd.t_row = 1; sd.t_col = c->pp; }
+    }
+    return per_row_finish(c, which, h, pert, nn, rf);
 }
 
 // V sweep in per-row form (cmf_solvers.py:432-486)
@@ -1016,7 +1069,23 @@ static int sweep_v_rows(cmf_ctx *c, double alpha, double l1, double l2, int x_li
         else { h.A1 = WY; h.lda1 = c->pp; h.a1_tn = false; h.KR1 = (const float *)c->kr2.p; h.kred1 = c->pp; }
         (void)A;
     }
-    return per_row_finish(c, CMF_V, h, pert, nn);
+    RefineSpec rf;
+    if (c->opt_refine && c->hess_psd && c->X && c->Y && !(x_shared && y_shared)) {
+        rf.on = true; rf.l1 = l1; rf.l2 = l2;
+        RowSide sx, sy;
+        sx.active = true; sx.O = c->F[CMF_U]; sx.scale = alpha; sx.link = x_link; sx.n = c->m; sx.per = mx ? per_x : c->m;
+        sx.T = c->X; sx.t_row = 1; sx.t_col = c->dp;
+        sy.active = true; sy.O = c->F[CMF_Z]; sy.scale = 1.0 - alpha; sy.link = y_link; sy.n = c->p; sy.per = my ? per_y : c->p;
+        sy.T = c->Y; sy.t_row = c->pp; sy.t_col = 1;
+        if (mx) CHK(sample_lists(c, c->lists1, c->mask1, vx_idx, c->d, per_x, c->m, 2, &sx.lists));
+        if (my) CHK(sample_lists(c, c->lists2, c->mask2, vy_idx, c->d, per_y, c->p, 3, &sy.lists));
+        // a shared side enters the refined Hessian as scale * Gram (float64) and the refined gradient as an unsampled linear side
+        if (x_shared) { rf.shared.F = c->F[CMF_U]; rf.shared.rows_pad = c->mp; rf.shared.scale = alpha; rf.shs = sx; }
+        else rf.s1 = sx;
+        if (y_shared) { rf.shared.F = c->F[CMF_Z]; rf.shared.rows_pad = c->pp; rf.shared.scale = 1.0 - alpha; rf.shs = sy; }
+        else rf.s2 = sy;
+    }
+    return per_row_finish(c, CMF_V, h, pert, nn, rf);
 }
 
 // ---- fused per-row path (cmf_rowhess.hip.h): only the sampled rows are touched ---------------
@@ -1100,7 +1169,7 @@ static int launch_row_hess(cmf_ctx *c, const RowHessArgs &a, int64_t nrows, doub
 
 // device index lists for one sweep side: from the host lists (parity mode) or from the device sampler
 static int sample_lists(cmf_ctx *c, DevBuf &lb, DevBuf &mb, const int32_t *host_idx, int64_t nlists, int64_t per, int64_t n,
-                        int salt, const int32_t **out, DevBuf *sorted_buf = nullptr, const int32_t **sorted_out = nullptr) {
+                        int salt, const int32_t **out, DevBuf *sorted_buf, const int32_t **sorted_out) {
     *out = nullptr;
     if (sorted_out) *sorted_out = nullptr;
     if (nlists * per == 0) return CMF_OK;
@@ -1131,23 +1200,6 @@ static int sample_lists(cmf_ctx *c, DevBuf &lb, DevBuf &mb, const int32_t *host_
     return CMF_OK;
 }
 
-struct RowSide {
-    bool active = false;
-    const float *O = nullptr;   // other factor
-    const int32_t *lists = nullptr;
-    int64_t per = 0;            // samples per row
-    const float *T = nullptr;
-    int64_t t_row = 0, t_col = 0;
-    double scale = 1.0;
-    int link = 0;
-    int cls = 0;                // > 0: shared partial sums over groups of `cls` rows (linear link, sampled; cmf_rowhess.hip.h)
-    int64_t n = 0;              // candidates the lists draw from
-    int slot = 0;               // which of the two class-list buffers
-    // natively sparse data on this side: the row kernel runs with zero targets and the stored values of data row i that lie in
-    // its sample enter the gradient afterwards (sparse_target_term); `sp` = CSR image whose row i belongs to factor row i
-    const CsrDev *sp = nullptr;
-    const int32_t *sorted = nullptr; // ascending copies of the lists (null: not sampled)
-};
 
 // zero targets for a native sparse side: one float of zeros read with strides 0
 static int zero_targets(cmf_ctx *c, RowSide &sd, const CsrDev *sp) {
@@ -1258,12 +1310,6 @@ static int class_side_gradient(cmf_ctx *c, bool x_side, bool by_row, const RowSi
 
 // finish a sweep of factor `which` whose per-row parts come from up to two fused sides;
 // c->num must already hold any shared-side gradient part if `grad_preloaded`
-// the shared part of a sweep's Hessians as the refinement needs it: scale * F^T F, re-formed in float64
-struct SharedPart {
-    const float *F = nullptr;
-    int64_t rows_pad = 0;
-    double scale = 0.0;
-};
 
 // Float64 refinement of the rows clamp_stats listed for this chunk (c->bad_host): per sample z = o_j . f_i, residual and Hessian
 // weight in float64 (exact products of the float32 factor rows and data values, float64 sums); H_i = diag I + shared part + the
@@ -1462,7 +1508,7 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
                                (float *)nullptr, (int *)c->certflag.p, c->k, c->kp, kk, (float)(pert - diag), (int)ncert, 1);
             HIPCHK(hipGetLastError());
         }
-        CHK(safe_solve_rows(c, Hc, grad + r0 * c->kp, step + r0 * c->kp, nr, c->k, c->kp, pert, cert, !global_cert)); // certified sweeps never clamp
+        CHK(safe_solve_rows(c, Hc, grad + r0 * c->kp, step + r0 * c->kp, nr, c->k, c->kp, pert, cert, true));
         CHK(refine_rows64(c, which, s1, s2, shared, shside, diag, l1, l2, r0, step + r0 * c->kp, pert));
     }
     return launch_ew(c, newton_apply_kernel, rows_pad * c->kp, c->F[which], (const float *)step, rows, c->kp, c->k, rows_pad * c->kp,

@@ -24,7 +24,7 @@ OPTIONS = {"row_classes": [-1, 0, 2, 3, 5], "row_certificates": [0, 1], "lowrank
            "row_chunk": [0, 256, 512], "small_gram": [0, 1], "gemm_split": [0, 1, 3], "row_symmetric": [0, 1, 3],
            "row_kernel": [0, 1], "direct_newton_step": [0, 1], "small_tile_update": [0, 1], "fused_mu_update": [0, 1],
            "split_reduce_in_kernel": [0, 1], "spmm_blocked": [0, 1], "newton_schulz": [0, 1], "safe_inverse_cholesky": [0, 1],
-           "factor_times_tile": [64, 128, 256], "graph": [0, 1], "refine_rows": [0, 1]}
+           "factor_times_tile": [64, 128, 256], "graph": [0, 1]}
 
 
 def log_int(rng, lo, hi):
@@ -112,6 +112,11 @@ def run_case(c, seed, info=None):
                 errs.append(float("inf"))
             else:
                 errs.append(float(np.abs(got[w] - ref).max() / max(1e-3, np.abs(ref).max())))
+        if info is not None and info.get("want_rows"):       # debugging aid: the V rows furthest from the oracle
+            dv = np.abs(got[1] - Vr).max(axis=1) / max(1e-3, np.abs(Vr).max())
+            order = np.argsort(-dv)[:6]
+            info["worst_v_rows"] = [(int(i), float("%.2e" % dv[i])) for i in order]
+            info["v_rows_above_1e-3"] = int((dv > 1e-3).sum())
         if info is not None and newton:
             info["clamp_rows"], info["clamp_ratio"], info["refined_rows"] = ctx.newton_clamp_stats()
         if info is not None and np.isfinite(errs).all():
