@@ -70,6 +70,45 @@ def test_ill_conditioned_rows_are_redone_in_float64(lib):
     assert np.abs(got[1] - Vr).max() / np.abs(Vr).max() < 0.02 * err32
 
 
+def test_refinement_across_chunks_and_with_sampling(lib):
+    """Rows to refine in every chunk of a sweep split into several (option row_chunk), index lists in play (ratio 0.5) and
+    a native CSR X: chunk-relative row numbers, absolute list rows and the sparse target term of the float64 path."""
+    import scipy.sparse as sp
+    from oracle import cmf_oracle as O
+    rng = np.random.RandomState(5)
+    m, d, p, k = 48, 600, 6, 70
+    X = np.abs(rng.randn(m, d)); X[rng.rand(m, d) < 0.8] = 0.0
+    Y = (rng.rand(d, p) < 0.3).astype(float)
+    sc = 0.4 / np.sqrt(k / 8.0)
+    U, V, Z = sc * rng.randn(m, k), np.abs(sc * rng.randn(d, k)), sc * rng.randn(p, k)
+    ratio, alpha, l1, l2, pert = 0.5, 0.6, 0.1, 0.0, 0.002
+    np.random.seed(11)
+    masks = {"U": [], "Z": [], "V": []}
+    Ur, Vr, Zr = U.copy(), V.copy(), Z.copy()
+    O.newton_update_step(X, Y, Ur, Vr, Zr, alpha, l1, l2, "linear", "logit", False, True, False, ratio, pert, masks=masks)
+    su, sm, sp_ = int(d * ratio), int(m * ratio), int(p * ratio)
+    lists = [np.array(masks["U"], dtype=np.int32).reshape(m, su), np.array(masks["Z"], dtype=np.int32).reshape(p, su),
+             np.array([a for a, _ in masks["V"]], dtype=np.int32).reshape(d, sm),
+             np.array([b for _, b in masks["V"]], dtype=np.int32).reshape(d, sp_)]
+    outs = []
+    for opts in ([("row_chunk", 256)], []):
+        ctx = lib.Context(0)
+        ctx.set_problem(m, d, p, k)
+        for n, v in opts:
+            ctx.set_option(n, v)
+        ctx.set_data(0, sp.csr_matrix(X)); ctx.set_data(1, Y)
+        for w, F in enumerate((U, V, Z)):
+            ctx.set_factor(w, F)
+        ctx.newton_step(alpha, l1, l2, "linear", "logit", 2, 7, pert, ratio, *lists)
+        rows, ratio_left, refined = ctx.newton_clamp_stats()
+        assert refined >= d and ratio_left <= 1e4          # k > samples per row, l2 = 0: every V row qualifies
+        outs.append([ctx.get_factor(w) for w in range(3)])
+        ctx.close()
+    for w, ref in enumerate((Ur, Vr, Zr)):
+        np.testing.assert_allclose(outs[0][w], ref, rtol=0, atol=1e-3 * np.abs(ref).max())
+        np.testing.assert_array_equal(outs[0][w], outs[1][w])  # the chunking changes nothing
+
+
 @pytest.mark.parametrize("line", range(10))
 def test_flagged_campaign_cases_with_refinement(lib, line):
     """The cases tools/fuzz_campaign.py flagged in round 3 (V off by 1e-2 .. 0.4 in float32: clamped rows with ||H|| / pert >= 6e4,
