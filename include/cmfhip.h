@@ -221,7 +221,8 @@ int cmf_safe_invert_batch(cmf_ctx *ctx, const double *H, double *out, int n, int
  * eigenvalues are resolved to about eps32 * ||H||, so the clamped directions of the inverse carry a relative error of the order
  * eps32 * ||H|| / pert (the reference works in float64).  rows = matrices the float32 clamp acted on since the last reset,
  * max_ratio = the largest ||H||_F / pert among them (0 when there were none).  The stated tolerances hold
- * for max_ratio up to ~1e4.  Rows above that ratio (option "refine_rows_ratio") are REDONE IN FLOAT64 (Hessian from float64 sums,
+ * for max_ratio up to ~1e4.  Clamped rows above 3e3 (option "refine_rows_ratio"; plain solves above a condition estimate of 1e3,
+ * "refine_rows_cond") are REDONE IN FLOAT64 (Hessian from float64 sums,
  * float64 clamp, float64 step; option "refine_rows", default on, at most "refine_rows_max" = 16384 rows per sweep, k <= 256) and
  * counted in `refined` instead; only rows left in float32 enter rows / max_ratio, and the estimator warns when max_ratio
  * exceeds 1e4.  The shared Hessians of the linear unsampled sweeps are formed and clamped in float64 and never appear here.
