@@ -178,7 +178,7 @@ struct cmf_ctx {
     DevBuf badbuf, rw64, rh64;            // float64 refinement of ill-conditioned rows: [count, list], sample weights, one Hessian
     std::vector<int> bad_host;            // rows of the current chunk to redo in float64 (relative to the chunk)
     int opt_refine = 1;                   // redo clamped rows with ||H||_F / pert > refine_ratio in float64 (0: float32 only, recorded)
-    double opt_refine_ratio = 3.0e3;       // clamped rows: ||H||_F / pert above this (campaign: 2.7e3 -> 3e-4 off the oracle, 9.8e3 -> 1.9e-3)
+    double opt_refine_ratio = 3.0e3;       // clamped rows: ||H||_F / pert above this (campaign: 2.7e3 -> 3e-4 off the float64 reference, 9.8e3 -> 1.9e-3)
     double opt_refine_cond = 1.0e3;        // plain Cholesky solves: max H_ii / min L_ii^2 (a LOWER bound of cond H) above this
     int64_t opt_refine_max = 16384;       // at most this many rows per sweep (a float64 clamp is ~170 small launches); beyond: float32, recorded
     int64_t refined_sweep = 0, refined_total = 0;
