@@ -162,15 +162,18 @@ def cpu_baseline(w, budget_s=20.0):
 def launch_ranks(n, argv):
     """``python bench.py --gpus N`` without a launcher: start N fresh rank processes (one per GPU) BEFORE anything in
     this process touches the GPU, wait for them, forward rank 0's JSON line.  Never exec: the parent only supervises."""
+    import shutil
     import socket
     import subprocess
+    from pycmf_amd.comm import fresh_job_env
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    base_env, job_dir = fresh_job_env()     # private, empty rendezvous directory + random key: nothing stale, nobody else's
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+        env = dict(base_env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
@@ -190,8 +193,10 @@ def launch_ranks(n, argv):
                 q.kill()
         for q in procs:
             q.wait()
+        shutil.rmtree(job_dir, ignore_errors=True)
         raise SystemExit("bench.py: rank %d exited with code %s" % (failed, procs[failed].returncode))
     out = procs[0].stdout.read().decode()
+    shutil.rmtree(job_dir, ignore_errors=True)
     line = next((ln for ln in reversed(out.splitlines()) if ln.startswith("{")), None)
     if line is None:
         raise SystemExit("bench.py: rank 0 printed no JSON line")
@@ -208,6 +213,9 @@ def main():
     ap.add_argument("--overlap-chunks", type=int, default=1,
                     help="N > 1 GPUs, MU on dense data: reduce the (d + k) k buffer in this many row blocks on a side stream while the "
                          "next block's partial is computed (default 1: one serial all-reduce)")
+    ap.add_argument("--mu-collective", choices=("rsag", "allreduce"), default=None,
+                    help="N > 1 GPUs, MU: 'rsag' (default) = reduce-scatter of the partial, V epilogue on the rank's row block, all-gather of V; "
+                         "'allreduce' = ONE all-reduce of the (d + k) k buffer and the replicated epilogue")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="cmf_set_option knob for A/B runs (e.g. row_symmetric=0); recorded in config")
     args = ap.parse_args()
@@ -287,7 +295,8 @@ def main():
         coll = init_collectives(ctx, rank, world, timed=True)
 
     if not newton:
-        drv = make_sharded_mu(ctx, coll, chunks=args.overlap_chunks if "nnz_per_row" not in w and not bf16x6 else 1)
+        drv = make_sharded_mu(ctx, coll, chunks=args.overlap_chunks if "nnz_per_row" not in w and not bf16x6 else 1,
+                              mode=args.mu_collective if args.overlap_chunks <= 1 else "allreduce")
 
         def do_step(it):
             drv.step(0.0, 0.0, 7)
@@ -350,6 +359,15 @@ def main():
     series_ms = [b_ - a_ for a_, b_ in zip(marks, marks[1:])]
     coll_stats = coll.stats() if coll else None
     coll_exposed = coll.exposed_ms() if coll and hasattr(coll, "exposed_ms") else None
+    coll_kinds = coll.stats_by_kind() if coll and hasattr(coll, "stats_by_kind") else {}
+    replicas = None
+    if coll and not rows_mode:
+        # V is replicated: after the timed iterations every rank must hold the same V, bit for bit (a collective that summed
+        # the wrong chunks, or ranks that never met, shows up here and not only as a strange residual)
+        vsum = float(np.abs(ctx.get_factor(_lib.CMF_V)).sum(dtype=np.float64))
+        hi = float(coll.all_reduce_host([vsum], "max")[0])
+        lo = -float(coll.all_reduce_host([-vsum], "max")[0])
+        replicas = {"sum_abs_V_max_over_ranks": hi, "sum_abs_V_min_over_ranks": lo, "identical": hi == lo}
 
     names = ("gemm_nn", "gemm_tn", "gemm_small", "gemm_nt", "spmm", "rowhess", "eigen", "elementwise")
     classes = {c: tuple(sum(v) for v in zip(*(c_.kernel_time(c) for c_ in ctxs))) for c in names}
@@ -484,8 +502,9 @@ def main():
                    "parallelism": "single GPU: X, Y and all three factors resident on one device, no collective" if not use_dist else ("rows of U, V, Z sharded x%d (every sweep row-parallel; X and Y held by rows and by "
                                    "columns), factor rows reassembled by 3 in-place RCCL all-gathers, (m+p+d)*k f32 in all "
                                    "per iteration" % world) if rows_mode else
-                                  ("X/U row-sharded, Y/Z column-sharded x%d, V replicated, "
-                                   "1 RCCL all-reduce of (d+k)*k f32 per iteration" % world)},
+                                  ("X/U row-sharded, Y/Z column-sharded x%d, V replicated; the one sum over the ranks per iteration, (d+k)*k f32, "
+                                   "as %s" % (world, "reduce-scatter + row-blocked V epilogue + all-gather (+ two k^2 all-reduces)"
+                                              if getattr(drv, "mode", None) == "rsag" else "1 RCCL all-reduce"))},
         "roofline": roof,
         "rel_residual": {"x": (ex2 / x2) ** 0.5 if x2 > 0 else None, "y": (ey2 / y2) ** 0.5 if y2 > 0 else None,
                          "note": "rank-0 shard, after warmup+steps iterations"},
@@ -494,14 +513,23 @@ def main():
                         "note": "HIP events on the launch stream of rank 0, one per iteration inside the timed region"}
     if use_dist:
         calls, nbytes, cms = coll_stats if coll_stats else (0, 0, 0.0)
+        exposed = (cms if args.overlap_chunks <= 1 else coll_exposed)
         out["collective"] = {"backend": coll.backend, "ranks": world,
+                             "ranks_seen": getattr(coll, "ranks_seen", None), "rank_seen": getattr(coll, "rank_seen", None),
+                             "protocol": getattr(drv, "mode", None) or ("all_gather x3" if rows_mode else "all_reduce"),
                              "calls_per_iteration": calls / args.steps, "payload_bytes_per_iteration": nbytes / args.steps,
                              "ms_per_iteration": cms / args.steps,
+                             "per_kind": {kname: {"calls_per_iteration": kv[0] / args.steps, "payload_bytes_per_iteration": kv[1] / args.steps,
+                                                  "us_per_call": (kv[2] / kv[0] * 1e3) if kv[0] else None}
+                                          for kname, kv in coll_kinds.items() if kv[0]},
                              "overlap_chunks": args.overlap_chunks,
-                             "exposed_ms_per_iteration": (cms if args.overlap_chunks <= 1 else coll_exposed) / args.steps,
+                             "exposed_ms_per_iteration": exposed / args.steps,
                              "hidden_ms_per_iteration": (0.0 if args.overlap_chunks <= 1 else max(0.0, cms - coll_exposed)) / args.steps,
+                             "compute_ms_per_iteration": ms_per_step - exposed / args.steps,
+                             "replicas": replicas,
                              "note": "rank 0; ms = events on the launch stream around every collective (waiting for the "
-                                     "slowest rank included)"}
+                                     "slowest rank included); ranks_seen = ncclCommCount of the communicator; replicas = every "
+                                     "rank's copy of V compared after the run"}
     for key in ("x_link", "y_link", "ratio", "l1", "l2", "nn_mask"):
         if key in w:
             out["config"][key] = w[key]

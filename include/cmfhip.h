@@ -162,6 +162,21 @@ int cmf_mu_v_partials(cmf_ctx *ctx, float *dev_buf);
 int cmf_mu_v_partials_rows(cmf_ctx *ctx, float *dev_buf, int64_t row0, int64_t nrows, int with_gram);
 int cmf_mu_v_apply(cmf_ctx *ctx, const float *dev_buf, double l1, double l2);
 int cmf_mu_uz_update(cmf_ctx *ctx, double l1, double l2, int update_mask);
+/* row-blocked V update: the same single sum over the ranks, cut in two around the epilogue (SURVEY.md 8(e) "Partitioning": reduce-
+ * scatter + epilogue + all-gather).  Block r of V = rows [r B, (r + 1) B), B = block_rows (a multiple of 256, world * B >= d_pad;
+ * cmf_mu_blocked_layout also grows the allocation behind V to world * B rows so that the all-gather runs in place on
+ * cmf_factor_dev_ptr(V) -- query that pointer AFTER this call).  Per iteration:
+ *   cmf_mu_v_partials_split(P, G)                     P: pbuf_elems floats, zero beyond d_pad rows; G: k_pad^2 floats
+ *   all-reduce G (k_pad^2), reduce-scatter P (block_rows * k_pad per rank)
+ *   cmf_mu_v_apply_rows(P + r B k_pad, G, r B, rows)  rows = the part of block r inside d_pad (may be 0)
+ *   cmf_mu_gram_v_rows(r B, rows, G2); all-reduce G2; all-gather V (block_rows * k_pad per rank)
+ *   cmf_mu_uz_update_gram(G2, ...)
+ * cmf_solvers.py:242-246, :230-240; the sums over rows are the same sums, regrouped.                                          */
+int cmf_mu_blocked_layout(cmf_ctx *ctx, int world, int64_t *block_rows, int64_t *pbuf_elems);
+int cmf_mu_v_partials_split(cmf_ctx *ctx, float *dev_P, float *dev_G);
+int cmf_mu_v_apply_rows(cmf_ctx *ctx, const float *dev_P_rows, const float *dev_G, int64_t row0, int64_t nrows, double l1, double l2);
+int cmf_mu_gram_v_rows(cmf_ctx *ctx, int64_t row0, int64_t nrows, float *dev_G2);
+int cmf_mu_uz_update_gram(cmf_ctx *ctx, const float *dev_G2, double l1, double l2, int update_mask);
 
 /* ---- Newton solver: NewtonSolver.update_step, cmf_solvers.py:510-522 --- */
 /* sample index lists (parity mode): for sg_ratio < 1 the caller passes the
@@ -302,6 +317,12 @@ int cmf_comm_exposed_ms(cmf_ctx *ctx, double *ms, int reset);
 /* in-place all-gather of equal chunks (factor rows of the row-sharded Newton): rank r's elems_per_rank floats already sit at
  * dev_full + r * elems_per_rank                                                                                             */
 int cmf_comm_allgather_f32(cmf_ctx *ctx, float *dev_full, int64_t elems_per_rank);
+/* in-place reduce-scatter of equal chunks: every rank holds world * elems_per_rank floats; afterwards chunk `rank` of the rank's
+ * own buffer is the sum over the ranks of that chunk.  With cmf_comm_allgather_f32 on the updated rows it is the ONE all-reduce of
+ * the MU V update (cmf_solvers.py:242-246) cut in two around the row-blocked epilogue (cmf_mu_v_apply_rows)                   */
+int cmf_comm_reduce_scatter_f32(cmf_ctx *ctx, float *dev_full, int64_t elems_per_rank);
+/* what RCCL reports about the communicator (ncclCommCount, ncclCommUserRank) -- not what the launcher's environment says   */
+int cmf_comm_count(cmf_ctx *ctx, int *ranks_seen, int *rank_seen);
 /* at most 16 host scalars, op 0 = sum, 1 = max; waits for the result (convergence test on the global error, the slowest
  * rank's clock of bench.py); cmf_comm_barrier = one such reduction                                                          */
 int cmf_comm_allreduce_host_f64(cmf_ctx *ctx, double *vals, int n, int op);
@@ -310,6 +331,9 @@ int cmf_comm_barrier(cmf_ctx *ctx);
  * occupied the stream (events around each one, waiting for the slowest rank included)                                       */
 int cmf_comm_timing(cmf_ctx *ctx, int enable);
 int cmf_comm_stats(cmf_ctx *ctx, int64_t *calls, int64_t *bytes, double *ms, int reset);
+/* the same per kind of collective (no reset: read before cmf_comm_stats(..., 1))                                            */
+enum { CMF_COMM_ALLREDUCE_F32 = 0, CMF_COMM_ALLREDUCE_F64 = 1, CMF_COMM_ALLGATHER_F32 = 2, CMF_COMM_REDUCE_SCATTER_F32 = 3, CMF_COMM_KINDS = 4 };
+int cmf_comm_stats_kind(cmf_ctx *ctx, int kind, int64_t *calls, int64_t *bytes, double *ms);
 /* raw copies between caller-held device pointers (scratch, partial buffers) and host memory on the context's stream; both wait */
 int cmf_copy_to_host(cmf_ctx *ctx, const void *dev, void *host, int64_t bytes);
 int cmf_copy_from_host(cmf_ctx *ctx, void *dev, const void *host, int64_t bytes);

@@ -57,6 +57,11 @@ PROTOTYPES = {
     "cmf_mu_v_apply": [_vp, _vp, _dbl, _dbl],
     "cmf_mu_v_partials_rows": [_vp, _vp, _i64, _i64, _i32],
     "cmf_mu_uz_update": [_vp, _dbl, _dbl, _i32],
+    "cmf_mu_blocked_layout": [_vp, _i32, _pi64, _pi64],
+    "cmf_mu_v_partials_split": [_vp, _vp, _vp],
+    "cmf_mu_v_apply_rows": [_vp, _vp, _vp, _i64, _i64, _dbl, _dbl],
+    "cmf_mu_gram_v_rows": [_vp, _i64, _i64, _vp],
+    "cmf_mu_uz_update_gram": [_vp, _vp, _dbl, _dbl, _i32],
     "cmf_newton_step": [_vp, _dbl, _dbl, _dbl, _i32, _i32, _i32, _i32, _dbl, _dbl,
                         _pi32, _pi32, _pi32, _pi32],
     "cmf_newton_step_device_sampled": [_vp, _dbl, _dbl, _dbl, _i32, _i32, _i32, _i32, _dbl, _dbl, C.c_uint64],
@@ -94,6 +99,9 @@ PROTOTYPES = {
     "cmf_comm_join": [_vp],
     "cmf_comm_exposed_ms": [_vp, _pd, _i32],
     "cmf_comm_allgather_f32": [_vp, _vp, _i64],
+    "cmf_comm_reduce_scatter_f32": [_vp, _vp, _i64],
+    "cmf_comm_count": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "cmf_comm_stats_kind": [_vp, _i32, _pi64, _pi64, _pd],
     "cmf_comm_allreduce_host_f64": [_vp, _pd, _i32, _i32],
     "cmf_comm_barrier": [_vp],
     "cmf_comm_timing": [_vp, _i32],
@@ -371,6 +379,30 @@ class Context:
     def mu_uz_update(self, l1, l2, mask=7):
         check(self._lib.cmf_mu_uz_update(self._h, l1, l2, mask))
 
+    # row-blocked V update (reduce-scatter + epilogue on the rank's block + all-gather): include/cmfhip.h
+    def mu_blocked_layout(self, world):
+        """(rows per block, floats of the partial buffer); grows the allocation behind V so that the all-gather runs in place."""
+        b, n = C.c_int64(0), C.c_int64(0)
+        check(self._lib.cmf_mu_blocked_layout(self._h, int(world), C.byref(b), C.byref(n)))
+        return b.value, n.value
+
+    def mu_v_partials_split(self, dev_p, dev_g):
+        check(self._lib.cmf_mu_v_partials_split(self._h, _vp(dev_p), _vp(dev_g)))
+
+    def mu_v_apply_rows(self, dev_p_rows, dev_g, row0, nrows, l1, l2):
+        check(self._lib.cmf_mu_v_apply_rows(self._h, _vp(dev_p_rows), _vp(dev_g), row0, nrows, l1, l2))
+
+    def mu_gram_v_rows(self, row0, nrows, dev_g2):
+        check(self._lib.cmf_mu_gram_v_rows(self._h, row0, nrows, _vp(dev_g2)))
+
+    def mu_uz_update_gram(self, dev_g2, l1, l2, mask=7):
+        check(self._lib.cmf_mu_uz_update_gram(self._h, _vp(dev_g2), l1, l2, mask))
+
+    def factor_dev_ptr(self, which):
+        p = _pf()
+        check(self._lib.cmf_factor_dev_ptr(self._h, which, C.byref(p)))
+        return C.cast(p, _vp).value
+
     # ---- Newton
     def newton_step(self, alpha, l1, l2, x_link, y_link, nn_mask, upd_mask, pert, ratio,
                     u_idx=None, z_idx=None, vx_idx=None, vy_idx=None):
@@ -475,6 +507,21 @@ class Context:
 
     def comm_allgather(self, full, elems_per_rank):
         check(self._lib.cmf_comm_allgather_f32(self._h, _vp(full.data_ptr()), elems_per_rank))
+
+    def comm_reduce_scatter(self, full, elems_per_rank):
+        check(self._lib.cmf_comm_reduce_scatter_f32(self._h, _vp(full.data_ptr()), elems_per_rank))
+
+    def comm_count(self):
+        """(ranks, this rank) as RCCL reports them (ncclCommCount / ncclCommUserRank)."""
+        n, r = C.c_int(0), C.c_int(0)
+        check(self._lib.cmf_comm_count(self._h, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def comm_stats_kind(self, kind):
+        """(calls, payload bytes, ms) of one kind of collective: 0 all-reduce f32, 1 all-reduce f64, 2 all-gather, 3 reduce-scatter."""
+        calls, nbytes, ms = C.c_int64(0), C.c_int64(0), C.c_double(0)
+        check(self._lib.cmf_comm_stats_kind(self._h, int(kind), C.byref(calls), C.byref(nbytes), C.byref(ms)))
+        return calls.value, nbytes.value, ms.value
 
     def comm_allreduce_host(self, values, op="sum"):
         a = np.ascontiguousarray(values, dtype=np.float64).copy()

@@ -27,15 +27,45 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def _launcher_start():
+    """(clock ticks since boot, seconds since the epoch) at which the parent process -- the launcher all ranks of a job share --
+    started; (None, None) where /proc is not available."""
+    try:
+        with open("/proc/%d/stat" % os.getppid()) as f:
+            ticks = int(f.read().rsplit(")", 1)[1].split()[19])      # field 22: starttime
+        with open("/proc/stat") as f:
+            btime = next(int(ln.split()[1]) for ln in f if ln.startswith("btime"))
+        return ticks, btime + ticks / os.sysconf("SC_CLK_TCK")
+    except Exception:
+        return None, None
+
+
 def _job_key():
+    """What the ranks of ONE job share and no other job does: CMF_COMM_KEY when the launcher sets it, else the launcher's pid AND
+    start time (a recycled pid gets a different key), MASTER_PORT and torchrun's restart count (a restarted worker group must not
+    meet the previous group's files)."""
     key = os.environ.get("CMF_COMM_KEY")
     if key:
         return key
-    return "%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"))
+    ticks, _ = _launcher_start()
+    return "%d_%s_%s_%s" % (os.getppid(), ticks if ticks is not None else "x", os.environ.get("MASTER_PORT", "0"),
+                            os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
 
 
 def _job_dir():
     return os.environ.get("CMF_COMM_DIR") or tempfile.gettempdir()
+
+
+def fresh_job_env(env=None):
+    """For launchers (bench.launch_ranks, multi_gpu.fit_multi_gpu): a private, empty rendezvous directory (mkdtemp, mode 0700) and
+    a random key for ONE job, as environment entries for its ranks.  Nothing stale can be in it and no other user can write
+    there.  Returns (env, directory); the launcher removes the directory when its ranks have exited."""
+    import uuid
+    env = dict(os.environ if env is None else env)
+    d = tempfile.mkdtemp(prefix="cmf_comm_")
+    env["CMF_COMM_DIR"] = d
+    env["CMF_COMM_KEY"] = uuid.uuid4().hex
+    return env, d
 
 
 def _timeout():
@@ -50,6 +80,34 @@ def _wait_for(path, timeout, what):
         time.sleep(0.01)
 
 
+def _write_private(path, payload):
+    """Create `path` with O_EXCL and mode 0600 and write payload atomically (a reader sees all of it or no file).  A file of the
+    same name can only be a leftover of THIS launcher instance (the key holds its pid and start time): it is replaced."""
+    tmp = "%s.tmp%d" % (path, os.getpid())
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+    try:
+        os.write(fd, payload)
+    finally:
+        os.close(fd)
+    try:
+        os.unlink(path)
+    except OSError:
+        pass
+    os.rename(tmp, path)
+
+
+def _check_fresh(path):
+    """A rendezvous file must belong to this user, be writable by nobody else, and not predate the launcher (a leftover of an
+    earlier job whose key happened to repeat would make ncclCommInitRank wait for ranks that no longer exist)."""
+    st = os.stat(path)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        raise RuntimeError("pycmf_amd.comm: %s is not a private file of this user (uid %d, mode %o): refusing it"
+                           % (path, st.st_uid, st.st_mode & 0o777))
+    _, started = _launcher_start()
+    if started is not None and st.st_mtime < started - 2.0 and not os.environ.get("CMF_COMM_KEY"):
+        raise RuntimeError("pycmf_amd.comm: %s is older than this job's launcher: a leftover of an earlier job; remove it" % path)
+
+
 def exchange_unique_id(rank, world, timeout=None):
     """The job's RCCL unique id: created by rank 0, read by everybody else."""
     path = os.path.join(_job_dir(), "cmf_comm_%s.id" % _job_key())
@@ -58,12 +116,10 @@ def exchange_unique_id(rank, world, timeout=None):
         import ctypes as C
         buf = C.create_string_buffer(128)
         _lib.check(lib.cmf_comm_unique_id(buf))
-        tmp = path + ".tmp%d" % os.getpid()
-        with open(tmp, "wb") as f:
-            f.write(buf.raw)
-        os.replace(tmp, path)           # atomic: a reader sees all 128 bytes or no file
+        _write_private(path, buf.raw)
         return buf.raw, path
     _wait_for(path, timeout or _timeout(), "rank 0's RCCL unique id")
+    _check_fresh(path)
     with open(path, "rb") as f:
         raw = f.read()
     if len(raw) != 128:
@@ -82,6 +138,10 @@ class RcclCollectives:
         uid, path = exchange_unique_id(rank, world)
         ctx.comm_init(rank, world, uid)
         ctx.comm_barrier()              # every rank has read the id file
+        self.ranks_seen, self.rank_seen = ctx.comm_count()   # RCCL's own view (bench.py prints it)
+        if (self.ranks_seen, self.rank_seen) != (world, rank):
+            raise RuntimeError("pycmf_amd.comm: RCCL reports rank %d of %d, the launcher said rank %d of %d"
+                               % (self.rank_seen, self.ranks_seen, rank, world))
         if rank == 0:
             try:
                 os.remove(path)
@@ -105,6 +165,14 @@ class RcclCollectives:
 
     def all_gather(self, full, chunk=None):
         self.ctx.comm_allgather(full, full.numel() // self.world)
+
+    def reduce_scatter(self, full):
+        """In place: chunk `rank` of the rank's buffer becomes the sum over the ranks of that chunk."""
+        self.ctx.comm_reduce_scatter(full, full.numel() // self.world)
+
+    def stats_by_kind(self):
+        names = ("all_reduce_f32", "all_reduce_f64", "all_gather_f32", "reduce_scatter_f32")
+        return {n: self.ctx.comm_stats_kind(k) for k, n in enumerate(names)}
 
     def all_reduce_host(self, values, op="sum"):
         return self.ctx.comm_allreduce_host(values, op)
@@ -136,6 +204,8 @@ class HostStagedCollectives:
         self.dir, self.key, self.seq = _job_dir(), _job_key(), 0
         self.calls = self.bytes = 0
         self.ms = 0.0
+        self.kinds = {}
+        self.ranks_seen, self.rank_seen = world, rank
         self.barrier()
 
     def _path(self, seq, rank):
@@ -144,15 +214,17 @@ class HostStagedCollectives:
     def _exchange(self, mine):
         timeout = _timeout()
         self.seq += 1
-        tmp = self._path(self.seq, self.rank) + ".tmp.npy"
-        np.save(tmp, mine)
-        os.replace(tmp, self._path(self.seq, self.rank))
+        import io
+        bio = io.BytesIO()
+        np.save(bio, mine)
+        _write_private(self._path(self.seq, self.rank), bio.getvalue())
         parts = []
         for r in range(self.world):
             if r == self.rank:
                 parts.append(mine)
                 continue
             _wait_for(self._path(self.seq, r), timeout, "rank %d in collective %d" % (r, self.seq))
+            _check_fresh(self._path(self.seq, r))
             parts.append(np.load(self._path(self.seq, r)))
         if self.seq > 1:
             try:
@@ -161,10 +233,16 @@ class HostStagedCollectives:
                 pass
         return parts
 
-    def _account(self, nbytes, t0):
+    def _account(self, nbytes, t0, kind="all_reduce_f32"):
+        dt = (time.perf_counter() - t0) * 1e3
         self.calls += 1
         self.bytes += nbytes
-        self.ms += (time.perf_counter() - t0) * 1e3
+        self.ms += dt
+        c, b, m = self.kinds.get(kind, (0, 0, 0.0))
+        self.kinds[kind] = (c + 1, b + nbytes, m + dt)
+
+    def stats_by_kind(self):
+        return dict(self.kinds)
 
     def all_reduce(self, buf):
         t0 = time.perf_counter()
@@ -174,7 +252,7 @@ class HostStagedCollectives:
         for q in parts[1:]:
             total += q
         self.ctx.copy_from_host(buf, total)
-        self._account(mine.nbytes, t0)
+        self._account(mine.nbytes, t0, "all_reduce_f64" if mine.dtype == np.float64 else "all_reduce_f32")
 
     all_reduce_bg = all_reduce          # the double has no streams: the background form is the blocking one
 
@@ -190,7 +268,21 @@ class HostStagedCollectives:
         whole = self.ctx.copy_to_host(full).reshape(-1)
         parts = self._exchange(whole[self.rank * per:(self.rank + 1) * per].copy())
         self.ctx.copy_from_host(full, np.concatenate(parts))
-        self._account(whole.nbytes, t0)
+        self._account(whole.nbytes, t0, "all_gather_f32")
+
+    def reduce_scatter(self, full):
+        t0 = time.perf_counter()
+        per = full.numel() // self.world
+        whole = self.ctx.copy_to_host(full).reshape(-1)
+        parts = self._exchange(whole)
+        lo, hi = self.rank * per, (self.rank + 1) * per
+        total = parts[0][lo:hi].copy()
+        for q in parts[1:]:
+            total += q[lo:hi]
+        whole = whole.copy()
+        whole[lo:hi] = total            # the other chunks stay as they were, like ncclReduceScatter in place
+        self.ctx.copy_from_host(full, whole)
+        self._account(whole.nbytes, t0, "reduce_scatter_f32")
 
     def all_reduce_host(self, values, op="sum"):
         parts = self._exchange(np.ascontiguousarray(values, dtype=np.float64))
@@ -202,6 +294,7 @@ class HostStagedCollectives:
     def reset(self):
         self.calls = self.bytes = 0
         self.ms = 0.0
+        self.kinds = {}
 
     def stats(self):
         self.ctx.sync()
@@ -234,11 +327,18 @@ class NullCollectives:
 
     def __init__(self, ctx, rank, world, timed=False):
         self.ctx, self.rank, self.world = ctx, rank, world
+        self.ranks_seen, self.rank_seen = 1, rank
 
     def all_reduce(self, buf):
         pass
 
     all_reduce_bg = all_reduce
+
+    def reduce_scatter(self, full):
+        pass
+
+    def stats_by_kind(self):
+        return {}
 
     def join(self):
         pass

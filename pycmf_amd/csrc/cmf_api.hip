@@ -138,6 +138,7 @@ struct cmf_ctx {
     DevBuf spmm_bar;                  // rendezvous counters of the blocked SpMM (8 x 16 bytes)
     float *F[3] = {nullptr, nullptr, nullptr};
     int64_t frows[3] = {0, 0, 0}, frows_pad[3] = {0, 0, 0};
+    int64_t v_rows_alloc = 0;         // rows allocated behind F[CMF_V] (>= dp: the row-blocked MU driver all-gathers world equal blocks in place)
 
     // workspaces
     float *num = nullptr, *den = nullptr; // max(mp,dp,pp) x kp
@@ -151,6 +152,7 @@ struct cmf_ctx {
     DevBuf tickets;                       // one arrival counter per output tile of a split-K GEMM (zero between launches)
     int opt_inred = 0;                    // 0: split-K partials summed by a chip-wide kernel | 1: by the last-arriving workgroup of each tile
                                           // inside the GEMM kernel (A/B option; measured slower)
+    int opt_narrow_update = 1;            // fused factor updates with few row tiles run on 256 x 128 / 256 x 64 tiles (gemm())
     int opt_fused_mu = 1;                 // 1: F <- F num / reg(F G) in the epilogue of the F G product | 0: separate kernel
     int opt_small_tile = 1;               // 1: k_pad 64 / 128 factor updates on 64-row tiles (factor_update_kernel) | 0: gemm_kernel's 256-row tile
     DevBuf resid;                         // Newton residual / weights scratch (grow-only)
@@ -442,6 +444,13 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
     DevBuf &slabbuf = c->slab_sel ? c->slabs_b : c->slabs;
     if (kred % 32 || n % 32) return fail(CMF_EINVAL, "gemm: unpadded extent (k=%lld n=%lld)", (long long)kred, (long long)n);
     GemmPlan pl = plan_gemm(c, mout, n, kred, mu == nullptr, data_pass);
+    if (mu && c->opt_narrow_update && pl.ntiles_n == 1 && pl.tile == 0) {
+        // a factor-side product with a fused update cannot split its reduction (K = k_pad), and one 256 x 256 x 256 tile is 55 us of
+        // one CU whatever the row count: with few row tiles (a rank's 8192-row shard of U at C4 / 8 GPUs: 32) cut the tile's
+        // columns instead -- same arithmetic per element, bit-identical results, 4 x the workgroups
+        while (pl.bn > 64 && pl.tiles_m * (n / pl.bn) * 2 <= (int64_t)c->num_cu) pl.bn /= 2;
+        pl.ntiles_n = (int)(n / pl.bn);
+    }
     GemmArgs a;
     memset(&a, 0, sizeof a);
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb;
@@ -454,7 +463,7 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
     const bool in_kernel = mu != nullptr || pl.nsplit == 1 || (c->opt_inred != 0 && (int64_t)pl.tiles_m * pl.ntiles_n >= 16 && pl.nsplit <= 16);
     const bool direct = (pl.nsplit == 1 && !accumulate);
     if (mu) {
-        if (mode != MODE_NN || pl.ntiles_n != 1 || pl.nsplit != 1) return fail(CMF_EINVAL, "fused update needs one N tile and no split");
+        if (mode != MODE_NN || pl.nsplit != 1) return fail(CMF_EINVAL, "fused update needs an unsplit NN product");
         a.epi = mu->kind; a.epi_F = mu->F; a.epi_P = mu->P; a.epi_out = mu->out;
         a.epi_a = (float)mu->a; a.epi_b = (float)mu->b; a.epi_c = (float)mu->c;
         a.epi_rows = mu->rows; a.epi_kvalid = mu->kvalid; a.epi_nn = mu->nn;
@@ -743,6 +752,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_gram32_shares = (int)std::max<int64_t>(1, std::min<int64_t>(value, 1024));
     } else if (!strcmp(name, "small_gram")) {
         c->opt_gram32 = value != 0;
+    } else if (!strcmp(name, "narrow_update")) {
+        c->opt_narrow_update = value != 0;
     } else if (!strcmp(name, "gemm_tile512")) {
         c->opt_tile512 = value != 0;
     } else if (!strcmp(name, "gemm_rounds")) {
@@ -868,6 +879,7 @@ extern "C" int cmf_set_problem(cmf_ctx *c, int64_t m, int64_t d, int64_t p, int 
     CHK(dev_alloc(c, (void **)&c->F[CMF_U], (size_t)(c->mp + c->pp) * c->kp * sizeof(float)));
     c->F[CMF_Z] = c->F[CMF_U] + c->mp * c->kp;
     CHK(dev_alloc(c, (void **)&c->F[CMF_V], (size_t)c->dp * c->kp * sizeof(float)));
+    c->v_rows_alloc = c->dp;
     const int64_t rmax = std::max(c->mp, std::max(c->dp, c->pp));
     CHK(dev_alloc(c, (void **)&c->num, (size_t)rmax * c->kp * sizeof(float)));
     CHK(dev_alloc(c, (void **)&c->den, (size_t)rmax * c->kp * sizeof(float)));
@@ -1282,6 +1294,7 @@ extern "C" int cmf_mu_v_apply(cmf_ctx *c, const float *buf, double l1, double l2
     return mu_update(c, c->F[CMF_V], Gs, P, c->dp, l1, l2);
 }
 
+static int mu_uz_update_with(cmf_ctx *c, const float *G2, double l1, double l2, int mask);
 // U *= X V / reg(U V^T V), Z *= Y^T V / reg(Z V^T V): cmf_solvers.py:230-240, :257-263.
 // (U V^T) V is evaluated as U (V^T V): same value, 2mk^2 instead of 4mdk flops.
 extern "C" int cmf_mu_uz_update(cmf_ctx *c, double l1, double l2, int mask) {
@@ -1289,19 +1302,95 @@ extern "C" int cmf_mu_uz_update(cmf_ctx *c, double l1, double l2, int mask) {
     DeviceGuard dg(c->device);
     if (!(mask & (CMF_UPD_U | CMF_UPD_Z))) return CMF_OK;
     CHK(gram32(c, c->F[CMF_V], c->dp, c->G2));
+    return mu_uz_update_with(c, c->G2, l1, l2, mask);
+}
+
+// ---- row-blocked V update: the ONE all-reduce of the MU iteration cut in two around the epilogue ("Partitioning") ----
+// With N ranks, block r of V = rows [r B, (r + 1) B), B = 256 ceil(d_pad / 256 / N).  Every rank forms the whole partial
+// P = X_g^T U_g + Y_g Z_g (cmf_mu_v_partials_split), a reduce-scatter leaves rank r with the SUM of block r, rank r alone applies
+// V_r *= P_r / reg(V_r G) to its B rows (cmf_mu_v_apply_rows) and forms its share of V^T V (cmf_mu_gram_v_rows), an all-gather
+// reassembles V in place.  Against the replicated epilogue this removes (N - 1) / N of the 2 d k^2 product V G and of the d-row
+// Gram V^T V from every rank -- 0.3 of the 0.5 ms a C4 rank spends outside its four data passes at N = 8.  The two k x k Grams
+// (U^T U + Z^T Z before the epilogue, V^T V after it) are summed by two latency-bound all-reduces of k_pad^2 floats.
+// cmf_solvers.py:242-246 (V), :230-240 (U, Z): sums over rows are associative, so the iterates equal the unsharded ones up to the
+// order of the float32 additions across ranks.
+static int grow_v(cmf_ctx *c, int64_t rows) {
+    if (rows <= c->v_rows_alloc) return CMF_OK;
+    invalidate_graphs(c);
+    float *nv = nullptr;
+    CHK(dev_alloc(c, (void **)&nv, (size_t)rows * c->kp * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(nv, c->F[CMF_V], (size_t)c->dp * c->kp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_free(c, c->F[CMF_V]);
+    c->F[CMF_V] = nv;
+    c->v_rows_alloc = rows;
+    return CMF_OK;
+}
+extern "C" int cmf_mu_blocked_layout(cmf_ctx *c, int world, int64_t *block_rows, int64_t *pbuf_elems) {
+    NEED_PROBLEM(c);
+    if (world < 1) return fail(CMF_EINVAL, "world must be >= 1");
+    DeviceGuard dg(c->device);
+    const int64_t tiles = c->dp / 256;
+    const int64_t B = 256 * ((tiles + world - 1) / world);
+    CHK(grow_v(c, B * world)); // the in-place all-gather writes world equal blocks behind F[V]; rows >= d_pad stay zero
+    if (block_rows) *block_rows = B;
+    if (pbuf_elems) *pbuf_elems = B * world * c->kp;
+    return CMF_OK;
+}
+// P (d_pad x k_pad, written; the caller's buffer may be longer: rows >= d_pad are not touched) and G (k_pad x k_pad) of this shard
+extern "C" int cmf_mu_v_partials_split(cmf_ctx *c, float *P, float *G) {
+    NEED_PROBLEM(c);
+    if (!P || !G) return fail(CMF_EINVAL, "null buffer");
+    if (!have_data(c, 0) || !have_data(c, 1)) return fail(CMF_EINVAL, "X and Y must be set before a V update");
+    DeviceGuard dg(c->device);
+    CHK(gram32(c, c->F[CMF_U], c->mp + c->pp, G));
+    CHK(data_times(c, 0, true, c->F[CMF_U], P));
+    CHK(data_times(c, 1, false, c->F[CMF_Z], P, true));
+    return CMF_OK;
+}
+// V[row0 .. row0 + nrows) *= P_rows / reg(V_rows G): P_rows points at the (summed) rows of the partial that belong to these V rows
+extern "C" int cmf_mu_v_apply_rows(cmf_ctx *c, const float *P_rows, const float *G, int64_t row0, int64_t nrows, double l1, double l2) {
+    NEED_PROBLEM(c);
+    if (!P_rows || !G) return fail(CMF_EINVAL, "null buffer");
+    if (row0 < 0 || nrows < 0 || row0 % 256 || nrows % 256 || row0 + nrows > c->dp) return fail(CMF_EINVAL, "row block must be 256-aligned inside [0, d_pad)");
+    if (nrows == 0) return CMF_OK;
+    DeviceGuard dg(c->device);
+    return mu_update(c, c->F[CMF_V] + row0 * c->kp, G, P_rows, nrows, l1, l2);
+}
+// G2 = V_rows^T V_rows of a 256-aligned block of V rows (zero for an empty block): this rank's share of V^T V
+extern "C" int cmf_mu_gram_v_rows(cmf_ctx *c, int64_t row0, int64_t nrows, float *G2) {
+    NEED_PROBLEM(c);
+    if (!G2) return fail(CMF_EINVAL, "null buffer");
+    if (row0 < 0 || nrows < 0 || row0 % 256 || nrows % 256 || row0 + nrows > c->dp) return fail(CMF_EINVAL, "row block must be 256-aligned inside [0, d_pad)");
+    DeviceGuard dg(c->device);
+    if (nrows == 0) {
+        HIPCHK(hipMemsetAsync(G2, 0, (size_t)c->kp * c->kp * sizeof(float), c->stream));
+        return CMF_OK;
+    }
+    return gram32(c, c->F[CMF_V] + row0 * c->kp, nrows, G2);
+}
+static int mu_uz_update_with(cmf_ctx *c, const float *G2, double l1, double l2, int mask) {
     if (mask & CMF_UPD_U) {
         if (!have_data(c, 0)) return fail(CMF_EINVAL, "X must be set before a U update");
         SlabRef sl;
         CHK(data_times(c, 0, false, c->F[CMF_V], c->num, false, small_tile_ok(c, c->mp) ? &sl : nullptr));
-        CHK(mu_update(c, c->F[CMF_U], c->G2, c->num, c->mp, l1, l2, &sl));
+        CHK(mu_update(c, c->F[CMF_U], G2, c->num, c->mp, l1, l2, &sl));
     }
     if (mask & CMF_UPD_Z) {
         if (!have_data(c, 1)) return fail(CMF_EINVAL, "Y must be set before a Z update");
         SlabRef sl;
         CHK(data_times(c, 1, true, c->F[CMF_V], c->num, false, small_tile_ok(c, c->pp) ? &sl : nullptr));
-        CHK(mu_update(c, c->F[CMF_Z], c->G2, c->num, c->pp, l1, l2, &sl));
+        CHK(mu_update(c, c->F[CMF_Z], G2, c->num, c->pp, l1, l2, &sl));
     }
     return CMF_OK;
+}
+// cmf_mu_uz_update with V^T V supplied by the caller (the all-reduced sum of the ranks' cmf_mu_gram_v_rows)
+extern "C" int cmf_mu_uz_update_gram(cmf_ctx *c, const float *G2, double l1, double l2, int mask) {
+    NEED_PROBLEM(c);
+    if (!G2) return fail(CMF_EINVAL, "null buffer");
+    DeviceGuard dg(c->device);
+    if (!(mask & (CMF_UPD_U | CMF_UPD_Z))) return CMF_OK;
+    return mu_uz_update_with(c, G2, l1, l2, mask);
 }
 
 // Run `eager` (a fixed sequence of launches on c->stream) directly, or capture it into a hipGraph

@@ -17,6 +17,9 @@ struct RcclApi {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclReduceScatter) ReduceScatter = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 static RcclApi g_rccl;
@@ -40,6 +43,9 @@ static int rccl_load() {
     CMF_RCCL_SYM(CommDestroy, "ncclCommDestroy")
     CMF_RCCL_SYM(AllReduce, "ncclAllReduce")
     CMF_RCCL_SYM(AllGather, "ncclAllGather")
+    CMF_RCCL_SYM(ReduceScatter, "ncclReduceScatter")
+    CMF_RCCL_SYM(CommCount, "ncclCommCount")
+    CMF_RCCL_SYM(CommUserRank, "ncclCommUserRank")
     CMF_RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef CMF_RCCL_SYM
     g_rccl = a;
@@ -55,8 +61,10 @@ struct CmfComm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     bool timed = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events; // around every collective while `timed`
+    struct Ev { hipEvent_t a, b; int kind; };
+    std::vector<Ev> events;     // around every collective while `timed`
     int64_t calls = 0, bytes = 0;
+    int64_t kcalls[CMF_COMM_KINDS] = {0}, kbytes[CMF_COMM_KINDS] = {0}; // per kind (CMF_COMM_ALLREDUCE_F32 ...)
     double *dscratch = nullptr; // 16 doubles on the device for the host-value reductions
     // background collectives (cmf_comm_allreduce_f32_bg): a side stream ordered behind / in front of the context's stream by events
     hipStream_t side = nullptr;
@@ -106,7 +114,7 @@ extern "C" int cmf_comm_destroy(cmf_ctx *c) {
     CmfComm *cm = c->comm;
     (void)hipStreamSynchronize(c->stream);
     if (cm->side) (void)hipStreamSynchronize(cm->side);
-    for (auto &e : cm->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : cm->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : cm->joins) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &e : cm->ev_ready) if (e) (void)hipEventDestroy(e);
     if (cm->ev_done) (void)hipEventDestroy(cm->ev_done);
@@ -119,14 +127,15 @@ extern "C" int cmf_comm_destroy(cmf_ctx *c) {
 }
 
 struct CommTimed { // events on the collective's stream around it (bench.py: bytes and ms per iteration)
-    cmf_ctx *c; CmfComm *cm; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
-    CommTimed(cmf_ctx *c_, CmfComm *cm_, int64_t nbytes, hipStream_t st_ = nullptr) : c(c_), cm(cm_), st(st_ ? st_ : c_->stream) {
+    cmf_ctx *c; CmfComm *cm; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; int kind;
+    CommTimed(cmf_ctx *c_, CmfComm *cm_, int64_t nbytes, int kind_, hipStream_t st_ = nullptr) : c(c_), cm(cm_), st(st_ ? st_ : c_->stream), kind(kind_) {
         cm->calls += 1; cm->bytes += nbytes;
+        cm->kcalls[kind] += 1; cm->kbytes[kind] += nbytes;
         if (cm->timed && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, st);
         else a = b = nullptr;
     }
     ~CommTimed() {
-        if (a && b) { (void)hipEventRecord(b, st); cm->events.push_back({a, b}); }
+        if (a && b) { (void)hipEventRecord(b, st); cm->events.push_back({a, b, kind}); }
     }
 };
 #define NEED_COMM(c)                                                                                  \
@@ -140,7 +149,7 @@ extern "C" int cmf_comm_allreduce_f32(cmf_ctx *c, float *dev_buf, int64_t n) {
     NEED_COMM(c);
     if (!dev_buf || n < 0) return fail(CMF_EINVAL, "bad buffer");
     DeviceGuard dg(c->device);
-    CommTimed tm(c, c->comm, n * 4);
+    CommTimed tm(c, c->comm, n * 4, CMF_COMM_ALLREDUCE_F32);
     RCCLCHK(g_rccl.AllReduce(dev_buf, dev_buf, (size_t)n, ncclFloat32, ncclSum, c->comm->comm, c->stream));
     return CMF_OK;
 }
@@ -148,7 +157,7 @@ extern "C" int cmf_comm_allreduce_f64(cmf_ctx *c, double *dev_buf, int64_t n) {
     NEED_COMM(c);
     if (!dev_buf || n < 0) return fail(CMF_EINVAL, "bad buffer");
     DeviceGuard dg(c->device);
-    CommTimed tm(c, c->comm, n * 8);
+    CommTimed tm(c, c->comm, n * 8, CMF_COMM_ALLREDUCE_F64);
     RCCLCHK(g_rccl.AllReduce(dev_buf, dev_buf, (size_t)n, ncclFloat64, ncclSum, c->comm->comm, c->stream));
     return CMF_OK;
 }
@@ -169,7 +178,7 @@ extern "C" int cmf_comm_allreduce_f32_bg(cmf_ctx *c, float *dev_buf, int64_t n) 
     HIPCHK(hipEventRecord(ready, c->stream));
     HIPCHK(hipStreamWaitEvent(cm->side, ready, 0));
     {
-        CommTimed tm(c, cm, n * 4, cm->side);
+        CommTimed tm(c, cm, n * 4, CMF_COMM_ALLREDUCE_F32, cm->side);
         RCCLCHK(g_rccl.AllReduce(dev_buf, dev_buf, (size_t)n, ncclFloat32, ncclSum, cm->comm, cm->side));
     }
     HIPCHK(hipEventRecord(cm->ev_done, cm->side));
@@ -214,8 +223,31 @@ extern "C" int cmf_comm_allgather_f32(cmf_ctx *c, float *dev_full, int64_t elems
     NEED_COMM(c);
     if (!dev_full || elems_per_rank < 0) return fail(CMF_EINVAL, "bad buffer");
     DeviceGuard dg(c->device);
-    CommTimed tm(c, c->comm, elems_per_rank * 4 * c->comm->world);
+    CommTimed tm(c, c->comm, elems_per_rank * 4 * c->comm->world, CMF_COMM_ALLGATHER_F32);
     RCCLCHK(g_rccl.AllGather(dev_full + (int64_t)c->comm->rank * elems_per_rank, dev_full, (size_t)elems_per_rank, ncclFloat32, c->comm->comm, c->stream));
+    return CMF_OK;
+}
+// in-place reduce-scatter of equal chunks: every rank holds world * elems_per_rank floats at dev_full; afterwards rank r's chunk
+// [r * elems_per_rank, (r + 1) * elems_per_rank) of ITS buffer holds the sum over the ranks of that chunk (the other chunks are
+// left as they were).  First half of the decomposed all-reduce of the row-blocked MU V update (cmf_mu_v_apply_rows); the second
+// half is cmf_comm_allgather_f32 on the updated factor.
+extern "C" int cmf_comm_reduce_scatter_f32(cmf_ctx *c, float *dev_full, int64_t elems_per_rank) {
+    NEED_COMM(c);
+    if (!dev_full || elems_per_rank < 0) return fail(CMF_EINVAL, "bad buffer");
+    DeviceGuard dg(c->device);
+    CommTimed tm(c, c->comm, elems_per_rank * 4 * c->comm->world, CMF_COMM_REDUCE_SCATTER_F32);
+    RCCLCHK(g_rccl.ReduceScatter(dev_full, dev_full + (int64_t)c->comm->rank * elems_per_rank, (size_t)elems_per_rank, ncclFloat32, ncclSum, c->comm->comm, c->stream));
+    return CMF_OK;
+}
+// what RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank): the bench line reports these, not the launcher's
+// environment, so a run in which the ranks did not find each other cannot pass for an N-GPU run
+extern "C" int cmf_comm_count(cmf_ctx *c, int *ranks_seen, int *rank_seen) {
+    NEED_COMM(c);
+    int n = 0, r = -1;
+    RCCLCHK(g_rccl.CommCount(c->comm->comm, &n));
+    RCCLCHK(g_rccl.CommUserRank(c->comm->comm, &r));
+    if (ranks_seen) *ranks_seen = n;
+    if (rank_seen) *rank_seen = r;
     return CMF_OK;
 }
 // a few host scalars (convergence test: two squared residuals; bench: the slowest rank's time): op 0 = sum, 1 = max.  Waits.
@@ -255,16 +287,35 @@ extern "C" int cmf_comm_stats(cmf_ctx *c, int64_t *calls, int64_t *bytes, double
     double total = 0.0;
     for (auto &e : cm->events) {
         float t = 0.f;
-        if (hipEventElapsedTime(&t, e.first, e.second) == hipSuccess) total += t;
+        if (hipEventElapsedTime(&t, e.a, e.b) == hipSuccess) total += t;
     }
     if (calls) *calls = cm->calls;
     if (bytes) *bytes = cm->bytes;
     if (ms) *ms = total;
     if (reset) {
-        for (auto &e : cm->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        for (auto &e : cm->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         cm->events.clear();
         cm->calls = 0; cm->bytes = 0;
+        for (int k = 0; k < CMF_COMM_KINDS; ++k) cm->kcalls[k] = cm->kbytes[k] = 0;
     }
+    return CMF_OK;
+}
+// the same accounting for ONE kind of collective (CMF_COMM_ALLREDUCE_F32 ...), never resets: call before cmf_comm_stats(reset)
+extern "C" int cmf_comm_stats_kind(cmf_ctx *c, int kind, int64_t *calls, int64_t *bytes, double *ms) {
+    NEED_COMM(c);
+    if (kind < 0 || kind >= CMF_COMM_KINDS) return fail(CMF_EINVAL, "unknown collective kind %d", kind);
+    DeviceGuard dg(c->device);
+    CmfComm *cm = c->comm;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (cm->side) HIPCHK(hipStreamSynchronize(cm->side));
+    double total = 0.0;
+    for (auto &e : cm->events) {
+        float t = 0.f;
+        if (e.kind == kind && hipEventElapsedTime(&t, e.a, e.b) == hipSuccess) total += t;
+    }
+    if (calls) *calls = cm->kcalls[kind];
+    if (bytes) *bytes = cm->kbytes[kind];
+    if (ms) *ms = total;
     return CMF_OK;
 }
 

@@ -89,6 +89,8 @@ __device__ __forceinline__ void store_wt(float *p, float v) { asm volatile("glob
 // output tile, 16-deep K-step -- wave tile 128 x 64 like the 256 x 256 kernel's 64 x 128 (six fragment reads per eight MFMAs
 // instead of four per four, half the B-tile fill per flop), the same MFMA work per barrier as the 256 x 128 x 32 step, and
 // 98 KB of LDS double-buffered (a 32-deep step of this tile would need 180 KB).
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+
 template <int MODE, int BN, int TILE = 0>
 struct GemmCfg {
     static constexpr int BM = TILE ? 512 : 256, BK = TILE ? 16 : 32, PADK = BK + 4, NT = 512;
@@ -185,6 +187,9 @@ template <int MODE, int BN, int ROLE = 0, int PIPE = 0, int TILE = 0>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
     using C = GemmCfg<MODE, BN, TILE>;
     static_assert(TILE == 0 || (BN == 128 && MODE != MODE_NT && ROLE == 0 && PIPE == 4), "the 512 x 128 x 16 tile: k_pad = 128 data passes only");
+    // (shifts and masks, not / and %: with the signed division hipcc stopped folding the four A-tile LDS addresses of a thread into
+    // one base + immediate offsets, and that alone cost the TN pass 2.7 % and 0.5 GB of extra operand fetch per launch at C4 --
+    // profiles/HISTORY.md, round 4, A/B of the library builds)
     constexpr int F4K = C::BK / 4;   // 16-byte chunks per row of a k-contiguous tile
     constexpr int F4M = C::BM / 4;   // ... per row of the [k][rows] tile of the TN form
     constexpr int NGRP = C::BK / 2;  // MFMA groups (k pairs) per K-step
@@ -225,13 +230,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
         for (int p = 0; p < C::A_LD; ++p) {
             const int idx = t + C::NT * p;
             if constexpr (C::A_KC) {
-                const int r = idx / F4K, c4 = idx % F4K;
+                const int r = idx >> ilog2(F4K), c4 = idx & (F4K - 1);
                 ra[p] = *reinterpret_cast<const f32x4 *>(g.A + (row0 + r) * g.lda + k0 + 4 * c4);
             } else {
                 // branch-free: a conditional load makes hipcc wait for the loads it has just
                 // issued (it must assume the skipped path); out-of-range columns are clamped
                 // here and zeroed when the tile is written to LDS
-                const int r = idx / F4M, c4 = idx % F4M;
+                const int r = idx >> ilog2(F4M), c4 = idx & (F4M - 1);
                 int64_t col = row0 + 4 * c4;
                 if (ROLE == 1 && col > g.Mout - 4) col = g.Mout - 4;
                 ra[p] = *reinterpret_cast<const f32x4 *>(g.A + (k0 + r) * g.lda + col);
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
             const int idx = t + C::NT * p;
             if (C::B_F4 >= C::NT || idx < C::B_F4) {
                 if constexpr (C::B_KC) {
-                    const int r = idx / F4K, c4 = idx % F4K;
+                    const int r = idx >> ilog2(F4K), c4 = idx & (F4K - 1);
                     rb[p] = *reinterpret_cast<const f32x4 *>(Bbase + (n0 + r) * g.ldb + k0 + 4 * c4);
                 } else {
                     constexpr int F4R = BN / 4;
@@ -257,10 +262,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
         if (p < C::A_LD) {
             const int idx = t + C::NT * p;
             if constexpr (C::A_KC) {
-                const int r = idx / F4K, c4 = idx % F4K;
+                const int r = idx >> ilog2(F4K), c4 = idx & (F4K - 1);
                 *reinterpret_cast<f32x4 *>(As + r * C::PADK + 4 * c4) = ra[p];
             } else {
-                const int r = idx / F4M, c4 = idx % F4M;
+                const int r = idx >> ilog2(F4M), c4 = idx & (F4M - 1);
                 f32x4 v = ra[p];
                 if (ROLE == 1 && row0 + 4 * c4 >= g.Mout) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f32x4 *>(As + r * C::BM + 4 * c4) = v;
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
             const int idx = t + C::NT * pb;
             if (C::B_F4 >= C::NT || idx < C::B_F4) {
                 if constexpr (C::B_KC) {
-                    const int r = idx / F4K, c4 = idx % F4K;
+                    const int r = idx >> ilog2(F4K), c4 = idx & (F4K - 1);
                     *reinterpret_cast<f32x4 *>(Bs + r * C::PADK + 4 * c4) = rb[pb];
                 } else {
                     constexpr int F4R = BN / 4;

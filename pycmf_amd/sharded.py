@@ -78,6 +78,36 @@ class HipShardBackend:
     def partials_rows(self, buf, row0, nrows, with_gram):
         self.ctx.mu_v_partials_rows(buf.data_ptr(), row0, nrows, with_gram)
 
+    # row-blocked V update (ShardedMU mode 'rsag')
+    def blocked_layout(self, world):
+        """(rows per block, d_pad, k_pad); also grows the allocation behind V to world blocks."""
+        rows, _ = self.ctx.mu_blocked_layout(world)
+        _, dp, _, kp = self.ctx.geometry()
+        return rows, dp, kp
+
+    def small_buffers(self):
+        from . import _lib
+        kp = self.ctx.geometry()[3]
+        return _lib.DeviceArray(self.ctx, kp, kp), _lib.DeviceArray(self.ctx, kp, kp)
+
+    def partials_split(self, pbuf, gbuf):
+        self.ctx.mu_v_partials_split(pbuf.data_ptr(), gbuf.data_ptr())
+
+    def apply_v_rows(self, p_rows, gbuf, row0, nrows, l1, l2):
+        self.ctx.mu_v_apply_rows(p_rows.data_ptr(), gbuf.data_ptr(), row0, nrows, l1, l2)
+
+    def gram_v_rows(self, row0, nrows, g2buf):
+        self.ctx.mu_gram_v_rows(row0, nrows, g2buf.data_ptr())
+
+    def update_uz_gram(self, g2buf, l1, l2, mask):
+        self.ctx.mu_uz_update_gram(g2buf.data_ptr(), l1, l2, mask)
+
+    def v_full(self, rows):
+        """The factor V itself as a (world * block_rows) x k_pad device array: what the all-gather reassembles in place."""
+        from . import _lib
+        kp = self.ctx.geometry()[3]
+        return _lib.DeviceArray(self.ctx, rows, kp, _ptr=self.ctx.factor_dev_ptr(_lib.CMF_V), _owner=None)
+
     def row_blocks(self, chunks):
         """256-aligned blocks of the d_pad rows of the partial, at most `chunks` of them."""
         _, dp, _, kp = self.ctx.geometry()
@@ -90,23 +120,55 @@ class HipShardBackend:
 class ShardedMU:
     """One MU iteration across ``world`` ranks (order V -> U -> Z, cmf_solvers.py:248-263).
 
+    ``mode='allreduce'``: partials -> ONE all-reduce of the (d + k) k buffer -> the identical V epilogue on every rank -> U / Z.
     ``chunks > 1`` (opt-in; needs ``coll`` with background collectives and dense X, Y): the partial is formed in row blocks of
     V, and block c is all-reduced on the communicator's side stream while block c + 1 is computed -- the same single buffer,
-    summed in `chunks` pieces.  Nothing else in the iteration is independent of the reduced buffer, so this is the only overlap
-    there is; it trades GEMM launches with fewer output tiles for a hidden collective (priced as a wash at
-    N = 8, unmeasured)."""
+    summed in `chunks` pieces.
 
-    def __init__(self, backend, buf, world=1, all_reduce=None, chunks=1, coll=None):
+    ``mode='rsag'`` (default of ``make_sharded_mu``): the same sum cut in two around the epilogue ("Partitioning":
+    reduce-scatter + epilogue + all-gather).  The partial P is reduce-scattered in ``world`` equal row blocks, rank r applies
+    ``V_r *= P_r / reg(V_r G)`` to ITS block only and forms its share of V^T V, V is all-gathered in place; the two k x k Grams
+    (U^T U + Z^T Z, V^T V) travel as two latency-bound all-reduces of k_pad^2 floats.  Same bytes on the links as the all-reduce;
+    (world - 1) / world of the replicated epilogue and of the d-row Gram disappear from every rank."""
+
+    def __init__(self, backend, buf, world=1, all_reduce=None, chunks=1, coll=None, mode="allreduce", rank=0):
         self.backend = backend
         self.buf = buf
         self.world = world
         self.all_reduce = all_reduce
         self.chunks, self.coll = chunks, coll
+        self.mode, self.rank = mode, rank
         self.blocks = None
-        if chunks > 1 and coll is not None:
+        if mode not in ("allreduce", "rsag"):
+            raise ValueError("mode must be 'allreduce' or 'rsag'")
+        if mode == "rsag":
+            self.block_rows, self.d_pad, self.kp = backend.blocked_layout(world)   # buf: world * block_rows * k_pad floats
+            self.gbuf, self.g2buf = backend.small_buffers()
+            lo = min(rank * self.block_rows, self.d_pad)
+            self.own = (lo, min(lo + self.block_rows, self.d_pad) - lo)             # (first row, rows) of this rank's block of V
+        elif chunks > 1 and coll is not None:
             self.blocks, self.dp, self.kp = backend.row_blocks(chunks)
 
+    def _step_rsag(self, l1, l2, mask):
+        b, coll = self.backend, self.coll
+        if mask & 2:
+            b.partials_split(self.buf, self.gbuf)
+            coll.all_reduce(self.gbuf)                           # k_pad^2 floats
+            coll.reduce_scatter(self.buf)                        # first half of the one large sum
+            r0, nr = self.own
+            b.apply_v_rows(self.buf[self.rank * self.block_rows:(self.rank + 1) * self.block_rows], self.gbuf, r0, nr, l1, l2)
+        r0, nr = self.own
+        if mask & 5:
+            b.gram_v_rows(r0, nr, self.g2buf)
+            coll.all_reduce(self.g2buf)                          # k_pad^2 floats
+        if mask & 2:
+            coll.all_gather(b.v_full(self.world * self.block_rows))   # second half, in place on the factor
+        if mask & 5:
+            b.update_uz_gram(self.g2buf, l1, l2, mask)
+
     def step(self, l1=0.0, l2=0.0, mask=7):
+        if self.mode == "rsag":
+            return self._step_rsag(l1, l2, mask)
         if mask & 2:
             if self.blocks and len(self.blocks) > 1:
                 last = len(self.blocks) - 1
@@ -298,15 +360,26 @@ def make_sharded_newton_rows(ctx_uz, ctx_v, bounds, shape, coll, alpha, x_link, 
     return drv
 
 
-def make_sharded_mu(ctx, coll, chunks=1):
-    """MU driver of one rank: with ``coll`` None the context's own fused step, else partials -> ONE all-reduce -> apply
-    (``chunks`` > 1: the buffer reduced in that many row blocks, overlapped with the partials of the next block)."""
+def make_sharded_mu(ctx, coll, chunks=1, mode=None):
+    """MU driver of one rank: with ``coll`` None the context's own fused step; else ``mode`` 'rsag' (default: reduce-scatter ->
+    epilogue on the rank's row block of V -> all-gather) or 'allreduce' (partials -> ONE all-reduce -> replicated epilogue;
+    ``chunks`` > 1: the buffer reduced in that many row blocks, overlapped with the partials of the next block).
+    ``PYCMF_AMD_MU_COLLECTIVE`` overrides the default mode."""
+    import os
     from . import _lib
     backend = HipShardBackend(ctx)
     if coll is None:
         return SingleGpuStep(lambda l1, l2, mask: ctx.mu_step(l1, l2, mask))
-    buf = _lib.DeviceArray(ctx, backend.buf_elems(), 1)
-    drv = ShardedMU(backend, buf, coll.world, coll.all_reduce, chunks=chunks, coll=coll)
+    if mode is None:
+        mode = os.environ.get("PYCMF_AMD_MU_COLLECTIVE", "rsag") if chunks <= 1 else "allreduce"
+    if mode == "rsag":
+        block_rows, nelem = ctx.mu_blocked_layout(coll.world)
+        # (world * block_rows) x k_pad, zero-filled: the rows beyond d_pad of the last blocks stay zero
+        buf = _lib.DeviceArray(ctx, coll.world * block_rows, nelem // (coll.world * block_rows))
+        drv = ShardedMU(backend, buf, coll.world, coll.all_reduce, coll=coll, mode="rsag", rank=coll.rank)
+    else:
+        buf = _lib.DeviceArray(ctx, backend.buf_elems(), 1)
+        drv = ShardedMU(backend, buf, coll.world, coll.all_reduce, chunks=chunks, coll=coll)
     drv.collectives = coll
     return drv
 
@@ -319,11 +392,21 @@ def make_sharded_newton(ctx, coll, alpha, nn_mask=0, pert=0.2, single_collective
     if coll is None:
         return SingleGpuStep(lambda l1, l2, mask: ctx.newton_step(alpha, l1, l2, "linear", "linear", nn_mask, mask, pert, 1.0))
     _, dp, _, kp = ctx.geometry()
+    gbuf = None
+    if not single_collective:
+        # the re-associated three-stage sweep needs the float64 shared Hessian (k_pad <= 1024, options shared_hessian_f64 and
+        # newton_reassoc on): where the context reports it unavailable, every rank falls back to the gradient form with its ONE
+        # all-reduce -- what the single-GPU step does in the same configuration (every rank holds the same options, so they agree)
+        gbuf = _lib.DeviceArray(ctx, kp, kp, itemsize=8)
+        try:
+            backend.gram(gbuf)
+        except NotImplementedError:
+            gbuf.release()
+            gbuf, single_collective = None, True
     if single_collective:
         drv = ShardedNewtonLinear(backend, _lib.DeviceArray(ctx, backend.buf_elems(), 1), coll.world, coll.all_reduce)
     else:
-        drv = ShardedNewtonLinear(backend, _lib.DeviceArray(ctx, dp, kp), coll.world, coll.all_reduce,
-                                  gbuf=_lib.DeviceArray(ctx, kp, kp, itemsize=8))
+        drv = ShardedNewtonLinear(backend, _lib.DeviceArray(ctx, dp, kp), coll.world, coll.all_reduce, gbuf=gbuf)
     drv.collectives = coll
     return drv
 

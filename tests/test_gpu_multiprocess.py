@@ -41,8 +41,11 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_fit_two_processes(tmp_path, world):
+@pytest.mark.parametrize("world,mode", [(2, "rsag"), (3, "rsag"), (2, "allreduce"), (3, "allreduce")])
+def test_sharded_fit_two_processes(tmp_path, world, mode):
+    """fit_mu_sharded on real rank processes.  'rsag' (the default): reduce-scatter of the partial, V epilogue on the rank's row
+    block, all-gather of V in place on the factor -- d_pad = 512 gives blocks of 256 rows, so with three ranks the last block is
+    EMPTY (its rank applies nothing and contributes a zero Gram); 'allreduce': one all-reduce, replicated epilogue."""
     from pycmf_amd import _lib
     from pycmf_amd.solver_shell import HipMUSolver
     if _lib.device_count() < 1:
@@ -58,7 +61,7 @@ def test_sharded_fit_two_processes(tmp_path, world):
     script.write_text(WORKER % {"root": ROOT, "data": data, "out": str(tmp_path / "out")})
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, str(script)],
-                              env=_rank_env(r, world, port, tmp_path),
+                              env=dict(_rank_env(r, world, port, tmp_path), PYCMF_AMD_MU_COLLECTIVE=mode),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = [q.communicate(timeout=1800)[0].decode() for q in procs]
     for r, (q, o) in enumerate(zip(procs, outs)):
@@ -163,8 +166,14 @@ def test_bench_launches_its_own_ranks(workload):
     assert len(out["series_ms"]["per_iteration"]) == 3
     coll = out["collective"]
     assert coll["ranks"] == 2 and coll["payload_bytes_per_iteration"] > 0 and coll["ms_per_iteration"] > 0
-    # MU: ONE all-reduce; per-row Newton: 3 all-gathers of factor rows; linear Newton: the k^2 float64 Gram + ONE d x k partial
-    assert coll["calls_per_iteration"] == {"tiny": 1, "tiny3": 3, "tiny5": 2}[workload]
+    assert coll["ranks_seen"] == 2 and coll["rank_seen"] == 0 and "exposed_ms_per_iteration" in coll and coll["per_kind"]
+    # MU: the one sum cut in two (reduce-scatter, all-gather) + the two k^2 Grams; per-row Newton: 3 all-gathers of factor rows;
+    # linear Newton: the k^2 float64 Gram + ONE d x k partial
+    assert coll["calls_per_iteration"] == {"tiny": 4, "tiny3": 3, "tiny5": 2}[workload]
+    if workload == "tiny":
+        assert coll["protocol"] == "rsag" and set(coll["per_kind"]) == {"all_reduce_f32", "reduce_scatter_f32", "all_gather_f32"}
+    if workload != "tiny3":
+        assert coll["replicas"]["identical"], coll["replicas"]     # every rank ends with the same V, bit for bit
     one = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", workload, "--no-cpu-baseline"], {})
     assert one["n_gpus"] == 1 and "collective" not in one
     # same synthetic problem, same iteration count: the sharded run ends at the same residuals (rank 0's shard of X / Y
@@ -176,12 +185,22 @@ def test_bench_launches_its_own_ranks(workload):
 def test_bench_rccl_single_rank():
     """The RCCL branch of bench.py with one rank (all a 1-GPU box can offer RCCL): unique id through the job file,
     ncclCommInitRank inside libcmfhip, the all-reduce of the (d + k) k partial buffer on the context's stream, teardown."""
-    out = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "tiny", "--no-cpu-baseline"],
+    out = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "tiny", "--no-cpu-baseline", "--mu-collective", "allreduce"],
                      {"CMF_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1"})
     assert out["collective"]["backend"] == "rccl" and out["collective"]["calls_per_iteration"] == 1
+    assert out["collective"]["ranks_seen"] == 1 and out["collective"]["rank_seen"] == 0     # ncclCommCount / ncclCommUserRank
     assert out["collective"]["payload_bytes_per_iteration"] == (1024 + 64) * 64 * 4
     ref = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "tiny", "--no-cpu-baseline"], {})
     assert out["rel_residual"] == ref["rel_residual"]      # a 1-rank all-reduce is the identity: bit-identical iterates
+    # the default protocol: ncclReduceScatter and ncclAllGather in place (one rank: both the identity) + two k^2 all-reduces
+    out = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "tiny", "--no-cpu-baseline"],
+                     {"CMF_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1"})
+    coll = out["collective"]
+    assert coll["protocol"] == "rsag" and coll["calls_per_iteration"] == 4 and coll["replicas"]["identical"]
+    assert coll["payload_bytes_per_iteration"] == 2 * 1024 * 64 * 4 + 2 * 64 * 64 * 4
+    assert coll["per_kind"]["reduce_scatter_f32"]["calls_per_iteration"] == 1 and coll["per_kind"]["all_gather_f32"]["calls_per_iteration"] == 1
+    for key in ("x", "y"):
+        assert abs(out["rel_residual"][key] - ref["rel_residual"][key]) <= 1e-5 * ref["rel_residual"][key]
     # linear Newton on native CSR: float64 Gram + float32 partial per iteration
     out = _run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "tiny5", "--no-cpu-baseline"],
                      {"CMF_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1"})
@@ -196,7 +215,7 @@ def test_bench_overlapped_all_reduce_in_row_blocks():
     host-staged double."""
     base = ["--steps", "3", "--warmup", "1", "--workload", "tiny", "--no-cpu-baseline"]
     env = {"CMF_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1"}
-    serial = _run_bench(["--gpus", "1"] + base, env)
+    serial = _run_bench(["--gpus", "1", "--mu-collective", "allreduce"] + base, env)
     over = _run_bench(["--gpus", "1", "--overlap-chunks", "4"] + base, env)
     cs, co = serial["collective"], over["collective"]
     assert cs["calls_per_iteration"] == 1 and co["calls_per_iteration"] == 4 and co["overlap_chunks"] == 4
@@ -239,10 +258,16 @@ def test_rccl_abi_single_rank(tmp_path, monkeypatch):
     np.testing.assert_array_equal(ctx.copy_to_host(g), np.arange(9, dtype=np.float64).reshape(3, 3) / 7.0)
     coll.all_gather(a)
     np.testing.assert_array_equal(ctx.copy_to_host(a), ref)
+    coll.reduce_scatter(a)                       # one rank: its chunk is the whole buffer, the sum is the buffer itself
+    np.testing.assert_array_equal(ctx.copy_to_host(a), ref)
+    assert (coll.ranks_seen, coll.rank_seen) == (1, 0) == ctx.comm_count()
     np.testing.assert_array_equal(coll.all_reduce_host([1.5, -2.0], "max"), [1.5, -2.0])
     coll.barrier()
+    kinds = coll.stats_by_kind()
+    assert kinds["all_reduce_f32"][:2] == (1, 120) and kinds["all_reduce_f64"][:2] == (1, 72)
+    assert kinds["all_gather_f32"][:2] == (1, 120) and kinds["reduce_scatter_f32"][:2] == (1, 120)
     calls, nbytes, ms = coll.stats()
-    assert calls == 3 and nbytes == 120 + 72 + 120 and ms >= 0.0
+    assert calls == 4 and nbytes == 120 + 72 + 120 + 120 and ms >= 0.0
     coll.close()
     ctx.close()
 

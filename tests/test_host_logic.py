@@ -260,6 +260,121 @@ def test_sharded_mu_world2_gloo(tmp_path):
         assert "rank %d ok" % r in o
 
 
+RSAG_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from pycmf_amd.sharded import ShardedMU, shard_bounds
+from oracle import cmf_oracle as O
+
+class OracleBlocked:
+    # test double for the row-blocked methods of HipShardBackend: float64 NumPy arithmetic on one shard; V is held as
+    # world * block_rows rows (zero beyond d), like the grown allocation behind the device factor
+    def __init__(self, X, Y, U, V, Z, world):
+        self.X, self.Y, self.U, self.Z = X, Y, U, Z
+        self.d, self.k = V.shape
+        self.B = -(-self.d // world)
+        self.Vfull = torch.zeros(world * self.B, self.k, dtype=torch.float64)
+        self.Vfull[: self.d] = torch.from_numpy(V)
+        self.V = self.Vfull.numpy()[: self.d]
+    def blocked_layout(self, world):
+        return self.B, self.d, self.k
+    def small_buffers(self):
+        return torch.zeros(self.k, self.k, dtype=torch.float64), torch.zeros(self.k, self.k, dtype=torch.float64)
+    def partials_split(self, pbuf, gbuf):
+        pbuf[: self.d] = torch.from_numpy(self.X.T @ self.U + self.Y @ self.Z)
+        gbuf[:] = torch.from_numpy(self.U.T @ self.U + self.Z.T @ self.Z)
+    def apply_v_rows(self, p_rows, gbuf, row0, nrows, l1, l2):
+        if nrows == 0:
+            return
+        Vr = self.V[row0:row0 + nrows]
+        Vr *= O.mu_ratio(p_rows.numpy()[:nrows], Vr @ gbuf.numpy(), l1, l2, Vr)
+    def gram_v_rows(self, row0, nrows, g2buf):
+        Vr = self.V[row0:row0 + nrows]
+        g2buf[:] = torch.from_numpy(Vr.T @ Vr)
+    def v_full(self, rows):
+        assert rows == self.Vfull.shape[0]
+        return self.Vfull
+    def update_uz_gram(self, g2buf, l1, l2, mask):
+        G2 = g2buf.numpy()
+        if mask & 1:
+            self.U *= O.mu_ratio(self.X @ self.V, self.U @ G2, l1, l2, self.U)
+        if mask & 4:
+            self.Z *= O.mu_ratio(self.Y.T @ self.V, self.Z @ G2, l1, l2, self.Z)
+
+class GlooColl:
+    def __init__(self, rank, world):
+        self.rank, self.world, self.log = rank, world, []
+    def all_reduce(self, t):
+        self.log.append(("ar", t.numel()))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    def reduce_scatter(self, full):
+        # gloo has no reduce-scatter: the semantics of the in-place form (only the rank's own chunk is defined afterwards)
+        self.log.append(("rs", full.numel()))
+        tot = full.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        per = full.shape[0] // self.world
+        full[:] = float("nan")
+        full[self.rank * per:(self.rank + 1) * per] = tot[self.rank * per:(self.rank + 1) * per]
+    def all_gather(self, full, chunk=None):
+        self.log.append(("ag", full.numel()))
+        per = full.shape[0] // self.world
+        dist.all_gather_into_tensor(full, full[self.rank * per:(self.rank + 1) * per].clone())
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+rng = np.random.RandomState(0)
+m, d, p, k = 23, 11, 9, 4
+X, Y = np.abs(rng.randn(m, d)), np.abs(rng.randn(d, p))
+U, V, Z = np.abs(rng.randn(m, k)), np.abs(rng.randn(d, k)), np.abs(rng.randn(p, k))
+r0, r1 = shard_bounds(m, world, rank)
+c0, c1 = shard_bounds(p, world, rank)
+be = OracleBlocked(X[r0:r1], Y[:, c0:c1], U[r0:r1].copy(), V.copy(), Z[c0:c1].copy(), world)
+coll = GlooColl(rank, world)
+buf = torch.zeros(world * be.B, k, dtype=torch.float64)
+drv = ShardedMU(be, buf, world, coll.all_reduce, coll=coll, mode="rsag", rank=rank)
+for _ in range(3):
+    drv.step(0.1, 0.2, 7)
+n = world * be.B * k
+assert coll.log == [("ar", k * k), ("rs", n), ("ar", k * k), ("ag", n)] * 3, coll.log
+Ur, Vr, Zr = U.copy(), V.copy(), Z.copy()
+for _ in range(3):
+    O.mu_update_step(X, Y, Ur, Vr, Zr, 0.1, 0.2)
+np.testing.assert_allclose(be.V, Vr, rtol=1e-10)
+assert not np.any(be.Vfull.numpy()[d:])            # the rows beyond d stay zero through the all-gathers
+np.testing.assert_allclose(be.U, Ur[r0:r1], rtol=1e-10)
+np.testing.assert_allclose(be.Z, Zr[c0:c1], rtol=1e-10)
+# partial updates keep the protocol consistent: U / Z only (no V epilogue, V^T V still summed over the blocks)
+drv.step(0.1, 0.2, 5)
+O.mu_update_step(X, Y, Ur, Vr, Zr, 0.1, 0.2, update_V=False)
+np.testing.assert_allclose(be.U, Ur[r0:r1], rtol=1e-10)
+np.testing.assert_allclose(be.V, Vr, rtol=1e-10)
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+import pytest as _pytest
+
+
+@_pytest.mark.parametrize("world", [2, 3])
+def test_sharded_mu_rsag_gloo(tmp_path, world):
+    "Two / three ranks, gloo on CPU: the row-blocked protocol (k^2 all-reduce, reduce-scatter of the partial, V epilogue on the rank's block, k^2 all-reduce of V^T V, in-place all-gather of V, local U / Z) reproduces the unsharded reference step; d = 11 is not a multiple of the block, so the last block is ragged (world 2) or short (world 3)."
+    script = tmp_path / "worker.py"
+    script.write_text(RSAG_WORKER % {"root": ROOT})
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
+        assert "rank %d ok" % r in o
+
+
 ROWS_WORKER = r'''
 import os, sys
 sys.path.insert(0, %(root)r)
