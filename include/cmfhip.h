@@ -61,6 +61,9 @@ enum {
 };
 
 const char *cmf_last_error(void);
+/* sha256 of the sources the library was built from (csrc/*, this header): pycmf_amd/_lib.py refuses a library whose stamp differs
+ * from the sources next to it                                                                                                   */
+const char *cmf_source_hash(void);
 int cmf_device_count(int *count);
 
 /* ---- context ---------------------------------------------------------- */
@@ -291,6 +294,29 @@ int cmf_scratch_free(cmf_ctx *ctx, void *dev_ptr);
 int cmf_export_factor_rows(cmf_ctx *ctx, int which, float *dev_dst);
 int cmf_import_factor_rows(cmf_ctx *ctx, int which, const float *dev_src);
 
+
+/* ---- the outer loop: _IterativeCMFSolver.fit_iterative_update, pycmf/cmf_solvers.py:132-195 --------------------------------
+ * error at init (:170); for n_iter = 1 .. max_iter: one update_step (:172) -- cmf_mu_step, cmf_newton_step, or
+ * cmf_newton_step_device_sampled(seed + n_iter) when sg_ratio < 1 (host-drawn index lists cannot enter here: that configuration
+ * keeps its loop on the host) --; every check_every-th iteration (the reference: 10) when tol > 0 the error
+ * alpha_err ||X - f(U V^T)||_F + (1 - alpha_err) ||Y - f(V Z^T)||_F (:128-130) and the stopping test
+ * (previous - error) / error_at_init < tol (:183-186).  *n_iter = the iteration the loop stopped at (max_iter when it ran out,
+ * exactly Python's loop variable).  err_trace / time_trace (nullable, trace_cap entries each): the error at init and at every
+ * check, and the seconds since the call started at those points; *n_trace = how many there were.  One 16-byte read-back per
+ * check is all that crosses the boundary; the step body is replayed from a hipGraph where it is a fixed launch sequence.      */
+enum { CMF_SOLVER_MU = 0, CMF_SOLVER_NEWTON = 1 };
+typedef struct {
+    int solver;                 /* CMF_SOLVER_MU | CMF_SOLVER_NEWTON */
+    double l1, l2;
+    double alpha;               /* Newton: weight of the X side (cmf_solvers.py:510-522); MU: unused */
+    double alpha_err;           /* weight of the X side in the error metric (MU: the constructor default 0.5, :99) */
+    int x_link, y_link;         /* CMF_LINK_* (MU: both linear) */
+    int nn_mask, update_mask;
+    double hessian_pertubation, sg_ratio;
+    uint64_t seed;              /* device sampler: iteration n_iter draws under seed + n_iter */
+} cmf_run_params;
+int cmf_run(cmf_ctx *ctx, const cmf_run_params *params, int max_iter, double tol, int check_every, int *n_iter,
+            double *err_trace, double *time_trace, int trace_cap, int *n_trace);
 
 /* ---- collectives of the sharded solvers: RCCL over xGMI, one communicator per context -------------
  * The reference is single-process; what is replaced here is the sum over row blocks hidden in its products

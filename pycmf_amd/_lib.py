@@ -110,6 +110,17 @@ PROTOTYPES = {
     "cmf_copy_from_host": [_vp, _vp, _vp, _i64],
 }
 
+
+
+class RunParams(C.Structure):
+    """cmf_run_params of include/cmfhip.h"""
+    _fields_ = [("solver", C.c_int), ("l1", C.c_double), ("l2", C.c_double), ("alpha", C.c_double), ("alpha_err", C.c_double),
+                ("x_link", C.c_int), ("y_link", C.c_int), ("nn_mask", C.c_int), ("update_mask", C.c_int),
+                ("hessian_pertubation", C.c_double), ("sg_ratio", C.c_double), ("seed", C.c_uint64)]
+
+
+PROTOTYPES["cmf_run"] = [_vp, C.POINTER(RunParams), _i32, _dbl, _i32, C.POINTER(C.c_int), _pd, _pd, _i32, C.POINTER(C.c_int)]
+
 _lib = None
 
 
@@ -150,6 +161,20 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.cmf_last_error.restype = C.c_char_p
     lib.cmf_last_error.argtypes = []
+    # the library must have been compiled from the sources next to it (it is git-ignored and travels with the working tree)
+    if os.environ.get("PYCMF_AMD_SKIP_HASH_CHECK") != "1" and os.path.isdir(os.path.join(_HERE, "csrc")):
+        from . import build as _build
+        try:
+            lib.cmf_source_hash.restype = C.c_char_p
+            lib.cmf_source_hash.argtypes = []
+            have = lib.cmf_source_hash().decode()
+        except AttributeError:
+            have = "unstamped"
+        want = _build.source_hash()
+        if have != want:
+            raise RuntimeError("pycmf_amd: %s was built from other sources than the ones in pycmf_amd/csrc and include/ "
+                               "(library %s..., sources %s...): rebuild it with `python -m pycmf_amd.build`"
+                               % (LIB_PATH, have[:12], want[:12]))
     for name, args in PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.restype = C.c_int
@@ -402,6 +427,20 @@ class Context:
         p = _pf()
         check(self._lib.cmf_factor_dev_ptr(self._h, which, C.byref(p)))
         return C.cast(p, _vp).value
+
+    def run(self, solver, max_iter, tol, l1=0.0, l2=0.0, alpha=0.5, alpha_err=0.5, x_link="linear", y_link="linear", nn_mask=0,
+            update_mask=7, pert=0.2, ratio=1.0, seed=0, check_every=10):
+        """The whole outer loop in C (cmf_run): returns (n_iter, errors, seconds) -- errors[0] is the error at init, one more
+        entry per convergence check, seconds the time since the call at those points."""
+        prm = RunParams(0 if solver == "mu" else 1, l1, l2, alpha, alpha_err, LINKS[x_link], LINKS[y_link], nn_mask, update_mask,
+                        pert, ratio, int(seed))
+        cap = max_iter // max(check_every, 1) + 2
+        errs, secs = (C.c_double * cap)(), (C.c_double * cap)()
+        n_iter, n_trace = C.c_int(0), C.c_int(0)
+        check(self._lib.cmf_run(self._h, C.byref(prm), int(max_iter), float(tol), int(check_every), C.byref(n_iter), errs, secs, cap,
+                                C.byref(n_trace)))
+        n = min(n_trace.value, cap)
+        return n_iter.value, [errs[i] for i in range(n)], [secs[i] for i in range(n)]
 
     # ---- Newton
     def newton_step(self, alpha, l1, l2, x_link, y_link, nn_mask, upd_mask, pert, ratio,

@@ -26,15 +26,36 @@ def _hipcc():
     return exe
 
 
-def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
+def source_hash():
+    """sha256 over the bytes of every source the library is compiled from (csrc/*, include/cmfhip.h), in a fixed order: compiled
+    into the library (``cmf_source_hash()``) and compared by ``_lib.load()`` with the sources next to it -- a library built from
+    other sources than the ones in the tree is refused instead of silently used."""
+    import hashlib
+    h = hashlib.sha256()
     for d in DEPS:
         p = d if os.path.isabs(d) else os.path.join(CSRC, d)
-        if os.path.exists(p) and os.path.getmtime(p) > t:
-            return True
-    return False
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def library_hash(path=LIB):
+    """The source hash a built library carries (None: no library, or one from before the stamp)."""
+    import ctypes
+    if not os.path.exists(path):
+        return None
+    try:
+        lib = ctypes.CDLL(path, mode=getattr(os, "RTLD_LOCAL", 0))
+        fn = lib.cmf_source_hash
+    except (OSError, AttributeError):
+        return None
+    fn.restype = ctypes.c_char_p
+    return fn().decode()
+
+
+def needs_build():
+    return library_hash() != source_hash()
 
 
 def build(force=False, verbose=False, diag=False):
@@ -43,6 +64,7 @@ def build(force=False, verbose=False, diag=False):
     if not force and not diag and not needs_build():
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
+           "-DCMF_SOURCE_HASH=\"%s\"" % source_hash(),
            "-I", os.path.join(ROOT, "include"), "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if diag:
         cmd.append("-DCMF_DIAG_BUILD")

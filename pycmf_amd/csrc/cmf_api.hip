@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -102,8 +103,8 @@ struct cmf_ctx {
     bool have_problem = false;
     unsigned long long *dbg_stamps = nullptr; // set by cmf_debug_clock for its own launches only
     bool diag_ok = false;  // CMF_DIAG=1 in the environment: the timing-only knobs (wrong results) may be set
-    int opt_graph = 0;     // replay MU / linear-Newton steps from a captured hipGraph (opt-in: measured neutral,
-                           // the ~4 us per dependent kernel boundary is device-side, not host launch cost)
+    int opt_graph = -1;    // replay MU / linear-Newton steps from a captured hipGraph: 1 always | 0 never | -1 (default) inside cmf_run
+                           // only (single steps measured neutral: the ~4 us per dependent kernel boundary is device-side)
     StepGraph mu_graph, newton_graph;
     int opt_pipe_small = 4; // staging schedule of the factor-side products (0 or 4; 4 measured +5..15 %, tools/ab_small.py)
     int opt_pipe = 4;      // GEMM staging schedule (see gemm_kernel PIPE); 4 measured best (tools/ab_gemm.py)
@@ -629,6 +630,12 @@ static int mu_apply(cmf_ctx *c, float *F, const float *num, const float *den, in
 // ------------------------------------------------------------------ C ABI: basics
 extern "C" const char *cmf_last_error(void) { return g_err.c_str(); }
 
+// sha256 of the sources this library was compiled from (pycmf_amd/build.py passes it; _lib.load() compares it with the tree)
+#ifndef CMF_SOURCE_HASH
+#define CMF_SOURCE_HASH "unstamped"
+#endif
+extern "C" const char *cmf_source_hash(void) { return CMF_SOURCE_HASH; }
+
 extern "C" int cmf_device_count(int *count) {
     if (!count) return fail(CMF_EINVAL, "null argument");
     int n = 0;
@@ -736,7 +743,7 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return fail(CMF_EINVAL, "null argument");
     invalidate_graphs(c);
     if (!strcmp(name, "graph")) {
-        c->opt_graph = value != 0;
+        c->opt_graph = value < 0 ? -1 : (value != 0);
         return CMF_OK;
     }
     if (!strcmp(name, "gemm_pipe")) {
@@ -1399,7 +1406,7 @@ extern "C" int cmf_mu_uz_update_gram(cmf_ctx *c, const float *G2, double l1, dou
 // are then paced by one graph launch instead.
 template <typename F>
 static int run_graphed(cmf_ctx *c, StepGraph &g, const double *key, int nkey, F &&eager) {
-    if (!c->opt_graph || c->timing) return eager();
+    if (c->opt_graph <= 0 || c->timing) return eager();
     bool same = true;
     for (int i = 0; i < nkey; ++i) same = same && (g.key[i] == key[i]);
     if (!same) {

@@ -1703,7 +1703,7 @@ extern "C" int cmf_newton_step(cmf_ctx *c, double alpha, double l1, double l2, i
                                const int32_t *vy_idx) {
     NEED_PROBLEM(c);
     if (x_link == CMF_LINK_LINEAR && y_link == CMF_LINK_LINEAR && ratio >= 1.0 && have_data(c, 0) && have_data(c, 1) &&
-        c->opt_graph && use_shared64(c) && c->k <= 64) {
+        c->opt_graph > 0 && use_shared64(c) && c->k <= 64) {
         // all three sweeps take the shared-Hessian form and the float64 inverse of k <= 64 decides everything on the device:
         // a fixed launch sequence with no host round trip -> graph replay.  (Larger k read two flags back per inverse:
         // those steps are not captured.)
@@ -1884,4 +1884,65 @@ extern "C" int cmf_data_matmul_f64(cmf_ctx *c, int which, int trans, const doubl
     (void)hipFree(dB);
     (void)hipFree(dO);
     return rc;
+}
+
+
+// ---- the whole outer loop: _IterativeCMFSolver.fit_iterative_update, pycmf/cmf_solvers.py:132-195 ---------------------------
+// error at init (:170), then for n_iter = 1 .. max_iter: update_step (:172); every `check_every`-th iteration when tol > 0 the
+// error (:175-176) and the stopping test (previous - error) / error_at_init < tol (:183-186).  The error is
+// alpha_err ||X - f(U V^T)|| + (1 - alpha_err) ||Y - f(V Z^T)|| (:128-130; a side that is not set counts as 0) -- one 16-byte
+// read-back per check, nothing else crosses the boundary while the loop runs.  The step body of MU and of the graph-capturable
+// Newton configurations is replayed from a hipGraph (option "graph": -1 = inside cmf_run only, the default).
+// err_trace (nullable, trace_cap entries): [0] = error at init, then one entry per check; time_trace (nullable): seconds since
+// the call started at the same points (what the reference's verbose lines print, :178-181).
+extern "C" int cmf_run(cmf_ctx *c, const cmf_run_params *p, int max_iter, double tol, int check_every, int *n_iter_out,
+                       double *err_trace, double *time_trace, int trace_cap, int *n_trace) {
+    NEED_PROBLEM(c);
+    if (!p || max_iter < 0 || check_every < 1) return fail(CMF_EINVAL, "cmf_run: bad argument");
+    if (p->solver != CMF_SOLVER_MU && p->solver != CMF_SOLVER_NEWTON) return fail(CMF_EINVAL, "cmf_run: solver must be CMF_SOLVER_MU or CMF_SOLVER_NEWTON");
+    DeviceGuard dg(c->device);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    const bool hx = have_data(c, 0), hy = have_data(c, 1);
+    int nt = 0;
+    auto error = [&](double *e) -> int {
+        double ex2 = 0.0, ey2 = 0.0;
+        CHK(cmf_residual_sq(c, p->x_link, p->y_link, hx ? &ex2 : nullptr, hy ? &ey2 : nullptr));
+        *e = p->alpha_err * (hx ? std::sqrt(ex2) : 0.0) + (1.0 - p->alpha_err) * (hy ? std::sqrt(ey2) : 0.0);
+        if (nt < trace_cap) {
+            if (err_trace) err_trace[nt] = *e;
+            if (time_trace) time_trace[nt] = elapsed();
+        }
+        ++nt;
+        return CMF_OK;
+    };
+    struct GraphScope { // "graph" = -1: replay inside the loop, eager for single steps
+        cmf_ctx *c; int saved;
+        ~GraphScope() { c->opt_graph = saved; }
+    } gs{c, c->opt_graph};
+    if (c->opt_graph < 0) c->opt_graph = 1;
+    double prev = 0.0, at_init = 0.0;
+    CHK(error(&at_init));
+    prev = at_init;
+    int it = 0;
+    for (it = 1; it <= max_iter; ++it) {
+        if (p->solver == CMF_SOLVER_MU) CHK(cmf_mu_step(c, p->l1, p->l2, p->update_mask));
+        else if (p->sg_ratio < 1.0)
+            CHK(cmf_newton_step_device_sampled(c, p->alpha, p->l1, p->l2, p->x_link, p->y_link, p->nn_mask, p->update_mask, p->hessian_pertubation,
+                                               p->sg_ratio, p->seed + (uint64_t)it));
+        else
+            CHK(cmf_newton_step(c, p->alpha, p->l1, p->l2, p->x_link, p->y_link, p->nn_mask, p->update_mask, p->hessian_pertubation, 1.0,
+                                nullptr, nullptr, nullptr, nullptr));
+        if (tol > 0.0 && it % check_every == 0) {
+            double e = 0.0;
+            CHK(error(&e));
+            if ((prev - e) / at_init < tol) break;
+            prev = e;
+        }
+    }
+    if (it > max_iter) it = max_iter; // the loop ran out: Python's `for n_iter in range(1, max_iter + 1)` leaves max_iter
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n_iter_out) *n_iter_out = it;
+    if (n_trace) *n_trace = nt;
+    return CMF_OK;
 }

@@ -180,10 +180,16 @@ class CMF(BaseEstimator, TransformerMixin):
     attributes ``reconstruction_err_``, ``n_components_``, ``x_weights``,
     ``components``, ``y_weights``, ``n_iter_`` (:697-704).
 
-    Extra keywords: ``device`` (GPU ordinal, default 0), ``sg_sampler`` ('numpy' = the
-    reference's host RNG stream, default; 'device' = counter-based sampler on the GPU) and
-    ``n_gpus`` (default 1; N > 1 = ``fit`` runs data-parallel on N GPUs of the node, one worker process
-    per GPU, V reassembled by one RCCL all-reduce per iteration; ``transform`` always uses one GPU).
+    Extra keywords: ``device`` (GPU ordinal, default 0), ``sg_sampler`` and ``n_gpus`` (default 1; N > 1 = ``fit`` runs
+    data-parallel on N GPUs of the node, one worker process per GPU, V reassembled by one sum over the ranks per iteration
+    -- RCCL reduce-scatter + all-gather around the row-blocked V update; ``transform`` always uses one GPU).
+
+    ``sg_sampler`` (only read when ``sg_sample_ratio < 1``): ``'numpy'`` (default) draws every row's sample from NumPy's global
+    stream on the host, in the reference's order -- results reproduce the reference's for the same ``random_state``, but the
+    host RNG costs one ``np.random.permutation`` per row per sweep: fine at the reference's own sizes, seconds per iteration
+    beyond ~1e7 drawn indices (a ``RuntimeWarning`` says so; BASELINE config C3 would spend ~16 s per iteration there).
+    ``'device'`` draws the same distribution (exactly ``int(n * ratio)`` distinct indices per row, uniform) on the GPU from a
+    counter-based generator: the benchmarked path (C3: 0.24 s per iteration), statistically but not numerically NumPy's stream.
     """
 
     def __init__(self, n_components=None, x_init=None, y_init=None, solver='mu', alpha='auto',

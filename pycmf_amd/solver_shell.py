@@ -179,12 +179,32 @@ class _HipIterativeSolver:
         ex, ey = self._device_error()
         return ex + ey
 
+    def _run_params(self):
+        """Keyword arguments of Context.run for this solver, or None when the loop has to stay on the host (index lists drawn from
+        NumPy's stream)."""
+        raise NotImplementedError("Implement in concrete subclass to use")
+
     def fit_iterative_update(self, X, Y, U, V, Z):
-        """Alternating minimisation loop (cmf_solvers.py:132-195)."""
+        """Alternating minimisation loop (cmf_solvers.py:132-195).  The loop itself runs inside libcmfhip (``cmf_run``: error at
+        init, one step per iteration, the check every 10th iteration, early stop) unless the per-row samples come from NumPy's
+        global stream, which only the host can draw from; the verbose lines of the reference are printed from the trace the
+        C loop returns (same text, same elapsed times, after the loop instead of during it)."""
         start_time = time.time()
         self._bind(X, Y, U, V, Z)
         self._push_factors(U, V, Z)
         self._fit_begin()
+        params = self._run_params()
+        if params is not None and os.environ.get("PYCMF_AMD_HOST_LOOP") != "1":
+            n_iter, errs, secs = self._ctx.run(max_iter=self.max_iter, tol=self.tol, **params)
+            self._after_run(n_iter)
+            if self.verbose:
+                for i, (e, t) in enumerate(zip(errs[1:], secs[1:]), start=1):
+                    print("Epoch %02d reached after %.3f seconds, error: %f" % (10 * i, t, e))
+                if self.tol == 0 or n_iter % 10 != 0:
+                    print("Epoch %02d reached after %.3f seconds." % (n_iter, time.time() - start_time))
+            self._fit_end()
+            self._pull_factors(U, V, Z)
+            return U, V, Z, n_iter
         ex, ey = self._device_error()
         previous_error = error_at_init = self.alpha * ex + (1 - self.alpha) * ey
 
@@ -209,6 +229,9 @@ class _HipIterativeSolver:
         self._pull_factors(U, V, Z)
         return U, V, Z, n_iter
 
+    def _after_run(self, n_iter):
+        pass
+
     def _fit_begin(self):
         pass
 
@@ -221,6 +244,9 @@ class HipMUSolver(_HipIterativeSolver):
 
     def _device_step(self, l1_reg, l2_reg, alpha):
         self._ctx.mu_step(l1_reg, l2_reg, self._update_mask())
+
+    def _run_params(self):
+        return dict(solver="mu", l1=self.l1_reg, l2=self.l2_reg, alpha_err=self.alpha, update_mask=self._update_mask())
 
 
 class HipNewtonSolver(_HipIterativeSolver):
@@ -239,8 +265,23 @@ class HipNewtonSolver(_HipIterativeSolver):
     #: (tools/fuzz_campaign.py: every case within 3e-3 of the float64 reference below it)
     CLAMP_RATIO_WARN = 1.0e4
 
+    #: index entries per iteration above which drawing the per-row samples from NumPy's stream on the host dominates the iteration
+    #: (one np.random.permutation per row plus the upload of the lists: ~16 s per iteration at BASELINE config C3, against 0.24 s
+    #: for the whole iteration with sg_sampler='device')
+    HOST_SAMPLER_WARN_ENTRIES = 1.0e7
+
     def _fit_begin(self):
         self._ctx.newton_clamp_stats(reset=True)
+        if self.sg_sample_ratio < 1. and self.sg_sampler == "numpy":
+            m, d, p, _ = self._ctx.shape
+            r = self.sg_sample_ratio
+            entries = ((m + p) * int(d * r) if (self.update_U or self.update_Z) else 0) + (d * (int(m * r) + int(p * r)) if self.update_V else 0)
+            if entries > self.HOST_SAMPLER_WARN_ENTRIES:
+                import warnings
+                warnings.warn("pycmf_amd: sg_sampler='numpy' draws every row's sample from NumPy's global stream on the host, like the "
+                              "reference (pycmf/cmf_solvers.py:328-344): %.1e list entries per iteration here -- the host RNG and the "
+                              "upload of the lists will dominate the iteration.  sg_sampler='device' draws the same distribution on "
+                              "the GPU (the benchmarked path; not NumPy's stream)." % entries, RuntimeWarning, stacklevel=3)
 
     def _fit_end(self):
         self.clamped_rows_, self.clamp_ratio_, self.refined_rows_ = self._ctx.newton_clamp_stats()
@@ -253,6 +294,17 @@ class HipNewtonSolver(_HipIterativeSolver):
                           "at least as large as the perturbation, or fewer components than samples per row, keeps the Hessians well "
                           "conditioned." % (self.clamped_rows_, self.hessian_pertubation, self.clamp_ratio_),
                           RuntimeWarning, stacklevel=3)
+
+    def _run_params(self):
+        if self.sg_sample_ratio < 1. and self.sg_sampler != "device":
+            return None                 # NumPy's stream: the lists are drawn on the host, iteration by iteration
+        return dict(solver="newton", l1=self.l1_reg, l2=self.l2_reg, alpha=self.alpha, alpha_err=self.alpha, x_link=self.x_link,
+                    y_link=self.y_link, nn_mask=self._nn_mask(), update_mask=self._update_mask(), pert=self.hessian_pertubation,
+                    ratio=min(float(self.sg_sample_ratio), 1.0), seed=self._sample_seed)
+
+    def _after_run(self, n_iter):
+        if self.sg_sample_ratio < 1.:
+            self._sample_seed += n_iter     # the C loop drew iteration i under seed + i, like _device_step would have
 
     def _draw(self, rows, n, ratio):
         size = int(n * ratio)

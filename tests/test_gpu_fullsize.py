@@ -290,22 +290,29 @@ def _feed(monkeypatch, O, lists):
     monkeypatch.setattr(O, "draw_sample", lambda n, ratio: next(it))
 
 
-def test_c3_full_size_newton_sampled_rows_vs_fp64(lib, monkeypatch):
+@pytest.mark.parametrize("x_link", ["linear", "logit"])
+def test_c3_full_size_newton_sampled_rows_vs_fp64(lib, monkeypatch, x_link):
     """BASELINE configs[2] (32768 x 16384 / 16384 x 8192, k = 256, y logit, sg_sample_ratio 0.5, device sampler): rows of
     U, Z and V after their sweeps against the oracle's per-row arithmetic (pycmf/cmf_solvers.py:394-508) on the index lists the
-    device drew for exactly those rows (cmf_sample_lists) -- which also ties the drawn lists to what the row kernels consumed."""
+    device drew for exactly those rows (cmf_sample_lists) -- which also ties the drawn lists to what the row kernels consumed.
+    x_link = 'logit': "sigmoid link" on BOTH sides (the U sweep's logit Hessian carries no l2, :426-428; no row shares partial
+    sums with its neighbours: every weight is the row's own)."""
     from oracle import cmf_oracle as O
+    from threadpoolctl import threadpool_limits
     m, d, p, k = 32768, 16384, 8192, 256
     alpha, l1, l2, pert, ratio, seed = 0.5, 0.0, 0.1, 0.2, 0.5, 1000
     rng = np.random.RandomState(1)
     ctx = _synthetic(lib, m, d, p, k)
     ctx.fill_data_synthetic(1, 43, 0, 0, 1)            # targets of the logit side: sigmoid(N(0,1)), as bench.py's c3
+    if x_link == "logit":
+        ctx.fill_data_synthetic(0, 42, 0, 0, 1)
+    limit = threadpool_limits(limits=1)                # the oracle's 256 x 256 eigh is 15 x slower on a multi-threaded BLAS
     U0, V0, Z0 = (ctx.get_factor(w) for w in range(3))
 
     def tol(ref):
         return dict(rtol=0, atol=2e-3 * np.abs(ref).max())
 
-    ctx.newton_step_device_sampled(alpha, l1, l2, "linear", "logit", 0, lib.CMF_UPD_U, pert, ratio, seed)
+    ctx.newton_step_device_sampled(alpha, l1, l2, x_link, "logit", 0, lib.CMF_UPD_U, pert, ratio, seed)
     U1 = ctx.get_factor(0)
     rows = _spread(m, 3, rng)
     lists = [ctx.sample_lists(0, seed, ratio, i, 1)[0] for i in rows]
@@ -313,11 +320,11 @@ def test_c3_full_size_newton_sampled_rows_vs_fp64(lib, monkeypatch):
     Xs = np.vstack([ctx.get_data_block(0, i, 1, 0, d) for i in rows]).astype(np.float64)
     Us = U0[rows].copy()
     _feed(monkeypatch, O, lists)
-    O.newton_sweep_U(Us, V0, Xs, alpha, l1, l2, "linear", False, ratio, pert)
+    O.newton_sweep_U(Us, V0, Xs, alpha, l1, l2, x_link, False, ratio, pert)
     np.testing.assert_allclose(U1[rows], Us, **tol(Us))
     assert np.abs(U1[rows] - U0[rows]).max() > 1e-3 * np.abs(U0).max()
 
-    ctx.newton_step_device_sampled(alpha, l1, l2, "linear", "logit", 0, lib.CMF_UPD_Z, pert, ratio, seed)
+    ctx.newton_step_device_sampled(alpha, l1, l2, x_link, "logit", 0, lib.CMF_UPD_Z, pert, ratio, seed)
     Z1 = ctx.get_factor(2)
     cols = _spread(p, 3, rng)
     lists = [ctx.sample_lists(1, seed, ratio, c, 1)[0] for c in cols]
@@ -327,7 +334,7 @@ def test_c3_full_size_newton_sampled_rows_vs_fp64(lib, monkeypatch):
     O.newton_sweep_Z(Zs, V0, Ys, alpha, l1, l2, "logit", False, ratio, pert)
     np.testing.assert_allclose(Z1[cols], Zs, **tol(Zs))
 
-    ctx.newton_step_device_sampled(alpha, l1, l2, "linear", "logit", 0, lib.CMF_UPD_V, pert, ratio, seed)
+    ctx.newton_step_device_sampled(alpha, l1, l2, x_link, "logit", 0, lib.CMF_UPD_V, pert, ratio, seed)
     V1 = ctx.get_factor(1)
     rows = _spread(d, 3, rng)
     lists = []
@@ -337,8 +344,9 @@ def test_c3_full_size_newton_sampled_rows_vs_fp64(lib, monkeypatch):
     Ys = np.vstack([ctx.get_data_block(1, q, 1, 0, p) for q in rows]).astype(np.float64)
     Vs = V0[rows].copy()
     _feed(monkeypatch, O, lists)
-    O.newton_sweep_V(Vs, U1, Z1, Xs, Ys, alpha, l1, l2, "linear", "logit", False, ratio, pert)
+    O.newton_sweep_V(Vs, U1, Z1, Xs, Ys, alpha, l1, l2, x_link, "logit", False, ratio, pert)
     np.testing.assert_allclose(V1[rows], Vs, **tol(Vs))
+    limit.restore_original_limits()
     ctx.close()
 
 

@@ -101,7 +101,21 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libcmfhip.so does not export %s" % n
     # and the ctypes table covers the header
-    assert set(_lib.PROTOTYPES) | {"cmf_last_error"} == set(names)
+    assert set(_lib.PROTOTYPES) | {"cmf_last_error", "cmf_source_hash"} == set(names)   # the two that return strings
+
+
+def test_stale_library_is_refused(monkeypatch):
+    """The library carries the sha256 of the sources it was compiled from; _lib.load() compares it with the sources in the tree
+    and refuses a library built from anything else (the .so is git-ignored and travels with the working tree)."""
+    from pycmf_amd import _lib, build
+    assert build.library_hash() == build.source_hash(), "the in-tree library must be built from the in-tree sources"
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(build, "source_hash", lambda: "0" * 64)
+    with pytest.raises(RuntimeError, match="built from other sources"):
+        _lib.load()
+    monkeypatch.undo()
+    _lib._lib = None
+    _lib.load()
 
 
 def test_no_device_is_a_loud_error():
