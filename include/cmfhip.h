@@ -61,7 +61,7 @@ enum {
 };
 
 const char *cmf_last_error(void);
-/* sha256 of the sources the library was built from (csrc/*, this header): pycmf_amd/_lib.py refuses a library whose stamp differs
+/* sha256 of the sources the library was built from (everything under csrc/ and this header): pycmf_amd/_lib.py refuses a library whose stamp differs
  * from the sources next to it                                                                                                   */
 const char *cmf_source_hash(void);
 int cmf_device_count(int *count);

@@ -4,6 +4,7 @@
 #include "../../include/cmfhip.h"
 #include "cmf_kernels.hip.h"
 #include "cmf_eigen.hip.h"
+#include "cmf_chol_mfma.hip.h"
 #include "cmf_sparse.hip.h"
 #include "cmf_rowhess.hip.h"
 #include "cmf_bf16x6.hip.h"
@@ -118,6 +119,7 @@ struct cmf_ctx {
     int opt_pipe_nt = 4;   // staging schedule of the NT (residual / error) GEMMs: 0 | 4
     int opt_choldiag = 0;  // timing diagnostics of chol_solve_kernel (wrong results)
     int opt_chol = 1;      // Cholesky fast path of the safe inverse (0: always Jacobi)
+    int opt_chol_mfma = 1; // k_pad = 256 per-row solves: blocked Cholesky on the matrix pipe (0: the rank-1 register kernel chol_solve_kernel<16>)
     int opt_zlogit_l2 = 1;  // 0: Cython-twin numerics (Z's logit Hessian without l2 I, pyx:287-290)
     int opt_rowdiag = 0;    // diagnostic builds of row_hess_kernel<256> (1: no staging, 2: stage only, 3: gather only)
     int opt_rowsym = 3;     // row_hess_kernel<256>: 0 full blocks | 1 upper block triangle, raw + weighted images | 3 ... one sqrt-weighted image
@@ -759,6 +761,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_gram32_shares = (int)std::max<int64_t>(1, std::min<int64_t>(value, 1024));
     } else if (!strcmp(name, "small_gram")) {
         c->opt_gram32 = value != 0;
+    } else if (!strcmp(name, "chol_mfma")) {
+        c->opt_chol_mfma = value != 0;
     } else if (!strcmp(name, "narrow_update")) {
         c->opt_narrow_update = value != 0;
     } else if (!strcmp(name, "gemm_tile512")) {

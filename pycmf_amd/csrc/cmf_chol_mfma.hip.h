@@ -26,6 +26,13 @@
 
 namespace cmfk {
 
+#ifdef CMF_DIAG_BUILD // cycle stamps of one workgroup's phases (tools/chol_mfma_test.hip); never in the product build
+__device__ unsigned long long cm_prof[128];
+#define CM_STAMP(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) cm_prof[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CM_STAMP(i) do { } while (0)
+#endif
+
 typedef float cm_f32x16 __attribute__((ext_vector_type(16)));
 
 struct CholMfma {
@@ -43,35 +50,53 @@ __device__ __forceinline__ float cm_readlane(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
-// one column step of the chain: diagonal block D (symmetric, both triangles) and the companion E
+// TWO column steps of the chain (columns j, j + 1, j even) as ONE rank-2 MFMA per block: rows j and j + 1 of the diagonal block D
+// (symmetric, both triangles) sit in registers rj, rj + 1 of the same lane half hj; column j is scaled, applied to row j + 1 by
+// one FMA, column j + 1 is scaled, and a v_permlane32_swap puts the two columns side by side -- column j in lanes 0-31 (k-slot 0),
+// column j + 1 in lanes 32-63 (k-slot 1) -- which is the operand layout of v_mfma_f32_32x32x2_f32.  The companion E (starts as
+// the identity, ends as L_JJ^-1) takes the same two row operations.  No comparison, no branch: the smallest pivot is tracked
+// and judged once per panel (a pivot <= floor, or a NaN after it, only ever produces garbage that the caller discards; the
+// padding beyond the valid order carries max |H_ii| on its diagonal, so it can neither be the smallest pivot nor fall under the floor).
 template <int J_>
-__device__ __forceinline__ void cm_chain_step(cm_f32x16 &D, cm_f32x16 &E, int h, int n31, float floor_, float &pmin, bool &ok) {
+__device__ __forceinline__ void cm_chain_pair(cm_f32x16 &D, cm_f32x16 &E, int h, int n31, float &pmin) {
+    static_assert((J_ & 1) == 0, "pairs start at even columns");
     constexpr int rj = (J_ & 3) + 4 * (J_ >> 3), hj = (J_ >> 2) & 1;
-    const float piv = cm_readlane(D[rj], 32 * hj + J_);
-    const bool good = piv > floor_;
-    ok = ok && good;
-    pmin = fminf(pmin, piv);
-    const float inv = good ? __builtin_amdgcn_rsqf(piv) : 0.f;
+    const float piv0 = cm_readlane(D[rj], 32 * hj + J_);
+    const float inv0 = __builtin_amdgcn_rsqf(piv0);
+    const float l0 = D[rj] * inv0;                               // L[n][j] in lane n of half hj (n = j: the diagonal entry)
+    const float c = cm_readlane(l0, 32 * hj + J_ + 1);           // L[j + 1][j]
+    const float a1 = D[rj + 1] - c * l0;                         // row j + 1 after column j
+    const float piv1 = cm_readlane(a1, 32 * hj + J_ + 1);
+    const float inv1 = __builtin_amdgcn_rsqf(piv1);
+    const float l1 = a1 * inv1;
+    pmin = fminf(pmin, fminf(piv0, piv1));
+    const float f0 = E[rj] * inv0;                               // final rows j, j + 1 of E
+    const float f1 = (E[rj + 1] - c * f0) * inv1;
     const bool mine = (h == hj);
-    const float l = (mine && n31 > J_) ? D[rj] * inv : 0.f;     // L[n][j], n > j, in k-slot hj; zero in the other slot
-    const float e = mine ? E[rj] * inv : E[rj];                  // row j of E is final after the scaling
-    E[rj] = e;
-    const float eb = mine ? e : 0.f;
-    const float nl = -l;
-    D = __builtin_amdgcn_mfma_f32_32x32x2f32(nl, l, D, 0, 0, 0);
-    E = __builtin_amdgcn_mfma_f32_32x32x2f32(nl, eb, E, 0, 0, 0);
+    E[rj] = mine ? f0 : E[rj];
+    E[rj + 1] = mine ? f1 : E[rj + 1];
+    const bool below = n31 > J_ + 1;
+    const unsigned x = __float_as_uint(below ? l0 : 0.f), y = __float_as_uint(below ? l1 : 0.f);
+    const auto sl = __builtin_amdgcn_permlane32_swap(x, y, false, false);   // [0] = {x.lo, y.lo}, [1] = {x.hi, y.hi}
+    const auto se = __builtin_amdgcn_permlane32_swap(__float_as_uint(f0), __float_as_uint(f1), false, false);
+    const float ol = __uint_as_float(hj == 0 ? sl[0] : sl[1]);
+    const float oe = __uint_as_float(hj == 0 ? se[0] : se[1]);
+    const float nl = -ol;
+    D = __builtin_amdgcn_mfma_f32_32x32x2f32(nl, ol, D, 0, 0, 0);
+    E = __builtin_amdgcn_mfma_f32_32x32x2f32(nl, oe, E, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int J0, int J1>
 struct CmChain {
-    static __device__ __forceinline__ void run(cm_f32x16 &D, cm_f32x16 &E, int h, int n31, float floor_, float &pmin, bool &ok) {
-        cm_chain_step<J0>(D, E, h, n31, floor_, pmin, ok);
-        CmChain<J0 + 1, J1>::run(D, E, h, n31, floor_, pmin, ok);
+    static __device__ __forceinline__ void run(cm_f32x16 &D, cm_f32x16 &E, int h, int n31, float &pmin) {
+        cm_chain_pair<J0>(D, E, h, n31, pmin);
+        CmChain<J0 + 2, J1>::run(D, E, h, n31, pmin);
     }
 };
 template <int J1>
 struct CmChain<J1, J1> {
-    static __device__ __forceinline__ void run(cm_f32x16 &, cm_f32x16 &, int, int, float, float &, bool &) {}
+    static __device__ __forceinline__ void run(cm_f32x16 &, cm_f32x16 &, int, int, float &) {}
 };
 
 // sums of each of the 16 values over the 32 lanes of a half: lane (bits b4 b3 b2 b1 b0 of l & 31) ends with the total of
@@ -100,29 +125,51 @@ __device__ __forceinline__ float cm_transpose_reduce(const float (&v)[16], int n
     return s;
 }
 
+// The chain of panel J: the owner wave of block (J, J) turns it into L_JJ (discarded) and publishes L_JJ^-1 to LDS.
+template <int J>
+__device__ __forceinline__ void cm_chain_panel(cm_f32x16 (&acc)[10], float *linv, int *iflag, int h, int n31, int lane, float floor_, float &pmin) {
+    using C = CholMfma;
+    // (lane coordinates through an opaque asm: the lane masks of a chain are the same in all eight panels and would otherwise be
+    // computed once and pinned in SGPRs for the whole kernel)
+    int ho = h, no = n31;
+    asm volatile("" : "+v"(ho), "+v"(no));
+    cm_f32x16 E;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) E[r] = (cm_row(r, ho) == no) ? 1.f : 0.f;
+    CmChain<0, 32>::run(acc[cm_slot(J >> 1, J >> 1)], E, ho, no, pmin);
+    float *dst = linv + J * (32 * C::LP) + no;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[cm_row(r, ho) * C::LP] = E[r];
+    if (!(pmin > floor_) && lane == 0) iflag[0] = 1;
+}
+
+// acc(p, q) -= L'_KJ (x) L'_IJ for one trailing block; af = the negated raw image of L'_KJ
+template <int P, int Q>
+__device__ __forceinline__ void cm_trail_block(cm_f32x16 (&acc)[10], const float (&af)[16], const float *lx, int I, int lane) {
+    const float *sb = lx + I * (16 * 64) + lane;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[cm_slot(P, Q)] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], sb[s * 64], acc[cm_slot(P, Q)], 0, 0, 0);
+}
+
 // One panel step J of the factorisation (J compile-time: every slot index and most predicates fold away; a, b stay run-time,
-// wave-uniform).  Returns with `failed` set (uniformly) when a pivot of the diagonal block was not above `floor_`.
+// wave-uniform).  On entry the chain of panel J has been run by its owner (cm_chain_panel: before the first step, or as the
+// LOOK-AHEAD of step J - 1).  Look-ahead: the owner of block (J + 1, J + 1) updates that block first, runs the chain of panel
+// J + 1 and only then its other trailing blocks -- the chain, one wave's 16 dependent rank-2 steps, runs beside the trailing
+// products of the other three waves instead of in front of a barrier they all wait at.
+// Returns with `failed` set (uniformly) when a pivot of the diagonal block was not above `floor_`.
 template <int J>
 __device__ __forceinline__ void cm_panel_step(cm_f32x16 (&acc)[10], float *linv, float *lx, int *iflag, int a, int b, int h, int n31, int lane,
                                               int nblk, float floor_, float &pmin, bool &failed) {
     using C = CholMfma;
     constexpr int Jp = J >> 1, Jb = J & 1;
     if (J >= nblk || failed) return;
-    // ---- 1. chain on the diagonal block (its owner wave alone), in place; E starts as the identity and ends as L_JJ^-1
-    if (a == Jb && b == Jb) {
-        cm_f32x16 E;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) E[r] = (cm_row(r, h) == n31) ? 1.f : 0.f;
-        bool ok = true;
-        CmChain<0, 32>::run(acc[cm_slot(Jp, Jp)], E, h, n31, floor_, pmin, ok);
-        float *dst = linv + J * (32 * C::LP) + n31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dst[cm_row(r, h) * C::LP] = E[r];
-        if (!ok && lane == 0) iflag[0] = 1;
-    }
-    __syncthreads();
+    // wave coordinates and order through an opaque asm per step: the ~80 block predicates below are loop invariants of the whole
+    // kernel otherwise, each pinned in SGPRs from the first instruction on
+    asm volatile("" : "+s"(a), "+s"(b), "+s"(nblk));
+    __syncthreads();                       // L_JJ^-1 and the verdict on its pivots are published
+    CM_STAMP(8 + 3 * J);
     if (iflag[0]) { failed = true; return; }
-    // ---- 2. panel blocks (I, J), I > J:  L' = L_JJ^-1 D'
+    // ---- panel blocks (I, J), I > J:  L' = L_JJ^-1 D'
     if (b == Jb) {
         float af[16];
         const float *src = linv + J * (32 * C::LP) + n31 * C::LP + 4 * h;
@@ -143,10 +190,26 @@ __device__ __forceinline__ void cm_panel_step(cm_f32x16 (&acc)[10], float *linv,
 #pragma unroll
                 for (int s = 0; s < 16; ++s) dst[s * 64] = o[s];
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();
-    // ---- 3. trailing blocks (I, K), I >= K > J
+    CM_STAMP(9 + 3 * J);
+    // ---- trailing blocks (I, K), I >= K > J; block (J + 1, J + 1) first, then (its owner) the chain of the next panel
+    constexpr int N = J + 1, Np = N >> 1, Nb = N & 1;
+    const bool next_owner = (N < 8) && a == Nb && b == Nb && N < nblk;
+    if constexpr (N < 8) {
+        if (next_owner) {
+            float af[16];
+            const float *sa = lx + N * (16 * 64) + lane;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) af[s] = -sa[s * 64];
+            cm_trail_block<Np, Np>(acc, af, lx, N, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            cm_chain_panel<N>(acc, linv, iflag, h, n31, lane, floor_, pmin);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 #pragma unroll
     for (int q = Jp; q < 4; ++q) {
         const int K = 2 * q + b;
@@ -159,19 +222,23 @@ __device__ __forceinline__ void cm_panel_step(cm_f32x16 (&acc)[10], float *linv,
 #pragma unroll
             for (int p = q; p < 4; ++p) {
                 const int I = 2 * p + a;
-                const bool on = (p > q || a >= b) && I < nblk;
+                const bool on = (p > q || a >= b) && I < nblk && !(next_owner && p == Np && q == Np);
                 if (on) {
-                    const float *sb = lx + I * (16 * 64) + lane;
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) acc[cm_slot(p, q)] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], sb[s * 64], acc[cm_slot(p, q)], 0, 0, 0);
+                    if (p == 0) cm_trail_block<0, (0 <= 0 ? 0 : 0)>(acc, af, lx, I, lane);   // p >= q: the only slot with p == 0 is (0, 0)
+                    else if (p == 1) { if (q == 0) cm_trail_block<1, 0>(acc, af, lx, I, lane); else cm_trail_block<1, 1>(acc, af, lx, I, lane); }
+                    else if (p == 2) { if (q == 0) cm_trail_block<2, 0>(acc, af, lx, I, lane); else if (q == 1) cm_trail_block<2, 1>(acc, af, lx, I, lane); else cm_trail_block<2, 2>(acc, af, lx, I, lane); }
+                    else { if (q == 0) cm_trail_block<3, 0>(acc, af, lx, I, lane); else if (q == 1) cm_trail_block<3, 1>(acc, af, lx, I, lane); else if (q == 2) cm_trail_block<3, 2>(acc, af, lx, I, lane); else cm_trail_block<3, 3>(acc, af, lx, I, lane); }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
+    CM_STAMP(10 + 3 * J);
 }
 
 // Arguments as chol_solve_kernel (cmf_eigen.hip.h); sub-block images (sub > 1) and the timing diagnostics are not offered here.
-__global__ __launch_bounds__(256, 1) void chol_solve_mfma_kernel(const float *Hin, const float *grad, float *step, int *need_jacobi, int n, int kp,
+__global__ __launch_bounds__(256, 2) void chol_solve_mfma_kernel(const float *Hin, const float *grad, float *step, int *need_jacobi, int n, int kp,
                                                                  int64_t stride, float pert, int nmat, const int *rowidx, const int *cert,
                                                                  int cert_rows, int cert_split, float *condest) {
     using C = CholMfma;
@@ -189,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void chol_solve_mfma_kernel(const float *Hi
     if (mat >= nmat) return;
     const float *H = Hin + (int64_t)mat * stride;
     const int ldh = kp;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int a = w & 1, b = w >> 1, h = lane >> 5, n31 = lane & 31;
     const int64_t orow = rowidx ? rowidx[mat] : mat;
     const int nblk = (n + 31) >> 5;
@@ -205,33 +272,53 @@ __global__ __launch_bounds__(256, 1) void chol_solve_mfma_kernel(const float *Hi
 
     cm_f32x16 acc[10];
     float pmin_all = 3.0e38f;
+    CM_STAMP(0);
 
-    for (int pass = certified ? 1 : 0; pass < 2; ++pass) {
+    // pert == 0 (the images of the spectral clamp, already >= pert by construction): ONE factorisation, with the positivity floor
+    const bool one_pass = certified || pert == 0.f;
+    for (int pass = one_pass ? 1 : 0; pass < 2; ++pass) {
         const float shift = pass == 0 ? pert : 0.f;
-        const float floor_ = pass == 0 ? 4.0e-6f * dmax : 0.f;
-        // ---- load: block (I, K) transposed; identity outside the valid n x n part
+        const float floor_ = (pass == 0 || !certified) && (pass == 0 || pert == 0.f) ? 4.0e-6f * dmax : 0.f;
+        // ---- load: block (I, K) transposed; max |H_ii| I outside the valid n x n part
+        // (the pointer and the order pass through an opaque asm: otherwise the 160 load addresses and their masks are hoisted out
+        // of the pass loop as loop invariants and held in registers across everything -- 800 spilled registers)
+        const float *Hp = H;
+        int nn = n;
+        asm volatile("" : "+s"(Hp), "+s"(nn));
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int q = 0; q <= p; ++q) {
                 const int I = 2 * p + a, K = 2 * q + b;
                 const int gc = 32 * I + n31, gr0 = 32 * K + 4 * h;
-                const float *src = H + (int64_t)gr0 * ldh + gc;
-                const bool live = I >= K && gc < n;
+                const float *src = Hp + (int64_t)gr0 * ldh + gc;
                 cm_f32x16 v;
+                if (I >= K && 32 * I + 32 <= nn) { // the whole block lies inside the valid part: sixteen plain loads
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dr = (r & 3) + 8 * (r >> 2), gr = gr0 + dr;
-                    float x = (gr == gc) ? 1.f : 0.f;
-                    if (live && gr < n) x = src[(int64_t)dr * ldh] - (gr == gc ? shift : 0.f);
-                    v[r] = x;
+                    for (int r = 0; r < 16; ++r) v[r] = src[(int64_t)((r & 3) + 8 * (r >> 2)) * ldh];
+                    if (p == q && a == b) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] -= (gr0 + (r & 3) + 8 * (r >> 2) == gc) ? shift : 0.f;
+                    }
+                } else {
+                    const bool live = I >= K && gc < nn;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dr = (r & 3) + 8 * (r >> 2), gr = gr0 + dr;
+                        float x = (gr == gc) ? dmax : 0.f;
+                        if (live && gr < nn) x = src[(int64_t)dr * ldh] - (gr == gc ? shift : 0.f);
+                        v[r] = x;
+                    }
                 }
                 acc[cm_slot(p, q)] = v;
+                __builtin_amdgcn_sched_barrier(0);
             }
         if (t == 0) iflag[0] = 0;
         __syncthreads();
+        CM_STAMP(1);
         float pmin = 3.0e38f;
         bool failed = false;
+        if (w == 0) cm_chain_panel<0>(acc, linv, iflag, h, n31, lane, floor_, pmin);   // panel 0; the later chains run as look-ahead
         cm_panel_step<0>(acc, linv, lx, iflag, a, b, h, n31, lane, nblk, floor_, pmin, failed);
         cm_panel_step<1>(acc, linv, lx, iflag, a, b, h, n31, lane, nblk, floor_, pmin, failed);
         cm_panel_step<2>(acc, linv, lx, iflag, a, b, h, n31, lane, nblk, floor_, pmin, failed);
@@ -247,33 +334,35 @@ __global__ __launch_bounds__(256, 1) void chol_solve_mfma_kernel(const float *Hi
         pmin_all = pmin;
         if (pass == 0) __syncthreads(); // lx / linv are rewritten by the second factorisation
     }
+    CM_STAMP(2);
     if (t == 0) need_jacobi[orow] = 0;
     if (condest) { // max H_ii / min L_ii^2 <= cond(H) (cmf_newton.hip.h, clamp_stats)
         for (int off = 32; off > 0; off >>= 1) pmin_all = fminf(pmin_all, __shfl_xor(pmin_all, off, 64));
         if (lane == 0) red[8 + w] = pmin_all;
     }
-    // ---- forward substitution  L y = g
+    // ---- forward substitution  L y = g.  ONE barrier per block row: every wave forms the block's right-hand side and solves the
+    // 32 x 32 diagonal system itself (redundantly, through L_JJ^-1 in LDS), then adds its own blocks' products to its own
+    // partial sums -- nobody waits for a designated solver wave
     for (int i = t; i < 4 * C::VEC; i += 256) part[i] = 0.f;
-    __syncthreads();
-    if (condest && t == 0) condest[orow] = dmax / fmaxf(fminf(fminf(red[8], red[9]), fminf(red[10], red[11])), 1.0e-37f);
+    float *rw = rt + 64 * w;               // wave-private: [0, 32) block right-hand side, [32, 64) block solution
     for (int J = 0; J < nblk; ++J) {
         const int Jp = J >> 1, Jb = J & 1;
-        if (w == 0) {
-            const int i0 = 32 * J + n31;
-            const float r = vg[i0] - (part[i0] + part[C::VEC + i0] + part[2 * C::VEC + i0] + part[3 * C::VEC + i0]);
-            if (h == 0) rt[n31] = r;
-            const float *Lr = linv + J * (32 * C::LP) + n31 * C::LP + 16 * h; // row c = n31, columns 16 h ..
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s += Lr[i] * rt[16 * h + i];
-            s += __shfl_xor(s, 32, 64);
-            if (h == 0) vy[i0] = s;
-        }
         __syncthreads();
+        if (J == 0 && condest && t == 0) condest[orow] = dmax / fmaxf(fminf(fminf(red[8], red[9]), fminf(red[10], red[11])), 1.0e-37f);
+        const int i0 = 32 * J + n31;
+        const float r = vg[i0] - (part[i0] + part[C::VEC + i0] + part[2 * C::VEC + i0] + part[3 * C::VEC + i0]);
+        if (h == 0) rw[n31] = r;
+        const float *Lr = linv + J * (32 * C::LP) + n31 * C::LP + 16 * h; // row c = n31, columns 16 h ..
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += Lr[i] * rw[16 * h + i];
+        s += __shfl_xor(s, 32, 64);
+        if (h == 0) rw[32 + n31] = s;
+        if (w == 0 && h == 0) vy[i0] = s;
         if (b == Jb) {
             float yv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) yv[r] = vy[32 * J + cm_row(r, h)];
+            for (int r4 = 0; r4 < 16; ++r4) yv[r4] = rw[32 + cm_row(r4, h)];
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -281,35 +370,32 @@ __global__ __launch_bounds__(256, 1) void chol_solve_mfma_kernel(const float *Hi
                     const int I = 2 * p + a;
                     if (q == Jp && I > J && I < nblk) {
                         const cm_f32x16 d = acc[cm_slot(p, q)];
-                        float s = 0.f;
+                        float sum = 0.f;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) s += d[r] * yv[r];
-                        s += __shfl_xor(s, 32, 64);
-                        if (h == 0) part[w * C::VEC + 32 * I + n31] += s;
+                        for (int r4 = 0; r4 < 16; ++r4) sum += d[r4] * yv[r4];
+                        sum += __shfl_xor(sum, 32, 64);
+                        if (h == 0) part[w * C::VEC + 32 * I + n31] += sum;
                     }
                 }
         }
-        __syncthreads();
     }
-    // ---- back substitution  L^T x = y
-    for (int i = t; i < 4 * C::VEC; i += 256) part[i] = 0.f;
+    CM_STAMP(3);
+    // ---- back substitution  L^T x = y, the same way (the block solution stays in registers: lane i holds x_i)
     __syncthreads();
+    for (int i = t; i < 4 * C::VEC; i += 256) part[i] = 0.f;
     for (int J = nblk - 1; J >= 0; --J) {
         const int Jp = J >> 1, Jb = J & 1;
-        if (w == 0) {
-            const int i0 = 32 * J + n31;
-            const float r = vy[i0] - (part[i0] + part[C::VEC + i0] + part[2 * C::VEC + i0] + part[3 * C::VEC + i0]);
-            if (h == 0) rt[n31] = r;
-            const float *Lc = linv + J * (32 * C::LP) + (16 * h) * C::LP + n31; // column i = n31, rows 16 h ..
-            float s = 0.f;
-#pragma unroll
-            for (int cc = 0; cc < 16; ++cc) s += Lc[cc * C::LP] * rt[16 * h + cc];
-            s += __shfl_xor(s, 32, 64);
-            if (h == 0) vg[i0] = s;
-        }
         __syncthreads();
+        const int i0 = 32 * J + n31;
+        const float r = vy[i0] - (part[i0] + part[C::VEC + i0] + part[2 * C::VEC + i0] + part[3 * C::VEC + i0]);
+        if (h == 0) rw[n31] = r;
+        const float *Lc = linv + J * (32 * C::LP) + (16 * h) * C::LP + n31; // column i = n31, rows 16 h ..
+        float xs = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) xs += Lc[cc * C::LP] * rw[16 * h + cc];
+        xs += __shfl_xor(xs, 32, 64);
+        if (w == 0 && h == 0) vg[i0] = xs;
         if (a == Jb) { // blocks (J, K), K < J: the block row of J
-            const float xl = vg[32 * J + n31];
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -319,15 +405,16 @@ __global__ __launch_bounds__(256, 1) void chol_solve_mfma_kernel(const float *Hi
                         const cm_f32x16 d = acc[cm_slot(p, q)];
                         float v[16];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) v[r] = d[r] * xl;
-                        const float s = cm_transpose_reduce(v, n31);
-                        const int r = ((n31 >> 4) & 1) * 8 + ((n31 >> 3) & 1) * 4 + ((n31 >> 2) & 1) * 2 + ((n31 >> 1) & 1);
-                        if (!(n31 & 1)) part[w * C::VEC + 32 * K + cm_row(r, h)] += s;
+                        for (int r4 = 0; r4 < 16; ++r4) v[r4] = d[r4] * xs;
+                        const float sum = cm_transpose_reduce(v, n31);
+                        const int r4 = ((n31 >> 4) & 1) * 8 + ((n31 >> 3) & 1) * 4 + ((n31 >> 2) & 1) * 2 + ((n31 >> 1) & 1);
+                        if (!(n31 & 1)) part[w * C::VEC + 32 * K + cm_row(r4, h)] += sum;
                     }
                 }
         }
-        __syncthreads();
     }
+    __syncthreads();
+    CM_STAMP(4);
     for (int i = t; i < kp; i += 256) step[orow * kp + i] = (i < n) ? vg[i] : 0.f;
 }
 

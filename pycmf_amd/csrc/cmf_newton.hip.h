@@ -289,7 +289,11 @@ static int ns_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, f
     Timed tm(c, CMF_K_EIGEN);
     const dim3 grid((unsigned)nf), block(256);
     const int64_t istride = 256 * 256;
-    if (kp == 256)
+    if (kp == 256 && c->opt_chol_mfma) {
+        CHK(allow_big_lds(c, reinterpret_cast<const void *>(&chol_solve_mfma_kernel), (int)CholMfma::LDS_BYTES));
+        hipLaunchKernelGGL(chol_solve_mfma_kernel, grid, block, CholMfma::LDS_BYTES, c->stream, (const float *)M, grad, step, flags, n, kp, istride, 0.0f, nf,
+                           (const int *)idx, (const int *)nullptr, 1, 0, (float *)nullptr);
+    } else if (kp == 256)
         hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, (const float *)M, grad, step, flags, n, kp, istride, 0.0f, nf, 0,
                            (const int *)idx, 1);
     else
@@ -329,6 +333,12 @@ static int safe_solve_rows(cmf_ctx *c, float *Hc, const float *grad, float *step
                                               (const int *)nullptr, 1, cert.flags, cert.rows, cert.split, condest);
         else if (n <= 128) hipLaunchKernelGGL((chol_solve_kernel<8>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag,
                                                (const int *)nullptr, 1, cert.flags, cert.rows, cert.split, condest);
+        else if (kp == 256 && c->opt_chol_mfma && !c->opt_choldiag) {
+            // 128 < n <= 256: blocked Cholesky on the matrix pipe (cmf_chol_mfma.hip.h), two barriers per 32-column panel
+            CHK(allow_big_lds(c, reinterpret_cast<const void *>(&chol_solve_mfma_kernel), (int)CholMfma::LDS_BYTES));
+            hipLaunchKernelGGL(chol_solve_mfma_kernel, grid, block, CholMfma::LDS_BYTES, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr,
+                               (const int *)nullptr, cert.flags, cert.rows, cert.split, condest);
+        }
         else hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag,
                                 (const int *)nullptr, 1, cert.flags, cert.rows, cert.split, condest);
         HIPCHK(hipGetLastError());

@@ -160,6 +160,20 @@ int main(int argc, char **argv) {
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 best = std::min(best, ms);
             }
+#ifdef CMF_DIAG_BUILD
+            if (variant == 1) {
+                unsigned long long pr[128];
+                CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(cmfk::cm_prof), sizeof pr));
+                const double tick = 1.0; // s_memtime: shader-clock cycles here
+                printf("profile of one workgroup (cycles): load %.0f", (pr[1] - pr[0]) * tick);
+                unsigned long long prev = pr[1];
+                for (int J = 0; J < 8; ++J) {
+                    printf(" | J%d chain %.0f panel %.0f trail %.0f", J, (pr[8 + 3 * J] - prev) * tick, (pr[9 + 3 * J] - pr[8 + 3 * J]) * tick, (pr[10 + 3 * J] - pr[9 + 3 * J]) * tick);
+                    prev = pr[10 + 3 * J];
+                }
+                printf(" | to-solve %.0f forward %.0f backward %.0f total %.0f\n", (pr[2] - prev) * tick, (pr[3] - pr[2]) * tick, (pr[4] - pr[3]) * tick, (pr[4] - pr[0]) * tick);
+            }
+#endif
             printf("%s, %s: %d systems of 256 in %.3f ms = %.3f us each (chip-wide)\n", variant < 2 ? "chol_solve_mfma_kernel" : "chol_solve_kernel<16>   ",
                    (variant & 1) ? "certified (one factorisation)" : "threshold test + solve (two factorisations)", nt, best, best * 1e3 / nt);
             if (cert) CK(hipFree(cert));
