@@ -58,7 +58,7 @@ __device__ __forceinline__ float cm_readlane(float v, int lane) {
 // and judged once per panel (a pivot <= floor, or a NaN after it, only ever produces garbage that the caller discards; the
 // padding beyond the valid order carries max |H_ii| on its diagonal, so it can neither be the smallest pivot nor fall under the floor).
 template <int J_>
-__device__ __forceinline__ void cm_chain_pair(cm_f32x16 &D, cm_f32x16 &E, int h, int n31, float &pmin) {
+__device__ __forceinline__ void cm_chain_pair(cm_f32x16 &D, cm_f32x16 &E, int h, int n31, int &pmin_bits) {
     static_assert((J_ & 1) == 0, "pairs start at even columns");
     constexpr int rj = (J_ & 3) + 4 * (J_ >> 3), hj = (J_ >> 2) & 1;
     const float piv0 = cm_readlane(D[rj], 32 * hj + J_);
@@ -69,7 +69,10 @@ __device__ __forceinline__ void cm_chain_pair(cm_f32x16 &D, cm_f32x16 &E, int h,
     const float piv1 = cm_readlane(a1, 32 * hj + J_ + 1);
     const float inv1 = __builtin_amdgcn_rsqf(piv1);
     const float l1 = a1 * inv1;
-    pmin = fminf(pmin, fminf(piv0, piv1));
+    // smallest pivot on the SCALAR unit: pivots are wave-uniform (readlane results), and signed-integer order is float order for
+    // positive floats while every negative float is a negative integer -- so min_i32 yields the exact minimum when all pivots
+    // are positive (the condition estimate) and some negative value as soon as one is not (the failure test): no vector work
+    pmin_bits = min(pmin_bits, min(__builtin_bit_cast(int, piv0), __builtin_bit_cast(int, piv1)));
     const float f0 = E[rj] * inv0;                               // final rows j, j + 1 of E
     const float f1 = (E[rj + 1] - c * f0) * inv1;
     const bool mine = (h == hj);
@@ -89,14 +92,14 @@ __device__ __forceinline__ void cm_chain_pair(cm_f32x16 &D, cm_f32x16 &E, int h,
 
 template <int J0, int J1>
 struct CmChain {
-    static __device__ __forceinline__ void run(cm_f32x16 &D, cm_f32x16 &E, int h, int n31, float &pmin) {
-        cm_chain_pair<J0>(D, E, h, n31, pmin);
-        CmChain<J0 + 2, J1>::run(D, E, h, n31, pmin);
+    static __device__ __forceinline__ void run(cm_f32x16 &D, cm_f32x16 &E, int h, int n31, int &pmin_bits) {
+        cm_chain_pair<J0>(D, E, h, n31, pmin_bits);
+        CmChain<J0 + 2, J1>::run(D, E, h, n31, pmin_bits);
     }
 };
 template <int J1>
 struct CmChain<J1, J1> {
-    static __device__ __forceinline__ void run(cm_f32x16 &, cm_f32x16 &, int, int, float &) {}
+    static __device__ __forceinline__ void run(cm_f32x16 &, cm_f32x16 &, int, int, int &) {}
 };
 
 // sums of each of the 16 values over the 32 lanes of a half: lane (bits b4 b3 b2 b1 b0 of l & 31) ends with the total of
@@ -136,7 +139,9 @@ __device__ __forceinline__ void cm_chain_panel(cm_f32x16 (&acc)[10], float *linv
     cm_f32x16 E;
 #pragma unroll
     for (int r = 0; r < 16; ++r) E[r] = (cm_row(r, ho) == no) ? 1.f : 0.f;
-    CmChain<0, 32>::run(acc[cm_slot(J >> 1, J >> 1)], E, ho, no, pmin);
+    int pbits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pmin));
+    CmChain<0, 32>::run(acc[cm_slot(J >> 1, J >> 1)], E, ho, no, pbits);
+    pmin = __builtin_bit_cast(float, pbits);
     float *dst = linv + J * (32 * C::LP) + no;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dst[cm_row(r, ho) * C::LP] = E[r];
@@ -265,7 +270,8 @@ __global__ __launch_bounds__(256, 2) void chol_solve_mfma_kernel(const float *Hi
     for (int i = t; i < n; i += 256) dmax = fmaxf(dmax, fabsf(H[(int64_t)i * ldh + i]));
     for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off, 64));
     if (lane == 0) red[w] = dmax;
-    for (int i = t; i < C::VEC; i += 256) vg[i] = (i < n) ? grad[orow * kp + i] : 0.f;
+    const bool test_only = grad == nullptr;   // threshold test alone (group certificates): the flag is the whole result
+    for (int i = t; i < C::VEC; i += 256) vg[i] = (!test_only && i < n) ? grad[orow * kp + i] : 0.f;
     __syncthreads();
     dmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     const bool certified = cert && cert[(mat / cert_rows) * 2 + ((mat % cert_rows) >= cert_split ? 1 : 0)] == 0;
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void chol_solve_mfma_kernel(const float *Hi
                     }
                 }
                 acc[cm_slot(p, q)] = v;
-                __builtin_amdgcn_sched_barrier(0);
+                if ((cm_slot(p, q) & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // two blocks' loads in flight, not all ten
             }
         if (t == 0) iflag[0] = 0;
         __syncthreads();
@@ -332,6 +338,10 @@ __global__ __launch_bounds__(256, 2) void chol_solve_mfma_kernel(const float *Hi
             return;
         }
         pmin_all = pmin;
+        if (test_only) {
+            if (t == 0) need_jacobi[orow] = 0;
+            return;
+        }
         if (pass == 0) __syncthreads(); // lx / linv are rewritten by the second factorisation
     }
     CM_STAMP(2);
@@ -353,9 +363,10 @@ __global__ __launch_bounds__(256, 2) void chol_solve_mfma_kernel(const float *Hi
         const float r = vg[i0] - (part[i0] + part[C::VEC + i0] + part[2 * C::VEC + i0] + part[3 * C::VEC + i0]);
         if (h == 0) rw[n31] = r;
         const float *Lr = linv + J * (32 * C::LP) + n31 * C::LP + 16 * h; // row c = n31, columns 16 h ..
-        float s = 0.f;
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};   // four independent chains: a 16-term dependent FMA chain is 130 cycles of latency
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s += Lr[i] * rw[16 * h + i];
+        for (int i = 0; i < 16; ++i) s4[i & 3] += Lr[i] * rw[16 * h + i];
+        float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
         s += __shfl_xor(s, 32, 64);
         if (h == 0) rw[32 + n31] = s;
         if (w == 0 && h == 0) vy[i0] = s;
@@ -370,9 +381,10 @@ __global__ __launch_bounds__(256, 2) void chol_solve_mfma_kernel(const float *Hi
                     const int I = 2 * p + a;
                     if (q == Jp && I > J && I < nblk) {
                         const cm_f32x16 d = acc[cm_slot(p, q)];
-                        float sum = 0.f;
+                        float q4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int r4 = 0; r4 < 16; ++r4) sum += d[r4] * yv[r4];
+                        for (int r4 = 0; r4 < 16; ++r4) q4[r4 & 3] += d[r4] * yv[r4];
+                        float sum = (q4[0] + q4[1]) + (q4[2] + q4[3]);
                         sum += __shfl_xor(sum, 32, 64);
                         if (h == 0) part[w * C::VEC + 32 * I + n31] += sum;
                     }
@@ -390,27 +402,36 @@ __global__ __launch_bounds__(256, 2) void chol_solve_mfma_kernel(const float *Hi
         const float r = vy[i0] - (part[i0] + part[C::VEC + i0] + part[2 * C::VEC + i0] + part[3 * C::VEC + i0]);
         if (h == 0) rw[n31] = r;
         const float *Lc = linv + J * (32 * C::LP) + (16 * h) * C::LP + n31; // column i = n31, rows 16 h ..
-        float xs = 0.f;
+        float x4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int cc = 0; cc < 16; ++cc) xs += Lc[cc * C::LP] * rw[16 * h + cc];
+        for (int cc = 0; cc < 16; ++cc) x4[cc & 3] += Lc[cc * C::LP] * rw[16 * h + cc];
+        float xs = (x4[0] + x4[1]) + (x4[2] + x4[3]);
         xs += __shfl_xor(xs, 32, 64);
         if (w == 0 && h == 0) vg[i0] = xs;
-        if (a == Jb) { // blocks (J, K), K < J: the block row of J
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-#pragma unroll
-                for (int q = 0; q <= p; ++q) {
-                    const int K = 2 * q + b;
-                    if (p == Jp && K < J) {
-                        const cm_f32x16 d = acc[cm_slot(p, q)];
-                        float v[16];
-#pragma unroll
-                        for (int r4 = 0; r4 < 16; ++r4) v[r4] = d[r4] * xs;
-                        const float sum = cm_transpose_reduce(v, n31);
-                        const int r4 = ((n31 >> 4) & 1) * 8 + ((n31 >> 3) & 1) * 4 + ((n31 >> 2) & 1) * 2 + ((n31 >> 1) & 1);
-                        if (!(n31 & 1)) part[w * C::VEC + 32 * K + cm_row(r4, h)] += sum;
-                    }
-                }
+        if (a == Jb) { // blocks (J, K), K < J: the block row of J, all in ONE basic block (a block that does not exist -- K >= J --
+                       // runs on zeros) so that the five exchange stages of the up to four transpose-reduces overlap
+            const int r4 = ((n31 >> 4) & 1) * 8 + ((n31 >> 3) & 1) * 4 + ((n31 >> 2) & 1) * 2 + ((n31 >> 1) & 1);
+            float *pw = part + w * C::VEC + cm_row(r4, h);
+#define CM_BACK_ROW(P)                                                                                        \
+    do {                                                                                                      \
+        float sums[P + 1];                                                                                    \
+        _Pragma("unroll") for (int q = 0; q <= P; ++q) {                                                      \
+            const float xm = (2 * q + b < J) ? xs : 0.f;                                                      \
+            float v[16];                                                                                      \
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) v[k] = acc[cm_slot(P, q)][k] * xm;                 \
+            sums[q] = cm_transpose_reduce(v, n31);                                                            \
+        }                                                                                                     \
+        if (!(n31 & 1)) {                                                                                     \
+            _Pragma("unroll") for (int q = 0; q <= P; ++q) pw[32 * (2 * q + b)] += sums[q];                   \
+        }                                                                                                     \
+    } while (0)
+            switch (Jp) {
+            case 0: CM_BACK_ROW(0); break;
+            case 1: CM_BACK_ROW(1); break;
+            case 2: CM_BACK_ROW(2); break;
+            default: CM_BACK_ROW(3); break;
+            }
+#undef CM_BACK_ROW
         }
     }
     __syncthreads();

@@ -1514,6 +1514,12 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
         if (cert.flags && !global_cert) { // test the certificates (threshold test only): part + diag I - pert I positive definite?
             Timed tm(c, CMF_K_EIGEN);
             const int64_t ncert = 2 * ((nr + cert.rows - 1) / cert.rows);
+            if (c->kp == 256 && c->opt_chol_mfma) {
+                CHK(allow_big_lds(c, reinterpret_cast<const void *>(&chol_solve_mfma_kernel), (int)CholMfma::LDS_BYTES));
+                hipLaunchKernelGGL(chol_solve_mfma_kernel, dim3((unsigned)ncert), dim3(256), CholMfma::LDS_BYTES, c->stream, (const float *)c->certimg.p,
+                                   (const float *)nullptr, (float *)nullptr, (int *)c->certflag.p, c->k, c->kp, kk, (float)(pert - diag), (int)ncert,
+                                   (const int *)nullptr, (const int *)nullptr, 1, 0, (float *)nullptr);
+            } else
             hipLaunchKernelGGL((chol_solve_kernel<16>), dim3((unsigned)ncert), dim3(256), 0, c->stream, (const float *)c->certimg.p, (const float *)nullptr,
                                (float *)nullptr, (int *)c->certflag.p, c->k, c->kp, kk, (float)(pert - diag), (int)ncert, 1);
             HIPCHK(hipGetLastError());
