@@ -43,6 +43,12 @@ WORKLOADS = {
     "c3": dict(m=32768, d=16384, p=8192, k=256, solver="newton", x_link="linear", y_link="logit", ratio=0.5, y_kind=1,
                desc="BASELINE configs[2]: CMF(n_components=256, solver='newton', y_link='logit', "
                     "sg_sample_ratio=0.5, device sampler) on dense 32768x16384 X, 16384x8192 Y"),
+    "c3z": dict(m=32768, d=16384, p=8192, k=256, solver="newton", x_link="linear", y_link="logit", ratio=0.5, y_kind=1, l2=0.0,
+                desc="BASELINE configs[2] with the reference's default l2_reg = 0 (pycmf/cmf.py:622): CMF(n_components=256, solver='newton', "
+                     "y_link='logit', sg_sample_ratio=0.5, device sampler) on dense 32768x16384 X, 16384x8192 Y"),
+    "c3x": dict(m=32768, d=16384, p=8192, k=256, solver="newton", x_link="logit", y_link="logit", ratio=0.5, x_kind=1, y_kind=1,
+                desc="BASELINE configs[2] with the sigmoid link on BOTH sides: CMF(n_components=256, solver='newton', x_link='logit', "
+                     "y_link='logit', sg_sample_ratio=0.5, device sampler) on dense 32768x16384 X, 16384x8192 Y (sigmoid(N(0,1)) targets)"),
     "c5": dict(m=1000000, d=100000, p=64, k=256, solver="newton", x_link="linear", y_link="linear", ratio=1.0,
                nnz_per_row=100,
                desc="BASELINE configs[4]: CSR X 1e6 x 1e5 at 0.1% nnz (100 per row, values 1.0, native CSR), "
@@ -110,6 +116,8 @@ def cpu_baseline(w, budget_s=20.0):
         ms, ds, ps, ks = 96, 64, 32, k  # per-row eigh(k x k) in Python: keep it to a few hundred rows
     rng = np.random.RandomState(42)
     X, Y = np.abs(rng.randn(ms, ds)), np.abs(rng.randn(ds, ps))
+    if w.get("x_kind") == 1:
+        X = 1.0 / (1.0 + np.exp(-rng.randn(ms, ds)))
     if w.get("y_kind") == 2:
         Y = (rng.rand(ds, ps) < w.get("y_param", 0.1)).astype(np.float64)
     elif w.get("y_link") == "logit":
@@ -278,7 +286,7 @@ def main():
         del X
         scale = (npr / d / k) ** 0.5
     else:
-        ctx.fill_data_synthetic(0, 42, r0, 0)   # X rows [r0,r1): values depend only on global coordinates
+        ctx.fill_data_synthetic(0, 42, r0, 0, w.get("x_kind", 0))   # X rows [r0,r1): values depend only on global coordinates
         scale = (0.7979 / k) ** 0.5             # 'random' init rule sqrt(mean / k), pycmf/cmf.py:111
     # Y columns [c0,c1): |N(0,1)|, or the targets of a logit side: sigmoid(N(0,1)) as in
     # benchmarks/benchmark_cmf.py:78, {0,1} labels as in samples/toxic_comments.ipynb
@@ -315,7 +323,7 @@ def main():
             name, _, val = kv.partition("=")
             ctx_v.set_option(name, int(val))
         ctx_v.set_problem(m, q1 - q0, p, k)
-        ctx_v.fill_data_synthetic(0, 42, 0, q0)
+        ctx_v.fill_data_synthetic(0, 42, 0, q0, w.get("x_kind", 0))
         ctx_v.fill_data_synthetic(1, 43, q0, 0, w.get("y_kind", 0), w.get("y_param", 0.0))
         ctx_v.fill_factor_synthetic(_lib.CMF_U, 101, 0, scale)
         ctx_v.fill_factor_synthetic(_lib.CMF_V, 102, q0, scale)

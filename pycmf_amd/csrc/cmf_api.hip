@@ -10,6 +10,7 @@
 #include "cmf_bf16x6.hip.h"
 #include "cmf_rowhess6.hip.h"
 #include "cmf_shared64.hip.h"
+#include "cmf_refine64.hip.h"
 
 #include <hip/hip_runtime.h>
 
@@ -136,7 +137,7 @@ struct cmf_ctx {
     double sp_sq[2] = {0.0, 0.0};     // sum of squares of the stored values
     int opt_sparse = 0;               // 0 auto, 1 always expand to dense, 2 always native CSR
     int opt_spmm_blocked = 1;         // column-blocked output-stationary SpMM: 0 never | 1 when the gathered operand exceeds L2 | 2 always
-    int64_t opt_spmm_block_cols = 0;  // gathered rows per column block (0: 2 MB worth)
+    int64_t opt_spmm_block_cols = 0;  // gathered rows per column block (0: 3 MB worth)
     int64_t opt_spmm_stretch = 0;     // entries of a group between two re-alignments of its XCD class (0: 8192)
     DevBuf spmm_bar;                  // rendezvous counters of the blocked SpMM (8 x 16 bytes)
     float *F[3] = {nullptr, nullptr, nullptr};
@@ -180,12 +181,14 @@ struct cmf_ctx {
     DevBuf eigws;                         // Jacobi workspace when k_pad > 128
     DevBuf eigflag, eigcopy;              // Cholesky fast path: per-matrix fallback flags, input copy
     DevBuf clampstat;                     // [count (u64), max ||H||_F / pert (float bits)] of the float32 spectral clamp (cmf_newton_clamp_stats)
-    DevBuf badbuf, rw64, rh64;            // float64 refinement of ill-conditioned rows: [count, list], sample weights, one Hessian
+    DevBuf badbuf, rw64, rh64;            // float64 refinement of ill-conditioned rows: [count, list], sample weights, Hessians
+    DevBuf ref_w, ref_w2, ref_g, ref_i, ref_ns; // its batched form (cmf_refine64.hip.h): factor images, gradients, index lists, scratch rows, clamp images
+    int opt_refine_batched = 1;           // 1: listed rows redone together (64 < n_components <= 256) | 0: one at a time (round-3 path)
     std::vector<int> bad_host;            // rows of the current chunk to redo in float64 (relative to the chunk)
     int opt_refine = 1;                   // redo clamped rows with ||H||_F / pert > refine_ratio in float64 (0: float32 only, recorded)
     double opt_refine_ratio = 3.0e3;       // clamped rows: ||H||_F / pert above this (campaign: 2.7e3 -> 3e-4 off the float64 reference, 9.8e3 -> 1.9e-3)
     double opt_refine_cond = 1.0e3;        // plain Cholesky solves: max H_ii / min L_ii^2 (a LOWER bound of cond H) above this
-    int64_t opt_refine_max = 16384;       // at most this many rows per sweep (a float64 clamp is ~170 small launches); beyond: float32, recorded
+    int64_t opt_refine_max = (int64_t)1 << 40; // cap on the rows redone per sweep (no cap since the refinement is batched; the option remains); beyond: float32, recorded
     int64_t refined_sweep = 0, refined_total = 0;
     DevBuf bfp[2][2], bff;                // gemm_arith = 1: bf16 planes of X / Y (normal, transposed) and of the factor operand
     bool bfp_valid[2][2] = {{false, false}, {false, false}};
@@ -827,6 +830,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_ft_tile = (value == 64 || value == 256) ? (int)value : 128;   // 64: 64 x 64 tile | 128: 64 x 128 | 256: 128 rows x 64 columns, eight waves
     } else if (!strcmp(name, "refine_rows")) {
         c->opt_refine = value != 0;
+    } else if (!strcmp(name, "refine_rows_batched")) {
+        c->opt_refine_batched = value != 0;
     } else if (!strcmp(name, "refine_rows_ratio")) {
         c->opt_refine_ratio = (double)std::max<int64_t>(1, value);
     } else if (!strcmp(name, "refine_rows_cond")) {

@@ -788,6 +788,17 @@ __global__ __launch_bounds__(256) void factor_update_kernel(FactorUpdArgs g) {
             *reinterpret_cast<f32x4 *>(As + (idx / (KP / 4)) * LA + 4 * (idx % (KP / 4))) = ab[q];
         }
     }
+    // the epilogue's own operand F is requested before the MFMA loop (its latency hides under the product), not after it
+    float fpre[NB][16];
+    {
+        const bool needf = (g.epi != EPI_DIRECT && g.epi != EPI_COMBINE);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const float *Fb = g.F + (row0 + wr + 4 * lh) * KP + wc + 32 * j + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) fpre[j][r] = needf ? Fb[((r & 3) + 8 * (r >> 2)) * KP] : 0.f;
+        }
+    }
     __syncthreads();
     f32x16 acc[NB];
 #pragma unroll
@@ -810,9 +821,8 @@ __global__ __launch_bounds__(256) void factor_update_kernel(FactorUpdArgs g) {
     for (int j = 0; j < NB; ++j) {
         const int col = wc + 32 * j + l31;
         float fv[16], pv[16];
-        const float *Fb = g.F + (row0 + wr + 4 * lh) * KP + col;   // register r: + ((r & 3) + 8 (r >> 2)) rows
 #pragma unroll
-        for (int r = 0; r < 16; ++r) fv[r] = (g.epi != EPI_DIRECT && g.epi != EPI_COMBINE) ? Fb[((r & 3) + 8 * (r >> 2)) * KP] : 0.f;
+        for (int r = 0; r < 16; ++r) fv[r] = fpre[j][r];
 #pragma unroll
         for (int r = 0; r < 16; ++r) pv[r] = 0.f;
         if (g.epi != EPI_APPLY && g.epi != EPI_DIRECT) {
@@ -939,8 +949,17 @@ __global__ __launch_bounds__(256) void gram32_reduce_kernel(const float *slab, i
         if (ti == tj) { ir = r % ts; ic = c % ts; }       // diagonal tiles are stored whole
         const int tile = ti * T - ti * (ti - 1) / 2 + (tj - ti);
         const float *p = slab + (int64_t)tile * ts * ts + ir * ts + ic;
+        const int64_t st = (int64_t)ntile * ts * ts;
         float s = 0.f;
-        for (int q = 0; q < nsplit; ++q) s += p[(int64_t)q * ntile * ts * ts];
+        int q = 0;
+        for (; q + 8 <= nsplit; q += 8) { // eight loads in flight, added in share order (a chain of single dependent loads was 12 us for 1.5 MB)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(q + u) * st];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; q < nsplit; ++q) s += p[q * st];
         G[idx] = s;
     }
 }

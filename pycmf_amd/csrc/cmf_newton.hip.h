@@ -1328,9 +1328,167 @@ static int class_side_gradient(cmf_ctx *c, bool x_side, bool by_row, const RowSi
 // test, spectral clamp by float64 matrix polynomials; Jacobi for k <= 64); step = g_i H_i^-1 rounded once to float32.  One row
 // at a time (~200 small launches for a clamped k = 256 row): the exception path of ill-conditioned problems, not a throughput
 // path.  Reference: pycmf/cmf_solvers.py:394-508 with :346-356 on float64 Hessians.
+// The batched form (cmf_refine64.hip.h) for 64 < n <= 256: the rows of the list travel together, `bs` at a time.
+static int refine_rows64_batched(cmf_ctx *c, int which, const RowSide &s1, const RowSide &s2, const SharedPart &sh, const RowSide *shside,
+                                 double diag, double l1, double l2, int64_t r0, float *step, double pert) {
+    const int kp = c->kp, n = c->k;
+    const int64_t kk = (int64_t)kp * kp;
+    const RowSide *sides[3] = {&s1, &s2, shside};
+    int64_t smax = 1;
+    for (const RowSide *sd : sides)
+        if (sd && sd->active) smax = std::max(smax, sd->per);
+    const std::vector<int> bad = c->bad_host;
+    c->bad_host.clear();
+    if (!(s1.active || s2.active)) return CMF_OK; // no per-row side: nothing to redo
+    // batch size: Hessian + two factor images per row, three weight / residual rows; the clamp's images (6 kk) only for its rows
+    const int64_t per_row = (3 * kk + 4 * smax + kp) * (int64_t)sizeof(double);
+    const int64_t bs = std::max<int64_t>(1, std::min<int64_t>((int64_t)bad.size(), std::min<int64_t>(4096, ((int64_t)6 << 30) / per_row)));
+    CHK(ensure(c, c->rw64, (size_t)bs * 4 * smax * sizeof(double)));
+    CHK(ensure(c, c->rh64, (size_t)(bs + 1) * kk * sizeof(double)));
+    CHK(ensure(c, c->ref_w, (size_t)bs * 2 * kk * sizeof(double)));
+    CHK(ensure(c, c->ref_g, (size_t)bs * kp * sizeof(double)));
+    CHK(ensure(c, c->ref_i, (size_t)bs * 8 * sizeof(int)));
+    double *w1 = (double *)c->rw64.p, *w2 = w1 + bs * smax, *r = w2 + bs * smax, *wx = r + bs * smax;
+    double *H64 = (double *)c->rh64.p, *S64 = nullptr, *W = (double *)c->ref_w.p, *g = (double *)c->ref_g.p;
+    int *dbad = (int *)c->ref_i.p, *dflag = dbad + bs, *dlidx = dflag + 2 * bs, *drows = dlidx + bs; // bad | flags (2 per row) | factor slot | batch row
+    if (sh.F) {
+        S64 = H64 + bs * kk;
+        CHK(gram64(c, sh.F, sh.rows_pad, S64, nullptr));
+    }
+    auto side64 = [&](const RowSide *sd) {
+        Ref64Side o;
+        o.O = sd->O; o.lists = sd->lists; o.per = (int)sd->per; o.T = sd->T; o.t_row = sd->t_row; o.t_col = sd->t_col; o.scale = sd->scale;
+        o.link = sd->link == CMF_LINK_LOGIT ? 1 : 0;
+        return o;
+    };
+    Timed tm(c, CMF_K_EIGEN);
+    for (size_t b0 = 0; b0 < bad.size(); b0 += (size_t)bs) {
+        const int nb = (int)std::min<size_t>((size_t)bs, bad.size() - b0);
+        HIPCHK(hipMemcpyAsync(dbad, bad.data() + b0, (size_t)nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        // ---- residuals, weights, gradients
+        bool first_g = true;
+        Ref64GramSide gs[2];
+        for (int q = 0; q < 3; ++q) {
+            const RowSide *sd = sides[q];
+            if (!sd || !sd->active) continue;
+            const Ref64Side o = side64(sd);
+            double *wq = q == 0 ? w1 : (q == 1 ? w2 : wx); // (the shared side of a V sweep only enters the gradient: its weights are discarded)
+            if (o.per > 0) {
+                double *rq = r;
+                hipLaunchKernelGGL(ref64_terms_kernel, dim3((unsigned)((o.per + 3) / 4), (unsigned)nb), dim3(256), 0, c->stream, o, (const float *)c->F[which], kp,
+                                   (const int *)dbad, r0, rq, wq, smax);
+                hipLaunchKernelGGL(ref64_grad_kernel, dim3((unsigned)(kp / 32), (unsigned)nb), dim3(256), 0, c->stream, o, kp, (const int *)dbad, r0,
+                                   (const double *)rq, smax, g, first_g ? 1 : 0);
+            } else if (first_g) {
+                HIPCHK(hipMemsetAsync(g, 0, (size_t)nb * kp * sizeof(double), c->stream));
+            }
+            first_g = false;
+            if (sd->sp)
+                hipLaunchKernelGGL(ref64_sparse_grad_kernel, dim3((unsigned)((kp + 255) / 256), (unsigned)nb), dim3(256), 0, c->stream,
+                                   (const int64_t *)sd->sp->indptr, (const int32_t *)sd->sp->idx, (const float *)sd->sp->val, sd->O, kp, sd->sorted,
+                                   sd->per, sd->scale, (const int *)dbad, r0, g);
+            if (q < 2) {
+                gs[q].O = sd->O; gs[q].lists = sd->lists; gs[q].per = (int)sd->per; gs[q].scale = sd->scale;
+                gs[q].w = sd->link == CMF_LINK_LOGIT ? wq : nullptr;
+            }
+            HIPCHK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(ref64_grad_finish_kernel, dim3((unsigned)((kp + 255) / 256), (unsigned)nb), dim3(256), 0, c->stream, g, (const float *)c->F[which],
+                           (const int *)dbad, r0, l1, l2, n, kp);
+        // ---- Hessians on the float64 matrix pipe
+        {
+            const int T = kp / 64, ntile = T * (T + 1) / 2;
+            hipLaunchKernelGGL(ref64_wgram_kernel, dim3((unsigned)ntile, (unsigned)nb), dim3(256), 0, c->stream, gs[0], gs[1], smax, kp, n, (const int *)dbad, r0,
+                               diag, (const double *)S64, sh.scale, H64);
+        }
+        // ---- threshold test and factor: H - pert I -> W[2 b], H -> W[2 b + 1]
+        if (n <= 128) hipLaunchKernelGGL((chol64_reg_kernel<4>), dim3((unsigned)(2 * nb)), dim3(1024), 0, c->stream, (const double *)H64, n, kp, W, kk, kp, pert, 0.0, dflag, kk, 2);
+        else hipLaunchKernelGGL((chol64_reg_kernel<8>), dim3((unsigned)(2 * nb)), dim3(1024), 0, c->stream, (const double *)H64, n, kp, W, kk, kp, pert, 0.0, dflag, kk, 2);
+        HIPCHK(hipGetLastError());
+        std::vector<int> flags((size_t)2 * nb);
+        HIPCHK(hipMemcpyAsync(flags.data(), dflag, flags.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        std::vector<int> plain_l, plain_r, clamp_r;
+        for (int b = 0; b < nb; ++b) {
+            if (!flags[2 * b] && !flags[2 * b + 1]) { plain_l.push_back(2 * b + 1); plain_r.push_back(b); } // lambda_min >= pert: the clamp is the identity
+            else clamp_r.push_back(b);
+        }
+        // ---- rows the clamp acts on: M = max(H, pert I) by the float64 matrix polynomials of shared_inverse64, batched
+        if (!clamp_r.empty() && c->hess_psd) {
+            const int ncl = (int)clamp_r.size();
+            CHK(ensure(c, c->ref_ns, (size_t)ncl * 7 * kk * sizeof(double) + (size_t)ncl * sizeof(double)));
+            double *Hc = (double *)c->ref_ns.p, *Bm = Hc + ncl * kk, *X = Bm + ncl * kk, *X2 = X + ncl * kk, *Y = X2 + ncl * kk, *Z = Y + ncl * kk, *M = Z + ncl * kk;
+            double *cn = M + ncl * kk;
+            HIPCHK(hipMemcpyAsync(drows, clamp_r.data(), (size_t)ncl * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(ref64_gather_kernel, dim3(64, (unsigned)ncl), dim3(256), 0, c->stream, (const double *)H64, (const int *)drows, Hc, kk);
+            hipLaunchKernelGGL(ns64_prepare_kernel, dim3((unsigned)ncl), dim3(1024), 0, c->stream, (const double *)Hc, Bm, X, n, kp, pert, cn, kk);
+            HIPCHK(hipGetLastError());
+            std::vector<double> hc((size_t)ncl);
+            HIPCHK(hipMemcpyAsync(hc.data(), cn, hc.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            double hmax = pert;
+            for (double v : hc) hmax = std::max(hmax, v);
+            const double delta = 1e-6 * pert;
+            int nq = (int)std::ceil(std::log(hmax / delta) / std::log(3.4445));
+            nq = std::min(std::max(nq, 4), 48);
+            const dim3 gg((unsigned)(kp / 32), (unsigned)(kp / 32), (unsigned)ncl);
+            auto mm = [&](const double *A, const double *B, double *Cc, const double *D, double al, double be, double ga) {
+                hipLaunchKernelGGL((gemm64_kernel<false>), gg, dim3(256), 0, c->stream, A, B, Cc, D, al, be, ga, kp, (float *)nullptr, 0, (const int *)nullptr, 0, kk);
+            };
+            for (int it = 0; it < nq; ++it) {
+                mm(X, X, Y, nullptr, 1.0, 0.0, 0.0);
+                mm(Y, Y, Z, Y, 2.0315, -4.7750, 3.4445);
+                mm(X, Z, X2, nullptr, 1.0, 0.0, 0.0);
+                std::swap(X, X2);
+            }
+            for (int it = 0; it < 8; ++it) {
+                mm(X, X, Y, nullptr, 1.0, 0.0, 0.0);
+                mm(X, Y, X2, X, -0.5, 1.5, 0.0);
+                std::swap(X, X2);
+            }
+            mm(X, Bm, M, Bm, 0.5, 0.5, pert);
+            HIPCHK(hipGetLastError());
+            // factor M into the rows' first factor slot (the failed H - pert I attempt left it unused)
+            CHK(ensure(c, c->ref_w2, (size_t)ncl * kk * sizeof(double) + (size_t)ncl * sizeof(int)));
+            double *WM = (double *)c->ref_w2.p;
+            int *mflag = (int *)(WM + (int64_t)ncl * kk);
+            if (n <= 128) hipLaunchKernelGGL((chol64_reg_kernel<4>), dim3((unsigned)ncl), dim3(1024), 0, c->stream, (const double *)M, n, kp, WM, kk, kp, 0.0, 0.0, mflag, kk, 1);
+            else hipLaunchKernelGGL((chol64_reg_kernel<8>), dim3((unsigned)ncl), dim3(1024), 0, c->stream, (const double *)M, n, kp, WM, kk, kp, 0.0, 0.0, mflag, kk, 1);
+            HIPCHK(hipGetLastError());
+            std::vector<int> mf((size_t)ncl);
+            HIPCHK(hipMemcpyAsync(mf.data(), mflag, mf.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            std::vector<int> cl, cr;
+            for (int q = 0; q < ncl; ++q)
+                if (!mf[q]) { cl.push_back(q); cr.push_back(clamp_r[q]); } // (a failed factorisation of M: not reached for PSD Hessians; the float32 step stands)
+            if (!cl.empty()) {
+                HIPCHK(hipMemcpyAsync(dlidx, cl.data(), cl.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(hipMemcpyAsync(drows, cr.data(), cr.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+                hipLaunchKernelGGL(ref64_solve_kernel, dim3((unsigned)cl.size()), dim3(256), 0, c->stream, (const double *)WM, kk, (const int *)dlidx, (const int *)drows,
+                                   (int)cl.size(), (const double *)g, (const int *)dbad, step, n, kp);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(c->stream)); // dlidx / drows are reused below
+                c->refined_total += (int64_t)cl.size();
+            }
+        }
+        if (!plain_l.empty()) {
+            HIPCHK(hipMemcpyAsync(dlidx, plain_l.data(), plain_l.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(drows, plain_r.data(), plain_r.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(ref64_solve_kernel, dim3((unsigned)plain_l.size()), dim3(256), 0, c->stream, (const double *)W, kk, (const int *)dlidx, (const int *)drows,
+                               (int)plain_l.size(), (const double *)g, (const int *)dbad, step, n, kp);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(c->stream)); // the host vectors above go out of scope
+            c->refined_total += (int64_t)plain_l.size();
+        }
+    }
+    return CMF_OK;
+}
+
 static int refine_rows64(cmf_ctx *c, int which, const RowSide &s1, const RowSide &s2, const SharedPart &sh, const RowSide *shside,
                          double diag, double l1, double l2, int64_t r0, float *step, double pert) {
     if (c->bad_host.empty()) return CMF_OK;
+    if (c->opt_refine_batched && c->k > 64 && c->k <= 256 && c->hess_psd)
+        return refine_rows64_batched(c, which, s1, s2, sh, shside, diag, l1, l2, r0, step, pert);
     const int kp = c->kp, n = c->k;
     const size_t kk = (size_t)kp * kp;
     const RowSide *sides[3] = {&s1, &s2, shside};

@@ -407,13 +407,16 @@ __global__ __launch_bounds__(1024) void chol64_kernel(const double *H, int n, in
 // blocked kernel below working out of L2.  Workgroup b factors H - shift_b I; L goes to W_b (lower triangle).
 template <int NB>
 __global__ __launch_bounds__(1024) void chol64_reg_kernel(const double *H, int n, int ldh, double *Wbase, int64_t wstride, int ld,
-                                                         double shift0, double shift1, int *flag) {
+                                                         double shift0, double shift1, int *flag, int64_t hstride = 0, int per_matrix = 0) {
+    // batched use (cmf_refine64.hip.h): workgroup b works on matrix b / per_matrix (stride hstride) with shift (b % per_matrix == 0 ?
+    // shift0 : shift1); per_matrix = 0: the one matrix H, workgroup 0 with shift0, the others with shift1
     constexpr int CB = 32 * NB + 2;
     __shared__ __attribute__((aligned(16))) double col[2 * CB];
     __shared__ double red[16];
     const int t = threadIdx.x, ti = t & 31, tc = t >> 5, lane = t & 63, wid = t >> 6;
     double *W = Wbase + (int64_t)blockIdx.x * wstride;
-    const double shift = blockIdx.x == 0 ? shift0 : shift1;
+    if (per_matrix > 0) H += (int64_t)(blockIdx.x / per_matrix) * hstride;
+    const double shift = (per_matrix > 0 ? (blockIdx.x % per_matrix == 0) : (blockIdx.x == 0)) ? shift0 : shift1;
     double dmax = 0.0;
     for (int i = t; i < n; i += 1024) dmax = fmax(dmax, fabs(H[(int64_t)i * ldh + i]));
     for (int off = 32; off > 0; off >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
@@ -592,8 +595,14 @@ __global__ __launch_bounds__(256) void tri_inverse64_reg_kernel(const double *L,
 // LDS pitches: k-contiguous tiles 34 doubles, n-contiguous B tile 48 doubles (conflict-free ds_read_b64 fragments).
 template <bool TRANS_B>
 __global__ __launch_bounds__(256) void gemm64_kernel(const double *A, const double *B, double *C, const double *D, double alpha, double beta,
-                                                     double gamma, int kp, float *C32, int nvalid, const int *limit, int iter) {
+                                                     double gamma, int kp, float *C32, int nvalid, const int *limit, int iter, int64_t bstride = 0) {
     if (limit && iter >= *limit) return;
+    if (bstride) { // batched (grid z): the same operation on matrix images bstride apart
+        const int64_t off = (int64_t)blockIdx.z * bstride;
+        A += off; B += off;
+        if (C) C += off;
+        if (D) D += off;
+    }
     constexpr int LA = 34, LBN = 48;
     __shared__ __attribute__((aligned(16))) double As[32 * LA];
     __shared__ __attribute__((aligned(16))) double Bs[32 * LBN];
@@ -719,8 +728,13 @@ __global__ __launch_bounds__(256) void f32_to_f64_kernel(double *out, const floa
 
 // Newton-Schulz start: Bm = H - pert I on the valid block (padding: c on the diagonal), c = min(||B||_F, ||B||_inf),
 // X = Bm / c;  out[0] = c.  One 1024-thread workgroup (H is symmetric: column sums = row sums).
-__global__ __launch_bounds__(1024) void ns64_prepare_kernel(const double *H, double *Bm, double *X, int n, int kp, double pert, double *out) {
+__global__ __launch_bounds__(1024) void ns64_prepare_kernel(const double *H, double *Bm, double *X, int n, int kp, double pert, double *out,
+                                                           int64_t bstride = 0) {
     __shared__ double red_f[16], red_m[16];
+    if (bstride) { // batched (grid x): matrix images bstride apart, one norm per image
+        const int64_t off = (int64_t)blockIdx.x * bstride;
+        H += off; Bm += off; X += off; out += blockIdx.x;
+    }
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     double fro = 0.0, cmaxv = 0.0;
     for (int col = t; col < n; col += 1024) {

@@ -70,6 +70,29 @@ def test_ill_conditioned_rows_are_redone_in_float64(lib):
     assert np.abs(got[1] - Vr).max() / np.abs(Vr).max() < 0.02 * err32
 
 
+@pytest.mark.parametrize("k,pert", [(100, 0.2), (200, 0.2), (200, 2.0)])
+def test_batched_refinement_equals_row_by_row(lib, k, pert):
+    """The batched float64 refinement (cmf_refine64.hip.h: Hessians of all listed rows on the float64 matrix pipe, batched Cholesky test,
+    blocked float64 substitutions, batched Newton-Schulz images for the rows the clamp acts on -- pert 2 makes it act on every row)
+    against the one-row-at-a-time form of round 3, every row forced through either: the same steps to float64 round-off of the
+    different summation orders, and both at the float64 oracle."""
+    from oracle import cmf_oracle as O
+    m, d, p = 70, 333, 9
+    X, Y, U, V, Z = _problem(3, m, d, p, k)
+    args = (0.6, 0.01, 0.05, "linear", "logit", 0, 7, pert, 1.0)
+    outs = []
+    for batched in (1, 0):
+        got, (rows, ratio, refined) = _step(lib, X, Y, U, V, Z, k, args, [("refine_rows_batched", batched), ("refine_rows_ratio", 1), ("refine_rows_cond", 1)])
+        assert refined >= d + p                      # every Z and V row (logit / two-sided sweeps) went through the float64 path
+        outs.append(got)
+    for a, b in zip(*outs):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-6 * np.abs(b).max())
+    Ur, Vr, Zr = U.copy(), V.copy(), Z.copy()
+    O.newton_update_step(X, Y, Ur, Vr, Zr, 0.6, 0.01, 0.05, "linear", "logit", False, False, False, 1.0, pert)
+    for a, ref in zip(outs[0], (Ur, Vr, Zr)):
+        np.testing.assert_allclose(a, ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+
+
 def test_refinement_across_chunks_and_with_sampling(lib):
     """Rows to refine in every chunk of a sweep split into several (option row_chunk), index lists in play (ratio 0.5) and
     a native CSR X: chunk-relative row numbers, absolute list rows and the sparse target term of the float64 path."""
