@@ -486,7 +486,7 @@ def main():
         roof["mfma_executed_tflops"] = achieved * (36 * 2048.0 + 4 * kp) / (kp * (kp + 1.0) + 4 * kp)
     roof["traffic_provenance"] = (None if roof.get("traffic") is None else
                                   "stored: profiles/traffic_%s.json, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                  "command (tools/refresh_r03.sh, gfx950 corrections of MI355X_MICROARCH.md); PMC collection cannot run "
+                                  "command (tools/refresh_r04.sh, gfx950 corrections of MI355X_MICROARCH.md); PMC collection cannot run "
                                   "inside a timed bench run, so this figure is NOT measured by the run that printed this line" % args.workload)
     roof["per_class_ms_per_step"] = {c: v[0] / extra for c, v in other.items() if v[1]}
     roof["per_class_note"] = ("%d extra iterations after the timed region with HIP events around every launch; inside the timed region "

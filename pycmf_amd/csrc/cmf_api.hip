@@ -156,6 +156,10 @@ struct cmf_ctx {
     DevBuf tickets;                       // one arrival counter per output tile of a split-K GEMM (zero between launches)
     int opt_inred = 0;                    // 0: split-K partials summed by a chip-wide kernel | 1: by the last-arriving workgroup of each tile
                                           // inside the GEMM kernel (A/B option; measured slower)
+    int opt_side_gram = 1;                // small Grams (k_pad 64 / 128) on a side stream beside the data pass that follows them (cmf_mu_step)
+    hipStream_t side = nullptr;           // ... that stream, with the two events of a fork / join
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool side_pending = false;
     int opt_narrow_update = 1;            // fused factor updates with few row tiles run on 256 x 128 / 256 x 64 tiles (gemm())
     int opt_fused_mu = 1;                 // 1: F <- F num / reg(F G) in the epilogue of the F G product | 0: separate kernel
     int opt_small_tile = 1;               // 1: k_pad 64 / 128 factor updates on 64-row tiles (factor_update_kernel) | 0: gemm_kernel's 256-row tile
@@ -518,19 +522,51 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
 
 // G (k_pad x k_pad) = F^T F over rows_pad rows of a factor-sized operand: the dedicated small-Gram kernels at k_pad 64 / 128
 // (cmf_kernels.hip.h), else the TN GEMM
-static int gram32(cmf_ctx *c, const float *F, int64_t rows_pad, float *G) {
+// Fork / join of the side stream: a small Gram whose consumer sits BEHIND the next data pass (U^T U + Z^T Z before the V update,
+// V^T V before the U / Z updates) is launched on a second stream that starts where the main stream stands and is joined in front
+// of the consumer -- its 96 small workgroups (24 KB of LDS, 256 threads) run in the slots the data pass leaves free on every CU
+// (one 512-thread workgroup with 98 KB of LDS at k_pad = 128) instead of in front of it.  Captured into the step graph as a fork.
+static bool side_gram_ok(const cmf_ctx *c, int64_t rows_pad) {
+    return c->opt_side_gram && !c->timing && c->opt_gram32 && (c->kp == 64 || c->kp == 128) && rows_pad >= 1024 && c->opt_arith == 0;
+}
+static int side_fork(cmf_ctx *c) {
+    if (!c->side) {
+        HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    return CMF_OK;
+}
+static int side_join(cmf_ctx *c) {
+    if (!c->side_pending) return CMF_OK;
+    HIPCHK(hipEventRecord(c->ev_join, c->side));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    c->side_pending = false;
+    return CMF_OK;
+}
+
+static int gram32(cmf_ctx *c, const float *F, int64_t rows_pad, float *G, bool on_side = false) {
     // (k_pad = 256, C4: measured equal to the TN GEMM + slab sum, 0.70 against 0.53 + 0.13 ms per iteration -- not used there)
     if (!(c->opt_gram32 && (c->kp == 64 || c->kp == 128) && rows_pad >= 1024))
         return gemm(c, MODE_TN, F, c->kp, F, c->kp, G, c->kp, c->kp, rows_pad);
+    CHK(side_join(c)); // (the partial slabs are shared: one small Gram in flight at a time)
     const int T = c->kp / 64, ntile = T * (T + 1) / 2;
     // row shares: 32 for a few thousand rows (C2); long factors (C4: 131072 stacked rows) take one share per 1024 rows
     int64_t nsplit = std::min<int64_t>(std::max<int64_t>(c->opt_gram32_shares, std::min<int64_t>(256, rows_pad / 1024)), rows_pad / 32);
     const int64_t chunk = rup((rows_pad + nsplit - 1) / nsplit, 32);
     nsplit = (rows_pad + chunk - 1) / chunk;
     CHK(ensure(c, c->gslab32, (size_t)nsplit * ntile * 64 * 64 * sizeof(float)));
+    hipStream_t st = c->stream;
+    if (on_side && side_gram_ok(c, rows_pad)) {
+        CHK(side_fork(c));
+        st = c->side;
+        c->side_pending = true;
+    }
     Timed tm(c, CMF_K_GEMM_SMALL, 2.0 * (double)rows_pad * c->kp * c->kp);
-    hipLaunchKernelGGL(gram32_partial_kernel, dim3((unsigned)ntile, (unsigned)nsplit), dim3(256), 0, c->stream, F, c->kp, rows_pad, chunk, (float *)c->gslab32.p);
-    hipLaunchKernelGGL(gram32_reduce_kernel, dim3((unsigned)std::min(64, (c->kp * c->kp + 255) / 256)), dim3(256), 0, c->stream, (const float *)c->gslab32.p,
+    hipLaunchKernelGGL(gram32_partial_kernel, dim3((unsigned)ntile, (unsigned)nsplit), dim3(256), 0, st, F, c->kp, rows_pad, chunk, (float *)c->gslab32.p);
+    hipLaunchKernelGGL(gram32_reduce_kernel, dim3((unsigned)std::min(64, (c->kp * c->kp + 255) / 256)), dim3(256), 0, st, (const float *)c->gslab32.p,
                        c->kp, (int)nsplit, G);
     HIPCHK(hipGetLastError());
     return CMF_OK;
@@ -739,6 +775,9 @@ extern "C" int cmf_ctx_destroy(cmf_ctx *c) {
         pin_give(c->pin[b]);
         if (c->pin_ev[b]) (void)hipEventDestroy(c->pin_ev[b]);
     }
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return CMF_OK;
@@ -766,6 +805,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_gram32 = value != 0;
     } else if (!strcmp(name, "chol_mfma")) {
         c->opt_chol_mfma = value != 0;
+    } else if (!strcmp(name, "side_gram")) {
+        c->opt_side_gram = value != 0;
     } else if (!strcmp(name, "narrow_update")) {
         c->opt_narrow_update = value != 0;
     } else if (!strcmp(name, "gemm_tile512")) {
@@ -1317,7 +1358,7 @@ extern "C" int cmf_mu_uz_update(cmf_ctx *c, double l1, double l2, int mask) {
     NEED_PROBLEM(c);
     DeviceGuard dg(c->device);
     if (!(mask & (CMF_UPD_U | CMF_UPD_Z))) return CMF_OK;
-    CHK(gram32(c, c->F[CMF_V], c->dp, c->G2));
+    CHK(gram32(c, c->F[CMF_V], c->dp, c->G2, true));   // V^T V beside the first data pass of the U / Z updates
     return mu_uz_update_with(c, c->G2, l1, l2, mask);
 }
 
@@ -1387,18 +1428,20 @@ extern "C" int cmf_mu_gram_v_rows(cmf_ctx *c, int64_t row0, int64_t nrows, float
 }
 static int mu_uz_update_with(cmf_ctx *c, const float *G2, double l1, double l2, int mask) {
     if (mask & CMF_UPD_U) {
-        if (!have_data(c, 0)) return fail(CMF_EINVAL, "X must be set before a U update");
+        if (!have_data(c, 0)) { (void)side_join(c); return fail(CMF_EINVAL, "X must be set before a U update"); }
         SlabRef sl;
         CHK(data_times(c, 0, false, c->F[CMF_V], c->num, false, small_tile_ok(c, c->mp) ? &sl : nullptr));
+        CHK(side_join(c)); // G2 (when it was formed on the side stream)
         CHK(mu_update(c, c->F[CMF_U], G2, c->num, c->mp, l1, l2, &sl));
     }
     if (mask & CMF_UPD_Z) {
-        if (!have_data(c, 1)) return fail(CMF_EINVAL, "Y must be set before a Z update");
+        if (!have_data(c, 1)) { (void)side_join(c); return fail(CMF_EINVAL, "Y must be set before a Z update"); }
         SlabRef sl;
         CHK(data_times(c, 1, true, c->F[CMF_V], c->num, false, small_tile_ok(c, c->pp) ? &sl : nullptr));
+        CHK(side_join(c));
         CHK(mu_update(c, c->F[CMF_Z], G2, c->num, c->pp, l1, l2, &sl));
     }
-    return CMF_OK;
+    return side_join(c);
 }
 // cmf_mu_uz_update with V^T V supplied by the caller (the all-reduced sum of the ranks' cmf_mu_gram_v_rows)
 extern "C" int cmf_mu_uz_update_gram(cmf_ctx *c, const float *G2, double l1, double l2, int mask) {
@@ -1465,7 +1508,7 @@ static int mu_v_fused(cmf_ctx *c, double l1, double l2) {
     float *P = c->vbuf, *Gs = c->vbuf + c->dp * c->kp;
     SlabRef s1, s2;
     // the Gram first: its own split goes through slab set 0, which the deferred products below must own until the update
-    CHK(gram32(c, c->F[CMF_U], c->mp + c->pp, Gs));
+    CHK(gram32(c, c->F[CMF_U], c->mp + c->pp, Gs, true));             // beside the data passes below; joined in front of the update
     CHK(data_times(c, 0, true, c->F[CMF_U], P, false, &s1));           // X^T U: slabs (set 0) or, unsplit, P itself
     const float *direct = s1.nslab > 0 ? nullptr : P;
     if (s1.nslab > 0) {
@@ -1477,6 +1520,7 @@ static int mu_v_fused(cmf_ctx *c, double l1, double l2) {
     } else {
         CHK(data_times(c, 1, false, c->F[CMF_Z], P, true));            // accumulate onto P as usual
     }
+    CHK(side_join(c));
     Epilogue e;
     e.kind = EPI_MU; e.F = c->F[CMF_V]; e.out = c->F[CMF_V]; e.a = l1; e.b = l2; e.c = 1.1920928955078125e-07;
     e.P = direct; e.Pslabs = &s1; e.Pslabs2 = &s2;
