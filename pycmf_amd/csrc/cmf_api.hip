@@ -156,7 +156,9 @@ struct cmf_ctx {
     DevBuf tickets;                       // one arrival counter per output tile of a split-K GEMM (zero between launches)
     int opt_inred = 0;                    // 0: split-K partials summed by a chip-wide kernel | 1: by the last-arriving workgroup of each tile
                                           // inside the GEMM kernel (A/B option; measured slower)
-    int opt_side_gram = 1;                // small Grams (k_pad 64 / 128) on a side stream beside the data pass that follows them (cmf_mu_step)
+    int opt_side_gram = 0;                // A/B option: small Grams (k_pad 64 / 128) on a side stream beside the data pass that follows them
+                                          // (cmf_mu_step).  Measured at C2, interleaved: 1204-1205 it/s with, 1215-1216 without -- the Gram's
+                                          // workgroups take LDS bandwidth and issue slots from the data pass for longer than they save; default off
     hipStream_t side = nullptr;           // ... that stream, with the two events of a fork / join
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_pending = false;
@@ -527,7 +529,7 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
 // of the consumer -- its 96 small workgroups (24 KB of LDS, 256 threads) run in the slots the data pass leaves free on every CU
 // (one 512-thread workgroup with 98 KB of LDS at k_pad = 128) instead of in front of it.  Captured into the step graph as a fork.
 static bool side_gram_ok(const cmf_ctx *c, int64_t rows_pad) {
-    return c->opt_side_gram && !c->timing && c->opt_gram32 && (c->kp == 64 || c->kp == 128) && rows_pad >= 1024 && c->opt_arith == 0;
+    return c->opt_side_gram && c->timing != 1 && c->opt_gram32 && (c->kp == 64 || c->kp == 128) && rows_pad >= 1024 && c->opt_arith == 0;
 }
 static int side_fork(cmf_ctx *c) {
     if (!c->side) {
