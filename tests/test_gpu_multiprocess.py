@@ -346,3 +346,20 @@ def test_cmf_n_gpus_sparse_linear_newton_takes_north_stars_partition(monkeypatch
     np.testing.assert_allclose(two.reconstruction_err_, one.reconstruction_err_, rtol=1e-4)
     for a, b in ((U2, U1), (V2, V1), (Z2, Z1)):
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-4 * np.abs(b).max())
+
+
+@pytest.mark.parametrize("workload,extra", [("tiny", []), ("tiny", ["--mu-collective", "allreduce"]), ("tiny", ["--overlap-chunks", "2"]), ("tiny5", [])])
+def test_real_rccl_two_gpus(workload, extra):
+    """Boxes with at least two GPUs only (the pool's test boxes have one: skipped there): bench.py --gpus 2 over REAL RCCL -- the
+    reduce-scatter / all-gather protocol, the single all-reduce, the side-stream overlap and the float64 Gram all-reduce of the
+    linear Newton -- every rank ends with the same V and the residuals match the one-GPU run."""
+    from pycmf_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    base = ["--steps", "3", "--warmup", "1", "--workload", workload, "--no-cpu-baseline"]
+    two = _run_bench(["--gpus", "2"] + base + extra, {"MASTER_ADDR": "127.0.0.1"})
+    one = _run_bench(["--gpus", "1"] + base, {})
+    coll = two["collective"]
+    assert coll["backend"] == "rccl" and coll["ranks_seen"] == 2 and coll["replicas"]["identical"], coll
+    for key in ("x", "y"):
+        assert abs(two["rel_residual"][key] - one["rel_residual"][key]) < 0.05 * one["rel_residual"][key]

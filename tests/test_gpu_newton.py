@@ -703,3 +703,36 @@ def test_split_row_launches_for_few_rows_with_long_lists(lib, k, link):
         O.newton_update_step(X.astype(np.float64), Y, U, V, Z, 0.5, 0.01, 0.3, "linear", "logit", False, False, False, 1.0, 0.2,
                              update_U=False, update_V=False)
         np.testing.assert_allclose(got[1], Z, rtol=0, atol=1e-3 * np.abs(Z).max())
+
+
+@pytest.mark.parametrize("k", [129, 200, 256])
+def test_blocked_mfma_cholesky_matches_the_rank1_kernel(lib, k):
+    """Per-row solves at k_pad = 256: the blocked Cholesky on the matrix pipe (cmf_chol_mfma.hip.h; valid orders that end inside a
+    32-column panel, and the full 256) against the rank-1 register kernel it replaces (option chol_mfma = 0) -- the same
+    threshold decisions, the same steps to float32 round-off of two different elimination orders -- and both against the
+    float64 oracle (pycmf/cmf_solvers.py:346-356, :321-326)."""
+    from oracle import cmf_oracle as O
+    rng = np.random.RandomState(k)
+    m, d, p = 96, 420, 24
+    X, Y = np.abs(rng.randn(m, d)), rng.rand(d, p)
+    sc = 0.4 / np.sqrt(k / 8.0)
+    U, V, Z = sc * rng.randn(m, k), sc * rng.randn(d, k), sc * rng.randn(p, k)
+    args = (0.5, 0.0, 0.3, "logit", "logit", 0, 7, 0.2, 1.0)
+    outs = []
+    for opt in (1, 0):
+        ctx = lib.Context(0)
+        ctx.set_option("chol_mfma", opt)
+        ctx.set_problem(m, d, p, k)
+        ctx.set_data(0, X); ctx.set_data(1, Y)
+        for w, F in enumerate((U, V, Z)):
+            ctx.set_factor(w, F)
+        ctx.newton_step(*args)
+        outs.append(([ctx.get_factor(w) for w in range(3)], ctx.newton_clamp_stats()))
+        ctx.close()
+    assert outs[0][1][0] == outs[1][1][0]                 # the same rows went to the spectral clamp
+    for a, b in zip(outs[0][0], outs[1][0]):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-5 * np.abs(b).max())
+    Ur, Vr, Zr = U.copy(), V.copy(), Z.copy()
+    O.newton_update_step(X, Y, Ur, Vr, Zr, 0.5, 0.0, 0.3, "logit", "logit", False, False, False, 1.0, 0.2)
+    for a, ref in zip(outs[0][0], (Ur, Vr, Zr)):
+        np.testing.assert_allclose(a, ref, rtol=0, atol=2e-4 * np.abs(ref).max())

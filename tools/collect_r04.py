@@ -18,11 +18,17 @@ def counters(path):
     return out
 
 
+LINES_ONLY = len(sys.argv) > 1 and sys.argv[1] == "lines"   # after `bash tools/refresh_r04.sh lines`: only the bench lines are new
 for w in ("c4", "c2", "c3", "c5", "c5l"):
     shutil.copy(os.path.join(SRC, "%s.json" % w), os.path.join(DST, "%s_%s_n1_bench.json" % (TAG, w)))
-    shutil.copy(os.path.join(SRC, "prof_%s" % w, "%s_kernel_stats.csv" % w), os.path.join(DST, "%s_%s_n1_kernel_stats.csv" % (TAG, w)))
+    if not LINES_ONLY:
+        shutil.copy(os.path.join(SRC, "prof_%s" % w, "%s_kernel_stats.csv" % w), os.path.join(DST, "%s_%s_n1_kernel_stats.csv" % (TAG, w)))
 for w in ("c3z", "c3x"):
     shutil.copy(os.path.join(SRC, "%s.json" % w), os.path.join(DST, "%s_%s_n1_bench.json" % (TAG, w)))
+if LINES_ONLY:
+    for w in ("c3z", "c3x"):
+        shutil.copy(os.path.join(SRC, "%s.json" % w), os.path.join(DST, "%s_%s_n1_bench.json" % (TAG, w)))
+    sys.exit(0)
 for n in (2, 4, 8):
     for mode in ("rsag", "allreduce"):
         shutil.copy(os.path.join(SRC, "c4_null%d_%s.json" % (n, mode)), os.path.join(DST, "%s_c4_rank0_of_%d_%s_null_collectives.json" % (TAG, n, mode)))

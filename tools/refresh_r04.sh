@@ -6,6 +6,10 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/r04
 mkdir -p "$O"
 cd "$R"
+# two stages: `bash tools/refresh_r04.sh` (everything), then -- after `python tools/collect_r04.py` has written profiles/traffic_*.json
+# from this run's PMC passes -- `bash tools/refresh_r04.sh lines`: the bench lines again, so that the stored traffic figure each line
+# quotes is the one measured on the same build
+MODE=${1:-all}
 python3 bench.py --steps 20 --warmup 5 > $O/c4.json 2> $O/c4.err
 python3 bench.py --workload c2 --steps 200 --warmup 20 > $O/c2.json 2> $O/c2.err
 python3 bench.py --workload c3 --steps 5 --warmup 2 > $O/c3.json 2> $O/c3.err
@@ -13,6 +17,7 @@ python3 bench.py --workload c3z --steps 5 --warmup 2 --no-cpu-baseline > $O/c3z.
 python3 bench.py --workload c3x --steps 3 --warmup 1 --no-cpu-baseline > $O/c3x.json 2> $O/c3x.err
 python3 bench.py --workload c5 --steps 10 --warmup 3 > $O/c5.json 2> $O/c5.err
 python3 bench.py --workload c5l --steps 3 --warmup 1 > $O/c5l.json 2> $O/c5l.err
+if [ "$MODE" = "lines" ]; then exit 0; fi
 # per-rank compute of the C4 shards (collectives stubbed out: CMF_COMM_BACKEND=null), both MU protocols; few steps: a rank without
 # peers diverges (its Grams are 1 / N of the true ones)
 for n in 2 4 8; do
