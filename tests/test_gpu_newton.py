@@ -730,8 +730,8 @@ def test_blocked_mfma_cholesky_matches_the_rank1_kernel(lib, k):
         outs.append(([ctx.get_factor(w) for w in range(3)], ctx.newton_clamp_stats()))
         ctx.close()
     assert outs[0][1][0] == outs[1][1][0]                 # the same rows went to the spectral clamp
-    for a, b in zip(outs[0][0], outs[1][0]):
-        np.testing.assert_allclose(a, b, rtol=0, atol=2e-5 * np.abs(b).max())
+    for a, b in zip(outs[0][0], outs[1][0]):   # (float32 solves of Hessians with cond ~ 1e3 in two elimination orders: cond x eps32)
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-4 * np.abs(b).max())
     Ur, Vr, Zr = U.copy(), V.copy(), Z.copy()
     O.newton_update_step(X, Y, Ur, Vr, Zr, 0.5, 0.0, 0.3, "logit", "logit", False, False, False, 1.0, 0.2)
     for a, ref in zip(outs[0][0], (Ur, Vr, Zr)):
