@@ -230,6 +230,9 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return launch_ranks(args.gpus, sys.argv[1:])
+    # (the host driver of this pool only supports dmabuf IPC: without this RCCL cannot open peer memory; it must be in the
+    # environment before the first HIP call of the process, i.e. before libcmfhip is loaded)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

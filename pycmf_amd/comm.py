@@ -127,7 +127,30 @@ def exchange_unique_id(rank, world, timeout=None):
     return raw, path
 
 
-class RcclCollectives:
+class _ProtocolCheck:
+    def self_test(self):
+        """Known-answer run of the in-place reduce-scatter and all-gather on this communicator (every rank must call it): True when
+        every rank saw the sums / the gathered chunks it had to see.  `make_sharded_mu` falls back to the single all-reduce
+        otherwise -- a wrong result of the row-blocked protocol would otherwise only show as a strange residual."""
+        from . import _lib
+        w, r, per = self.world, self.rank, 64
+        buf = _lib.DeviceArray(self.ctx, w * per, 1)
+        i = np.arange(w * per, dtype=np.float32)
+        self.ctx.copy_from_host(buf, (r + 1) + i)
+        self.reduce_scatter(buf)
+        got = self.ctx.copy_to_host(buf).reshape(-1)[r * per:(r + 1) * per]
+        ok = np.array_equal(got, w * (w + 1) / 2 + w * i[r * per:(r + 1) * per])
+        mine = np.full(w * per, -1.0, dtype=np.float32)
+        mine[r * per:(r + 1) * per] = 100.0 * (r + 1) + np.arange(per)
+        self.ctx.copy_from_host(buf, mine)
+        self.all_gather(buf)
+        want = np.concatenate([100.0 * (q + 1) + np.arange(per) for q in range(w)]).astype(np.float32)
+        ok = ok and np.array_equal(self.ctx.copy_to_host(buf).reshape(-1), want)
+        buf.release()
+        return bool(self.all_reduce_host([0.0 if ok else 1.0], "max")[0] == 0.0)
+
+
+class RcclCollectives(_ProtocolCheck):
     """The context's RCCL communicator behind the interface the sharded drivers use.  ``all_reduce`` / ``all_gather`` only enqueue
     on the context's stream; ``all_reduce_host`` and ``barrier`` wait."""
 
@@ -191,7 +214,7 @@ class RcclCollectives:
         self.ctx.comm_destroy()
 
 
-class HostStagedCollectives:
+class HostStagedCollectives(_ProtocolCheck):
     """TEST DOUBLE (one GPU shared by all ranks): the same interface, every collective staged through host memory.  A
     collective number s of rank r is the file ``<dir>/<key>_s_r.npy``; a rank publishes its contribution, waits for all of
     them, combines them in rank order (deterministic) and removes its file of collective s - 1 (every rank has read it by then:

@@ -372,6 +372,11 @@ def make_sharded_mu(ctx, coll, chunks=1, mode=None):
         return SingleGpuStep(lambda l1, l2, mask: ctx.mu_step(l1, l2, mask))
     if mode is None:
         mode = os.environ.get("PYCMF_AMD_MU_COLLECTIVE", "rsag") if chunks <= 1 else "allreduce"
+        if mode == "rsag" and hasattr(coll, "self_test") and not coll.self_test():
+            import warnings
+            warnings.warn("pycmf_amd: the known-answer test of the in-place reduce-scatter / all-gather failed on this communicator; "
+                          "falling back to the single all-reduce of the MU iteration", RuntimeWarning)
+            mode = "allreduce"
     if mode == "rsag":
         block_rows, nelem = ctx.mu_blocked_layout(coll.world)
         # (world * block_rows) x k_pad, zero-filled: the rows beyond d_pad of the last blocks stay zero
