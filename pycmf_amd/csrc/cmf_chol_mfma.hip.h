@@ -156,6 +156,46 @@ __device__ __forceinline__ void cm_trail_block(cm_f32x16 (&acc)[10], const float
     for (int s = 0; s < 16; ++s) acc[cm_slot(P, Q)] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], sb[s * 64], acc[cm_slot(P, Q)], 0, 0, 0);
 }
 
+// The trailing blocks of one panel step as compile-time recursions over the slot grid (q = block column pair, p = block row pair):
+// slot (P, Q) of wave (a, b) is block (2 P + a, 2 Q + b); it takes part when its column lies behind the panel (K > J), it exists
+// (I >= K, inside the valid order) and it is not the block the look-ahead has already updated.
+template <int J, int Q, int P>
+struct CmTrailRows {
+    static __device__ __forceinline__ void run(cm_f32x16 (&acc)[10], const float (&af)[16], const float *lx, int a, int b, int lane, int nblk, bool next_owner) {
+        constexpr int Np = (J + 1) >> 1;
+        const int I = 2 * P + a;
+        const bool on = (P > Q || a >= b) && I < nblk && !(next_owner && P == Np && Q == Np);
+        if (on) cm_trail_block<P, Q>(acc, af, lx, I, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        CmTrailRows<J, Q, P + 1>::run(acc, af, lx, a, b, lane, nblk, next_owner);
+    }
+};
+template <int J, int Q>
+struct CmTrailRows<J, Q, 4> {
+    static __device__ __forceinline__ void run(cm_f32x16 (&)[10], const float (&)[16], const float *, int, int, int, int, bool) {}
+};
+template <int J, int Q>
+struct CmTrailCols {
+    static __device__ __forceinline__ void run(cm_f32x16 (&acc)[10], const float *lx, int a, int b, int lane, int nblk, bool next_owner) {
+        constexpr int Jp = J >> 1, Jb = J & 1;
+        const int K = 2 * Q + b;
+        const bool kon = (Q > Jp || (Jb == 0 && b == 1)) && K < nblk;
+        if (kon) {
+            float af[16];
+            const float *sa = lx + K * (16 * 64) + lane;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) af[s] = -sa[s * 64];
+            CmTrailRows<J, Q, Q>::run(acc, af, lx, a, b, lane, nblk, next_owner);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        CmTrailCols<J, Q + 1>::run(acc, lx, a, b, lane, nblk, next_owner);
+    }
+};
+template <int J>
+struct CmTrailCols<J, 4> {
+    static __device__ __forceinline__ void run(cm_f32x16 (&)[10], const float *, int, int, int, int, bool) {}
+};
+
 // One panel step J of the factorisation (J compile-time: every slot index and most predicates fold away; a, b stay run-time,
 // wave-uniform).  On entry the chain of panel J has been run by its owner (cm_chain_panel: before the first step, or as the
 // LOOK-AHEAD of step J - 1).  Look-ahead: the owner of block (J + 1, J + 1) updates that block first, runs the chain of panel
@@ -215,30 +255,7 @@ __device__ __forceinline__ void cm_panel_step(cm_f32x16 (&acc)[10], float *linv,
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-#pragma unroll
-    for (int q = Jp; q < 4; ++q) {
-        const int K = 2 * q + b;
-        const bool kon = (q > Jp || (Jb == 0 && b == 1)) && K < nblk;
-        if (kon) {
-            float af[16];
-            const float *sa = lx + K * (16 * 64) + lane;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) af[s] = -sa[s * 64];
-#pragma unroll
-            for (int p = q; p < 4; ++p) {
-                const int I = 2 * p + a;
-                const bool on = (p > q || a >= b) && I < nblk && !(next_owner && p == Np && q == Np);
-                if (on) {
-                    if (p == 0) cm_trail_block<0, (0 <= 0 ? 0 : 0)>(acc, af, lx, I, lane);   // p >= q: the only slot with p == 0 is (0, 0)
-                    else if (p == 1) { if (q == 0) cm_trail_block<1, 0>(acc, af, lx, I, lane); else cm_trail_block<1, 1>(acc, af, lx, I, lane); }
-                    else if (p == 2) { if (q == 0) cm_trail_block<2, 0>(acc, af, lx, I, lane); else if (q == 1) cm_trail_block<2, 1>(acc, af, lx, I, lane); else cm_trail_block<2, 2>(acc, af, lx, I, lane); }
-                    else { if (q == 0) cm_trail_block<3, 0>(acc, af, lx, I, lane); else if (q == 1) cm_trail_block<3, 1>(acc, af, lx, I, lane); else if (q == 2) cm_trail_block<3, 2>(acc, af, lx, I, lane); else cm_trail_block<3, 3>(acc, af, lx, I, lane); }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    CmTrailCols<J, Jp>::run(acc, lx, a, b, lane, nblk, next_owner);
     CM_STAMP(10 + 3 * J);
 }
 

@@ -643,13 +643,24 @@ __global__ __launch_bounds__(256) void class_sum_blocks_kernel(float *H, const f
 #pragma unroll
         for (int m = 0; m < RMAX; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int ma = (1 << split) - 1, mb = (NC - 1) ^ ma;
-        for (int q = 1; q < NC; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(base + (int64_t)(q - 1) * KK);
+        // four class blocks in flight per thread, added in ascending class order (one dependent load per class left the kernel
+        // latency-bound at 3.9 TB/s of the 76 GB of class images a C3 iteration reads)
+        for (int q0 = 1; q0 < NC; q0 += 4) {
+            f32x4 v[4];
 #pragma unroll
-            for (int m = 0; m < RMAX; ++m)
-                if ((q >> m) & 1) acc[m] += v; // bits >= R are never set
-            if ((q & ma) == ma) pa += v;
-            if ((q & mb) == mb) pb += v;
+            for (int u = 0; u < 4; ++u)
+                v[u] = (q0 + u < NC) ? *reinterpret_cast<const f32x4 *>(base + (int64_t)(q0 + u - 1) * KK) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = q0 + u;
+                if (q < NC) {
+#pragma unroll
+                    for (int m = 0; m < RMAX; ++m)
+                        if ((q >> m) & 1) acc[m] += v[u]; // bits >= R are never set
+                    if ((q & ma) == ma) pa += v[u];
+                    if ((q & mb) == mb) pb += v[u];
+                }
+            }
         }
         if (cert) {
             *reinterpret_cast<f32x4 *>(cert + (2 * grp) * KK + off) = pa;
