@@ -380,7 +380,7 @@ def main():
         lo = -float(coll.all_reduce_host([-vsum], "max")[0])
         replicas = {"sum_abs_V_max_over_ranks": hi, "sum_abs_V_min_over_ranks": lo, "identical": hi == lo}
 
-    names = ("gemm_nn", "gemm_tn", "gemm_small", "gemm_nt", "spmm", "rowhess", "eigen", "elementwise")
+    names = ("gemm_nn", "gemm_tn", "gemm_pair", "gemm_small", "gemm_nt", "spmm", "rowhess", "eigen", "elementwise")
     classes = {c: tuple(sum(v) for v in zip(*(c_.kernel_time(c) for c_ in ctxs))) for c in names}
     rh_samples = tuple(sum(v) for v in zip(*(c_.rowhess_samples() for c_ in ctxs)))
     # the other kernel classes: a few more iterations OUTSIDE the timed region with events around every launch
@@ -407,7 +407,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     its = args.steps / elapsed
     # dominant kernel class = most device time on rank 0
-    dom = max(("gemm_nn", "gemm_tn", "spmm", "rowhess"), key=lambda c: classes[c][0])
+    dom = max(("gemm_nn", "gemm_tn", "gemm_pair", "spmm", "rowhess"), key=lambda c: classes[c][0])
     dms, dn, dfl = classes[dom]
     if dom == "spmm":
         # HBM-bound gather kernel (column-blocked, output-stationary SpMM).  Algorithmic (compulsory) bytes of one A*F
@@ -453,12 +453,15 @@ def main():
         if dom == "rowhess":
             kname = ("cmfk::row_hess_kernel<%d>  (fused per-row gradient + Hessian over the sampled rows; flops "
                      "credited for the symmetric half of each H_i, k(k+1) per sample row gathered)" % kp)
+        elif dom == "gemm_pair":
+            kname = ("cmfk::gemm_pair_kernel  (k_pad = 128: X^T U with Y Z, X V with Y^T V -- the two data passes of an MU "
+                     "half-iteration as one launch, their K-steps cut into equal quotas per CU)")
         else:
             kname = "cmfk::gemm_kernel<%d, %d, 0, 4>  (%s data pass)" % (
                 0 if dom == "gemm_nn" else 1, 256 if k >= 256 else kp,
                 "NN: X V / Y Z / W KR" if dom == "gemm_nn" else "TN: X^T U / Y^T V / W^T KR")
         peak = FP32_MFMA_PEAK_TFLOPS
-        if bf16x6 and dom in ("gemm_nn", "gemm_tn"):
+        if bf16x6 and dom in ("gemm_nn", "gemm_tn", "gemm_pair"):
             # optional arithmetic: 6 bf16 MFMA products per fp32-equivalent product -> the bound is the bf16 matrix peak / 6
             peak = BF16_MFMA_PEAK_TFLOPS / 6.0
             kname = ("cmfk::bf16x6_gemm_kernel  (data pass on v_mfma_f32_32x32x16_bf16, three bf16 planes per fp32 operand, "

@@ -57,7 +57,8 @@ enum {
     CMF_K_GEMM_SMALL = 5,/* factor-side products: Grams, F G, grad H^-1 */
     CMF_K_SPMM = 6,      /* native CSR: A F, A^T F, sum_nnz a_ij (l_i . r_j)  */
     CMF_K_ROWHESS = 7,   /* fused per-row gradient + Hessian over the sampled rows */
-    CMF_K_COUNT = 8
+    CMF_K_GEMM_PAIR = 8, /* k_pad = 128: the two data passes of an MU half-iteration as one balanced launch (X^T U with Y Z, X V with Y^T V) */
+    CMF_K_COUNT = 9
 };
 
 const char *cmf_last_error(void);

@@ -17,7 +17,7 @@ CMF_NN_U, CMF_NN_V, CMF_NN_Z = 1, 2, 4      # nn_mask bits
 LINKS = {"linear": 0, "logit": 1}
 UPD_U, UPD_V, UPD_Z = 1, 2, 4
 K_GEMM_NN, K_GEMM_TN, K_GEMM_NT, K_ELEMWISE, K_EIGEN = 0, 1, 2, 3, 4
-KERNEL_CLASSES = {"gemm_nn": 0, "gemm_tn": 1, "gemm_nt": 2, "elementwise": 3, "eigen": 4, "gemm_small": 5, "spmm": 6, "rowhess": 7}
+KERNEL_CLASSES = {"gemm_nn": 0, "gemm_tn": 1, "gemm_nt": 2, "elementwise": 3, "eigen": 4, "gemm_small": 5, "spmm": 6, "rowhess": 7, "gemm_pair": 8}
 
 _ERR = {1: ValueError, 2: RuntimeError, 3: MemoryError, 4: RuntimeError, 5: NotImplementedError}
 

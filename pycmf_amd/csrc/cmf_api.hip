@@ -3,6 +3,7 @@
 // (reference: pycmf/cmf_solvers.py:248-263 MU, :510-522 Newton, :36-42 error).
 #include "../../include/cmfhip.h"
 #include "cmf_kernels.hip.h"
+#include "cmf_gemm_pair.hip.h"
 #include "cmf_eigen.hip.h"
 #include "cmf_chol_mfma.hip.h"
 #include "cmf_sparse.hip.h"
@@ -111,6 +112,7 @@ struct cmf_ctx {
     int opt_pipe_small = 4; // staging schedule of the factor-side products (0 or 4; 4 measured +5..15 %, tools/ab_small.py)
     int opt_pipe = 4;      // GEMM staging schedule (see gemm_kernel PIPE); 4 measured best (tools/ab_gemm.py)
     int opt_split = -1;    // force split-K factor (<=0: heuristic)
+    int opt_pair = 1;      // k_pad = 128, dense X and Y: the two data passes of an MU half-iteration as one balanced launch (cmf_gemm_pair.hip.h) | 0: two split launches
     int opt_tile512 = 0;   // A/B: k_pad = 128 data passes on a 512 x 128 x 16 tile (GemmCfg TILE 1) instead of 256 x 128 x 32
     int opt_rounds = 1;    // split-K heuristic of the data passes: aim at this many workgroups per CU (A/B option: 2 measured within noise of 1 at C2)
     int opt_arith_min_tiles = 8;   // ... only for operands of at least this many 256-row tiles
@@ -258,7 +260,7 @@ struct Timed {
     bool on = false;
     double flops = 0.0;
     Timed(cmf_ctx *c_, int cls_, double flops_ = 0.0) : c(c_), cls(cls_), flops(flops_) {
-        const bool want = c->timing == 1 || (c->timing == 2 && (cls == CMF_K_GEMM_NN || cls == CMF_K_GEMM_TN || cls == CMF_K_SPMM || cls == CMF_K_ROWHESS));
+        const bool want = c->timing == 1 || (c->timing == 2 && (cls == CMF_K_GEMM_NN || cls == CMF_K_GEMM_TN || cls == CMF_K_GEMM_PAIR || cls == CMF_K_SPMM || cls == CMF_K_ROWHESS));
         if (want && ev_get(c, &a) == CMF_OK && ev_get(c, &b) == CMF_OK) {
             on = true;
             (void)hipEventRecord(a, c->stream);
@@ -433,6 +435,8 @@ struct SlabRef { // a split-K result left unreduced for a consumer that sums the
     const float *base = nullptr;
     int nslab = 0;
     int64_t stride = 0;
+    int64_t quota = 0, unit0 = 0; // slabs of a paired launch (quota > 0): a 256-row tile has pair_slots(quota, unit0, ksteps, tile) of them
+    int ksteps = 0;
 };
 
 struct Epilogue { // fused factor update in the epilogue of a factor-side product (gemm_kernel, epi != 0)
@@ -582,8 +586,14 @@ static int factor_update(cmf_ctx *c, const float *A, const float *B, const Epilo
     FactorUpdArgs g;
     memset(&g, 0, sizeof g);
     g.A = A; g.B = B; g.epi = e.kind; g.F = e.F; g.P = e.P; g.out = e.out;
-    if (e.Pslabs && e.Pslabs->nslab > 0) { g.S1 = e.Pslabs->base; g.n1 = e.Pslabs->nslab; g.stride1 = e.Pslabs->stride; }
-    if (e.Pslabs2 && e.Pslabs2->nslab > 0) { g.S2 = e.Pslabs2->base; g.n2 = e.Pslabs2->nslab; g.stride2 = e.Pslabs2->stride; }
+    if (e.Pslabs && e.Pslabs->nslab > 0) {
+        g.S1 = e.Pslabs->base; g.n1 = e.Pslabs->nslab; g.stride1 = e.Pslabs->stride;
+        g.q1 = e.Pslabs->quota; g.u1 = e.Pslabs->unit0; g.ks1 = e.Pslabs->ksteps;
+    }
+    if (e.Pslabs2 && e.Pslabs2->nslab > 0) {
+        g.S2 = e.Pslabs2->base; g.n2 = e.Pslabs2->nslab; g.stride2 = e.Pslabs2->stride;
+        g.q2 = e.Pslabs2->quota; g.u2 = e.Pslabs2->unit0; g.ks2 = e.Pslabs2->ksteps;
+    }
     g.a = (float)e.a; g.b = (float)e.b; g.c = (float)e.c; g.rows_valid = e.rows; g.kvalid = e.kvalid; g.nn = e.nn;
     Timed tm(c, CMF_K_GEMM_SMALL, 2.0 * (double)rows_pad * c->kp * c->kp);
     const dim3 grid((unsigned)(rows_pad / 64));
@@ -811,6 +821,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_side_gram = value != 0;
     } else if (!strcmp(name, "narrow_update")) {
         c->opt_narrow_update = value != 0;
+    } else if (!strcmp(name, "pair_passes")) {
+        c->opt_pair = value != 0;
     } else if (!strcmp(name, "gemm_tile512")) {
         c->opt_tile512 = value != 0;
     } else if (!strcmp(name, "gemm_rounds")) {
@@ -1353,6 +1365,64 @@ extern "C" int cmf_mu_v_apply(cmf_ctx *c, const float *buf, double l1, double l2
     return mu_update(c, c->F[CMF_V], Gs, P, c->dp, l1, l2);
 }
 
+// ---- paired data passes (cmf_gemm_pair.hip.h): product i = X or Y (which), transposed or not, times the factor B ----
+struct PairSide { int which; bool trans; const float *B; };
+static void pair_shape(const cmf_ctx *c, const PairSide &sd, int64_t *mout, int64_t *kred) {
+    const int64_t rp = sd.which == 0 ? c->mp : c->dp, cp = sd.which == 0 ? c->dp : c->pp;
+    *mout = sd.trans ? cp : rp; *kred = sd.trans ? rp : cp;
+}
+// worth it when BOTH products would otherwise split their reduction (few output tiles against the CUs), and only on the plain
+// fp32 path the kernel restates (k_pad = 128, staging schedule 4, dense inputs, slabs summed by factor_update_kernel)
+static bool pair_ok(const cmf_ctx *c, const PairSide &a0, const PairSide &a1) {
+    if (!c->opt_pair || c->kp != 128 || !c->X || !c->Y || c->opt_arith || c->opt_pipe != 4 || c->opt_tile512 || c->opt_split > 0 ||
+        c->opt_inred || !c->opt_fused_mu || !c->opt_small_tile)
+        return false;
+    for (const PairSide *sd : {&a0, &a1}) {
+        int64_t mout, kred;
+        pair_shape(c, *sd, &mout, &kred);
+        if (mout / 256 >= (int64_t)(c->num_cu * 3) / 4 || kred < 256 || !small_tile_ok(c, mout)) return false;
+    }
+    return true;
+}
+static int data_times_pair(cmf_ctx *c, const PairSide &a0, const PairSide &a1, SlabRef *s0, SlabRef *s1) {
+    PairArgs g;
+    memset(&g, 0, sizeof g);
+    const PairSide *sides[2] = {&a0, &a1};
+    SlabRef *refs[2] = {s0, s1};
+    DevBuf *bufs[2] = {&c->slabs, &c->slabs_b};
+    int64_t unit = 0, mout[2];
+    double flops = 0.0;
+    for (int i = 0; i < 2; ++i) {
+        int64_t kred;
+        pair_shape(c, *sides[i], &mout[i], &kred);
+        PairProb &p = g.p[i];
+        p.A = sides[i]->which == 0 ? c->X : c->Y; p.lda = sides[i]->which == 0 ? c->dp : c->pp;
+        p.B = sides[i]->B; p.ldb = c->kp;
+        p.mode = sides[i]->trans ? MODE_TN : MODE_NN;
+        p.tiles = (int)(mout[i] / 256); p.ksteps = (int)(kred / 32);
+        p.unit0 = unit; p.slab_stride = mout[i] * c->kp;
+        unit += (int64_t)p.tiles * p.ksteps;
+        flops += 2.0 * (double)mout[i] * (double)c->kp * (double)kred;
+    }
+    g.total = unit;
+    g.quota = (unit + c->num_cu - 1) / c->num_cu;
+    const int64_t nwg = (unit + g.quota - 1) / g.quota;
+    for (int i = 0; i < 2; ++i) {
+        PairProb &p = g.p[i];
+        const int64_t maxslots = (p.ksteps + g.quota - 1) / g.quota + 1;
+        CHK(ensure(c, *bufs[i], (size_t)maxslots * p.slab_stride * sizeof(float)));
+        p.C = (float *)bufs[i]->p;
+        refs[i]->base = p.C; refs[i]->nslab = (int)maxslots; refs[i]->stride = p.slab_stride;
+        refs[i]->quota = g.quota; refs[i]->unit0 = p.unit0; refs[i]->ksteps = p.ksteps;
+    }
+    constexpr size_t lds = GemmCfg<MODE_NN, 128>::LDS_BYTES > GemmCfg<MODE_TN, 128>::LDS_BYTES ? GemmCfg<MODE_NN, 128>::LDS_BYTES : GemmCfg<MODE_TN, 128>::LDS_BYTES;
+    CHK(allow_big_lds(c, reinterpret_cast<const void *>(&gemm_pair_kernel), (int)lds));
+    Timed tm(c, CMF_K_GEMM_PAIR, flops * c->flop_scale);
+    hipLaunchKernelGGL(gemm_pair_kernel, dim3((unsigned)nwg), dim3(512), lds, c->stream, g);
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+
 static int mu_uz_update_with(cmf_ctx *c, const float *G2, double l1, double l2, int mask);
 // U *= X V / reg(U V^T V), Z *= Y^T V / reg(Z V^T V): cmf_solvers.py:230-240, :257-263.
 // (U V^T) V is evaluated as U (V^T V): same value, 2mk^2 instead of 4mdk flops.
@@ -1429,6 +1499,16 @@ extern "C" int cmf_mu_gram_v_rows(cmf_ctx *c, int64_t row0, int64_t nrows, float
     return gram32(c, c->F[CMF_V] + row0 * c->kp, nrows, G2);
 }
 static int mu_uz_update_with(cmf_ctx *c, const float *G2, double l1, double l2, int mask) {
+    const PairSide xv{0, false, c->F[CMF_V]}, ytv{1, true, c->F[CMF_V]};
+    if ((mask & CMF_UPD_U) && (mask & CMF_UPD_Z) && pair_ok(c, xv, ytv)) {
+        // X V and Y^T V (cmf_solvers.py:232, :238) read the same V: one balanced launch, then the two updates
+        SlabRef su, sz;
+        CHK(data_times_pair(c, xv, ytv, &su, &sz));
+        CHK(side_join(c));
+        CHK(mu_update(c, c->F[CMF_U], G2, c->num, c->mp, l1, l2, &su));
+        CHK(mu_update(c, c->F[CMF_Z], G2, c->num, c->pp, l1, l2, &sz));
+        return CMF_OK;
+    }
     if (mask & CMF_UPD_U) {
         if (!have_data(c, 0)) { (void)side_join(c); return fail(CMF_EINVAL, "X must be set before a U update"); }
         SlabRef sl;
@@ -1511,6 +1591,15 @@ static int mu_v_fused(cmf_ctx *c, double l1, double l2) {
     SlabRef s1, s2;
     // the Gram first: its own split goes through slab set 0, which the deferred products below must own until the update
     CHK(gram32(c, c->F[CMF_U], c->mp + c->pp, Gs, true));             // beside the data passes below; joined in front of the update
+    const PairSide xtu{0, true, c->F[CMF_U]}, yz{1, false, c->F[CMF_Z]};
+    if (pair_ok(c, xtu, yz)) { // P = X^T U + Y Z (cmf_solvers.py:244) as one balanced launch, its partial tiles summed by the update
+        CHK(data_times_pair(c, xtu, yz, &s1, &s2));
+        CHK(side_join(c));
+        Epilogue e;
+        e.kind = EPI_MU; e.F = c->F[CMF_V]; e.out = c->F[CMF_V]; e.a = l1; e.b = l2; e.c = 1.1920928955078125e-07;
+        e.P = nullptr; e.Pslabs = &s1; e.Pslabs2 = &s2;
+        return factor_update(c, c->F[CMF_V], Gs, e, c->dp);
+    }
     CHK(data_times(c, 0, true, c->F[CMF_U], P, false, &s1));           // X^T U: slabs (set 0) or, unsplit, P itself
     const float *direct = s1.nslab > 0 ? nullptr : P;
     if (s1.nslab > 0) {

@@ -427,7 +427,25 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
             }
         } else {
             float a[2][C::TM], b[2][C::TN];
+            // k_pad = 128 tile: this lane's fragment bases of the K-step, as LDS pointers the optimiser cannot take apart.  Left
+            // alone, hipcc hoists (lane term + 2 sidx * row pitch) out of the K loop as 27 loop-invariant registers and rebuilds
+            // every fragment address with four vector adds per MFMA group; from a pinned base the 16 groups are one register
+            // plus immediate offsets, as in the 256-wide build (which folds them by itself and is left exactly as it was).
+            typedef __attribute__((address_space(3))) const float lds_cf;
+            constexpr bool PIN = (BN == 128 && TILE == 0);
+            lds_cf *Ap = (lds_cf *)(As + lh * C::BM + wrow0 + C::TM * l31);
+            lds_cf *Bp = (lds_cf *)(Bs + lh * BN + wcol0 + C::TN * l31);
+            if constexpr (PIN) asm volatile("" : "+v"(Ap), "+v"(Bp));
             auto ld_frag = [&](int sidx, float *da, float *db) {
+                if constexpr (PIN) {
+                    static_assert(!PIN || (C::TM == 2 && C::TN == 2), "pinned fragment reads: 64 x 64 wave tile");
+                    typedef __attribute__((address_space(3))) const f32x2 lds_cf2;
+                    const f32x2 va = *reinterpret_cast<lds_cf2 *>(Ap + 2 * sidx * C::BM);
+                    const f32x2 vb = *reinterpret_cast<lds_cf2 *>(Bp + 2 * sidx * BN);
+                    da[0] = va[0]; da[1] = va[1];
+                    db[0] = vb[0]; db[1] = vb[1];
+                    return;
+                }
                 const int kk = 2 * sidx + lh;
                 VecLoad<C::TM>::ld(As + kk * C::BM + wrow0 + C::TM * l31, da);
                 VecLoad<C::TN>::ld(Bs + kk * BN + wcol0 + C::TN * l31, db);
@@ -466,6 +484,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
         gload(kbeg);
         lstore(smem, smem + C::A_ELEMS);
         if (PIPE != 0 && nkt > 1) gload(kbeg + C::BK); // tile 1 waits in registers
+        // (asking for tiles 0 and 1 together through a second set of staging registers: no change at C2's 16-64 K-steps per
+        //  workgroup, 0.172 ms either way in the interleaved A/B)
         __syncthreads();
         for (int kt = 0; kt < nkt; ++kt) {
             float *cur = smem + (kt & 1) * C::STAGE;
@@ -743,6 +763,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
 // gemm_kernel's fused epilogues (EPI_MU / EPI_GRAD / EPI_APPLY).  The second operand P of the epilogue may arrive as the
 // UNREDUCED split-K slabs of the data pass that produced it (P = sum of nslab slabs, summed here in slab order -- the same
 // values sum_slabs_kernel would have written, without its launch and its round trip through HBM).
+// slots of a 256-row output tile in a paired launch (cmf_gemm_pair.hip.h): the workgroups whose unit ranges meet
+// [unit0 + tile S, unit0 + (tile + 1) S)
+__host__ __device__ __forceinline__ int pair_slots(int64_t quota, int64_t unit0, int ksteps, int64_t tile) {
+    const int64_t first = (unit0 + tile * ksteps) / quota, last = (unit0 + (tile + 1) * ksteps - 1) / quota;
+    return (int)(last - first + 1);
+}
+
 struct FactorUpdArgs {
     const float *A;      // left operand rows x KP (F for EPI_MU / EPI_GRAD, the gradient for EPI_APPLY), pitch KP
     const float *B;      // KP x KP right operand (Gram or inverse Hessian), pitch KP
@@ -752,6 +779,8 @@ struct FactorUpdArgs {
     const float *S1, *S2; // ... plus the unreduced split-K slabs of up to two data passes: P_total = P + sum S1 + sum S2
     int n1, n2;
     int64_t stride1, stride2;
+    int64_t q1, q2, u1, u2; // slabs of a paired launch (q > 0: quota, first unit): n = pair_slots(q, u, ks, row tile), not a constant
+    int ks1, ks2;
     float *out;
     float a, b, c;
     int64_t rows_valid;
@@ -850,8 +879,8 @@ __global__ __launch_bounds__(256) void factor_update_kernel(FactorUpdArgs g) {
                 }
             };
             if (g.P) add_slabs(g.P, 1, 0);
-            if (g.n1 > 0) add_slabs(g.S1, g.n1, g.stride1);
-            if (g.n2 > 0) add_slabs(g.S2, g.n2, g.stride2);
+            if (g.n1 > 0) add_slabs(g.S1, g.q1 > 0 ? pair_slots(g.q1, g.u1, g.ks1, row0 >> 8) : g.n1, g.stride1);
+            if (g.n2 > 0) add_slabs(g.S2, g.q2 > 0 ? pair_slots(g.q2, g.u2, g.ks2, row0 >> 8) : g.n2, g.stride2);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

@@ -84,6 +84,12 @@ struct IntC {
     static constexpr int value = V;
 };
 
+// Class images of the k_pad = 256 symmetric kernel are stored block-major: the 36 upper 32 x 32 blocks one after another (row
+// of blocks by row of blocks), each 4 KB in one piece and row-major inside -- the writer's stores and class_sum_blocks_kernel's
+// reads are whole 4 KB runs instead of 128-byte pieces 1 KB apart.
+constexpr int64_t CLS_IMAGE = 36 * 1024;
+__device__ __forceinline__ int cls_block(int ba, int bb) { return ba * 8 - ((ba * (ba - 1)) >> 1) + bb - ba; }
+
 // CLS = 1 (with SYM = 3): class launches only (cls_cnt set) -- no targets, no dot products, no gradient, constant weight;
 // only the 36 upper blocks are stored (class_sum_blocks_kernel mirrors them when it adds up a row's classes).
 // The class-only build is compiled for FOUR waves per SIMD (<= 128 VGPRs: 80 of them accumulators) and uses one 32 KB image per
@@ -363,13 +369,19 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
     }
 
     // ---- H_i tile out (rows interleaved like the TN GEMM form)
-    float *Hi = g.H + (int64_t)blockIdx.x * KP * KP;
+    float *Hi = g.H + (int64_t)blockIdx.x * (CLS ? CLS_IMAGE : KP * KP);
     if constexpr (SYM) {
         auto emit = [&](auto typ) {
             constexpr int TY = decltype(typ)::value;
 #pragma unroll
             for (int n = 0; n < sym_np(TY); ++n) {
                 const int ba = ablk[sym_ai(TY, n)], bb = bblk[sym_bi(TY, n)];
+                if constexpr (CLS) { // block-major image: upper block (ba, bb) is 4 KB in one piece, row-major inside
+                    float *blk = Hi + cls_block(ba, bb) * 1024 + 4 * lh * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) blk[((r & 3) + 8 * (r >> 2)) * 32] = hs[n][r];
+                    continue;
+                }
                 float *blk = Hi + (32 * ba + 4 * lh) * KP + 32 * bb + l31; // + (j + 8q) rows: register r = 4q + j
                 const int col = 32 * bb + l31;
 #pragma unroll
@@ -377,10 +389,6 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
                     const int row = 32 * ba + 4 * lh + (r & 3) + 8 * (r >> 2);
                     float *dst = blk + ((r & 3) + 8 * (r >> 2)) * KP;
                     float v = hs[n][r];
-                    if constexpr (CLS) {
-                        *dst = v;
-                        continue;
-                    }
                     if (g.accumulate & 1) v += *dst;
                     else { // the launch that starts H_i also adds the shared part and the diagonal (S is symmetric)
                         if (g.S) v += g.S[row * KP + col];
@@ -638,7 +646,7 @@ __global__ __launch_bounds__(256) void class_sum_blocks_kernel(float *H, const f
         while (rem >= 8 - ba) { rem -= 8 - ba; ++ba; }
         const int bb = ba + rem;
         const int off = (32 * ba + r) * KP + 32 * bb + 4 * c4;
-        const float *base = C + grp * (NC - 1) * KK + off;
+        const float *base = C + (grp * (NC - 1) * 36 + item % 36) * 1024 + 32 * r + 4 * c4; // block-major images: 4 KB per block
         f32x4 acc[RMAX], pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < RMAX; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -649,7 +657,7 @@ __global__ __launch_bounds__(256) void class_sum_blocks_kernel(float *H, const f
             f32x4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                v[u] = (q0 + u < NC) ? *reinterpret_cast<const f32x4 *>(base + (int64_t)(q0 + u - 1) * KK) : f32x4{0.f, 0.f, 0.f, 0.f};
+                v[u] = (q0 + u < NC) ? *reinterpret_cast<const f32x4 *>(base + (int64_t)(q0 + u - 1) * CLS_IMAGE) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int q = q0 + u;

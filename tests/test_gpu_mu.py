@@ -81,7 +81,8 @@ def test_mu_midsize_residual_parity(lib):
 
 
 @pytest.mark.parametrize("m,d,p,k", [(5, 4, 1, 4), (300, 260, 70, 5), (513, 257, 255, 37),
-                                      (700, 300, 520, 130), (1024, 768, 512, 256), (64, 2000, 40, 64)])
+                                      (700, 300, 520, 130), (1024, 768, 512, 256), (64, 2000, 40, 64),
+                                      (1000, 700, 300, 100), (260, 1030, 2050, 128)])
 def test_mu_vs_oracle_ragged(lib, m, d, p, k):
     from oracle import cmf_oracle as O
     X, Y, U0, V0, Z0 = _problem(m + k, m, d, p, k)
@@ -91,6 +92,39 @@ def test_mu_vs_oracle_ragged(lib, m, d, p, k):
         O.mu_update_step(X, Y, Ur, Vr, Zr, 0.01, 0.02)
     for a, b in ((U, Ur), (V, Vr), (Z, Zr)):
         np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("m,d,p,k", [(1000, 700, 300, 100), (513, 1030, 2050, 128), (3000, 257, 5000, 70), (256, 256, 256, 65)])
+def test_paired_data_passes_match_split_form(lib, m, d, p, k):
+    """k_pad = 128: the two data passes of an MU half-iteration as ONE balanced launch (cmf_gemm_pair.hip.h: work units cut
+    across output tiles and across the two products) against the split launches it replaces and against the oracle
+    (cmf_solvers.py:230-246).  Shapes whose quotas cross tile and product boundaries at odd places."""
+    from oracle import cmf_oracle as O
+    X, Y, U0, V0, Z0 = _problem(7 * m + k, m, d, p, k)
+    out = {}
+    for pair in (0, 1):
+        ctx = lib.Context(0)
+        ctx.set_option("pair_passes", pair)
+        ctx.set_problem(m, d, p, k)
+        ctx.set_data(0, X)
+        ctx.set_data(1, Y)
+        for w, F in enumerate((U0, V0, Z0)):
+            ctx.set_factor(w, F)
+        ctx.kernel_timing(1)
+        ctx.kernel_timing_reset()
+        for _ in range(3):
+            ctx.mu_step(0.01, 0.02, 7)
+        launches = ctx.kernel_time("gemm_pair")[1]
+        ctx.kernel_timing(False)
+        assert launches == (6 if pair else 0), "the paired launch must be the path that ran (or not, when switched off)"
+        out[pair] = [ctx.get_factor(w) for w in range(3)]
+        ctx.close()
+    Ur, Vr, Zr = U0.copy(), V0.copy(), Z0.copy()
+    for _ in range(3):
+        O.mu_update_step(X, Y, Ur, Vr, Zr, 0.01, 0.02)
+    for a, b, r in zip(out[1], out[0], (Ur, Vr, Zr)):
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-7)  # same products, another order of the float32 partial sums
+        np.testing.assert_allclose(a, r, rtol=2e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize("link", ["linear", "logit"])

@@ -64,7 +64,7 @@ out = {"_provenance": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate p
                       "over ALL launches of the data-pass symbol (one X pass and one Y pass per symbol and iteration); algorithmic bytes "
                       "= the mean of the two: data matrix once + factor operand + output." % TAG, "unit": "bytes per launch (mean of the X pass and the Y pass)"}
 algx = 4.0 * (mC * dC + (mC + dC) * kC); algy = 4.0 * (dC * pC + (dC + pC) * kC)
-for key, sym in (("gemm_tn", "gemm_kernel<1, 128, 0,"), ("gemm_nn", "gemm_kernel<0, 128, 0,")):
+for key, sym in (("gemm_tn", "gemm_kernel<1, 128, 0,"), ("gemm_nn", "gemm_kernel<0, 128, 0,"), ("gemm_pair", "gemm_pair_kernel")):
     fv = [v for (n, c), vs in f.items() if sym in n and c == "FETCH_SIZE" for v, _ in vs]
     wv = [v for (n, c), vs in wr.items() if sym in n and c == "WRITE_SIZE" for v, _ in vs]
     if fv and wv:
