@@ -112,6 +112,7 @@ struct cmf_ctx {
     int opt_pipe_small = 4; // staging schedule of the factor-side products (0 or 4; 4 measured +5..15 %, tools/ab_small.py)
     int opt_pipe = 4;      // GEMM staging schedule (see gemm_kernel PIPE); 4 measured best (tools/ab_gemm.py)
     int opt_split = -1;    // force split-K factor (<=0: heuristic)
+    int opt_class_depth = 4; // class blocks in flight per thread of class_sum_blocks_kernel (4 | 8 | 16)
     int opt_pair = 1;      // k_pad = 128, dense X and Y: the two data passes of an MU half-iteration as one balanced launch (cmf_gemm_pair.hip.h) | 0: two split launches
     int opt_tile512 = 0;   // A/B: k_pad = 128 data passes on a 512 x 128 x 16 tile (GemmCfg TILE 1) instead of 256 x 128 x 32
     int opt_rounds = 1;    // split-K heuristic of the data passes: aim at this many workgroups per CU (A/B option: 2 measured within noise of 1 at C2)
@@ -821,6 +822,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_side_gram = value != 0;
     } else if (!strcmp(name, "narrow_update")) {
         c->opt_narrow_update = value != 0;
+    } else if (!strcmp(name, "class_sum_depth")) {
+        c->opt_class_depth = (int)value;
     } else if (!strcmp(name, "pair_passes")) {
         c->opt_pair = value != 0;
     } else if (!strcmp(name, "gemm_tile512")) {

@@ -1619,8 +1619,13 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
                             certimg = (float *)c->certimg.p;
                         }
                         const unsigned grid = (unsigned)std::min<int64_t>(ng * 36, (int64_t)c->num_cu * 16);
-                        hipLaunchKernelGGL(class_sum_blocks_kernel, dim3(grid), dim3(256), 0, c->stream, Hc, (const float *)c->hclass.p,
-                                           have_h ? nullptr : S, have_h ? 0.f : (float)diag, nr, R, c->k, have_h ? 1 : 0, certimg, split);
+#define CMF_CLASS_SUM(NB_)                                                                                                     \
+    hipLaunchKernelGGL(class_sum_blocks_kernel<NB_>, dim3(grid), dim3(256), 0, c->stream, Hc, (const float *)c->hclass.p,      \
+                       have_h ? nullptr : S, have_h ? 0.f : (float)diag, nr, R, c->k, have_h ? 1 : 0, certimg, split)
+                        if (c->opt_class_depth >= 16) CMF_CLASS_SUM(16);
+                        else if (c->opt_class_depth >= 8) CMF_CLASS_SUM(8);
+                        else CMF_CLASS_SUM(4);
+#undef CMF_CLASS_SUM
                         if (want_cert) {
                             cert.flags = (const int *)c->certflag.p; cert.rows = R; cert.split = split;
                         }

@@ -632,6 +632,7 @@ __global__ __launch_bounds__(256) void class_sum_kernel(float *H, const float *C
 // cert (optional): per group two more sums over classes, the samples common to ALL rows of its first `split` rows and to
 // all of the remaining ones -- a positive semi-definite part of each of those rows' Hessians (upper blocks only: what the
 // Cholesky kernel reads), image [2 group + half].
+template <int NB>
 __global__ __launch_bounds__(256) void class_sum_blocks_kernel(float *H, const float *C, const float *S, float diag, int64_t nrows,
                                                                int R, int kvalid, int accumulate, float *cert, int split) {
     constexpr int KP = 256, RMAX = 6;
@@ -651,15 +652,14 @@ __global__ __launch_bounds__(256) void class_sum_blocks_kernel(float *H, const f
 #pragma unroll
         for (int m = 0; m < RMAX; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int ma = (1 << split) - 1, mb = (NC - 1) ^ ma;
-        // four class blocks in flight per thread, added in ascending class order (one dependent load per class left the kernel
-        // latency-bound at 3.9 TB/s of the 76 GB of class images a C3 iteration reads)
-        for (int q0 = 1; q0 < NC; q0 += 4) {
-            f32x4 v[4];
+        // NB class blocks in flight per thread, added in ascending class order
+        for (int q0 = 1; q0 < NC; q0 += NB) {
+            f32x4 v[NB];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < NB; ++u)
                 v[u] = (q0 + u < NC) ? *reinterpret_cast<const f32x4 *>(base + (int64_t)(q0 + u - 1) * CLS_IMAGE) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NB; ++u) {
                 const int q = q0 + u;
                 if (q < NC) {
 #pragma unroll

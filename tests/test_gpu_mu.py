@@ -157,14 +157,15 @@ def test_strided_and_fortran_inputs(lib):
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("k", [24, 100])
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_protocol_matches_unsharded(lib, world):
+def test_sharded_protocol_matches_unsharded(lib, world, k):
     """run `world` shards as separate contexts on this one GPU, emulate the
     all-reduce by summing their partial buffers on the device, and compare with the
     unsharded step (same kernels, different partition)."""
     import torch
     from pycmf_amd.sharded import ShardedMU, HipShardBackend, shard_bounds
-    m, d, p, k = 700, 300, 530, 24
+    m, d, p = 700, 300, 530   # (k = 100: k_pad = 128, the shards' U / Z updates take the paired launch of cmf_gemm_pair.hip.h)
     X, Y, U0, V0, Z0 = _problem(77, m, d, p, k)
     ref = _step(lib, X, Y, U0, V0, Z0, 0.01, 0.02, iters=2)
     ctxs, bufs, bounds = [], [], []
