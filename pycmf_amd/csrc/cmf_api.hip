@@ -583,8 +583,7 @@ static int gram32(cmf_ctx *c, const float *F, int64_t rows_pad, float *G, bool o
 static bool small_tile_ok(const cmf_ctx *c, int64_t rows_pad) {
     return c->opt_fused_mu && c->opt_small_tile && (c->kp == 64 || c->kp == 128) && rows_pad * c->kp <= ((int64_t)1 << 27);
 }
-static int factor_update(cmf_ctx *c, const float *A, const float *B, const Epilogue &e, int64_t rows_pad) {
-    FactorUpdArgs g;
+static void factor_update_args(FactorUpdArgs &g, const float *A, const float *B, const Epilogue &e) {
     memset(&g, 0, sizeof g);
     g.A = A; g.B = B; g.epi = e.kind; g.F = e.F; g.P = e.P; g.out = e.out;
     if (e.Pslabs && e.Pslabs->nslab > 0) {
@@ -596,6 +595,22 @@ static int factor_update(cmf_ctx *c, const float *A, const float *B, const Epilo
         g.q2 = e.Pslabs2->quota; g.u2 = e.Pslabs2->unit0; g.ks2 = e.Pslabs2->ksteps;
     }
     g.a = (float)e.a; g.b = (float)e.b; g.c = (float)e.c; g.rows_valid = e.rows; g.kvalid = e.kvalid; g.nn = e.nn;
+}
+// two MU updates with the same Gram in ONE launch (k_pad = 128): cmf_solvers.py:233-234 and :239-240 behind the paired data passes
+static int factor_update2(cmf_ctx *c, const float *A0, const Epilogue &e0, int64_t rows0, const float *A1, const Epilogue &e1, int64_t rows1, const float *B) {
+    FactorUpdArgs g0, g1;
+    factor_update_args(g0, A0, B, e0);
+    factor_update_args(g1, A1, B, e1);
+    Timed tm(c, CMF_K_GEMM_SMALL, 2.0 * (double)(rows0 + rows1) * c->kp * c->kp);
+    const size_t lds = (size_t)(128 * 128 + 64 * 132) * sizeof(float);
+    CHK(allow_big_lds(c, reinterpret_cast<const void *>(&factor_update2_kernel<128>), (int)lds));
+    hipLaunchKernelGGL((factor_update2_kernel<128>), dim3((unsigned)((rows0 + rows1) / 64)), dim3(256), lds, c->stream, g0, g1, (int)(rows0 / 64));
+    HIPCHK(hipGetLastError());
+    return CMF_OK;
+}
+static int factor_update(cmf_ctx *c, const float *A, const float *B, const Epilogue &e, int64_t rows_pad) {
+    FactorUpdArgs g;
+    factor_update_args(g, A, B, e);
     Timed tm(c, CMF_K_GEMM_SMALL, 2.0 * (double)rows_pad * c->kp * c->kp);
     const dim3 grid((unsigned)(rows_pad / 64));
     if (c->kp == 128) {
@@ -825,7 +840,7 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "class_sum_depth")) {
         c->opt_class_depth = (int)value;
     } else if (!strcmp(name, "pair_passes")) {
-        c->opt_pair = value != 0;
+        c->opt_pair = (int)value; // 0: split launches | 1: paired data passes, U and Z updates in one launch | 2: paired data passes, separate updates
     } else if (!strcmp(name, "gemm_tile512")) {
         c->opt_tile512 = value != 0;
     } else if (!strcmp(name, "gemm_rounds")) {
@@ -1508,9 +1523,14 @@ static int mu_uz_update_with(cmf_ctx *c, const float *G2, double l1, double l2, 
         SlabRef su, sz;
         CHK(data_times_pair(c, xv, ytv, &su, &sz));
         CHK(side_join(c));
-        CHK(mu_update(c, c->F[CMF_U], G2, c->num, c->mp, l1, l2, &su));
-        CHK(mu_update(c, c->F[CMF_Z], G2, c->num, c->pp, l1, l2, &sz));
-        return CMF_OK;
+        if (c->opt_pair == 2) { // A/B: the two updates as two launches
+            CHK(mu_update(c, c->F[CMF_U], G2, c->num, c->mp, l1, l2, &su));
+            return mu_update(c, c->F[CMF_Z], G2, c->num, c->pp, l1, l2, &sz);
+        }
+        Epilogue eu, ez;
+        eu.kind = EPI_MU; eu.F = c->F[CMF_U]; eu.out = c->F[CMF_U]; eu.a = l1; eu.b = l2; eu.c = 1.1920928955078125e-07; eu.Pslabs = &su;
+        ez = eu; ez.F = c->F[CMF_Z]; ez.out = c->F[CMF_Z]; ez.Pslabs = &sz;
+        return factor_update2(c, c->F[CMF_U], eu, c->mp, c->F[CMF_Z], ez, c->pp, G2);
     }
     if (mask & CMF_UPD_U) {
         if (!have_data(c, 0)) { (void)side_join(c); return fail(CMF_EINVAL, "X must be set before a U update"); }

@@ -788,7 +788,7 @@ struct FactorUpdArgs {
 };
 
 template <int KP>
-__global__ __launch_bounds__(256) void factor_update_kernel(FactorUpdArgs g) {
+__device__ __forceinline__ void factor_update_body(const FactorUpdArgs &g, const int64_t blk) {
     static_assert(KP == 64 || KP == 128, "small-tile factor update: k_pad 64 or 128");
     constexpr int LA = KP + 4;             // A tile pitch: 16-byte slot (KP / 4 + 1) * row: ds_read_b128 of 16 rows is conflict-free
     constexpr int NB = KP / 64;            // 32-column blocks per wave (wave tile 32 x KP / 2)
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(256) void factor_update_kernel(FactorUpdArgs g) {
     float *As = fsm + KP * KP;             // [64][LA]
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int64_t row0 = blk * 64;
     const int wr = (w & 1) * 32, wc = (w >> 1) * (KP / 2);
     {   // every global load of the workgroup is issued before the first LDS store: ONE memory latency for both operands
         constexpr int NBL = KP * KP / 4 / 256, NAL = 64 * KP / 4 / 256;
@@ -908,6 +908,15 @@ __global__ __launch_bounds__(256) void factor_update_kernel(FactorUpdArgs g) {
             g.out[row * KP + col] = res;
         }
     }
+}
+template <int KP>
+__global__ __launch_bounds__(256) void factor_update_kernel(FactorUpdArgs g) { factor_update_body<KP>(g, blockIdx.x); }
+// two independent updates in one grid (U and Z behind the paired launch of X V and Y^T V: Z's 64 workgroups alone leave three
+// quarters of the chip idle for a whole latency-bound launch): workgroups [0, nblk0) run g0, the rest g1
+template <int KP>
+__global__ __launch_bounds__(256) void factor_update2_kernel(FactorUpdArgs g0, FactorUpdArgs g1, int nblk0) {
+    if ((int)blockIdx.x < nblk0) factor_update_body<KP>(g0, blockIdx.x);
+    else factor_update_body<KP>(g1, (int64_t)blockIdx.x - nblk0);
 }
 
 // ------------------------------------------------------------------ small Grams (k_pad 64 / 128)
