@@ -1600,7 +1600,7 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
                 a.kvalid = c->k;
                 // k_pad = 256 with the single-image symmetric kernel: class images hold their 36 upper blocks only
                 const bool upper = c->kp == 256 && c->opt_rowsym == 3 && sd->scale >= 0.0 && c->opt_rowdiag == 0;
-                a.cls_upper = upper ? 1 : 0;
+                a.cls_upper = upper ? 1 : 0; a.cls_nc1 = NC1;
                 CHK(launch_row_hess(c, a, ng * NC1, (double)nr * (double)sd->per));
                 {
                     Timed tm(c, CMF_K_ELEMWISE);

@@ -40,7 +40,8 @@ struct RowHessArgs {
     // several factor rows -- its list starts at idx + cls_off[b] and holds cls_cnt[b] samples; only H is produced
     const int64_t *cls_off;
     const int32_t *cls_cnt;
-    int cls_upper;        // class launch of the k_pad = 256 symmetric kernel: store the 36 upper blocks only
+    int cls_upper;        // class launch of the k_pad = 256 symmetric kernel: store the 36 upper blocks only ...
+    int cls_nc1;          // ... of image blockIdx.x = group * cls_nc1 + class, block-major and class-minor (see CLS_BLOCK)
     // SPLIT mode (nsplit > 1; few rows with long sample lists, e.g. the Z sweep of a 64-column Y over 1e5 rows of V): workgroup
     // b serves chunk b / nrows of row b % nrows -- samples [chunk * split_len, ...) of its list -- and writes PARTIAL sums:
     // H to slot b (so the partials of chunk c form slab c of nrows images), G to G + chunk * g_split_stride.  The caller launches
@@ -84,10 +85,11 @@ struct IntC {
     static constexpr int value = V;
 };
 
-// Class images of the k_pad = 256 symmetric kernel are stored block-major: the 36 upper 32 x 32 blocks one after another (row
-// of blocks by row of blocks), each 4 KB in one piece and row-major inside -- the writer's stores and class_sum_blocks_kernel's
-// reads are whole 4 KB runs instead of 128-byte pieces 1 KB apart.
-constexpr int64_t CLS_IMAGE = 36 * 1024;
+// Class images of the k_pad = 256 symmetric kernel hold their 36 upper 32 x 32 blocks only, each 4 KB in one piece and row-major
+// inside, laid out [group][block][class]: the classes of one (group, block) -- what one workgroup of class_sum_blocks_kernel adds
+// up -- are ONE contiguous run of (2^R - 1) * 4 KB (252 KB at R = 6) instead of 63 pieces 144 KB apart; the scatter moves to the
+// writer, whose 36 block stores per class image ride under the other class workgroup's MFMAs.
+constexpr int64_t CLS_BLOCK = 1024;
 __device__ __forceinline__ int cls_block(int ba, int bb) { return ba * 8 - ((ba * (ba - 1)) >> 1) + bb - ba; }
 
 // CLS = 1 (with SYM = 3): class launches only (cls_cnt set) -- no targets, no dot products, no gradient, constant weight;
@@ -369,7 +371,12 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
     }
 
     // ---- H_i tile out (rows interleaved like the TN GEMM form)
-    float *Hi = g.H + (int64_t)blockIdx.x * (CLS ? CLS_IMAGE : KP * KP);
+    float *Hi = g.H + (int64_t)blockIdx.x * KP * KP;
+    if constexpr (CLS) { // block b of class q of group grp at ((grp * 36 + b) * nc1 + q) * 4 KB
+        const int64_t grp = blockIdx.x / g.cls_nc1, q = blockIdx.x % g.cls_nc1;
+        Hi = g.H + (grp * 36 * g.cls_nc1 + q) * CLS_BLOCK;
+    }
+    const int64_t cls_bstride = CLS ? (int64_t)g.cls_nc1 * CLS_BLOCK : 0;
     if constexpr (SYM) {
         auto emit = [&](auto typ) {
             constexpr int TY = decltype(typ)::value;
@@ -377,7 +384,7 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
             for (int n = 0; n < sym_np(TY); ++n) {
                 const int ba = ablk[sym_ai(TY, n)], bb = bblk[sym_bi(TY, n)];
                 if constexpr (CLS) { // block-major image: upper block (ba, bb) is 4 KB in one piece, row-major inside
-                    float *blk = Hi + cls_block(ba, bb) * 1024 + 4 * lh * 32 + l31;
+                    float *blk = Hi + cls_block(ba, bb) * cls_bstride + 4 * lh * 32 + l31;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) blk[((r & 3) + 8 * (r >> 2)) * 32] = hs[n][r];
                     continue;
@@ -647,7 +654,7 @@ __global__ __launch_bounds__(256) void class_sum_blocks_kernel(float *H, const f
         while (rem >= 8 - ba) { rem -= 8 - ba; ++ba; }
         const int bb = ba + rem;
         const int off = (32 * ba + r) * KP + 32 * bb + 4 * c4;
-        const float *base = C + (grp * (NC - 1) * 36 + item % 36) * 1024 + 32 * r + 4 * c4; // block-major images: 4 KB per block
+        const float *base = C + (grp * 36 + item % 36) * (NC - 1) * CLS_BLOCK + 32 * r + 4 * c4; // [group][block][class]: one run per item
         f32x4 acc[RMAX], pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < RMAX; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -657,7 +664,7 @@ __global__ __launch_bounds__(256) void class_sum_blocks_kernel(float *H, const f
             f32x4 v[NB];
 #pragma unroll
             for (int u = 0; u < NB; ++u)
-                v[u] = (q0 + u < NC) ? *reinterpret_cast<const f32x4 *>(base + (int64_t)(q0 + u - 1) * CLS_IMAGE) : f32x4{0.f, 0.f, 0.f, 0.f};
+                v[u] = (q0 + u < NC) ? *reinterpret_cast<const f32x4 *>(base + (int64_t)(q0 + u - 1) * CLS_BLOCK) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
                 const int q = q0 + u;
