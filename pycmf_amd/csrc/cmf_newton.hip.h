@@ -1543,6 +1543,10 @@ static int refine_rows64(cmf_ctx *c, int which, const RowSide &s1, const RowSide
     return CMF_OK;
 }
 
+// class images of the k_pad = 256 symmetric kernel hold their 36 upper 32 x 32 blocks only (cmf_rowhess.hip.h)
+static bool class_images_upper(const cmf_ctx *c, double scale) { return c->kp == 256 && c->opt_rowsym == 3 && scale >= 0.0 && c->opt_rowdiag == 0; }
+static int64_t class_image_floats(const cmf_ctx *c, double scale) { return class_images_upper(c, scale) ? 36 * CLS_BLOCK : (int64_t)c->kp * c->kp; }
+
 static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const RowSide &s2, const float *S, double diag, bool grad_preloaded,
                              double l1, double l2, double pert, bool nn, const SharedPart &shared = SharedPart(),
                              const RowSide *shside = nullptr) {
@@ -1552,13 +1556,14 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
     int64_t chunk = hessian_chunk_rows(c, rows_pad);
     if (c->opt_rowchunk > 0) chunk = std::min<int64_t>(chunk, rup(c->opt_rowchunk, 256)); // tests: force several chunks
     {
-        // class images of a chunk: (2^R - 1) / R images per row; keep them under 16 GiB (C3, R = 6: 5376 rows per chunk).
+        // class images of a chunk: (2^R - 1) / R images per row (36 upper blocks each at k_pad = 256); keep them under 16 GiB (C3, R = 6:
+        // 8192 rows per chunk, the cap of the Hessian chunk itself).
         // The memory cap is taken over BOTH class sides first; then ONE rounding to a common group boundary, lcm(256, R1, R2):
         // every chunk must start on a group boundary of every class side (g0 = r0 / R below)
         int64_t q = 256;
         for (const RowSide *sd : {&s1, &s2})
             if (sd->active && sd->cls) {
-                const int64_t per_row = (((int64_t)1 << sd->cls) - 1) * kk * (int64_t)sizeof(float) / sd->cls;
+                const int64_t per_row = (((int64_t)1 << sd->cls) - 1) * class_image_floats(c, sd->scale) * (int64_t)sizeof(float) / sd->cls;
                 chunk = std::min(chunk, std::max<int64_t>(256, (((int64_t)16 << 30) / per_row) / 256 * 256));
                 q = std::lcm(q, (int64_t)sd->cls);
             }
@@ -1591,7 +1596,7 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
                 // one launch forms the class images of the chunk's groups, a second one adds up each row's classes
                 const int R = sd->cls, NC1 = (1 << R) - 1;
                 const int64_t g0 = r0 / R, ng = (nr + R - 1) / R;
-                CHK(ensure(c, c->hclass, (size_t)((chunk + R - 1) / R) * NC1 * kk * sizeof(float)));
+                CHK(ensure(c, c->hclass, (size_t)((chunk + R - 1) / R) * NC1 * class_image_floats(c, sd->scale) * sizeof(float)));
                 a.idx = (const int32_t *)c->cls_idx[sd->slot].p;
                 a.cls_off = (const int64_t *)c->cls_off[sd->slot].p + g0 * NC1;
                 a.cls_cnt = (const int32_t *)c->cls_cnt[sd->slot].p + g0 * NC1;
@@ -1599,7 +1604,7 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
                 a.H = (float *)c->hclass.p; a.G = nullptr; a.accumulate = 0; a.row0 = 0; a.nrows = ng * NC1;
                 a.kvalid = c->k;
                 // k_pad = 256 with the single-image symmetric kernel: class images hold their 36 upper blocks only
-                const bool upper = c->kp == 256 && c->opt_rowsym == 3 && sd->scale >= 0.0 && c->opt_rowdiag == 0;
+                const bool upper = class_images_upper(c, sd->scale);
                 a.cls_upper = upper ? 1 : 0; a.cls_nc1 = NC1;
                 CHK(launch_row_hess(c, a, ng * NC1, (double)nr * (double)sd->per));
                 {
