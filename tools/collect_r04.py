@@ -62,7 +62,7 @@ f = counters(os.path.join(DST, "%s_c2_n1_pmc_FETCH_SIZE.csv" % TAG)); wr = count
 out = {"_provenance": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/refresh_r04.sh) of `python3 bench.py --workload c2 "
                       "--steps 3 --warmup 1 --no-cpu-baseline` (%s).  FETCH_SIZE KiB x1024 x2 (gfx950 correction) + WRITE_SIZE KiB x1024, averaged "
                       "over ALL launches of the data-pass symbol (one X pass and one Y pass per symbol and iteration); algorithmic bytes "
-                      "= the mean of the two: data matrix once + factor operand + output." % TAG, "unit": "bytes per launch (mean of the X pass and the Y pass)"}
+                      "= the mean of the two: data matrix once + factor operand + output." % TAG, "unit": "bytes per launch (gemm_pair: an X pass and a Y pass in one launch; gemm_tn / gemm_nn, option pair_passes=0: mean of the X pass and the Y pass)"}
 algx = 4.0 * (mC * dC + (mC + dC) * kC); algy = 4.0 * (dC * pC + (dC + pC) * kC)
 for key, sym in (("gemm_tn", "gemm_kernel<1, 128, 0,"), ("gemm_nn", "gemm_kernel<0, 128, 0,"), ("gemm_pair", "gemm_pair_kernel")):
     fv = [v for (n, c), vs in f.items() if sym in n and c == "FETCH_SIZE" for v, _ in vs]
@@ -70,8 +70,10 @@ for key, sym in (("gemm_tn", "gemm_kernel<1, 128, 0,"), ("gemm_nn", "gemm_kernel
     if fv and wv:
         fa, wa = sum(fv) / len(fv), sum(wv) / len(wv)
         out[key] = fa * 1024 * 2 + wa * 1024
-        out[key + "_detail"] = {"fetch_raw_KiB": fa, "write_KiB": wa, "launches": len(fv), "algorithmic_bytes": 0.5 * (algx + algy),
-                                "note": "split-K slabs (written once, read once by the consumer) are part of the moved bytes"}
+        out[key + "_detail"] = {"fetch_raw_KiB": fa, "write_KiB": wa, "launches": len(fv),
+                                "algorithmic_bytes": (algx + algy) if key == "gemm_pair" else 0.5 * (algx + algy),
+                                "note": ("one launch = an X pass and a Y pass; the partial tiles it writes (read once by the update kernel) are part of the moved bytes"
+                                         if key == "gemm_pair" else "split-K slabs (written once, read once by the consumer) are part of the moved bytes")}
 json.dump(out, open(os.path.join(DST, "traffic_c2.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 
