@@ -20,6 +20,7 @@ def _problem(seed, m, d, p, k, logit=False):
     ("mu", dict(l1_reg=0.01, l2_reg=0.02, max_iter=300, tol=1e-4)),
     ("mu", dict(max_iter=37, tol=0)),                                   # runs out: n_iter = max_iter, no check at all
     ("mu", dict(max_iter=0, tol=1e-4)),                                 # no iteration: n_iter = 0
+    ("mu", dict(l2_reg=0.02, max_iter=25, tol=0, _k=100)),              # k_pad = 128: the paired data-pass launch inside the replayed graph
     ("newton", dict(alpha=0.4, l2_reg=0.3, max_iter=60, tol=1e-4)),     # linear links: shared Hessians, graph-capturable at k <= 64
     ("newton", dict(alpha=0.4, l2_reg=0.05, y_link="logit", U_non_negative=False, V_non_negative=False, Z_non_negative=False,
                     max_iter=30, tol=1e-4)),
@@ -28,7 +29,8 @@ def _problem(seed, m, d, p, k, logit=False):
 def test_c_loop_equals_python_loop(solver, kw, monkeypatch):
     from pycmf_amd.solver_shell import HipMUSolver, HipNewtonSolver
     cls = HipMUSolver if solver == "mu" else HipNewtonSolver
-    X, Y, F0 = _problem(1, 310, 170, 90, 12, logit=kw.get("y_link") == "logit")
+    kw = dict(kw)
+    X, Y, F0 = _problem(1, 310, 170, 90, kw.pop("_k", 12), logit=kw.get("y_link") == "logit")
     outs = []
     for host_loop in ("1", "0"):
         monkeypatch.setenv("PYCMF_AMD_HOST_LOOP", host_loop)

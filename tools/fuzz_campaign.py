@@ -25,21 +25,25 @@ OPTIONS = {"row_classes": [-1, 0, 2, 3, 5], "row_certificates": [0, 1], "lowrank
            "row_kernel": [0, 1], "direct_newton_step": [0, 1], "small_tile_update": [0, 1], "fused_mu_update": [0, 1],
            "split_reduce_in_kernel": [0, 1], "spmm_blocked": [0, 1], "newton_schulz": [0, 1], "safe_inverse_cholesky": [0, 1],
            "factor_times_tile": [64, 128, 256], "graph": [0, 1], "chol_mfma": [0, 1], "refine_rows_batched": [0, 1], "narrow_update": [0, 1],
-           "side_gram": [0, 1]}
+           "side_gram": [0, 1], "pair_passes": [0, 1, 2]}
 
 
 def log_int(rng, lo, hi):
     return int(round(np.exp(rng.uniform(np.log(lo), np.log(hi)))))
 
 
-def draw_case(rng, solver):
+def draw_case(rng, solver, focus=None):
     k = int(rng.choice([1, 2, 3, 7, 10, 20, 33, 64, 65, 100, 128, 129, 200, 256, 300],
                        p=[.04, .04, .06, .08, .12, .12, .08, .1, .06, .06, .08, .04, .04, .06, .02]))
+    if focus == "pair":                     # dense MU at k_pad = 128, larger shapes: the balanced two-product launch (cmf_gemm_pair.hip.h)
+        k = int(rng.choice([65, 70, 100, 127, 128]))
     hi = 2500 if k <= 64 else (900 if k <= 130 else 400)
+    if focus == "pair":
+        hi = 6000
     m, d, p = (log_int(rng, 40, hi) for _ in range(3))
     if rng.rand() < 0.25:
         p = log_int(rng, 1, 64)             # the low-rank V sweep (p <= 64 < k)
-    c = {"solver": solver, "m": m, "d": d, "p": p, "k": k, "csr": bool(rng.rand() < 0.4), "l1": 0.0, "l2": 0.0}
+    c = {"solver": solver, "m": m, "d": d, "p": p, "k": k, "csr": bool(rng.rand() < 0.4) and focus != "pair", "l1": 0.0, "l2": 0.0}
     if rng.rand() < 0.7:
         c["l1"] = float(rng.choice([0.0, rng.rand() * 0.3, 2.0]))
         c["l2"] = float(rng.choice([0.0, rng.rand() * 0.5, 5.0]))
@@ -141,6 +145,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--threshold", type=float, default=3e-3)
     ap.add_argument("--replay", type=str, default=None, help="JSON of one case (a line of a previous run) to run again")
+    ap.add_argument("--focus", type=str, default=None, choices=[None, "pair"], help="pair: dense MU cases at k_pad = 128 only")
     args = ap.parse_args()
     if args.replay:
         c = json.loads(args.replay)
@@ -152,7 +157,7 @@ def main():
     t_end = time.time() + 60 * args.minutes
     n = bad = 0
     while time.time() < t_end:
-        c = draw_case(rng, "newton" if rng.rand() < 0.75 else "mu")
+        c = draw_case(rng, "mu", "pair") if args.focus == "pair" else draw_case(rng, "newton" if rng.rand() < 0.75 else "mu")
         c["seed"] = int(rng.randint(1, 2 ** 31 - 1))
         t0 = time.time()
         try:
