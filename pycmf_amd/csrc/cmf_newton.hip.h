@@ -546,7 +546,7 @@ static int shared_inverse(cmf_ctx *c, double pert, bool *plain = nullptr) {
 // products and Hinv multiplies its rounding error by up to cond(H); here O Hinv and E are formed in float64 from the float64
 // Hessian (k x k work), and the float32 data contraction T (O') is the LAST operation, so its rounding error reaches the factor
 // unamplified.  Measured on the clamped non-negative case of tests/test_gpu_shared64.py (cond 1e4): residual distance to the
-// float64 CPU reference after 8 iterations 1.7e-3 -> 5e-7 (tools/emul_newton_precision.py reproduces both on the CPU).
+// float64 CPU reference after 8 iterations 1.7e-3 -> 5e-7 (tests/tools/emul_newton_precision.py reproduces both on the CPU).
 static bool use_reassoc(const cmf_ctx *c) { return c->opt_reassoc && c->opt_shared64 && c->kp <= 1024; }
 
 // out[rows_pad x k_pad] = scale * O Hinv64  (float64 matrix pipe, one rounding)

@@ -262,7 +262,7 @@ class HipNewtonSolver(_HipIterativeSolver):
     """
 
     #: ||H||_F / hessian_pertubation above which the float32 spectral clamp of a row's Hessian leaves the stated tolerance
-    #: (tools/fuzz_campaign.py: every case within 3e-3 of the float64 reference below it)
+    #: (tests/tools/fuzz_campaign.py: every case within 3e-3 of the float64 reference below it)
     CLAMP_RATIO_WARN = 1.0e4
 
     #: index entries per iteration above which drawing the per-row samples from NumPy's stream on the host dominates the iteration

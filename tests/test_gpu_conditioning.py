@@ -1,6 +1,6 @@
 """The float32 limit of the per-row spectral clamp, made visible: `cmf_newton_clamp_stats` counts the row Hessians whose smallest
 eigenvalue was below the perturbation and keeps the largest ||H||_F / pert among them; `HipNewtonSolver` warns when that ratio
-leaves the range in which the stated tolerances hold (tools/fuzz_campaign.py).  Reference: `_safe_invert`,
+leaves the range in which the stated tolerances hold (tests/tools/fuzz_campaign.py).  Reference: `_safe_invert`,
 pycmf/cmf_solvers.py:346-356, on float64 Hessians."""
 import warnings
 
@@ -49,7 +49,7 @@ def test_ill_conditioned_rows_are_redone_in_float64(lib):
     _, stats = _step(lib, X, Y, U, V, Z, 8, (0.5, 0.0, 0.5, "linear", "logit", 0, 7, 0.2, 1.0))
     assert stats == (0, 0.0, 0)
     # (b) more components than samples and no l2: rank-deficient Hessians, every V row is clamped; after the U sweep's 1 / pert
-    # steps ||H|| / pert is ~1e5 -- beyond what float32 Hessians resolve (tools/fuzz_campaign.py found this case)
+    # steps ||H|| / pert is ~1e5 -- beyond what float32 Hessians resolve (tests/tools/fuzz_campaign.py found this case)
     m, d, p, k = 40, 103, 2, 100
     X, Y, U, V, Z = _problem(1, m, d, p, k)
     args = (0.75, 2.0, 0.0, "linear", "logit", 2, 7, 0.2, 1.0)
@@ -134,14 +134,14 @@ def test_refinement_across_chunks_and_with_sampling(lib):
 
 @pytest.mark.parametrize("line", range(10))
 def test_flagged_campaign_cases_with_refinement(lib, line):
-    """The cases tools/fuzz_campaign.py flagged in round 3 (V off by 1e-2 .. 0.4 in float32: clamped rows with ||H|| / pert >= 6e4,
+    """The cases tests/tools/fuzz_campaign.py flagged in round 3 (V off by 1e-2 .. 0.4 in float32: clamped rows with ||H|| / pert >= 6e4,
     and -- the last three -- plain Cholesky solves of Hessians with condition numbers >= 3e4), replayed with the default
     float64 refinement (fused row path for k_pad <= 256, masked-dense path above): within 2e-3 of the float64 oracle."""
     import json, os, sys
     here = os.path.dirname(os.path.abspath(__file__))
-    sys.path.insert(0, os.path.join(here, "..", "tools"))
+    sys.path.insert(0, os.path.join(here, "tools"))
     import fuzz_campaign as FC
-    case = json.loads(open(os.path.join(here, "..", "tools", "fuzz_flagged.jsonl")).read().splitlines()[line])["case"]
+    case = json.loads(open(os.path.join(here, "tools", "fuzz_flagged.jsonl")).read().splitlines()[line])["case"]
     case["options"] = {}
     info = {}
     err = FC.run_case(case, case["seed"], info)

@@ -60,7 +60,7 @@ def test_fit_level_parity_with_reference(solver):
     m = CMF(n_components=5, solver=solver, x_init="custom", y_init="custom", random_state=0, max_iter=1000)
     U, V, Z = m.fit_transform(g["fc_X"], g["fc_Y"], U=g["fc_U0"].copy(), V=g["fc_V0"].copy(), Z=g["fc_Z0"].copy())
     ref_iter, ref_err = int(g["fc_%s_n_iter" % solver]), float(g["fc_%s_err" % solver])
-    # measured (tools/measure_parity.py): mu 210/210 iterations, error 2e-6 rel, U 7e-6; newton 730/730, error 7e-5 rel, U 1e-4
+    # measured (tests/tools/measure_parity.py): mu 210/210 iterations, error 2e-6 rel, U 7e-6; newton 730/730, error 7e-5 rel, U 1e-4
     # (round 2, gradient form of the Newton sweeps: 7e-4 / 5e-3)
     assert m.n_iter_ == ref_iter
     ex = np.linalg.norm(g["fc_X"] - U @ V.T) + np.linalg.norm(g["fc_Y"] - V @ Z.T)

@@ -61,7 +61,7 @@ def test_newton_golden_steps(lib, name, fmt):
     for it in range(1, 4):
         s.update_step(X, Y, U, V, Z, l1, l2, 0.3)
         if it in (1, 3):
-            tol = 2e-5 if it == 1 else 5e-5   # measured <= 1e-6 (tools/measure_parity.py); round 2: 5e-4 / 5e-3
+            tol = 2e-5 if it == 1 else 5e-5   # measured <= 1e-6 (tests/tools/measure_parity.py); round 2: 5e-4 / 5e-3
             for n, a in (("U", U), ("V", V), ("Z", Z)):
                 ref = g["%s_%s_%s%d" % (name, fmt, n, it)]
                 np.testing.assert_allclose(a, ref, rtol=tol, atol=tol * max(1.0, np.abs(ref).max()))

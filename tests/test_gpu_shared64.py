@@ -82,7 +82,7 @@ PARITY_CASES = {
     # float64), so the contract is stated on a run that the reference itself converges on.  cond(H) = 1e4 here and the
     # hard clamp at 0 turns rounding into different active sets: the gradient form F - grad Hinv measured 1.7e-3 on the
     # residuals (float32 rounding of X V / X^T U times cond(H)); the re-associated form F E + T (O Hinv) -- float64 inverse
-    # applied to the other factor BEFORE the float32 data pass -- measures 5e-7 (tools/emul_newton_precision.py)
+    # applied to the other factor BEFORE the float32 data pass -- measures 5e-7 (tests/tools/emul_newton_precision.py)
     "linear_nonneg": ((900, 700, 300, 32, "linear", "linear", 1.0, True, False), 1.0),
     "linear_logit_ratio05": ((260, 200, 120, 24, "linear", "logit", 0.05, False, False), 0.5),
     "logit_logit": ((260, 200, 120, 24, "logit", "logit", 0.01, False, False), 1.0),

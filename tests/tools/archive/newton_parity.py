@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 from oracle import cmf_oracle as O
 from pycmf_amd.solver_shell import HipNewtonSolver
 rng = np.random.RandomState(0)

@@ -1,7 +1,7 @@
 """Per-iteration distance between the device iterates and the float64 oracle on a clamped, ill-conditioned linear Newton
 problem, with the float64 shared-Hessian treatment on and off."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 from oracle import cmf_oracle as O
 from pycmf_amd import _lib

@@ -1,6 +1,6 @@
 """Shared-Hessian safe inverse when eigenvalues dip under the perturbation (Jacobi path) at several k."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 from pycmf_amd import _lib
 from oracle import cmf_oracle as O

@@ -2,7 +2,7 @@
 case beside the float64 oracle."""
 import sys, os
 import numpy as np, scipy.sparse as sp
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from pycmf_amd import _lib
 

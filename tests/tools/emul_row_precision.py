@@ -1,9 +1,9 @@
-"""TEST INFRASTRUCTURE (CPU only): how much of the error of the cases in tools/fuzz_flagged.jsonl is inherent to float32 per-row
+"""TEST INFRASTRUCTURE (CPU only): how much of the error of the cases in tests/tools/fuzz_flagged.jsonl is inherent to float32 per-row
 Hessians?  Runs the float64 oracle three more times per case with (a) the inputs rounded to float32, (b) every per-row Hessian
 rounded to float32 before its (float64) eigen-decomposition, (c) every per-row gradient rounded to float32 (+ accumulation-sized
 noise), and prints the distance of each from the plain float64 result.  DESIGN.md section 7 quotes (b) and (c).
 
-    OMP_NUM_THREADS=4 python tools/emul_row_precision.py [max_k]
+    OMP_NUM_THREADS=4 python tests/tools/emul_row_precision.py [max_k]
 """
 import json
 import os
@@ -11,7 +11,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from oracle import cmf_oracle as O          # noqa: E402
 
 

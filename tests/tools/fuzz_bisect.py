@@ -1,5 +1,5 @@
-"""Replays the flagged cases of a tools/fuzz_campaign.py log: as drawn, with default options, and with each drawn option removed in
-turn -- which option (if any) carries the discrepancy.   python tools/fuzz_bisect.py gpurun_out/fuzz1.jsonl [...]"""
+"""Replays the flagged cases of a tests/tools/fuzz_campaign.py log: as drawn, with default options, and with each drawn option removed in
+turn -- which option (if any) carries the discrepancy.   python tests/tools/fuzz_bisect.py gpurun_out/fuzz1.jsonl [...]"""
 import json
 import sys
 

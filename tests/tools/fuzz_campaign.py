@@ -3,7 +3,7 @@ sampled / unsampled, dense / CSR X, random internal options -- one Newton step (
 float64 oracle.  tests/test_gpu_fuzz.py is the committed small-shape slice of this; the campaign is the long-running form used to
 look for latent defects on a GPU box:
 
-    python tools/fuzz_campaign.py --minutes 10 --seed 0 > gpurun_out/fuzz.jsonl
+    python tests/tools/fuzz_campaign.py --minutes 10 --seed 0 > gpurun_out/fuzz.jsonl
 
 One JSON line per case: the configuration, max |device - oracle| / max |oracle| per factor, and "bad" when above the threshold.
 """
@@ -16,7 +16,7 @@ import time
 import numpy as np
 import scipy.sparse as sp
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from oracle import cmf_oracle as O          # noqa: E402  (test infrastructure: the checker)
 from pycmf_amd import _lib                  # noqa: E402
 

@@ -1,9 +1,9 @@
 """Prints the measured distance of the Newton paths to the golden fixtures (what the tolerances in tests/ are set from).
-GPU box:  python tools/measure_parity.py"""
+GPU box:  python tests/tools/measure_parity.py"""
 import sys, os, warnings
 import numpy as np
 import scipy.sparse as sp
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_golden
 from test_oracle_golden import NEWTON_CASES

@@ -6,8 +6,8 @@ O=$R/gpurun_out/r04_step14
 mkdir -p "$O"
 cd "$R"
 timeout 300 python3 -m pytest tests/test_gpu_run_loop.py tests/test_gpu_mu.py -x -q -m gpu > "$O/pytest.txt" 2>&1; tail -n 3 "$O/pytest.txt"
-timeout 700 python3 tools/fuzz_campaign.py --minutes 8 --seed 41 --focus pair > "$O/fuzz_pair.jsonl" 2> "$O/fuzz_pair.err"
-timeout 900 python3 tools/fuzz_campaign.py --minutes 12 --seed 42 > "$O/fuzz_mix.jsonl" 2> "$O/fuzz_mix.err"
+timeout 700 python3 tests/tools/fuzz_campaign.py --minutes 8 --seed 41 --focus pair > "$O/fuzz_pair.jsonl" 2> "$O/fuzz_pair.err"
+timeout 900 python3 tests/tools/fuzz_campaign.py --minutes 12 --seed 42 > "$O/fuzz_mix.jsonl" 2> "$O/fuzz_mix.err"
 python3 - <<PY
 import json
 for n in ("fuzz_pair", "fuzz_mix"):
