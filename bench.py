@@ -37,6 +37,9 @@ WORKLOADS = {
     "c4": dict(m=65536, d=65536, p=65536, k=256, solver="mu",
                desc="BASELINE configs[3]: CMF(n_components=256, solver='mu'), dense 65536x65536 X, "
                     "65536x65536 Y, non-negative synthetic"),
+    "c4q": dict(m=16384, d=16384, p=16384, k=256, solver="mu",
+                desc="C4 at a quarter of its edge (the N = 8 dress rehearsal of the test suite): CMF(n_components=256, solver='mu'), dense "
+                     "16384x16384 X and Y, non-negative synthetic"),
     "c2": dict(m=16384, d=8192, p=4096, k=128, solver="mu",
                desc="BASELINE configs[1]: CMF(n_components=128, solver='mu', linear link), dense "
                     "16384x8192 X, 8192x4096 Y, non-negative synthetic"),
@@ -221,9 +224,14 @@ def main():
     ap.add_argument("--overlap-chunks", type=int, default=1,
                     help="N > 1 GPUs, MU on dense data: reduce the (d + k) k buffer in this many row blocks on a side stream while the "
                          "next block's partial is computed (default 1: one serial all-reduce)")
-    ap.add_argument("--mu-collective", choices=("rsag", "allreduce"), default=None,
-                    help="N > 1 GPUs, MU: 'rsag' (default) = reduce-scatter of the partial, V epilogue on the rank's row block, all-gather of V; "
-                         "'allreduce' = ONE all-reduce of the (d + k) k buffer and the replicated epilogue")
+    ap.add_argument("--mu-collective", choices=("auto", "rsag", "allreduce"), default=None,
+                    help="N > 1 GPUs, MU: 'allreduce' = ONE all-reduce of the (d + k) k buffer and the replicated epilogue (north_star's "
+                         "protocol); 'rsag' = reduce-scatter of the partial, V epilogue on the rank's row block, all-gather of V, the two "
+                         "k^2 Grams in the same two RCCL groups; 'auto' (default) = both timed on the live ranks before the warm-up, the "
+                         "faster kept (rsag only when it wins by > 2 %%), decision and timings in collective.protocol_trial")
+    ap.add_argument("--dump-rows", default=None, metavar="PREFIX",
+                    help="after the timed iterations every rank writes the rows it owns out of 16 fixed global rows of U, V, Z to "
+                         "PREFIX.rank<r>.npz (tools/compare_rows.py compares two such sets: the N = 8 dress rehearsal against N = 1)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="cmf_set_option knob for A/B runs (e.g. row_symmetric=0); recorded in config")
     args = ap.parse_args()
@@ -368,9 +376,21 @@ def main():
         elapsed = float(coll.all_reduce_host([elapsed], "max")[0])   # the slowest rank's clock
     marks = ctx.marker_times()
     series_ms = [b_ - a_ for a_, b_ in zip(marks, marks[1:])]
+    launch_points = coll.launch_points_seen() if coll and hasattr(coll, "launch_points_seen") else None
     coll_stats = coll.stats() if coll else None
     coll_exposed = coll.exposed_ms() if coll and hasattr(coll, "exposed_ms") else None
     coll_kinds = coll.stats_by_kind() if coll and hasattr(coll, "stats_by_kind") else {}
+    if args.dump_rows:
+        pick = np.random.RandomState(7)
+        dump = {}
+        for name, which, n, lo, hi in (("U", _lib.CMF_U, m, r0, r1), ("V", _lib.CMF_V, d, 0, d if rank == 0 else 0), ("Z", _lib.CMF_Z, p, c0, c1)):
+            rows = np.sort(pick.choice(n, size=min(16, n), replace=False))
+            mine = rows[(rows >= lo) & (rows < hi)]
+            F = ctx.get_factor(which)
+            dump[name + "_rows"] = mine
+            dump[name] = F[mine - lo]
+            dump[name + "_absmax"] = np.array([np.abs(F).max() if F.size else 0.0])
+        np.savez(args.dump_rows + ".rank%d.npz" % rank, **dump)
     replicas = None
     if coll and not rows_mode:
         # V is replicated: after the timed iterations every rank must hold the same V, bit for bit (a collective that summed
@@ -517,7 +537,7 @@ def main():
                                    "columns), factor rows reassembled by 3 in-place RCCL all-gathers, (m+p+d)*k f32 in all "
                                    "per iteration" % world) if rows_mode else
                                   ("X/U row-sharded, Y/Z column-sharded x%d, V replicated; the one sum over the ranks per iteration, (d+k)*k f32, "
-                                   "as %s" % (world, "reduce-scatter + row-blocked V epilogue + all-gather (+ two k^2 all-reduces)"
+                                   "as %s" % (world, "reduce-scatter + row-blocked V epilogue + all-gather, the two k^2 Gram all-reduces inside the same two RCCL groups"
                                               if getattr(drv, "mode", None) == "rsag" else "1 RCCL all-reduce"))},
         "roofline": roof,
         "rel_residual": {"x": (ex2 / x2) ** 0.5 if x2 > 0 else None, "y": (ey2 / y2) ** 0.5 if y2 > 0 else None,
@@ -531,10 +551,12 @@ def main():
         out["collective"] = {"backend": coll.backend, "ranks": world,
                              "ranks_seen": getattr(coll, "ranks_seen", None), "rank_seen": getattr(coll, "rank_seen", None),
                              "protocol": getattr(drv, "mode", None) or ("all_gather x3" if rows_mode else "all_reduce"),
+                             "protocol_chosen": getattr(drv, "mode", None), "protocol_trial": getattr(drv, "protocol_trial", None),
                              "calls_per_iteration": calls / args.steps, "payload_bytes_per_iteration": nbytes / args.steps,
+                             "launch_points_per_iteration": (launch_points / args.steps) if launch_points is not None else None,
                              "ms_per_iteration": cms / args.steps,
                              "per_kind": {kname: {"calls_per_iteration": kv[0] / args.steps, "payload_bytes_per_iteration": kv[1] / args.steps,
-                                                  "us_per_call": (kv[2] / kv[0] * 1e3) if kv[0] else None}
+                                                  "us_per_call": (kv[2] / kv[0] * 1e3) if kv[0] and kv[2] > 0 else None}
                                           for kname, kv in coll_kinds.items() if kv[0]},
                              "overlap_chunks": args.overlap_chunks,
                              "exposed_ms_per_iteration": exposed / args.steps,

@@ -348,6 +348,13 @@ int cmf_comm_allgather_f32(cmf_ctx *ctx, float *dev_full, int64_t elems_per_rank
  * own buffer is the sum over the ranks of that chunk.  With cmf_comm_allgather_f32 on the updated rows it is the ONE all-reduce of
  * the MU V update (cmf_solvers.py:242-246) cut in two around the row-blocked epilogue (cmf_mu_v_apply_rows)                   */
 int cmf_comm_reduce_scatter_f32(cmf_ctx *ctx, float *dev_full, int64_t elems_per_rank);
+/* ncclGroupStart / ncclGroupEnd around the collectives enqueued in between: ONE launch point on the context's stream.  The
+ * row-blocked MU iteration (cmf_solvers.py:242-246 cut around the epilogue) is two groups: {all-reduce of U^T U + Z^T Z,
+ * reduce-scatter of X^T U + Y Z} and {all-reduce of the ranks' shares of V^T V, all-gather of V}.  cmf_comm_launch_points:
+ * collectives outside groups + groups since the last cmf_comm_stats(reset)                                                    */
+int cmf_comm_group_start(cmf_ctx *ctx);
+int cmf_comm_group_end(cmf_ctx *ctx);
+int cmf_comm_launch_points(cmf_ctx *ctx, int64_t *n);
 /* what RCCL reports about the communicator (ncclCommCount, ncclCommUserRank) -- not what the launcher's environment says   */
 int cmf_comm_count(cmf_ctx *ctx, int *ranks_seen, int *rank_seen);
 /* at most 16 host scalars, op 0 = sum, 1 = max; waits for the result (convergence test on the global error, the slowest
@@ -359,8 +366,11 @@ int cmf_comm_barrier(cmf_ctx *ctx);
 int cmf_comm_timing(cmf_ctx *ctx, int enable);
 int cmf_comm_stats(cmf_ctx *ctx, int64_t *calls, int64_t *bytes, double *ms, int reset);
 /* the same per kind of collective (no reset: read before cmf_comm_stats(..., 1))                                            */
-enum { CMF_COMM_ALLREDUCE_F32 = 0, CMF_COMM_ALLREDUCE_F64 = 1, CMF_COMM_ALLGATHER_F32 = 2, CMF_COMM_REDUCE_SCATTER_F32 = 3, CMF_COMM_KINDS = 4 };
+enum { CMF_COMM_ALLREDUCE_F32 = 0, CMF_COMM_ALLREDUCE_F64 = 1, CMF_COMM_ALLGATHER_F32 = 2, CMF_COMM_REDUCE_SCATTER_F32 = 3, CMF_COMM_GROUP = 4, CMF_COMM_KINDS = 5 };
 int cmf_comm_stats_kind(cmf_ctx *ctx, int kind, int64_t *calls, int64_t *bytes, double *ms);
+/* dev[0 .. n) *= factor on the context's stream (the measurement double of the collectives stands in for the peers with the
+ * rank's own partial times the world size: finite iterates without a communicator)                                           */
+int cmf_scale_f32(cmf_ctx *ctx, float *dev, int64_t n, double factor);
 /* raw copies between caller-held device pointers (scratch, partial buffers) and host memory on the context's stream; both wait */
 int cmf_copy_to_host(cmf_ctx *ctx, const void *dev, void *host, int64_t bytes);
 int cmf_copy_from_host(cmf_ctx *ctx, void *dev, const void *host, int64_t bytes);

@@ -100,6 +100,10 @@ PROTOTYPES = {
     "cmf_comm_exposed_ms": [_vp, _pd, _i32],
     "cmf_comm_allgather_f32": [_vp, _vp, _i64],
     "cmf_comm_reduce_scatter_f32": [_vp, _vp, _i64],
+    "cmf_comm_group_start": [_vp],
+    "cmf_comm_group_end": [_vp],
+    "cmf_comm_launch_points": [_vp, _pi64],
+    "cmf_scale_f32": [_vp, _vp, _i64, _dbl],
     "cmf_comm_count": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "cmf_comm_stats_kind": [_vp, _i32, _pi64, _pi64, _pd],
     "cmf_comm_allreduce_host_f64": [_vp, _pd, _i32, _i32],
@@ -550,6 +554,21 @@ class Context:
     def comm_reduce_scatter(self, full, elems_per_rank):
         check(self._lib.cmf_comm_reduce_scatter_f32(self._h, _vp(full.data_ptr()), elems_per_rank))
 
+    def comm_group_start(self):
+        check(self._lib.cmf_comm_group_start(self._h))
+
+    def comm_group_end(self):
+        check(self._lib.cmf_comm_group_end(self._h))
+
+    def comm_launch_points(self):
+        n = C.c_int64(0)
+        check(self._lib.cmf_comm_launch_points(self._h, C.byref(n)))
+        return n.value
+
+    def scale(self, buf, factor):
+        """buf *= factor on the context's stream (device array)."""
+        check(self._lib.cmf_scale_f32(self._h, _vp(buf.data_ptr()), buf.numel(), float(factor)))
+
     def comm_count(self):
         """(ranks, this rank) as RCCL reports them (ncclCommCount / ncclCommUserRank)."""
         n, r = C.c_int(0), C.c_int(0)
@@ -557,7 +576,8 @@ class Context:
         return n.value, r.value
 
     def comm_stats_kind(self, kind):
-        """(calls, payload bytes, ms) of one kind of collective: 0 all-reduce f32, 1 all-reduce f64, 2 all-gather, 3 reduce-scatter."""
+        """(calls, payload bytes, ms) of one kind of collective: 0 all-reduce f32, 1 all-reduce f64, 2 all-gather, 3 reduce-scatter, 4 group
+        (calls = groups closed, ms = events around the whole group; the members are counted under their own kinds without ms)."""
         calls, nbytes, ms = C.c_int64(0), C.c_int64(0), C.c_double(0)
         check(self._lib.cmf_comm_stats_kind(self._h, int(kind), C.byref(calls), C.byref(nbytes), C.byref(ms)))
         return calls.value, nbytes.value, ms.value

@@ -40,18 +40,23 @@ def source_hash():
     return h.hexdigest()
 
 
+STAMP = b"cmfhip-source-sha256:"
+
+
 def library_hash(path=LIB):
-    """The source hash a built library carries (None: no library, or one from before the stamp)."""
-    import ctypes
+    """The source hash a built library carries (None: no library, or one from before the stamp).  Read from the file's BYTES:
+    dlopen-ing the product library here would pin the old image in this process (glibc returns the mapped image by name, so the
+    `_lib.load()` that follows a rebuild would still see the stale one) and would load a HIP runtime before
+    `_lib._preload_hip_runtime()` has chosen which."""
     if not os.path.exists(path):
         return None
-    try:
-        lib = ctypes.CDLL(path, mode=getattr(os, "RTLD_LOCAL", 0))
-        fn = lib.cmf_source_hash
-    except (OSError, AttributeError):
+    with open(path, "rb") as f:
+        blob = f.read()
+    i = blob.find(STAMP)
+    if i < 0:
         return None
-    fn.restype = ctypes.c_char_p
-    return fn().decode()
+    j = blob.find(b"\0", i)
+    return blob[i + len(STAMP):j].decode("ascii", "replace")
 
 
 def needs_build():
@@ -65,13 +70,14 @@ def build(force=False, verbose=False, diag=False):
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
            "-DCMF_SOURCE_HASH=\"%s\"" % source_hash(),
-           "-I", os.path.join(ROOT, "include"), "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-I", os.path.join(ROOT, "include"), "-o", LIB + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
     if diag:
         cmd.append("-DCMF_DIAG_BUILD")
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
+    os.replace(LIB + ".tmp", LIB)  # a new inode: an image of the old file that some process has mapped is never written over
     return LIB
 
 

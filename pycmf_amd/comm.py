@@ -127,7 +127,33 @@ def exchange_unique_id(rank, world, timeout=None):
     return raw, path
 
 
+class _Group:
+    """``with coll.group():`` -- the collectives enqueued inside go to the backend as one group (RCCL: ncclGroupStart / ncclGroupEnd,
+    one launch point on the stream; the doubles run them one after the other)."""
+
+    def __init__(self, coll):
+        self.coll = coll
+
+    def __enter__(self):
+        self.coll._group_start()
+        return self
+
+    def __exit__(self, et, ev, tb):
+        self.coll._group_end()
+        return False
+
+
 class _ProtocolCheck:
+    def group(self):
+        return _Group(self)
+
+    def _group_start(self):
+        self.launch_points = getattr(self, "launch_points", 0) + 1
+        self._in_group = True
+
+    def _group_end(self):
+        self._in_group = False
+
     def self_test(self):
         """Known-answer run of the in-place reduce-scatter and all-gather on this communicator (every rank must call it): True when
         every rank saw the sums / the gathered chunks it had to see.  `make_sharded_mu` falls back to the single all-reduce
@@ -146,6 +172,19 @@ class _ProtocolCheck:
         self.all_gather(buf)
         want = np.concatenate([100.0 * (q + 1) + np.arange(per) for q in range(w)]).astype(np.float32)
         ok = ok and np.array_equal(self.ctx.copy_to_host(buf).reshape(-1), want)
+        # the two grouped pairs of the row-blocked MU iteration: {small all-reduce, reduce-scatter}, {small all-reduce, all-gather}
+        small = _lib.DeviceArray(self.ctx, 16, 1)
+        for second in (self.reduce_scatter, self.all_gather):
+            self.ctx.copy_from_host(small, np.arange(16, dtype=np.float32) + r)
+            self.ctx.copy_from_host(buf, mine if second == self.all_gather else (r + 1) + i)
+            with self.group():
+                self.all_reduce(small)
+                second(buf)
+            ok = ok and np.array_equal(self.ctx.copy_to_host(small).reshape(-1), w * np.arange(16, dtype=np.float32) + w * (w - 1) / 2)
+            got = self.ctx.copy_to_host(buf).reshape(-1)
+            ok = ok and (np.array_equal(got, want) if second == self.all_gather else
+                         np.array_equal(got[r * per:(r + 1) * per], w * (w + 1) / 2 + w * i[r * per:(r + 1) * per]))
+        small.release()
         buf.release()
         return bool(self.all_reduce_host([0.0 if ok else 1.0], "max")[0] == 0.0)
 
@@ -193,8 +232,17 @@ class RcclCollectives(_ProtocolCheck):
         """In place: chunk `rank` of the rank's buffer becomes the sum over the ranks of that chunk."""
         self.ctx.comm_reduce_scatter(full, full.numel() // self.world)
 
+    def _group_start(self):
+        self.ctx.comm_group_start()
+
+    def _group_end(self):
+        self.ctx.comm_group_end()
+
+    def launch_points_seen(self):
+        return self.ctx.comm_launch_points()
+
     def stats_by_kind(self):
-        names = ("all_reduce_f32", "all_reduce_f64", "all_gather_f32", "reduce_scatter_f32")
+        names = ("all_reduce_f32", "all_reduce_f64", "all_gather_f32", "reduce_scatter_f32", "group")
         return {n: self.ctx.comm_stats_kind(k) for k, n in enumerate(names)}
 
     def all_reduce_host(self, values, op="sum"):
@@ -256,8 +304,13 @@ class HostStagedCollectives(_ProtocolCheck):
                 pass
         return parts
 
+    def launch_points_seen(self):
+        return getattr(self, "launch_points", 0)
+
     def _account(self, nbytes, t0, kind="all_reduce_f32"):
         dt = (time.perf_counter() - t0) * 1e3
+        if not getattr(self, "_in_group", False):
+            self.launch_points = getattr(self, "launch_points", 0) + 1
         self.calls += 1
         self.bytes += nbytes
         self.ms += dt
@@ -318,6 +371,7 @@ class HostStagedCollectives(_ProtocolCheck):
         self.calls = self.bytes = 0
         self.ms = 0.0
         self.kinds = {}
+        self.launch_points = 0
 
     def stats(self):
         self.ctx.sync()
@@ -341,24 +395,39 @@ class HostStagedCollectives(_ProtocolCheck):
                 pass
 
 
-class NullCollectives:
-    """MEASUREMENT HOOK (``CMF_COMM_BACKEND=null``): rank r of N with no peers -- every collective returns at once and changes
-    nothing, so a single GPU can time the per-rank COMPUTE of a sharded run (the shard's GEMM shapes, split-K choices, row-block
-    launches of --overlap-chunks) with the collective excluded.  The iterates are those of a rank whose peers contribute zero."""
+class NullCollectives(_ProtocolCheck):
+    """MEASUREMENT HOOK (``CMF_COMM_BACKEND=null``): rank r of N with no peers, so a single GPU can time the per-rank COMPUTE of a
+    sharded run (the shard's GEMM shapes, split-K choices, row-block launches of --overlap-chunks) with the collective excluded.
+    The peers' contributions are stood in for by the rank's own: a sum over the ranks returns the rank's buffer TIMES THE WORLD
+    SIZE (one elementwise launch on the stream, counted as compute), an all-gather leaves the other ranks' rows as they are
+    (the initial V: finite).  The iterates are then those of N identical shards -- finite, of the right magnitude -- instead of the
+    NaN a run with summands missing produces (clocks on NaN operands are not the clocks of a real run)."""
 
-    backend = "null (per-rank compute only, measurement hook)"
+    backend = "null (per-rank compute only, measurement hook; sums = own partial x world)"
 
     def __init__(self, ctx, rank, world, timed=False):
         self.ctx, self.rank, self.world = ctx, rank, world
         self.ranks_seen, self.rank_seen = 1, rank
+        self.launch_points = 0
+
+    def _count(self):
+        if not getattr(self, "_in_group", False):
+            self.launch_points += 1
 
     def all_reduce(self, buf):
-        pass
+        self._count()
+        if buf.element_size() == 4:
+            self.ctx.scale(buf, self.world)
 
     all_reduce_bg = all_reduce
 
     def reduce_scatter(self, full):
-        pass
+        self._count()
+        rows = full.shape[0] // self.world      # chunk `rank` of the rank's own buffer becomes "the sum"
+        self.ctx.scale(full[self.rank * rows:(self.rank + 1) * rows], self.world)
+
+    def launch_points_seen(self):
+        return self.launch_points
 
     def stats_by_kind(self):
         return {}
@@ -367,7 +436,7 @@ class NullCollectives:
         pass
 
     def all_gather(self, full, chunk=None):
-        pass
+        self._count()
 
     def all_reduce_host(self, values, op="sum"):
         return np.ascontiguousarray(values, dtype=np.float64)
@@ -375,8 +444,11 @@ class NullCollectives:
     def barrier(self):
         pass
 
+    def self_test(self):
+        return True
+
     def reset(self):
-        pass
+        self.launch_points = 0
 
     def stats(self):
         self.ctx.sync()

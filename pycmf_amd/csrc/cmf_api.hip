@@ -157,6 +157,7 @@ struct cmf_ctx {
     DevBuf slabs, slabs_b;                // split-K partial tiles (grow-only); second set for a product whose slabs must outlive the next one
     int slab_sel = 0;                     // which set gemm() writes
     DevBuf tickets;                       // one arrival counter per output tile of a split-K GEMM (zero between launches)
+    DevBuf narrow_tmp;                    // output image of an in-place fused update cut into column tiles (gemm(): the siblings of a row tile read all of F)
     int opt_inred = 0;                    // 0: split-K partials summed by a chip-wide kernel | 1: by the last-arriving workgroup of each tile
                                           // inside the GEMM kernel (A/B option; measured slower)
     int opt_side_gram = 0;                // A/B option: small Grams (k_pad 64 / 128) on a side stream beside the data pass that follows them
@@ -468,6 +469,14 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
         while (pl.bn > 64 && pl.tiles_m * (n / pl.bn) * 2 <= (int64_t)c->num_cu) pl.bn /= 2;
         pl.ntiles_n = (int)(n / pl.bn);
     }
+    // An in-place update (EPI_MU / EPI_COMBINE: A == out == F) on column tiles would let a late workgroup stream columns of F its
+    // siblings of the same row tile have already overwritten: the column tiles write a scratch image that is copied
+    // over F behind the launch (stream order).  Products whose output does not alias A (EPI_APPLY / DIRECT / GRAD) write directly.
+    float *alias_out = nullptr;
+    if (mu && pl.ntiles_n > 1 && mu->out == A) {
+        CHK(ensure(c, c->narrow_tmp, (size_t)rup(mout, 256) * n * sizeof(float)));
+        alias_out = mu->out;
+    }
     GemmArgs a;
     memset(&a, 0, sizeof a);
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb;
@@ -481,7 +490,7 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
     const bool direct = (pl.nsplit == 1 && !accumulate);
     if (mu) {
         if (mode != MODE_NN || pl.nsplit != 1) return fail(CMF_EINVAL, "fused update needs an unsplit NN product");
-        a.epi = mu->kind; a.epi_F = mu->F; a.epi_P = mu->P; a.epi_out = mu->out;
+        a.epi = mu->kind; a.epi_F = mu->F; a.epi_P = mu->P; a.epi_out = alias_out ? (float *)c->narrow_tmp.p : mu->out;
         a.epi_a = (float)mu->a; a.epi_b = (float)mu->b; a.epi_c = (float)mu->c;
         a.epi_rows = mu->rows; a.epi_kvalid = mu->kvalid; a.epi_nn = mu->nn;
         a.C = out; // unused
@@ -516,6 +525,7 @@ static int gemm(cmf_ctx *c, int mode, const float *A, int64_t lda, const float *
             else CHK((launch_gemm_mode<MODE_TN, 1>(c, a, pl)));
         }
     }
+    if (alias_out) HIPCHK(hipMemcpyAsync(alias_out, c->narrow_tmp.p, (size_t)rup(mout, 256) * n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     if (!direct && !in_kernel) {
         if (defer && !accumulate) { // the consumer sums the slabs (valid until the next GEMM reuses the slab workspace)
             defer->base = (const float *)slabbuf.p; defer->nslab = pl.nsplit; defer->stride = a.slab_stride;
@@ -703,7 +713,9 @@ extern "C" const char *cmf_last_error(void) { return g_err.c_str(); }
 #ifndef CMF_SOURCE_HASH
 #define CMF_SOURCE_HASH "unstamped"
 #endif
-extern "C" const char *cmf_source_hash(void) { return CMF_SOURCE_HASH; }
+// (the stamp is also findable in the file's bytes behind the marker, so that the build script never has to dlopen the library)
+static const char g_source_stamp[] = "cmfhip-source-sha256:" CMF_SOURCE_HASH;
+extern "C" const char *cmf_source_hash(void) { return g_source_stamp + sizeof("cmfhip-source-sha256:") - 1; }
 
 extern "C" int cmf_device_count(int *count) {
     if (!count) return fail(CMF_EINVAL, "null argument");
@@ -763,12 +775,13 @@ static void release_problem(cmf_ctx *c) {
     c->X = c->Y = nullptr;
     c->F[0] = c->F[1] = c->F[2] = nullptr;
     c->num = c->den = c->G = c->G2 = c->Hm = c->Hinv = c->Eye = c->vbuf = nullptr;
-    c->slabs = DevBuf(); c->slabs_b = DevBuf(); c->gslab32 = DevBuf(); c->slab_sel = 0; c->tickets = DevBuf(); c->resid = DevBuf(); c->resid2 = DevBuf(); c->resid3 = DevBuf(); c->dpart = DevBuf();
+    c->slabs = DevBuf(); c->slabs_b = DevBuf(); c->gslab32 = DevBuf(); c->slab_sel = 0; c->tickets = DevBuf(); c->narrow_tmp = DevBuf(); c->resid = DevBuf(); c->resid2 = DevBuf(); c->resid3 = DevBuf(); c->dpart = DevBuf();
     c->kr1 = DevBuf(); c->kr2 = DevBuf(); c->hrows = DevBuf(); c->mask1 = DevBuf(); c->mask2 = DevBuf();
     c->lists1 = DevBuf(); c->lists2 = DevBuf(); c->lists1s = DevBuf(); c->lists2s = DevBuf(); c->zerobuf = DevBuf(); c->lr_small = DevBuf(); c->lr_rows = DevBuf(); c->hpart = DevBuf();
     for (int q = 0; q < 2; ++q) { c->cls_idx[q] = DevBuf(); c->cls_off[q] = DevBuf(); c->cls_cnt[q] = DevBuf(); c->cls_pat[q] = DevBuf(); }
     c->hclass = DevBuf(); c->certimg = DevBuf(); c->certflag = DevBuf();
     c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf(); c->clampstat = DevBuf(); c->badbuf = DevBuf(); c->rw64 = DevBuf(); c->rh64 = DevBuf(); c->bad_host.clear();
+    c->ref_w = DevBuf(); c->ref_w2 = DevBuf(); c->ref_g = DevBuf(); c->ref_i = DevBuf(); c->ref_ns = DevBuf();
     c->nsidx = DevBuf(); c->nsws = DevBuf();
     c->spmm_bar = DevBuf();
     c->g64a = DevBuf(); c->g64b = DevBuf(); c->gmix64 = DevBuf(); c->h64 = DevBuf();
@@ -1465,7 +1478,7 @@ static int grow_v(cmf_ctx *c, int64_t rows) {
     if (rows <= c->v_rows_alloc) return CMF_OK;
     invalidate_graphs(c);
     float *nv = nullptr;
-    CHK(dev_alloc(c, (void **)&nv, (size_t)rows * c->kp * sizeof(float)));
+    CHK(dev_alloc(c, (void **)&nv, (size_t)rows * c->kp * sizeof(float))); // zero-filled (dev_alloc): rows >= d_pad stay zero
     HIPCHK(hipMemcpyAsync(nv, c->F[CMF_V], (size_t)c->dp * c->kp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     dev_free(c, c->F[CMF_V]);

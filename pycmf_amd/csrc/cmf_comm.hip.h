@@ -21,6 +21,8 @@ struct RcclApi {
     decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclCommUserRank) CommUserRank = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
 };
 static RcclApi g_rccl;
 static std::mutex g_rccl_mu;
@@ -47,6 +49,8 @@ static int rccl_load() {
     CMF_RCCL_SYM(CommCount, "ncclCommCount")
     CMF_RCCL_SYM(CommUserRank, "ncclCommUserRank")
     CMF_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+    CMF_RCCL_SYM(GroupStart, "ncclGroupStart")
+    CMF_RCCL_SYM(GroupEnd, "ncclGroupEnd")
 #undef CMF_RCCL_SYM
     g_rccl = a;
     return CMF_OK;
@@ -72,6 +76,11 @@ struct CmfComm {
     int ev_next = 0;
     bool bg_pending = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> joins; // on the context's stream around every join: the EXPOSED wait
+    // cmf_comm_group_start .. _end: the collectives in between are handed to RCCL as ONE group (one launch point on the stream);
+    // while timed, ONE event pair around the group (events recorded inside would bracket nothing: RCCL enqueues at ncclGroupEnd)
+    bool in_group = false;
+    hipEvent_t grp_a = nullptr, grp_b = nullptr;
+    int64_t launch_points = 0;  // collectives outside groups + groups
 };
 
 extern "C" int cmf_comm_unique_id(char *id128) {
@@ -131,7 +140,8 @@ struct CommTimed { // events on the collective's stream around it (bench.py: byt
     CommTimed(cmf_ctx *c_, CmfComm *cm_, int64_t nbytes, int kind_, hipStream_t st_ = nullptr) : c(c_), cm(cm_), st(st_ ? st_ : c_->stream), kind(kind_) {
         cm->calls += 1; cm->bytes += nbytes;
         cm->kcalls[kind] += 1; cm->kbytes[kind] += nbytes;
-        if (cm->timed && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, st);
+        if (!cm->in_group) cm->launch_points += 1;
+        if (!cm->in_group && cm->timed && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, st);
         else a = b = nullptr;
     }
     ~CommTimed() {
@@ -143,6 +153,35 @@ struct CommTimed { // events on the collective's stream around it (bench.py: byt
         if (!(c)) return fail(CMF_EINVAL, "null context");                                            \
         if (!(c)->comm) return fail(CMF_EINVAL, "cmf_comm_init has not been called on this context"); \
     } while (0)
+
+// The collectives enqueued between cmf_comm_group_start and cmf_comm_group_end go to RCCL as one group (ncclGroupStart / ncclGroupEnd):
+// one launch point on the context's stream instead of one per call -- the row-blocked MU protocol pairs its k_pad^2 all-reduce of
+// U^T U + Z^T Z with the reduce-scatter of the numerator, and the k_pad^2 all-reduce of V^T V with the all-gather of V.
+extern "C" int cmf_comm_group_start(cmf_ctx *c) {
+    NEED_COMM(c);
+    CmfComm *cm = c->comm;
+    if (cm->in_group) return fail(CMF_EINVAL, "cmf_comm_group_start: a group is already open");
+    DeviceGuard dg(c->device);
+    cm->grp_a = cm->grp_b = nullptr;
+    if (cm->timed && hipEventCreate(&cm->grp_a) == hipSuccess && hipEventCreate(&cm->grp_b) == hipSuccess) (void)hipEventRecord(cm->grp_a, c->stream);
+    else cm->grp_a = cm->grp_b = nullptr;
+    RCCLCHK(g_rccl.GroupStart());
+    cm->in_group = true;
+    cm->launch_points += 1;
+    return CMF_OK;
+}
+extern "C" int cmf_comm_group_end(cmf_ctx *c) {
+    NEED_COMM(c);
+    CmfComm *cm = c->comm;
+    if (!cm->in_group) return fail(CMF_EINVAL, "cmf_comm_group_end without cmf_comm_group_start");
+    DeviceGuard dg(c->device);
+    cm->in_group = false;
+    RCCLCHK(g_rccl.GroupEnd());
+    if (cm->grp_a && cm->grp_b) { (void)hipEventRecord(cm->grp_b, c->stream); cm->events.push_back({cm->grp_a, cm->grp_b, CMF_COMM_GROUP}); }
+    cm->grp_a = cm->grp_b = nullptr;
+    cm->kcalls[CMF_COMM_GROUP] += 1;
+    return CMF_OK;
+}
 
 // in-place sum over the ranks of n float32 / float64 values in device memory, on the context's stream
 extern "C" int cmf_comm_allreduce_f32(cmf_ctx *c, float *dev_buf, int64_t n) {
@@ -295,9 +334,16 @@ extern "C" int cmf_comm_stats(cmf_ctx *c, int64_t *calls, int64_t *bytes, double
     if (reset) {
         for (auto &e : cm->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         cm->events.clear();
-        cm->calls = 0; cm->bytes = 0;
+        cm->calls = 0; cm->bytes = 0; cm->launch_points = 0;
         for (int k = 0; k < CMF_COMM_KINDS; ++k) cm->kcalls[k] = cm->kbytes[k] = 0;
     }
+    return CMF_OK;
+}
+// launch points on the stream since the last reset: collectives outside groups + groups (read before cmf_comm_stats(reset))
+extern "C" int cmf_comm_launch_points(cmf_ctx *c, int64_t *n) {
+    NEED_COMM(c);
+    if (!n) return fail(CMF_EINVAL, "null argument");
+    *n = c->comm->launch_points;
     return CMF_OK;
 }
 // the same accounting for ONE kind of collective (CMF_COMM_ALLREDUCE_F32 ...), never resets: call before cmf_comm_stats(reset)
@@ -316,6 +362,18 @@ extern "C" int cmf_comm_stats_kind(cmf_ctx *c, int kind, int64_t *calls, int64_t
     if (calls) *calls = cm->kcalls[kind];
     if (bytes) *bytes = cm->kbytes[kind];
     if (ms) *ms = total;
+    return CMF_OK;
+}
+
+// dev[0..n) *= factor on the context's stream: the measurement double of the collectives (CMF_COMM_BACKEND=null) stands in for
+// the peers' contributions with the rank's own partial times the world size, so that the iterates stay finite
+extern "C" int cmf_scale_f32(cmf_ctx *c, float *dev, int64_t n, double factor) {
+    if (!c || !dev || n < 0) return fail(CMF_EINVAL, "bad argument");
+    if (n == 0) return CMF_OK;
+    DeviceGuard dg(c->device);
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(axpby_kernel, dim3(blocks), dim3(256), 0, c->stream, dev, (const float *)dev, (float)factor, (const float *)nullptr, 0.f, n);
+    HIPCHK(hipGetLastError());
     return CMF_OK;
 }
 

@@ -1414,7 +1414,12 @@ static int refine_rows64_batched(cmf_ctx *c, int which, const RowSide &s1, const
             else clamp_r.push_back(b);
         }
         // ---- rows the clamp acts on: M = max(H, pert I) by the float64 matrix polynomials of shared_inverse64, batched
-        if (!clamp_r.empty() && c->hess_psd) {
+        // (in sub-batches: seven k_pad^2 float64 images per row -- 3.7 MB at k_pad = 256 -- are kept under 2 GiB whatever the
+        // number of rows the clamp acts on: a sweep in which EVERY row of a 4096-row batch is clamped must not ask for 15 GiB)
+        const size_t clamp_cap = std::max<size_t>(1, ((size_t)2 << 30) / (7 * kk * sizeof(double)));
+        const std::vector<int> clamp_all = clamp_r;
+        for (size_t c0 = 0; c->hess_psd && c0 < clamp_all.size(); c0 += clamp_cap) {
+            clamp_r.assign(clamp_all.begin() + c0, clamp_all.begin() + std::min(clamp_all.size(), c0 + clamp_cap));
             const int ncl = (int)clamp_r.size();
             CHK(ensure(c, c->ref_ns, (size_t)ncl * 7 * kk * sizeof(double) + (size_t)ncl * sizeof(double)));
             double *Hc = (double *)c->ref_ns.p, *Bm = Hc + ncl * kk, *X = Bm + ncl * kk, *X2 = X + ncl * kk, *Y = X2 + ncl * kk, *Z = Y + ncl * kk, *M = Z + ncl * kk;

@@ -18,6 +18,8 @@ the gloo backend and a test double, while production uses ``HipShardBackend``:
     apply_v(buf, l1, l2)     V update from the reduced buffer
     update_uz(l1, l2, mask)  local U / Z update
 """
+import contextlib
+
 import numpy as np
 
 
@@ -125,11 +127,14 @@ class ShardedMU:
     V, and block c is all-reduced on the communicator's side stream while block c + 1 is computed -- the same single buffer,
     summed in `chunks` pieces.
 
-    ``mode='rsag'`` (default of ``make_sharded_mu``): the same sum cut in two around the epilogue ("Partitioning":
-    reduce-scatter + epilogue + all-gather).  The partial P is reduce-scattered in ``world`` equal row blocks, rank r applies
-    ``V_r *= P_r / reg(V_r G)`` to ITS block only and forms its share of V^T V, V is all-gathered in place; the two k x k Grams
-    (U^T U + Z^T Z, V^T V) travel as two latency-bound all-reduces of k_pad^2 floats.  Same bytes on the links as the all-reduce;
-    (world - 1) / world of the replicated epilogue and of the d-row Gram disappear from every rank."""
+    ``mode='rsag'``: the same sum cut in two around the epilogue ("Partitioning": reduce-scatter + epilogue +
+    all-gather).  The partial P is reduce-scattered in ``world`` equal row blocks, rank r applies ``V_r *= P_r / reg(V_r G)`` to
+    ITS block only and forms its share of V^T V, V is all-gathered in place; the two k x k Grams (U^T U + Z^T Z, V^T V) ride in the
+    SAME RCCL groups as the two halves (ncclGroupStart / End): two launch points per iteration.  Same bytes on the links as the
+    all-reduce; (world - 1) / world of the replicated epilogue and of the d-row Gram disappear from every rank.
+
+    Which of the two runs is MEASURED, not assumed (``make_sharded_mu(mode='auto')``, the default): a few iterations of each on the
+    live ranks when the driver is built; north_star's single all-reduce unless the row-blocked form is faster by a clear margin."""
 
     def __init__(self, backend, buf, world=1, all_reduce=None, chunks=1, coll=None, mode="allreduce", rank=0):
         self.backend = backend
@@ -149,20 +154,29 @@ class ShardedMU:
         elif chunks > 1 and coll is not None:
             self.blocks, self.dp, self.kp = backend.row_blocks(chunks)
 
+    def _group(self):
+        g = getattr(self.coll, "group", None)
+        return g() if g else contextlib.nullcontext()
+
     def _step_rsag(self, l1, l2, mask):
+        """Two launch points on the stream per iteration: {k^2 all-reduce of U^T U + Z^T Z, reduce-scatter of X^T U + Y Z} in front
+        of the epilogue, {k^2 all-reduce of the ranks' shares of V^T V, all-gather of V} behind it (RCCL: one group each)."""
         b, coll = self.backend, self.coll
+        r0, nr = self.own
         if mask & 2:
             b.partials_split(self.buf, self.gbuf)
-            coll.all_reduce(self.gbuf)                           # k_pad^2 floats
-            coll.reduce_scatter(self.buf)                        # first half of the one large sum
-            r0, nr = self.own
+            with self._group():
+                coll.all_reduce(self.gbuf)                           # k_pad^2 floats
+                coll.reduce_scatter(self.buf)                        # first half of the one large sum
             b.apply_v_rows(self.buf[self.rank * self.block_rows:(self.rank + 1) * self.block_rows], self.gbuf, r0, nr, l1, l2)
-        r0, nr = self.own
         if mask & 5:
             b.gram_v_rows(r0, nr, self.g2buf)
-            coll.all_reduce(self.g2buf)                          # k_pad^2 floats
-        if mask & 2:
-            coll.all_gather(b.v_full(self.world * self.block_rows))   # second half, in place on the factor
+        if mask & 7:
+            with self._group():
+                if mask & 5:
+                    coll.all_reduce(self.g2buf)                      # k_pad^2 floats
+                if mask & 2:
+                    coll.all_gather(b.v_full(self.world * self.block_rows))   # second half, in place on the factor
         if mask & 5:
             b.update_uz_gram(self.g2buf, l1, l2, mask)
 
@@ -360,23 +374,12 @@ def make_sharded_newton_rows(ctx_uz, ctx_v, bounds, shape, coll, alpha, x_link, 
     return drv
 
 
-def make_sharded_mu(ctx, coll, chunks=1, mode=None):
-    """MU driver of one rank: with ``coll`` None the context's own fused step; else ``mode`` 'rsag' (default: reduce-scatter ->
-    epilogue on the rank's row block of V -> all-gather) or 'allreduce' (partials -> ONE all-reduce -> replicated epilogue;
-    ``chunks`` > 1: the buffer reduced in that many row blocks, overlapped with the partials of the next block).
-    ``PYCMF_AMD_MU_COLLECTIVE`` overrides the default mode."""
-    import os
+TRIAL_ITERATIONS = 3      # timed iterations per protocol in the trial of make_sharded_mu(mode='auto') (after one untimed)
+TRIAL_MARGIN = 0.02       # the row-blocked protocol must beat north_star's single all-reduce by this fraction to be chosen
+
+
+def _build_mu_driver(ctx, backend, coll, mode, chunks=1):
     from . import _lib
-    backend = HipShardBackend(ctx)
-    if coll is None:
-        return SingleGpuStep(lambda l1, l2, mask: ctx.mu_step(l1, l2, mask))
-    if mode is None:
-        mode = os.environ.get("PYCMF_AMD_MU_COLLECTIVE", "rsag") if chunks <= 1 else "allreduce"
-        if mode == "rsag" and hasattr(coll, "self_test") and not coll.self_test():
-            import warnings
-            warnings.warn("pycmf_amd: the known-answer test of the in-place reduce-scatter / all-gather failed on this communicator; "
-                          "falling back to the single all-reduce of the MU iteration", RuntimeWarning)
-            mode = "allreduce"
     if mode == "rsag":
         block_rows, nelem = ctx.mu_blocked_layout(coll.world)
         # (world * block_rows) x k_pad, zero-filled: the rows beyond d_pad of the last blocks stay zero
@@ -386,6 +389,85 @@ def make_sharded_mu(ctx, coll, chunks=1, mode=None):
         buf = _lib.DeviceArray(ctx, backend.buf_elems(), 1)
         drv = ShardedMU(backend, buf, coll.world, coll.all_reduce, chunks=chunks, coll=coll)
     drv.collectives = coll
+    return drv
+
+
+def _release_mu_driver(drv):
+    for name in ("buf", "gbuf", "g2buf"):
+        b = getattr(drv, name, None)
+        if b is not None and hasattr(b, "release"):
+            b.release()
+
+
+def time_mu_protocols(ctx, coll, drivers, iterations=TRIAL_ITERATIONS):
+    """Milliseconds per iteration of each driver in `drivers` (name -> ShardedMU) on the LIVE ranks: the factors are saved on
+    the device, every candidate runs one untimed and `iterations` timed iterations from the same state (stream drained and ranks
+    met on both sides of the timed region, the slowest rank's clock), the factors are restored.  Every rank returns the same
+    numbers (they are max-reduced), so every rank takes the same decision."""
+    import time
+    from . import _lib
+    m_pad, d_pad, p_pad, kp = ctx.geometry()
+    saved = []
+    for which, rows in ((_lib.CMF_U, m_pad), (_lib.CMF_V, d_pad), (_lib.CMF_Z, p_pad)):
+        a = _lib.DeviceArray(ctx, max(rows, 1), kp)
+        ctx.export_factor_rows(which, a.data_ptr())
+        saved.append((which, a))
+    out = {}
+    for name, drv in drivers.items():
+        drv.step(0.0, 0.0, 7)
+        ctx.sync()
+        coll.barrier()
+        t0 = time.perf_counter()
+        for _ in range(iterations):
+            drv.step(0.0, 0.0, 7)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        out[name] = float(coll.all_reduce_host([dt], "max")[0]) / iterations * 1e3
+        for which, a in saved:
+            ctx.import_factor_rows(which, a.data_ptr())
+        ctx.sync()
+    for _, a in saved:
+        a.release()
+    return out
+
+
+def make_sharded_mu(ctx, coll, chunks=1, mode=None):
+    """MU driver of one rank: with ``coll`` None the context's own fused step; else ``mode``
+
+    * ``'allreduce'``: partials -> ONE all-reduce of (d + k) k floats -> replicated epilogue (north_star's protocol; ``chunks`` > 1:
+      the buffer reduced in that many row blocks, overlapped with the partials of the next block);
+    * ``'rsag'``: reduce-scatter -> epilogue on the rank's row block of V -> all-gather, the two k^2 Grams in the same two groups;
+    * ``'auto'`` (default; ``PYCMF_AMD_MU_COLLECTIVE`` overrides): both are built, ``TRIAL_ITERATIONS`` iterations of each are timed
+      on the live ranks from the same saved state (``time_mu_protocols``) and the faster one is kept -- the row-blocked form only
+      when it wins by more than ``TRIAL_MARGIN`` and passes the communicator's known-answer test; the decision and both timings
+      are left in ``drv.protocol_trial``."""
+    import os
+    backend = HipShardBackend(ctx)
+    if coll is None:
+        return SingleGpuStep(lambda l1, l2, mask: ctx.mu_step(l1, l2, mask))
+    if mode is None:
+        mode = os.environ.get("PYCMF_AMD_MU_COLLECTIVE", "auto") if chunks <= 1 else "allreduce"
+    if mode not in ("auto", "rsag", "allreduce"):
+        raise ValueError("MU collective mode must be 'auto', 'rsag' or 'allreduce', got %r" % (mode,))
+    trial = None
+    if mode in ("auto", "rsag") and hasattr(coll, "self_test") and not coll.self_test():
+        import warnings
+        warnings.warn("pycmf_amd: the known-answer test of the in-place reduce-scatter / all-gather failed on this communicator; "
+                      "falling back to the single all-reduce of the MU iteration", RuntimeWarning)
+        trial = {"chosen": "allreduce", "reason": "known-answer test of the grouped reduce-scatter / all-gather failed"}
+        mode = "allreduce"
+    if mode == "auto":
+        cands = {"allreduce": _build_mu_driver(ctx, backend, coll, "allreduce"), "rsag": _build_mu_driver(ctx, backend, coll, "rsag")}
+        ms = time_mu_protocols(ctx, coll, cands)
+        mode = "rsag" if ms["rsag"] < ms["allreduce"] * (1.0 - TRIAL_MARGIN) else "allreduce"
+        trial = {"chosen": mode, "ms_per_iteration": ms, "timed_iterations": TRIAL_ITERATIONS, "margin": TRIAL_MARGIN,
+                 "rule": "rsag only if faster than allreduce by more than the margin (tie-break: north_star's single all-reduce)"}
+        drv = cands.pop(mode)
+        for other in cands.values():
+            _release_mu_driver(other)
+    else:
+        drv = _build_mu_driver(ctx, backend, coll, mode, chunks)
+    drv.protocol_trial = trial
     return drv
 
 

@@ -195,11 +195,13 @@ class _HipIterativeSolver:
         self._fit_begin()
         params = self._run_params()
         if params is not None and os.environ.get("PYCMF_AMD_HOST_LOOP") != "1":
+            before_run = time.time() - start_time      # upload and binding: part of the reference's clock (it starts at :144)
             n_iter, errs, secs = self._ctx.run(max_iter=self.max_iter, tol=self.tol, **params)
             self._after_run(n_iter)
             if self.verbose:
+                every = int(params.get("check_every", 10))
                 for i, (e, t) in enumerate(zip(errs[1:], secs[1:]), start=1):
-                    print("Epoch %02d reached after %.3f seconds, error: %f" % (10 * i, t, e))
+                    print("Epoch %02d reached after %.3f seconds, error: %f" % (every * i, before_run + t, e))
                 if self.tol == 0 or n_iter % 10 != 0:
                     print("Epoch %02d reached after %.3f seconds." % (n_iter, time.time() - start_time))
             self._fit_end()

@@ -160,16 +160,17 @@ def test_bench_launches_its_own_ranks(workload):
     starts the two rank processes itself (before any GPU call in the parent) and prints rank 0's JSON line.  The test
     box has one GPU, so both ranks share it and the host-staged test double stands in for RCCL (which refuses two ranks on
     one device)."""
-    out = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", workload, "--no-cpu-baseline"],
+    out = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", workload, "--no-cpu-baseline", "--mu-collective", "rsag"],
                      {"CMF_BENCH_SAME_DEVICE": "1", "CMF_COMM_BACKEND": "host", "CMF_COMM_TIMEOUT": "120"})
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0
     assert len(out["series_ms"]["per_iteration"]) == 3
     coll = out["collective"]
     assert coll["ranks"] == 2 and coll["payload_bytes_per_iteration"] > 0 and coll["ms_per_iteration"] > 0
     assert coll["ranks_seen"] == 2 and coll["rank_seen"] == 0 and "exposed_ms_per_iteration" in coll and coll["per_kind"]
-    # MU: the one sum cut in two (reduce-scatter, all-gather) + the two k^2 Grams; per-row Newton: 3 all-gathers of factor rows;
-    # linear Newton: the k^2 float64 Gram + ONE d x k partial
+    # MU (--mu-collective rsag): the one sum cut in two (reduce-scatter, all-gather) + the two k^2 Grams, as TWO groups; per-row
+    # Newton: 3 all-gathers of factor rows; linear Newton: the k^2 float64 Gram + ONE d x k partial
     assert coll["calls_per_iteration"] == {"tiny": 4, "tiny3": 3, "tiny5": 2}[workload]
+    assert coll["launch_points_per_iteration"] == {"tiny": 2, "tiny3": 3, "tiny5": 2}[workload]
     if workload == "tiny":
         assert coll["protocol"] == "rsag" and set(coll["per_kind"]) == {"all_reduce_f32", "reduce_scatter_f32", "all_gather_f32"}
     if workload != "tiny3":
@@ -192,13 +193,28 @@ def test_bench_rccl_single_rank():
     assert out["collective"]["payload_bytes_per_iteration"] == (1024 + 64) * 64 * 4
     ref = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "tiny", "--no-cpu-baseline"], {})
     assert out["rel_residual"] == ref["rel_residual"]      # a 1-rank all-reduce is the identity: bit-identical iterates
-    # the default protocol: ncclReduceScatter and ncclAllGather in place (one rank: both the identity) + two k^2 all-reduces
-    out = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "tiny", "--no-cpu-baseline"],
+    # the row-blocked protocol: ncclReduceScatter and ncclAllGather in place (one rank: both the identity), each in ONE RCCL group
+    # (ncclGroupStart / ncclGroupEnd) with its k^2 all-reduce: four calls, two launch points
+    out = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "tiny", "--no-cpu-baseline", "--mu-collective", "rsag"],
                      {"CMF_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1"})
     coll = out["collective"]
     assert coll["protocol"] == "rsag" and coll["calls_per_iteration"] == 4 and coll["replicas"]["identical"]
+    assert coll["launch_points_per_iteration"] == 2 and coll["per_kind"]["group"]["calls_per_iteration"] == 2
     assert coll["payload_bytes_per_iteration"] == 2 * 1024 * 64 * 4 + 2 * 64 * 64 * 4
     assert coll["per_kind"]["reduce_scatter_f32"]["calls_per_iteration"] == 1 and coll["per_kind"]["all_gather_f32"]["calls_per_iteration"] == 1
+    for key in ("x", "y"):
+        assert abs(out["rel_residual"][key] - ref["rel_residual"][key]) <= 1e-5 * ref["rel_residual"][key]
+    # the default: both protocols timed on the live communicator before the warm-up, the decision and both timings in the line; the
+    # trial restores the factors, so the iterates are those of the run without it
+    out = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "tiny", "--no-cpu-baseline"],
+                     {"CMF_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1"})
+    coll = out["collective"]
+    trial = coll["protocol_trial"]
+    assert trial["chosen"] == coll["protocol_chosen"] == coll["protocol"] and trial["chosen"] in ("allreduce", "rsag")
+    assert set(trial["ms_per_iteration"]) == {"allreduce", "rsag"} and all(v > 0 for v in trial["ms_per_iteration"].values())
+    if trial["chosen"] == "rsag":
+        assert trial["ms_per_iteration"]["rsag"] < trial["ms_per_iteration"]["allreduce"] * (1 - trial["margin"])
+    assert coll["launch_points_per_iteration"] == (2 if trial["chosen"] == "rsag" else 1)
     for key in ("x", "y"):
         assert abs(out["rel_residual"][key] - ref["rel_residual"][key]) <= 1e-5 * ref["rel_residual"][key]
     # linear Newton on native CSR: float64 Gram + float32 partial per iteration
@@ -268,8 +284,42 @@ def test_rccl_abi_single_rank(tmp_path, monkeypatch):
     assert kinds["all_gather_f32"][:2] == (1, 120) and kinds["reduce_scatter_f32"][:2] == (1, 120)
     calls, nbytes, ms = coll.stats()
     assert calls == 4 and nbytes == 120 + 72 + 120 + 120 and ms >= 0.0
+    assert coll.launch_points_seen() == 4
+    # two collectives as ONE RCCL group (ncclGroupStart / ncclGroupEnd): one more launch point, one event pair around the group
+    with coll.group():
+        coll.all_reduce(a)
+        coll.reduce_scatter(a)
+    np.testing.assert_array_equal(ctx.copy_to_host(a), ref)
+    assert coll.launch_points_seen() == 5 and coll.stats()[0] == 6
+    assert coll.stats_by_kind()["group"][0] == 1 and coll.stats_by_kind()["group"][2] >= 0.0
+    with pytest.raises(ValueError, match="without cmf_comm_group_start"):
+        ctx.comm_group_end()
+    assert coll.self_test()                      # known answers of the plain and the grouped forms
+    # cmf_scale_f32 (the measurement double of the collectives)
+    ctx.scale(a, 3.0)
+    np.testing.assert_array_equal(ctx.copy_to_host(a), 3.0 * ref)
     coll.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "rsag"])
+def test_dress_rehearsal_eight_ranks_match_one(tmp_path, mode):
+    """The N = 8 code path of the headline configuration on ONE GPU: bench.py --gpus 8, eight rank processes
+    sharing the device, host-staged collectives, workload c4q (k = 256, 16384^3: the shard shapes of C4 / 8 scaled by four -- 2048-row
+    blocks of U, Z and of the row-blocked V update, i.e. the column-tiled fused updates).  After two iterations every rank holds the
+    same V, and 16 fixed rows of each of U, V, Z equal the single-GPU run's to 1e-5 of the factor's largest entry."""
+    base = ["--steps", "2", "--warmup", "0", "--workload", "c4q", "--no-cpu-baseline"]
+    one = _run_bench(["--gpus", "1", "--dump-rows", str(tmp_path / "one")] + base, {})
+    eight = _run_bench(["--gpus", "8", "--mu-collective", mode, "--dump-rows", str(tmp_path / "eight")] + base,
+                       {"CMF_BENCH_SAME_DEVICE": "1", "CMF_COMM_BACKEND": "host", "CMF_COMM_TIMEOUT": "300"})
+    coll = eight["collective"]
+    assert coll["ranks"] == 8 and coll["protocol"] == mode and coll["replicas"]["identical"], coll
+    assert coll["launch_points_per_iteration"] == (1 if mode == "allreduce" else 2)
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "compare_rows.py"), str(tmp_path / "one"), str(tmp_path / "eight"),
+                        "--tol", "1e-5"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert q.returncode == 0, q.stdout.decode() + q.stderr.decode()[-2000:]
+    for key in ("x", "y"):
+        assert np.isfinite(eight["rel_residual"][key]) and abs(eight["rel_residual"][key] - one["rel_residual"][key]) < 0.05 * one["rel_residual"][key]
 
 
 @pytest.mark.parametrize("solver,kw", [("mu", {}), ("newton", dict(y_link="logit", U_non_negative=False, V_non_negative=False,
