@@ -103,42 +103,61 @@ def algorithmic_flops(w):
 
 
 def cpu_baseline(w, budget_s=20.0):
-    """CPU oracle (reference operation order incl. the wasteful (U V^T) V, float64, all BLAS threads) per BASELINE.md
-    section 3: MU workloads time BASELINE config C2 IN FULL (16384 x 8192 / 8192 x 4096, k = 128: 3 warm-up + 5 timed
-    update_step) and scale to the bench shape by the reference-order flop ratio 8 k d (m + p) (C4 itself needs 140 GB of
-    float64 temporaries and minutes of data generation: 'scaled from C2', never a full C4 iteration here); Newton
-    workloads, whose per-row Python loop makes full shapes impractical, time a reduced shape and scale by algorithmic work."""
+    """CPU oracle (reference operation order incl. the wasteful (U V^T) V, float64) per BASELINE.md section 3.  MU workloads time
+    BASELINE config C2 IN FULL (16384 x 8192 / 8192 x 4096, k = 128: 3 warm-up + 5 timed update_step, all BLAS threads) and scale
+    to the bench shape by the reference-order flop ratio 8 k d (m + p) (C4 itself needs 140 GB of float64 temporaries and minutes
+    of data generation: 'scaled from C2', never a full C4 iteration here).  Newton workloads, whose per-row Python loop with one
+    eigh(k x k) per row makes full shapes impractical, time ONE update_step at a reduced shape with at least 1024 rows per
+    data-side factor ("reduced shape (<= 2048 rows per factor) and scaled") at the workload's own k, links,
+    ratio and regularisation, and scale by algorithmic work (scale factor >= 1e-3); the per-row sweeps run on ONE BLAS thread --
+    LAPACK's 256 x 256 eigh is an order of magnitude slower on a many-threaded OpenBLAS -- and say so (cores = 1)."""
     import numpy as np
     from oracle import cmf_oracle as O
     k = w["k"]
+    per_row = False
     if w["solver"] == "mu":
         ms, ds, ps, ks = 16384, 8192, 4096, 128
         if w["m"] * w["d"] < ms * ds:     # debug shapes: the shape itself
             ms, ds, ps, ks = w["m"], w["d"], w["p"], k
     else:
-        ms, ds, ps, ks = 96, 64, 32, k  # per-row eigh(k x k) in Python: keep it to a few hundred rows
+        per_row = w["x_link"] == "logit" or w["y_link"] == "logit" or w.get("ratio", 1.0) < 1.0
+        if "nnz_per_row" in w:   # C5 / C5L: keep p, d >= 1024 rows of V, many rows of U (shared Hessian on the X side: no eigh per row)
+            ms, ds, ps, ks = min(w["m"], 16384), min(w["d"], 1024 if per_row else 2048), w["p"], k
+        else:                    # C3: 1024 rows of U and V, 512 of Z (2560 eigh(k x k) per iteration)
+            ms, ds, ps, ks = min(w["m"], 1024), min(w["d"], 1024), min(w["p"], 512), k
     rng = np.random.RandomState(42)
-    X, Y = np.abs(rng.randn(ms, ds)), np.abs(rng.randn(ds, ps))
+    if "nnz_per_row" in w and w["solver"] != "mu":
+        X = (rng.rand(ms, ds) < float(w["nnz_per_row"]) / w["d"]).astype(np.float64)   # binary bag of words at the workload's density
+    else:
+        X = np.abs(rng.randn(ms, ds))
+    Y = np.abs(rng.randn(ds, ps))
     if w.get("x_kind") == 1:
         X = 1.0 / (1.0 + np.exp(-rng.randn(ms, ds)))
     if w.get("y_kind") == 2:
         Y = (rng.rand(ds, ps) < w.get("y_param", 0.1)).astype(np.float64)
     elif w.get("y_link") == "logit":
         Y = 1.0 / (1.0 + np.exp(-rng.randn(ds, ps)))
-    sc = np.sqrt(X.mean() / ks)
+    sc = np.sqrt(max(X.mean(), 1e-12) / ks)
     U, V, Z = (sc * np.abs(rng.randn(n, ks)) for n in (ms, ds, ps))
+    limit = None
     if w["solver"] == "mu":
         def step():
             O.mu_update_step(X, Y, U, V, Z)
         warm, timed = 3, 5
     else:
         np.random.seed(0)
+        if per_row:
+            try:
+                from threadpoolctl import threadpool_limits
+                limit = threadpool_limits(limits=1)
+            except Exception:
+                limit = None
 
         def step():
             nnm = w.get("nn_mask", 0)
             O.newton_update_step(X, Y, U, V, Z, 0.5, w.get("l1", 0.0), w.get("l2", 0.1), w["x_link"], w["y_link"],
                                  bool(nnm & 1), bool(nnm & 2), bool(nnm & 4), ratio=w.get("ratio", 1.0), pert=0.2)
-        warm, timed = 1, None
+        warm, timed = (0, 1) if per_row else (1, None)
     for _ in range(warm):
         step()
     t0 = time.perf_counter()
@@ -159,15 +178,20 @@ def cpu_baseline(w, budget_s=20.0):
             blas = ", ".join(sorted({"%s %s" % (i.get("internal_api", "?"), i.get("version", "?")) for i in info}))
     except Exception:
         pass
+    if limit is not None:
+        threads = 1
+        limit.restore_original_limits() if hasattr(limit, "restore_original_limits") else None
     if w["solver"] == "mu":   # reference-order flops: 8 k d (m + p) (+ Grams / applies, the same order in both shapes)
         ref = lambda m_, d_, p_, k_: 8.0 * k_ * d_ * (m_ + p_) + 4.0 * k_ * k_ * (m_ + d_ + p_)
         ratio = ref(ms, ds, ps, ks) / ref(w["m"], w["d"], w["p"], k)
     else:
-        sample = {key: val for key, val in w.items() if key != "nnz_per_row"}
+        sample = dict(w)
+        if "nnz_per_row" in w:   # the sample keeps the density: nnz per row scales with d
+            sample["nnz_per_row"] = w["nnz_per_row"] * float(ds) / w["d"]
         sample.update(m=ms, d=ds, p=ps)
         ratio = algorithmic_flops(sample) / algorithmic_flops(w)
     return dict(its=iters / el, shape=(ms, ds, ps, ks), iters=iters, seconds=el, threads=threads, blas=blas,
-                cpu_count=os.cpu_count() or 1, ratio=ratio)
+                cpu_count=os.cpu_count() or 1, ratio=ratio, per_row=per_row)
 
 
 def launch_ranks(n, argv):
@@ -592,7 +616,9 @@ def main():
             "host_cpu_count": cb["cpu_count"],
             "blas": cb["blas"],
             "kind": "port",
-            "cores_note": ("all host cores" if cb["threads"] >= cb["cpu_count"] else
+            "cores_note": ("one BLAS thread: the per-row sweeps call LAPACK's eigh on one k x k matrix at a time, which a many-threaded "
+                           "OpenBLAS runs an order of magnitude slower" if cb.get("per_row") else
+                           "all host cores" if cb["threads"] >= cb["cpu_count"] else
                            "the BLAS under NumPy (%s) is built for at most %d threads: that is every thread this build can use on the "
                            "%d-CPU host" % (cb["blas"], cb["threads"], cb["cpu_count"])),
             "sample": ("oracle/cmf_oracle %s update_step (NumPy float64, reference operation order) at m,d,p,k=%s%s: %d timed "

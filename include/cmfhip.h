@@ -143,6 +143,10 @@ int cmf_data_matmul_f64(cmf_ctx *ctx, int which, int trans, const double *B, int
 int cmf_rsvd(cmf_ctx *ctx, int which, int transpose, int k, int size, int n_iter, const double *omega,
              double *U, double *S, double *Vt);
 int cmf_data_sum(cmf_ctx *ctx, double *sum_x, double *sum_y);
+/* float64 sums of the dense device image of X / Y over blocks of 256 rows (axis 0: out[rows_pad / 256][cols_pad]) or 256 columns
+ * (axis 1: out[rows_pad][cols_pad / 256]): the inputs of the per-tile checksums of the full-size parity tests -- the column sums
+ * of a 256-row output tile of X^T U, X V, Y Z, Y^T V (cmf_solvers.py:232, :238, :244) are (block sums)^T times the factor        */
+int cmf_data_block_sums_f64(cmf_ctx *ctx, int which, int axis, double *out);
 /* read back a block of X or Y (tests) */
 int cmf_get_data_f32(cmf_ctx *ctx, int which, float *ptr, int64_t rs, int64_t cs);
 

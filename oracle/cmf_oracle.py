@@ -146,12 +146,33 @@ def mu_update_step(X, Y, U, V, Z, l1=0.0, l2=0.0,
 # --------------------------------------------------------------------------
 # Newton solver (live pure-Python path)         pycmf/cmf_solvers.py:318-522
 # --------------------------------------------------------------------------
+_BLAS_CONTROLLER = None
+
+
+def _one_blas_thread():
+    """Context in which BLAS / LAPACK run on ONE thread: the k x k ``eigh`` of ``safe_invert`` (k <= a few hundred) is an order of
+    magnitude SLOWER on a many-threaded OpenBLAS (measured on the 256-CPU test host: 10-20 s of a test were three 200 x 200
+    eigensolves).  Same algorithm, same result to rounding; a no-op without threadpoolctl."""
+    global _BLAS_CONTROLLER
+    if _BLAS_CONTROLLER is None:
+        try:
+            from threadpoolctl import ThreadpoolController
+            _BLAS_CONTROLLER = ThreadpoolController()
+        except Exception:
+            _BLAS_CONTROLLER = False
+    if not _BLAS_CONTROLLER:
+        import contextlib
+        return contextlib.nullcontext()
+    return _BLAS_CONTROLLER.limit(limits=1, user_api="blas")
+
+
 def safe_invert(H, pert):
     """Q diag(1/max(|lam|, pert)) Q^T            (cmf_solvers.py:346-356)."""
-    lam, Q = scipy.linalg.eigh(H)
-    lam = np.abs(lam)
-    lam[lam < pert] = pert
-    return (Q @ np.diag(1.0 / lam)) @ Q.T
+    with _one_blas_thread():
+        lam, Q = scipy.linalg.eigh(H)
+        lam = np.abs(lam)
+        lam[lam < pert] = pert
+        return (Q @ np.diag(1.0 / lam)) @ Q.T
 
 
 def draw_sample(n, ratio):

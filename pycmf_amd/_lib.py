@@ -49,6 +49,7 @@ PROTOTYPES = {
     "cmf_data_matmul_f64": [_vp, _i32, _i32, _pd, _i64, _i32, _pd],
     "cmf_rsvd": [_vp, _i32, _i32, _i32, _i32, _i32, _pd, _pd, _pd, _pd],
     "cmf_data_sum": [_vp, _pd, _pd],
+    "cmf_data_block_sums_f64": [_vp, _i32, _i32, _pd],
     "cmf_set_factor_f64": [_vp, _i32, _pd, _i64, _i64],
     "cmf_get_factor_f64": [_vp, _i32, _pd, _i64, _i64],
     "cmf_mu_step": [_vp, _dbl, _dbl, _i32],
@@ -195,6 +196,7 @@ def check(rc):
 
 def device_count():
     n = C.c_int(0)
+    _touch()
     check(load().cmf_device_count(C.byref(n)))
     return n.value
 
@@ -216,6 +218,20 @@ class _Scratch:
         if self._ptr and self._ctx._h:
             check(self._ctx._lib.cmf_scratch_free(self._ctx._h, _vp(self._ptr)))
         self._ptr = None
+
+
+_gpu_touched = False     # set by the first call that initialises the HIP runtime in this process
+
+
+def gpu_touched():
+    """Has this process made a HIP call through pycmf_amd yet?  (multi_gpu forks its ranks off the caller's process only while
+    the answer is no: a forked child must not inherit an initialised runtime.)"""
+    return _gpu_touched
+
+
+def _touch():
+    global _gpu_touched
+    _gpu_touched = True
 
 
 class DeviceArray:
@@ -260,6 +276,7 @@ class Context:
 
     def __init__(self, device=0, stream=None):
         self._lib = load()
+        _touch()
         self._h = _vp()
         check(self._lib.cmf_ctx_create(C.byref(self._h), int(device), _vp(stream or 0)))
         self.shape = None
@@ -553,6 +570,15 @@ class Context:
 
     def comm_reduce_scatter(self, full, elems_per_rank):
         check(self._lib.cmf_comm_reduce_scatter_f32(self._h, _vp(full.data_ptr()), elems_per_rank))
+
+    def data_block_sums(self, which, axis):
+        """float64 sums of the dense device image of X (0) / Y (1) over blocks of 256 rows (axis 0 -> [rows_pad / 256, cols_pad]) or
+        256 columns (axis 1 -> [rows_pad, cols_pad / 256]); padded extents."""
+        mp, dp, pp, _ = self.geometry()
+        rp, cp = (mp, dp) if which == 0 else (dp, pp)
+        out = np.empty((rp // 256, cp) if axis == 0 else (rp, cp // 256), dtype=np.float64)
+        check(self._lib.cmf_data_block_sums_f64(self._h, int(which), int(axis), out.ctypes.data_as(_pd)))
+        return out
 
     def comm_group_start(self):
         check(self._lib.cmf_comm_group_start(self._h))

@@ -15,15 +15,23 @@ def linear_newton(P):
 
 
 def main(job):
+    """A rank started as a fresh process: the job's data are the float32 files the parent wrote (memory-mapped: a rank touches the
+    pages of its own blocks only)."""
+    from pycmf_amd.multi_gpu import _load
+    meta = json.load(open(os.path.join(job, "job.json")))
+    run_rank(job, meta, _load(os.path.join(job, "X")), _load(os.path.join(job, "Y")))
+
+
+def run_rank(job, meta, X, Y, factors=None):
+    """One rank's fit.  X, Y: the WHOLE inputs as this process sees them -- memory-mapped job files (main) or, in a rank forked
+    from the caller's process before it ever touched a GPU, the caller's own arrays (no copy at all: multi_gpu.fit_multi_gpu);
+    ``factors``: the initial (U, V, Z) in the same way, else read from the job directory."""
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = 0 if os.environ.get("PYCMF_AMD_SAME_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", rank))
     os.environ.setdefault("CMF_COMM_DIR", job)
     os.environ.setdefault("CMF_COMM_KEY", "job")
-    from pycmf_amd.multi_gpu import _load
     from pycmf_amd.sharded import fit_mu_sharded, fit_newton_linear_sharded, fit_newton_sharded
-    meta = json.load(open(os.path.join(job, "job.json")))
     P, rows, cols = meta["params"], meta["rows"], meta["cols"]
-    X, Y = _load(os.path.join(job, "X")), _load(os.path.join(job, "Y"))
     fpath = os.path.join(job, "factors.npz")
     if P.get("init"):
         # initial factors on rank 0's GPU: the device-side initialisers need the whole matrices resident once; the other
@@ -49,15 +57,16 @@ def main(job):
         else:
             while not os.path.exists(fpath):
                 time.sleep(0.05)
-    F = np.load(fpath)
+    F = dict(zip("UVZ", factors)) if factors is not None and not P.get("init") else np.load(fpath)
     r0, r1, c0, c1 = rows[rank], rows[rank + 1], cols[rank], cols[rank + 1]
-    dense = lambda A: np.ascontiguousarray(A) if not sp.issparse(A) else A
+    # dense blocks go to the upload shim as VIEWS (any strides, float32 or float64: Context.set_data): no host copy of a block
+    dense = lambda A: A
     Xr = dense(X[r0:r1])
     Yc = dense(Y[:, c0:c1]) if not sp.issparse(Y) else Y[:, c0:c1].tocsr()
     U, V, Z = np.array(F["U"][r0:r1]), np.array(F["V"]), np.array(F["Z"][c0:c1])
     stats = {}
     common = dict(max_iter=P["max_iter"], tol=P["tol"], device=local, verbose=P["verbose"] if rank == 0 else 0, stats=stats,
-                  rank=rank, world=world)
+                  rank=rank, world=world, update_mask=int(P.get("update_mask", 7)))
     if meta["solver"] == "mu":
         U, V, Z, n_iter = fit_mu_sharded(Xr, Yc, U, V, Z, l1_reg=P["l1_reg"], l2_reg=P["l2_reg"], **common)
     elif linear_newton(P):

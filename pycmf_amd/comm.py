@@ -115,6 +115,7 @@ def exchange_unique_id(rank, world, timeout=None):
     if rank == 0:
         import ctypes as C
         buf = C.create_string_buffer(128)
+        _lib._touch()
         _lib.check(lib.cmf_comm_unique_id(buf))
         _write_private(path, buf.raw)
         return buf.raw, path

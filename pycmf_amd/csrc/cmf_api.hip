@@ -157,6 +157,7 @@ struct cmf_ctx {
     DevBuf slabs, slabs_b;                // split-K partial tiles (grow-only); second set for a product whose slabs must outlive the next one
     int slab_sel = 0;                     // which set gemm() writes
     DevBuf tickets;                       // one arrival counter per output tile of a split-K GEMM (zero between launches)
+    int timed_open = 0;                   // open Timed scopes that record (see Timed)
     DevBuf narrow_tmp;                    // output image of an in-place fused update cut into column tiles (gemm(): the siblings of a row tile read all of F)
     int opt_inred = 0;                    // 0: split-K partials summed by a chip-wide kernel | 1: by the last-arriving workgroup of each tile
                                           // inside the GEMM kernel (A/B option; measured slower)
@@ -262,14 +263,20 @@ struct Timed {
     bool on = false;
     double flops = 0.0;
     Timed(cmf_ctx *c_, int cls_, double flops_ = 0.0) : c(c_), cls(cls_), flops(flops_) {
-        const bool want = c->timing == 1 || (c->timing == 2 && (cls == CMF_K_GEMM_NN || cls == CMF_K_GEMM_TN || cls == CMF_K_GEMM_PAIR || cls == CMF_K_SPMM || cls == CMF_K_ROWHESS));
+        // scopes nest (a solve that falls through to the spectral clamp, the float64 refinement around its Grams and products): only
+        // the OUTERMOST open scope records, so a stretch of the stream is attributed to exactly one class and the classes of an
+        // iteration can never add up to more than the iteration (r04's bench lines double-counted the clamp path)
+        const bool want = c->timed_open == 0 &&
+                          (c->timing == 1 || (c->timing == 2 && (cls == CMF_K_GEMM_NN || cls == CMF_K_GEMM_TN || cls == CMF_K_GEMM_PAIR || cls == CMF_K_SPMM || cls == CMF_K_ROWHESS)));
         if (want && ev_get(c, &a) == CMF_OK && ev_get(c, &b) == CMF_OK) {
             on = true;
+            ++c->timed_open;
             (void)hipEventRecord(a, c->stream);
         }
     }
     ~Timed() {
         if (on) {
+            --c->timed_open;
             (void)hipEventRecord(b, c->stream);
             c->pending.push_back({a, b, cls, flops});
         }

@@ -53,6 +53,51 @@ extern "C" int cmf_data_sum(cmf_ctx *c, double *sx, double *sy) {
     return CMF_OK;
 }
 
+// ---- block sums of the dense device image of X / Y in float64: the per-tile checksums of the full-size parity tests.  For a product
+// P = A F the column sums of a 256-row tile of P are (sums of A over the tile's rows)^T F, for P = A^T F they are (sums of A over
+// the tile's columns)^T F -- k_pad-sized float64 work on the host against every output tile of a data pass.  Plain reductions,
+// nothing shared with the GEMM kernels they check.
+__global__ __launch_bounds__(256) void block_sums_cols_kernel(const float *A, int64_t ld, int64_t rows, int64_t nblk, double *out) {
+    // one wave per (row, block of 256 columns): out[row * nblk + t]
+    const int64_t id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (id >= rows * nblk) return;
+    const int64_t row = id / nblk, t = id % nblk;
+    const f32x4 a = reinterpret_cast<const f32x4 *>(A + row * ld + t * 256)[threadIdx.x & 63];
+    double v = (double)a[0] + (double)a[1] + (double)a[2] + (double)a[3];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) out[id] = v;
+}
+__global__ __launch_bounds__(256) void block_sums_rows_kernel(const float *A, int64_t ld, int64_t cols, double *out) {
+    // one thread per column, 256 rows each: out[blockIdx.y * cols + col]
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= cols) return;
+    const float *a = A + (int64_t)blockIdx.y * 256 * ld + col;
+    double v = 0.0;
+    for (int r = 0; r < 256; ++r) v += (double)a[(int64_t)r * ld];
+    out[(int64_t)blockIdx.y * cols + col] = v;
+}
+// axis 0: out[rows_pad / 256][cols_pad] = sums over blocks of 256 rows; axis 1: out[rows_pad][cols_pad / 256] = sums over blocks of
+// 256 columns (padded extents: cmf_get_geometry; the padding is zero).  Host array of float64.
+extern "C" int cmf_data_block_sums_f64(cmf_ctx *c, int which, int axis, double *out) {
+    NEED_PROBLEM(c);
+    if (!out || (axis != 0 && axis != 1)) return fail(CMF_EINVAL, "bad argument (axis 0: row blocks, 1: column blocks)");
+    DeviceGuard dg(c->device);
+    int64_t r, cc, rp, cp; float **slot;
+    CHK(data_dims(c, which, &r, &cc, &rp, &cp, &slot));
+    if (!*slot) return fail(CMF_EINVAL, "%s has no dense device image (native sparse input or not set)", which == 0 ? "X" : "Y");
+    const int64_t n = axis == 0 ? (rp / 256) * cp : rp * (cp / 256);
+    void *dev = nullptr;
+    CHK(dev_alloc(c, &dev, (size_t)n * sizeof(double), false));
+    if (axis == 0) hipLaunchKernelGGL(block_sums_rows_kernel, dim3((unsigned)(cp / 256), (unsigned)(rp / 256)), dim3(256), 0, c->stream, (const float *)*slot, cp, cp, (double *)dev);
+    else hipLaunchKernelGGL(block_sums_cols_kernel, dim3((unsigned)((rp * (cp / 256) + 3) / 4)), dim3(256), 0, c->stream, (const float *)*slot, cp, rp, cp / 256, (double *)dev);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(c, dev);
+    if (e != hipSuccess) return fail(CMF_EHIP, "cmf_data_block_sums_f64: %s", hipGetErrorString(e));
+    return CMF_OK;
+}
+
 // ---- host: eigen-decomposition of a symmetric n x n float64 matrix by cyclic Jacobi; eigenvalues descending, eigenvectors
 // in the COLUMNS of V (row-major n x n)
 static void jacobi_eigh_host(std::vector<double> &A, int n, std::vector<double> &V, std::vector<double> &lam) {

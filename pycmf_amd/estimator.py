@@ -87,6 +87,9 @@ def collective_matrix_factorization(X, Y, U=None, V=None, Z=None,
     else:
         raise ValueError("No such solver: %s" % solver)
 
+    if n_gpus > 1 and (X is None or Y is None):
+        n_gpus = 1     # a transform of one side only (cmf.py:726-747 with X or Y None): nothing to shard against, one GPU does it
+
     # Large inputs go to the GPU before the initialisers run, so that the randomized SVD behind
     # 'svd' / 'nndsvd*' can use the device copy for its products (the solver later reuses the upload).
     op_x = op_y = None
@@ -114,8 +117,6 @@ def collective_matrix_factorization(X, Y, U=None, V=None, Z=None,
 
     U, V, Z = _writable_f64(U), _writable_f64(V), _writable_f64(Z)
     if n_gpus > 1:
-        if not (update_U and update_V and update_Z):
-            raise ValueError("n_gpus > 1 fits all three factors; use n_gpus=1 for transform / partial updates")
         from .multi_gpu import fit_multi_gpu
         U, V, Z = (np.ascontiguousarray(F) for F in (U, V, Z))
         params = dict(l1_reg=l1_reg, l2_reg=l2_reg, max_iter=max_iter, tol=tol, verbose=verbose,
@@ -123,7 +124,10 @@ def collective_matrix_factorization(X, Y, U=None, V=None, Z=None,
                       U_non_negative=bool(U_non_negative), V_non_negative=bool(V_non_negative),
                       Z_non_negative=bool(Z_non_negative), hessian_pertubation=hessian_pertubation,
                       sg_sample_ratio=sg_sample_ratio,
-                      random_state=(int(random_state) if isinstance(random_state, (int, np.integer)) else None))
+                      random_state=(int(random_state) if isinstance(random_state, (int, np.integer)) else None),
+                      # transform / partial updates (cmf.py:726-747: one code path for fit and transform): the U and Z sweeps are
+                      # local to a rank, a fixed V simply skips the sum over the ranks
+                      update_mask=(1 if update_U else 0) | (2 if update_V else 0) | (4 if update_Z else 0))
         if defer_init:
             params["init"] = dict(init_spec, random_state=(None if random_state is None else int(random_state)))
         n_iter, result = fit_multi_gpu(X, Y, U, V, Z, solver, int(n_gpus), params)

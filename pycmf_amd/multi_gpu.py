@@ -34,10 +34,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _save(path, A):
+    """Dense inputs are written ONCE, as float32 -- the arithmetic type of the device (the upload shim rounds float64 the same
+    way) -- in row slabs straight from the caller's array (any strides): half the bytes of a float64 copy and no contiguous
+    temporary.  (r04 wrote np.save of the float64 arrays: a second 68.7 GB host copy at C4.)"""
     if sp.issparse(A):
         sp.save_npz(path + ".npz", A.tocsr(), compressed=False)
-    else:
-        np.save(path + ".npy", np.ascontiguousarray(A))
+        return
+    A = np.asarray(A)
+    out = np.lib.format.open_memmap(path + ".npy", mode="w+", dtype=np.float32, shape=A.shape)
+    step = max(1, (64 << 20) // max(1, A.shape[1] * 4))
+    for r in range(0, A.shape[0], step):
+        out[r:r + step] = A[r:r + step]
+    out.flush()
+    del out
 
 
 def _load(path):
@@ -93,11 +102,68 @@ def _nbytes(A):
     return np.asarray(A).nbytes
 
 
+def can_fork_ranks():
+    """May the ranks be forked off this process (they then read the caller's X, Y, U, V, Z in place -- no copy of the job at all)?
+    Only while this process has never initialised a GPU runtime: a forked child must not inherit one.  PYCMF_AMD_FORK_RANKS=0
+    forces the file path, =1 is the default behaviour."""
+    if os.environ.get("PYCMF_AMD_FORK_RANKS", "1") == "0" or not hasattr(os, "fork"):
+        return False
+    from . import _lib
+    if _lib.gpu_touched():
+        return False
+    torch = sys.modules.get("torch")
+    try:
+        if torch is not None and torch.cuda.is_initialized():
+            return False
+    except Exception:
+        return False
+    return True
+
+
+def _forked_rank(job, meta, X, Y, factors, env, rank):
+    """Body of a forked rank: the parent's arrays are this process's arrays (copy-on-write pages, never written)."""
+    try:
+        os.environ.update(env)
+        log = os.open(os.path.join(job, "rank%d.log" % rank), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+        os.dup2(log, 1)
+        os.dup2(log, 2)
+        from . import _worker
+        _worker.run_rank(job, meta, X, Y, factors)
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(1)
+
+
 def _linear(params):
     from ._worker import linear_newton
     return linear_newton(params)
 
 
+class _ForkedProc:
+    """subprocess.Popen's poll / kill / wait / returncode over a multiprocessing.Process."""
+
+    def __init__(self, p):
+        self.p = p
+
+    def poll(self):
+        return self.p.exitcode
+
+    @property
+    def returncode(self):
+        return self.p.exitcode
+
+    def kill(self):
+        self.p.kill()
+
+    def wait(self):
+        self.p.join()
+
+
+last_fit_info = {}               # how the most recent fit handed its data to the ranks: forked (no copy) or through float32 files
 last_collective_calls = [None]   # rank 0's collective count of the most recent fit (tests: one large all-reduce per iteration)
 
 
@@ -128,12 +194,17 @@ def fit_multi_gpu(X, Y, U, V, Z, solver, n_gpus, params, timeout=None):
     sparse_y = sp.issparse(Y)
     if solver == "newton" and sparse_y and not _linear(params):
         Y = Y.toarray()
-    job = tempfile.mkdtemp(prefix="pycmf_amd_job_", dir=_job_base(_nbytes(X) + _nbytes(Y) + U.nbytes + V.nbytes + Z.nbytes))
+    fork = can_fork_ranks()
+    job = tempfile.mkdtemp(prefix="pycmf_amd_job_", dir=None if fork else _job_base((_nbytes(X) + _nbytes(Y)) // (1 if sp.issparse(X) else 2) + U.nbytes + V.nbytes + Z.nbytes))
+    last_fit_info.clear()
+    last_fit_info.update(forked=fork, job_bytes=0)
     try:
-        _save(os.path.join(job, "X"), X)
-        _save(os.path.join(job, "Y"), Y)
-        if not params.get("init"):   # else rank 0 computes the start on its GPU and writes this file
-            np.savez(os.path.join(job, "factors.npz"), U=U, V=V, Z=Z)
+        if not fork:
+            _save(os.path.join(job, "X"), X)
+            _save(os.path.join(job, "Y"), Y)
+            if not params.get("init"):   # else rank 0 computes the start on its GPU and writes this file
+                np.savez(os.path.join(job, "factors.npz"), U=U, V=V, Z=Z)
+            last_fit_info["job_bytes"] = sum(os.path.getsize(os.path.join(job, f)) for f in os.listdir(job))
         rows, vrows, cols = partition(X, Y, solver, n_gpus, params)
         meta = dict(solver=solver, params=params, rows=[int(v) for v in rows], cols=[int(v) for v in cols],
                     vrows=None if vrows is None else [int(v) for v in vrows])
@@ -145,11 +216,19 @@ def fit_multi_gpu(X, Y, U, V, Z, solver, n_gpus, params, timeout=None):
         s.close()
         procs = []
         for r in range(n_gpus):
-            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), MASTER_ADDR="127.0.0.1",
-                       MASTER_PORT=str(port))
-            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+            env = dict(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             env["CMF_COMM_DIR"], env["CMF_COMM_KEY"] = job, "job"
+            if fork:
+                # the rank IS this process at this point in time: X, Y, U, V, Z are reachable without a copy; it has never touched a
+                # GPU, so the child initialises its own runtime
+                import multiprocessing as mp
+                q = mp.get_context("fork").Process(target=_forked_rank, args=(job, meta, X, Y, (U, V, Z), env, r), daemon=False)
+                q.start()
+                procs.append((_ForkedProc(q), None))
+                continue
+            env = dict(os.environ, **env)
+            env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
             log = open(os.path.join(job, "rank%d.log" % r), "wb")
             procs.append((subprocess.Popen([sys.executable, "-m", "pycmf_amd._worker", job], env=env, stdout=log,
                                            stderr=subprocess.STDOUT), log))
@@ -168,7 +247,8 @@ def fit_multi_gpu(X, Y, U, V, Z, solver, n_gpus, params, timeout=None):
             if q.poll() is None:
                 q.kill()      # exactly the processes started here
             q.wait()
-            log.close()
+            if log is not None:
+                log.close()
         if failed is not None:
             r = max(failed, 0)
             tail = open(os.path.join(job, "rank%d.log" % r), "rb").read().decode("utf-8", "replace")[-3000:]

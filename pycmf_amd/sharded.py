@@ -524,7 +524,7 @@ def _collectives_for(ctx, rank, world):
 
 
 def fit_mu_sharded(X_rows, Y_cols, U_rows, V, Z_rows, l1_reg=0.0, l2_reg=0.0, max_iter=200, tol=1e-4,
-                   device=0, verbose=0, stats=None, rank=None, world=None):
+                   device=0, verbose=0, stats=None, rank=None, world=None, update_mask=7):
     """Data-parallel MU fit: call from every rank (one process per GPU; RANK / WORLD_SIZE from the environment unless given).
 
     Rank g passes its row block of X (and the matching rows of U), the matching column block of Y (and rows
@@ -551,7 +551,9 @@ def fit_mu_sharded(X_rows, Y_cols, U_rows, V, Z_rows, l1_reg=0.0, l2_reg=0.0, ma
         ex2, ey2 = global_sq()
         return 0.5 * np.sqrt(ex2) + 0.5 * np.sqrt(ey2)
 
-    n_iter = _outer_loop(lambda it: drv.step(l1_reg, l2_reg, 7), global_error, max_iter, tol, verbose)
+    # update_mask: bit 0 U, 1 V, 2 Z (the reference's update_U / update_V / update_Z, pycmf/cmf_solvers.py:252-261; `transform` fits
+    # U and Z against a fixed V: both sweeps are local to the rank)
+    n_iter = _outer_loop(lambda it: drv.step(l1_reg, l2_reg, update_mask), global_error, max_iter, tol, verbose)
     ctx.sync()
     if stats is not None:   # squared global residuals of the final factors (reconstruction_err_ of the front end)
         stats["ex2"], stats["ey2"] = global_sq()
@@ -566,7 +568,7 @@ def fit_mu_sharded(X_rows, Y_cols, U_rows, V, Z_rows, l1_reg=0.0, l2_reg=0.0, ma
 
 def fit_newton_linear_sharded(X_rows, Y_cols, U_rows, V, Z_rows, alpha=0.5, l1_reg=0.0, l2_reg=0.0, U_non_negative=True,
                               V_non_negative=True, Z_non_negative=True, hessian_pertubation=0.2, max_iter=200, tol=1e-4,
-                              device=0, verbose=0, stats=None, rank=None, world=None, single_collective=False):
+                              device=0, verbose=0, stats=None, rank=None, world=None, single_collective=False, update_mask=7):
     """Newton fit with linear links and sg_sample_ratio == 1 on north_star's partition -- the same one as MU: rank g holds its row
     block of X / U (CSR X: nnz-balanced blocks) and column block of Y / rows of Z, V replicated, X and Y resident ONCE.  The U
     and Z sweeps are local; the V sweep sums the k^2 Gram and then the d x k partial over the ranks (ShardedNewtonLinear).
@@ -591,7 +593,7 @@ def fit_newton_linear_sharded(X_rows, Y_cols, U_rows, V, Z_rows, alpha=0.5, l1_r
         ex2, ey2 = global_sq()
         return alpha * np.sqrt(ex2) + (1 - alpha) * np.sqrt(ey2)
 
-    n_iter = _outer_loop(lambda it: drv.step(l1_reg, l2_reg, 7), global_error, max_iter, tol, verbose)
+    n_iter = _outer_loop(lambda it: drv.step(l1_reg, l2_reg, update_mask), global_error, max_iter, tol, verbose)
     ctx.sync()
     if stats is not None:
         stats["ex2"], stats["ey2"] = global_sq()
@@ -609,7 +611,7 @@ def fit_newton_linear_sharded(X_rows, Y_cols, U_rows, V, Z_rows, alpha=0.5, l1_r
 def fit_newton_sharded(X_rows, X_cols, Y_cols, Y_rows, U_rows, V, Z_rows, alpha=0.5, l1_reg=0.0, l2_reg=0.0,
                        x_link="linear", y_link="linear", U_non_negative=True, V_non_negative=True, Z_non_negative=True,
                        hessian_pertubation=0.2, sg_sample_ratio=1.0, random_state=None, max_iter=200, tol=1e-4,
-                       device=0, verbose=0, stats=None, rank=None, world=None):
+                       device=0, verbose=0, stats=None, rank=None, world=None, update_mask=7):
     """Row-sharded Newton fit for ANY link / sampling combination: call from every rank (one process per GPU).
 
     Rank g passes its row block of X and the SAME rows of U, the matching column block of Y with its rows of Z, and
@@ -660,7 +662,7 @@ def fit_newton_sharded(X_rows, X_cols, Y_cols, Y_rows, U_rows, V, Z_rows, alpha=
         return alpha * np.sqrt(ex2) + (1 - alpha) * np.sqrt(ey2)
 
     seed0 = (int(random_state) if isinstance(random_state, (int, np.integer)) else 0) << 20
-    n_iter = _outer_loop(lambda it: drv.step(l1_reg, l2_reg, 7, seed0 + it), global_error, max_iter, tol, verbose)
+    n_iter = _outer_loop(lambda it: drv.step(l1_reg, l2_reg, update_mask, seed0 + it), global_error, max_iter, tol, verbose)
     ctx_uz.sync()
     if stats is not None:
         stats["ex2"], stats["ey2"] = global_sq()

@@ -283,6 +283,87 @@ def test_c4_full_size_mu_sampled_rows_vs_fp64(lib):
     ctx.close()
 
 
+def _tile_sums(F):
+    """column sums of every 256-row tile of a rows x k array (rows padded with zeros to a multiple of 256)"""
+    rows, k = F.shape
+    pad = (-rows) % 256
+    if pad:
+        F = np.vstack([F, np.zeros((pad, k))])
+    return F.reshape(-1, 256, k).sum(axis=1)
+
+
+@pytest.mark.parametrize("shape", [(65536, 65536, 65536, 256), (16384, 8192, 4096, 128)], ids=["c4", "c2"])
+def test_full_size_mu_every_output_tile_checksum(lib, shape):
+    """BASELINE configs[3] and [1] at full size: EVERY 256-row output tile of the four data passes of one MU iteration
+    (X^T U + Y Z, X V, Y^T V: pycmf/cmf_solvers.py:244, :232, :238) and every element of the three fused epilogues (:212-228).
+    The products are recovered in float64 from the factors the device wrote -- V1 = V0 * P / (V0 G)  =>  P = V1 (V0 G) / V0 -- and the
+    column sums of each tile of P are compared with (block sums of X, Y)^T times the factor, the block sums coming from plain
+    float64 reductions of the device's data (cmf_data_block_sums_f64: nothing shared with the GEMM kernels).  A tile never
+    visited, a K-step dropped (1 / 2048 of a tile's sum at C4) or an index wrap would show in that tile's row; the sampled-row test
+    below checks single elements of a few rows, this one checks all tiles."""
+    m, d, p, k = shape
+    ctx = _synthetic(lib, m, d, p, k)
+    U0, V0, Z0 = (ctx.get_factor(w) for w in range(3))
+    mp, dp, pp, kp = ctx.geometry()
+    sx_cols = ctx.data_block_sums(0, 1)[:m]           # [m, d_pad / 256]: sums of X over blocks of 256 columns
+    sx_rows = ctx.data_block_sums(0, 0)[:, :d]        # [m_pad / 256, d]: sums of X over blocks of 256 rows
+    sy_cols = ctx.data_block_sums(1, 1)[:d]           # [d, p_pad / 256]
+    sy_rows = ctx.data_block_sums(1, 0)[:, :p]        # [d_pad / 256, p]
+    # the block sums themselves against the device's total (one more independent reduction)
+    tx, ty = ctx.data_sum()
+    assert abs(sx_cols.sum() - tx) <= 1e-9 * tx and abs(sx_rows.sum() - tx) <= 1e-9 * tx
+    assert abs(sy_cols.sum() - ty) <= 1e-9 * ty and abs(sy_rows.sum() - ty) <= 1e-9 * ty
+
+    def check(rec, ref, what):
+        got = _tile_sums(rec)
+        assert got.shape == ref.shape, what
+        err = np.abs(got - ref) / np.abs(ref).max(axis=1, keepdims=True)
+        worst = np.unravel_index(np.argmax(err), err.shape)
+        assert err.max() <= 2e-5, "%s: tile %d column %d off by %.3g of the tile's largest column sum" % (what, worst[0], worst[1], err.max())
+
+    ctx.mu_step(0.0, 0.0, lib.CMF_UPD_V)
+    V1 = ctx.get_factor(1)
+    assert np.all(V0 > 0)
+    P = V1 * (V0 @ (U0.T @ U0 + Z0.T @ Z0)) / V0                      # X^T U + Y Z as the device formed it (:244-245)
+    check(P, sx_cols.T @ U0 + sy_rows @ Z0, "X^T U + Y Z")
+    ctx.mu_step(0.0, 0.0, lib.CMF_UPD_U | lib.CMF_UPD_Z)
+    U1, Z1 = ctx.get_factor(0), ctx.get_factor(2)
+    G2 = V1.T @ V1
+    check(U1 * (U0 @ G2) / U0, sx_rows @ V1, "X V")                    # :232-233
+    check(Z1 * (Z0 @ G2) / Z0, sy_cols.T @ V1, "Y^T V")                # :238-239
+    ctx.close()
+
+
+def test_c4_residual_metric_vs_fp64(lib):
+    """The device error metric (cmf_residual_sq: the quantity of the stopping test and of reconstruction_err_,
+    pycmf/cmf_solvers.py:36-42, :128-130) at BASELINE configs[3]: the value of the whole 65536^2 problem equals the sum over eight
+    row / column slabs (each slab a context of its own: the NT pass with other extents), and the first slab -- 8192 rows of X with
+    their rows of U, 8192 columns of Y with their rows of Z, after one MU update -- equals ||X_s - U_s V^T||^2, ||Y_s - V Z_s^T||^2
+    evaluated in float64 on the host from the device's own data to 1e-5."""
+    m = d = p = 65536
+    k = 256
+    ctx = _synthetic(lib, m, d, p, k)
+    whole = np.array(ctx.residual_sq())
+    ctx.close()
+    parts = np.zeros(2)
+    for s in range(8):
+        sc = _synthetic(lib, m, d, p, k, s * 8192, s * 8192, 8192, 8192)
+        parts += np.array(sc.residual_sq())
+        if s == 0:
+            sc.mu_step(0.0, 0.0, 7)                                     # the metric on updated factors as well
+            ex, ey = sc.residual_sq()
+            U, V, Z = (sc.get_factor(w) for w in range(3))
+            X = sc.get_data(0).astype(np.float64)
+            rx = float(((X - U @ V.T) ** 2).sum())
+            del X
+            Y = sc.get_data(1).astype(np.float64)
+            ry = float(((Y - V @ Z.T) ** 2).sum())
+            del Y
+            assert abs(ex - rx) <= 1e-5 * rx and abs(ey - ry) <= 1e-5 * ry, (ex, rx, ey, ry)
+        sc.close()
+    np.testing.assert_allclose(parts, whole, rtol=1e-6)
+
+
 def _feed(monkeypatch, O, lists):
     """make the oracle's sampler hand out the given index lists, in order (it draws one per row, U / Z sweeps, or two per
     row, V sweep: X side then Y side -- pycmf/cmf_solvers.py:414, :494, :455-456)"""

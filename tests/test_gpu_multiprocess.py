@@ -413,3 +413,67 @@ def test_real_rccl_two_gpus(workload, extra):
     assert coll["backend"] == "rccl" and coll["ranks_seen"] == 2 and coll["replicas"]["identical"], coll
     for key in ("x", "y"):
         assert abs(two["rel_residual"][key] - one["rel_residual"][key]) < 0.05 * one["rel_residual"][key]
+
+
+@pytest.mark.parametrize("solver,kw", [("mu", {}), ("newton", dict(l2_reg=0.3, U_non_negative=False, V_non_negative=False, Z_non_negative=False))])
+def test_cmf_n_gpus_transform(solver, kw, monkeypatch):
+    """``CMF(n_gpus=2).transform`` (the reference has ONE code path for fit and transform, pycmf/cmf.py:726-747): U and Z are fitted
+    against the frozen components on two ranks -- both sweeps are local to a rank -- and equal the single-GPU transform; a
+    one-sided transform (Y None) needs nothing sharded and runs on one GPU."""
+    from pycmf_amd import CMF
+    monkeypatch.setenv("PYCMF_AMD_SAME_DEVICE", "1")
+    monkeypatch.setenv("CMF_COMM_BACKEND", "host")
+    monkeypatch.setenv("CMF_COMM_TIMEOUT", "120")
+    rng = np.random.RandomState(8)
+    m, d, p, k = 240, 130, 70, 5
+    X, Y = np.abs(rng.randn(m, d)), np.abs(rng.randn(d, p))
+    X2, Y2 = np.abs(rng.randn(m, d)), np.abs(rng.randn(d, p))
+    one = CMF(n_components=k, solver=solver, x_init="random", y_init="random", random_state=0, max_iter=30, n_gpus=1, **kw).fit(X, Y)
+    two = CMF(n_components=k, solver=solver, x_init="random", y_init="random", random_state=0, max_iter=30, n_gpus=2, **kw)
+    two.components, two.x_weights, two.y_weights, two.n_components_ = one.components.copy(), one.x_weights.copy(), one.y_weights.copy(), k
+    U1, V1, Z1 = one.transform(X2, Y2)
+    U2, V2, Z2 = two.transform(X2, Y2)
+    np.testing.assert_array_equal(V2, one.components)
+    for a, b in ((U2, U1), (Z2, Z1)):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-4 * np.abs(b).max())
+    Ua, _, _ = two.transform(X2, None)
+    Ub, _, _ = one.transform(X2, None)
+    np.testing.assert_allclose(Ua, Ub, rtol=0, atol=1e-6 * np.abs(Ub).max())
+
+
+FORK_SCRIPT = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from pycmf_amd import CMF, multi_gpu, _lib
+rng = np.random.RandomState(3)
+X, Y = np.abs(rng.randn(300, 170)), np.abs(rng.randn(170, 90))
+assert multi_gpu.can_fork_ranks() and not _lib.gpu_touched()
+two = CMF(n_components=6, solver="mu", x_init="random", y_init="random", random_state=0, max_iter=30, n_gpus=2).fit(X, Y)
+assert multi_gpu.last_fit_info == {"forked": True, "job_bytes": 0}, multi_gpu.last_fit_info   # the ranks read X, Y in place
+assert not _lib.gpu_touched()                     # the parent still has not touched a GPU
+one = CMF(n_components=6, solver="mu", x_init="random", y_init="random", random_state=0, max_iter=30, n_gpus=1).fit(X, Y)
+assert _lib.gpu_touched() and not multi_gpu.can_fork_ranks()
+assert two.n_iter_ == one.n_iter_
+np.testing.assert_allclose(two.components, one.components, rtol=0, atol=2e-4 * np.abs(one.components).max())
+np.testing.assert_allclose(two.x_weights, one.x_weights, rtol=0, atol=2e-4 * np.abs(one.x_weights).max())
+# from now on this process holds a GPU runtime: the ranks are fresh processes and the job travels as float32 files, once
+again = CMF(n_components=6, solver="mu", x_init="random", y_init="random", random_state=0, max_iter=30, n_gpus=2).fit(X, Y)
+info = multi_gpu.last_fit_info
+assert info["forked"] is False and 0 < info["job_bytes"] < 0.6 * (X.nbytes + Y.nbytes) + 200000, info
+np.testing.assert_allclose(again.components, two.components, rtol=0, atol=1e-6 * np.abs(two.components).max())
+print("fork ok")
+'''
+
+
+def test_cmf_n_gpus_hands_the_data_over_without_a_second_host_copy(tmp_path):
+    """``CMF(n_gpus=2)`` from a process that has not touched a GPU yet: the ranks are FORKED off the caller and read X, Y, U, V, Z
+    in place (no job files: r04 wrote a float64 copy of everything, 68.7 GB at C4); once the process holds a GPU runtime the
+    ranks are fresh processes and the data travel as float32 files (half the bytes).  Same fit either way."""
+    script = tmp_path / "fork.py"
+    script.write_text(FORK_SCRIPT % {"root": ROOT})
+    env = dict(os.environ, PYCMF_AMD_SAME_DEVICE="1", CMF_COMM_BACKEND="host", CMF_COMM_TIMEOUT="120")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    q = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert q.returncode == 0 and "fork ok" in q.stdout.decode(), q.stdout.decode()[-3000:]
