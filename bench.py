@@ -57,9 +57,11 @@ WORKLOADS = {
                desc="BASELINE configs[4]: CSR X 1e6 x 1e5 at 0.1% nnz (100 per row, values 1.0, native CSR), "
                     "dense Y 1e5 x 64, n_components=256, newton solver, linear links"),
     "c5l": dict(m=1000000, d=100000, p=64, k=256, solver="newton", x_link="linear", y_link="logit", ratio=1.0,
-                nnz_per_row=100, l1=2.0, l2=5.0, nn_mask=3, y_kind=2, y_param=0.1,
+                nnz_per_row=100, l1=2.0, l2=50.0, nn_mask=3, y_kind=2, y_param=0.1,
                 desc="BASELINE configs[4] with the reference's own Newton settings (samples/toxic_comments.ipynb:853-856: "
-                     "x_link='linear', y_link='logit', l1_reg=2, l2_reg=5, U and V non-negative): CSR X 1e6 x 1e5 at 0.1% nnz "
+                     "x_link='linear', y_link='logit', l1_reg=2, U and V non-negative; l2_reg = 50 = the notebook's 5 scaled by d / 1e4, "
+                     "the number of rows each Z gradient sums over -- with l2 = 5 the reference's undamped iteration itself diverges on "
+                     "this unstructured synthetic Y by iteration 3, profiles/r05_c5l_probe.txt): CSR X 1e6 x 1e5 at 0.1% nnz "
                      "(values 1.0, native CSR), dense Y 1e5 x 64 in {0,1} (10% ones), n_components=256"),
     "tiny5l": dict(m=20000, d=3000, p=64, k=64, solver="newton", x_link="linear", y_link="logit", ratio=1.0,
                    nnz_per_row=30, l1=0.02, l2=0.5, nn_mask=3, y_kind=2, y_param=0.1,
@@ -253,6 +255,10 @@ def main():
                          "protocol); 'rsag' = reduce-scatter of the partial, V epilogue on the rank's row block, all-gather of V, the two "
                          "k^2 Grams in the same two RCCL groups; 'auto' (default) = both timed on the live ranks before the warm-up, the "
                          "faster kept (rsag only when it wins by > 2 %%), decision and timings in collective.protocol_trial")
+    ap.add_argument("--tol", type=float, default=0.0,
+                    help="> 0: the reference's convergence check (pycmf/cmf_solvers.py:175-187: the error metric every 10th iteration, "
+                         "default tol of pycmf.CMF 1e-4) runs INSIDE the timed region -- the device error pass, its 16-byte read-back and, "
+                         "N > 1, the all-reduce of the two squared residuals; the stop itself is never taken (exactly --steps iterations)")
     ap.add_argument("--dump-rows", default=None, metavar="PREFIX",
                     help="after the timed iterations every rank writes the rows it owns out of 16 fixed global rows of U, V, Z to "
                          "PREFIX.rank<r>.npz (tools/compare_rows.py compares two such sets: the N = 8 dress rehearsal against N = 1)")
@@ -380,6 +386,16 @@ def main():
         if coll:
             coll.barrier()         # every rank's stream has drained
 
+    checks = []
+
+    def maybe_check(it):
+        # iteration numbers count from the first timed step, as a fit's would from its first iteration
+        if args.tol > 0 and (it + 1) % 10 == 0:
+            sq = np.array(ctx.residual_sq(w.get("x_link", "linear"), w.get("y_link", "linear")))
+            if coll:
+                sq = coll.all_reduce_host(sq)
+            checks.append(float(0.5 * sq[0] ** 0.5 + 0.5 * sq[1] ** 0.5))
+
     for it in range(args.warmup):
         do_step(it)
     for c_ in ctxs:
@@ -393,6 +409,7 @@ def main():
     ctx.marker()
     for it in range(args.steps):
         do_step(args.warmup + it)
+        maybe_check(it)
         ctx.marker()               # one event per iteration on the launch stream: the auditable time series
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -590,9 +607,19 @@ def main():
                              "note": "rank 0; ms = events on the launch stream around every collective (waiting for the "
                                      "slowest rank included); ranks_seen = ncclCommCount of the communicator; replicas = every "
                                      "rank's copy of V compared after the run"}
+    if args.tol > 0:
+        out["convergence_check"] = {"tol": args.tol, "every": 10, "checks_in_timed_region": len(checks), "errors": checks,
+                                    "note": "the reference's stopping test (pycmf/cmf_solvers.py:175-187) evaluated inside the timed region; "
+                                            "the stop is not taken, so that exactly `steps` iterations are timed"}
     for key in ("x_link", "y_link", "ratio", "l1", "l2", "nn_mask"):
         if key in w:
             out["config"][key] = w[key]
+    if newton:
+        out["config"]["l1"], out["config"]["l2"] = l1_reg, l2_reg
+        if "l2" not in w:
+            out["config"]["l2_note"] = ("l2_reg = 0.1 is this bench's choice, not BASELINE.json's (which names no regularisation) nor the "
+                                        "reference's default (0, pycmf/cmf.py:622): --workload c3z is the same configuration at l2 = 0")
+        out["config"]["workload"] += "; l1_reg = %g, l2_reg = %g" % (l1_reg, l2_reg)
     if args.option:
         out["config"]["options"] = list(args.option)
     if args.workload == "c4" and not bf16x6:

@@ -121,6 +121,7 @@ struct cmf_ctx {
     int opt_ns = 1;        // flagged per-row Hessians at k_pad = 256: Newton-Schulz spectral clamp (0: Jacobi)
     bool hess_psd = true;  // the Hessians of the current step are positive semi-definite by construction (0 <= alpha <= 1)
     int opt_pipe_nt = 4;   // staging schedule of the NT (residual / error) GEMMs: 0 | 4
+    int opt_nt_tile16 = 1; // NT passes on the 256 x 128 x 16 tile (two workgroups per CU) instead of 256 x 128 x 32 (one)
     int opt_choldiag = 0;  // timing diagnostics of chol_solve_kernel (wrong results)
     int opt_chol = 1;      // Cholesky fast path of the safe inverse (0: always Jacobi)
     int opt_chol_mfma = 1; // k_pad = 256 per-row solves: blocked Cholesky on the matrix pipe (0: the rank-1 register kernel chol_solve_kernel<16>)
@@ -387,7 +388,11 @@ static int launch_gemm_pipe(cmf_ctx *c, const GemmArgs &a, const GemmPlan &pl) {
     } while (0)
     if constexpr (MODE == MODE_NT) {
         if (pl.bn != 128) return fail(CMF_EINVAL, "NT tile width must be 128");
-        CMF_LAUNCH(128);
+        if (pl.tile == 2) { // 256 x 128 x 16: two workgroups per CU (GemmCfg TILE 2)
+            using Cfg = GemmCfg<MODE, 128, 2>;
+            CHK(allow_big_lds(c, reinterpret_cast<const void *>(&gemm_kernel<MODE, 128, ROLE, PIPE, 2>), (int)Cfg::LDS_BYTES));
+            hipLaunchKernelGGL((gemm_kernel<MODE, 128, ROLE, PIPE, 2>), grid, block, Cfg::LDS_BYTES, c->stream, a);
+        } else CMF_LAUNCH(128);
     } else {
         if constexpr (ROLE == 0 && PIPE == 4) {
             if (pl.tile == 1 && pl.bn == 128) { // A/B: 512 x 128 x 16 tile
@@ -677,6 +682,7 @@ static int gemm_nt(cmf_ctx *c, const float *L, int64_t rows_pad, int64_t rows_va
                    int64_t cols_pad, int64_t cols_valid, const NtOut &o) {
     GemmPlan pl;
     pl.bn = 128; pl.ntiles_n = (int)(cols_pad / 128); pl.tiles_m = rows_pad / 256; pl.nsplit = 1; pl.klen = c->kp;
+    pl.tile = c->opt_nt_tile16 ? 2 : 0;
     GemmArgs a;
     memset(&a, 0, sizeof a);
     a.A = L; a.lda = c->kp; a.B = Rt; a.ldb = c->kp;
@@ -855,6 +861,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_chol_mfma = value != 0;
     } else if (!strcmp(name, "side_gram")) {
         c->opt_side_gram = value != 0;
+    } else if (!strcmp(name, "nt_tile16")) {
+        c->opt_nt_tile16 = value != 0;
     } else if (!strcmp(name, "narrow_update")) {
         c->opt_narrow_update = value != 0;
     } else if (!strcmp(name, "class_sum_depth")) {

@@ -88,12 +88,16 @@ __device__ __forceinline__ void store_wt(float *p, float v) { asm volatile("glob
 // TILE 0: 256 x BN output tile, 32-deep K-step (everything).  TILE 1 (BN = 128 data passes, A/B option gemm_tile512): 512 x 128
 // output tile, 16-deep K-step -- wave tile 128 x 64 like the 256 x 256 kernel's 64 x 128 (six fragment reads per eight MFMAs
 // instead of four per four, half the B-tile fill per flop), the same MFMA work per barrier as the 256 x 128 x 32 step, and
-// 98 KB of LDS double-buffered (a 32-deep step of this tile would need 180 KB).
+// 98 KB of LDS double-buffered (a 32-deep step of this tile would need 180 KB).  TILE 2 (NT form, option nt_tile16): the 256 x 128
+// output tile with a 16-deep K-step -- 61 KB of LDS instead of 110, so that TWO workgroups share a CU: the NT passes reduce over
+// K = k_pad only (8 K-steps of 32 at k_pad = 256), a third of a workgroup's life is the fill in front of the first MFMA and the
+// epilogue behind the last one (targets from HBM, link, squared residual), and with one workgroup per CU the matrix pipe idles
+// through both; a second resident workgroup runs its K-steps meanwhile.
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 
 template <int MODE, int BN, int TILE = 0>
 struct GemmCfg {
-    static constexpr int BM = TILE ? 512 : 256, BK = TILE ? 16 : 32, PADK = BK + 4, NT = 512;
+    static constexpr int BM = TILE == 1 ? 512 : 256, BK = TILE ? 16 : 32, PADK = BK + 4, NT = 512;
     static constexpr bool A_KC = (MODE != MODE_TN);
     static constexpr bool B_KC = (MODE == MODE_NT);
     static constexpr int A_ELEMS = A_KC ? BM * PADK : BK * BM;
@@ -103,7 +107,7 @@ struct GemmCfg {
     static constexpr int WM = 8 / WN;
     static constexpr int WTM = BM / WM, WTN = BN / WN;
     static constexpr int TM = WTM / 32, TN = WTN / 32;
-    static constexpr int A_LD = 4;                                  // float4 per thread
+    static constexpr int A_LD = BM * BK / 4 / NT;                   // float4 per thread (4; 2 for the 256 x 128 x 16 tile)
     static constexpr int B_F4 = B_KC ? BN * BK / 4 : BK * BN / 4;   // float4 in B tile
     static constexpr int B_LD = (B_F4 + NT - 1) / NT;
     static constexpr size_t LDS_BYTES = 2 * STAGE * sizeof(float);
@@ -184,9 +188,10 @@ struct VecLoad<4> {
 //  with direct-to-LDS loads, 131/136 with register staging, against 142.5/141.7 for schedule 4 - a third wave
 //  per SIMD costs more than the staging instructions it takes off the MFMA waves)
 template <int MODE, int BN, int ROLE = 0, int PIPE = 0, int TILE = 0>
-__global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g) {
     using C = GemmCfg<MODE, BN, TILE>;
-    static_assert(TILE == 0 || (BN == 128 && MODE != MODE_NT && ROLE == 0 && PIPE == 4), "the 512 x 128 x 16 tile: k_pad = 128 data passes only");
+    static_assert(TILE == 0 || (TILE == 1 && BN == 128 && MODE != MODE_NT && ROLE == 0 && PIPE == 4) || (TILE == 2 && BN == 128 && MODE == MODE_NT),
+                  "the 512 x 128 x 16 tile: k_pad = 128 data passes only; the 256 x 128 x 16 tile: NT passes only");
     // (shifts and masks, not / and %: with the signed division hipcc stopped folding the four A-tile LDS addresses of a thread into
     // one base + immediate offsets, and that alone cost the TN pass 2.7 % and 0.5 GB of extra operand fetch per launch at C4 --
     // profiles/HISTORY.md, round 4, A/B of the library builds)
@@ -385,9 +390,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
                 lda_frag(0, a[0]);
                 ldb_frag(0, b[0]);
 #pragma unroll
-                for (int sidx = 0; sidx < 16; ++sidx) {
+                for (int sidx = 0; sidx < NGRP; ++sidx) {
                     const int q = sidx >> 2, e = sidx & 3;
-                    if (e == 0 && q + 1 < 4) {
+                    if (e == 0 && q + 1 < NGRP / 4) {
                         lda_frag(q + 1, a[(q + 1) & 1]);
                         ldb_frag(q + 1, b[(q + 1) & 1]);
                     }
@@ -671,39 +676,44 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(GemmArgs g) {
             // no byte mask (everything but the masked-dense Newton formulation): fetch ALL targets of the wave tile
             // first -- one latency for 64 loads in flight instead of 64 dependent load -> wait -> use rounds, which
             // made this epilogue longer than the 8 K-steps in front of it -- then the arithmetic
-            float tv[C::TM][16][C::TN];
-#pragma unroll
-            for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-#pragma unroll
-                    for (int j = 0; j < C::TN; ++j) tv[i][r][j] = 0.0f;
-            if (Tp) {
-#pragma unroll
-                for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-#pragma unroll
-                        for (int j = 0; j < C::TN; ++j) tv[i][r][j] = Tp[(32 * i + (r & 3) + 8 * (r >> 2)) * ldt + 32 * j];
-            }
+            // (TILE 2 -- two workgroups per CU, 128 registers per lane: one block row of the wave tile at a time, 32 loads in flight)
+            constexpr int IB = (TILE == 2) ? 1 : C::TM;   // block rows per batch
             const float lkf = g.link ? 1.0f : 0.0f, nlk = 1.0f - lkf;
             const float slope = g.w_is_slope ? 1.0f : 0.0f, nslope = 1.0f - slope;
 #pragma unroll
-            for (int i = 0; i < C::TM; ++i)
+            for (int i0 = 0; i0 < C::TM; i0 += IB) {
+                float tv[IB][16][C::TN];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rr = 32 * i + (r & 3) + 8 * (r >> 2);
+                for (int i = 0; i < IB; ++i)
 #pragma unroll
-                    for (int j = 0; j < C::TN; ++j) {
-                        const float s = acc[i][j][r];
-                        const float f = lkf * sigmoidf_(s) + nlk * s; // exact: one of the two terms is zero
-                        const float mk = (rr < rlim && 32 * j < clim) ? 1.0f : 0.0f;
-                        const float res = f - tv[i][r][j];
-                        sq += mk * res * res;
-                        if (Rp) Rp[rr * ldr + 32 * j] = g.scale_r * mk * res;
-                        if (Wp) Wp[rr * ldr + 32 * j] = g.scale_w * mk * (slope * (f * (1.0f - f)) + nslope);
-                    }
+                    for (int r = 0; r < 16; ++r)
+#pragma unroll
+                        for (int j = 0; j < C::TN; ++j) tv[i][r][j] = 0.0f;
+                if (Tp) {
+#pragma unroll
+                    for (int i = 0; i < IB; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+#pragma unroll
+                            for (int j = 0; j < C::TN; ++j) tv[i][r][j] = Tp[(32 * (i0 + i) + (r & 3) + 8 * (r >> 2)) * ldt + 32 * j];
                 }
+#pragma unroll
+                for (int i = 0; i < IB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = 32 * (i0 + i) + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                        for (int j = 0; j < C::TN; ++j) {
+                            const float s = acc[i0 + i][j][r];
+                            const float f = lkf * sigmoidf_(s) + nlk * s; // exact: one of the two terms is zero
+                            const float mk = (rr < rlim && 32 * j < clim) ? 1.0f : 0.0f;
+                            const float res = f - tv[i][r][j];
+                            sq += mk * res * res;
+                            if (Rp) Rp[rr * ldr + 32 * j] = g.scale_r * mk * res;
+                            if (Wp) Wp[rr * ldr + 32 * j] = g.scale_w * mk * (slope * (f * (1.0f - f)) + nslope);
+                        }
+                    }
+            }
         } else
 #pragma unroll
         for (int i = 0; i < C::TM; ++i) {
