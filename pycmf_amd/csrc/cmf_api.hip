@@ -121,6 +121,7 @@ struct cmf_ctx {
     int opt_ns = 1;        // flagged per-row Hessians at k_pad = 256: Newton-Schulz spectral clamp (0: Jacobi)
     bool hess_psd = true;  // the Hessians of the current step are positive semi-definite by construction (0 <= alpha <= 1)
     int opt_pipe_nt = 4;   // staging schedule of the NT (residual / error) GEMMs: 0 | 4
+    int opt_nt_raster = 1; // NT passes: XCD-aware tile order (blocks of 4 x 8 tiles per XCD; gemm_kernel)
     int opt_nt_tile16 = 1; // NT passes on the 256 x 128 x 16 tile (two workgroups per CU) instead of 256 x 128 x 32 (one)
     int opt_choldiag = 0;  // timing diagnostics of chol_solve_kernel (wrong results)
     int opt_chol = 1;      // Cholesky fast path of the safe inverse (0: always Jacobi)
@@ -683,6 +684,13 @@ static int gemm_nt(cmf_ctx *c, const float *L, int64_t rows_pad, int64_t rows_va
     GemmPlan pl;
     pl.bn = 128; pl.ntiles_n = (int)(cols_pad / 128); pl.tiles_m = rows_pad / 256; pl.nsplit = 1; pl.klen = c->kp;
     pl.tile = c->opt_nt_tile16 ? 2 : 0;
+    int ras_rb = 0, ras_cb = 0;
+    if (c->opt_nt_raster && pl.ntiles_n % 8 == 0 && pl.tiles_m * pl.ntiles_n >= 8 * 64) {
+        const int per_x = pl.ntiles_n / 8;
+        ras_cb = per_x % 8 == 0 ? 8 : (per_x % 4 == 0 ? 4 : (per_x % 2 == 0 ? 2 : 1));
+        ras_rb = 32 / ras_cb;
+        while (ras_rb > 1 && pl.tiles_m % ras_rb) ras_rb /= 2;
+    }
     GemmArgs a;
     memset(&a, 0, sizeof a);
     a.A = L; a.lda = c->kp; a.B = Rt; a.ldb = c->kp;
@@ -690,6 +698,7 @@ static int gemm_nt(cmf_ctx *c, const float *L, int64_t rows_pad, int64_t rows_va
     a.T = o.T; a.ldt = o.ldt; a.R = o.R; a.W = o.W; a.ldr = o.ldr; a.mask = o.mask; a.ldm = o.ldm;
     a.Mvalid = rows_valid; a.Nvalid = cols_valid;
     a.scale_r = o.scale_r; a.scale_w = o.scale_w; a.link = o.link; a.w_is_slope = o.w_is_slope;
+    a.ras_rb = ras_rb; a.ras_cb = ras_cb;
     const int64_t nwg = pl.tiles_m * pl.ntiles_n;
     if (o.sq) {
         CHK(ensure(c, c->dpart, (size_t)nwg * sizeof(double)));
@@ -861,6 +870,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_chol_mfma = value != 0;
     } else if (!strcmp(name, "side_gram")) {
         c->opt_side_gram = value != 0;
+    } else if (!strcmp(name, "nt_raster")) {
+        c->opt_nt_raster = value != 0;
     } else if (!strcmp(name, "nt_tile16")) {
         c->opt_nt_tile16 = value != 0;
     } else if (!strcmp(name, "narrow_update")) {

@@ -46,6 +46,8 @@ struct GemmArgs {
     float scale_r, scale_w;
     int link;            // 0 linear, 1 logit
     int w_is_slope;      // W = scale_w * sigma'(S) (1) or scale_w (0)
+    // XCD-aware tile order of the NT passes (ras_rb > 0): see the remap at the top of gemm_kernel
+    int ras_rb, ras_cb;
     unsigned long long *dbg; // diagnostic only: per-workgroup {memtime, memrealtime} at start and end (nullable)
     // ---- ROLE 2 (block-diagonal batch of k_pad = 256 products, NN form): row tile x multiplies its own B ----
     int64_t b_batch;     // elements between the B operands of consecutive row tiles
@@ -206,8 +208,25 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
     const int wm = wid / C::WN, wn = wid % C::WN;
     const int wrow0 = wm * C::WTM, wcol0 = wn * C::WTN;
 
-    const int64_t row0 = (int64_t)blockIdx.x * C::BM; // output-row tile origin
-    const int64_t n0 = (int64_t)blockIdx.y * BN;      // output-col tile origin
+    // NT passes reduce over K = k_pad only: a 256 x 128 tile reads 384 KB of factor rows for 16.8 MFLOP, and in launch order (row
+    // tile fastest, workgroups dealt round-robin over the XCDs) the 32 workgroups an XCD runs at a time touch 32 DIFFERENT row tiles
+    // (8 MB against 4 MB of L2): every operand byte comes from beyond L2, 2.5 TB/s at C4.  With ras_rb > 0 the workgroups that share
+    // an XCD (linear id mod 8, speed only -- nothing depends on the placement) walk their own eighth of the column tiles in blocks
+    // of ras_rb row tiles x ras_cb column tiles: 1 MB + 1 MB of operands per 32 tiles, re-read from the XCD's L2.
+    unsigned tile_x = blockIdx.x, tile_y = blockIdx.y;
+    if constexpr (MODE == MODE_NT) {
+        if (g.ras_rb > 0) {
+            const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+            const unsigned xcd = lin & 7u, q = lin >> 3;
+            const unsigned per_x = gridDim.y >> 3, blk = (unsigned)(g.ras_rb * g.ras_cb);
+            const unsigned b = q / blk, w = q % blk;
+            const unsigned nrb = gridDim.x / (unsigned)g.ras_rb;
+            tile_x = (b % nrb) * (unsigned)g.ras_rb + w % (unsigned)g.ras_rb;
+            tile_y = xcd * per_x + (b / nrb) * (unsigned)g.ras_cb + w / (unsigned)g.ras_rb;
+        }
+    }
+    const int64_t row0 = (int64_t)tile_x * C::BM; // output-row tile origin
+    const int64_t n0 = (int64_t)tile_y * BN;      // output-col tile origin
     const int64_t kbeg = (int64_t)blockIdx.z * g.klen;
     int64_t kend = kbeg + g.klen;
     if (kend > g.Kred) kend = g.Kred;
@@ -695,7 +714,8 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
 #pragma unroll
-                            for (int j = 0; j < C::TN; ++j) tv[i][r][j] = Tp[(32 * (i0 + i) + (r & 3) + 8 * (r >> 2)) * ldt + 32 * j];
+                            for (int j = 0; j < C::TN; ++j)   // read once: non-temporal, so that the targets do not push the operands out of L2
+                                tv[i][r][j] = __builtin_nontemporal_load(Tp + (32 * (i0 + i) + (r & 3) + 8 * (r >> 2)) * ldt + 32 * j);
                 }
 #pragma unroll
                 for (int i = 0; i < IB; ++i)
