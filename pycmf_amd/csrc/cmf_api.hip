@@ -122,7 +122,7 @@ struct cmf_ctx {
     bool hess_psd = true;  // the Hessians of the current step are positive semi-definite by construction (0 <= alpha <= 1)
     int opt_pipe_nt = 4;   // staging schedule of the NT (residual / error) GEMMs: 0 | 4
     int opt_nt_raster = 1; // NT passes: XCD-aware tile order (blocks of 4 x 8 tiles per XCD; gemm_kernel)
-    int opt_nt_tile16 = 1; // NT passes on the 256 x 128 x 16 tile (two workgroups per CU) instead of 256 x 128 x 32 (one)
+    int opt_nt_tile16 = 0; // NT passes on the 256 x 128 x 16 tile (two workgroups per CU) instead of 256 x 128 x 32 (one, with the targets prefetched): A/B option, measured 39.6 against 40.7 ms at C4 before the prefetch existed
     int opt_choldiag = 0;  // timing diagnostics of chol_solve_kernel (wrong results)
     int opt_chol = 1;      // Cholesky fast path of the safe inverse (0: always Jacobi)
     int opt_chol_mfma = 1; // k_pad = 256 per-row solves: blocked Cholesky on the matrix pipe (0: the rank-1 register kernel chol_solve_kernel<16>)
