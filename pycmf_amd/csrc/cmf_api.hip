@@ -121,8 +121,9 @@ struct cmf_ctx {
     int opt_ns = 1;        // flagged per-row Hessians at k_pad = 256: Newton-Schulz spectral clamp (0: Jacobi)
     bool hess_psd = true;  // the Hessians of the current step are positive semi-definite by construction (0 <= alpha <= 1)
     int opt_pipe_nt = 4;   // staging schedule of the NT (residual / error) GEMMs: 0 | 4
-    int opt_nt_raster = 1; // NT passes: XCD-aware tile order (blocks of 4 x 8 tiles per XCD; gemm_kernel)
-    int opt_nt_tile16 = 0; // NT passes on the 256 x 128 x 16 tile (two workgroups per CU) instead of 256 x 128 x 32 (one, with the targets prefetched): A/B option, measured 39.6 against 40.7 ms at C4 before the prefetch existed
+    int opt_nt_bn256 = 1;  // NT passes on 256 x 256 tiles where the column extent allows (else 256 x 128)
+    int opt_nt_raster = 0; // NT passes: XCD-aware tile order (blocks of 4 x 8 tiles per XCD; gemm_kernel) -- measured no gain at C4 (40.9 against 40.6 ms): the operands beyond L2 are not the bound
+    int opt_nt_tile16 = 1; // 256 x 128 NT passes on the 16-deep K-step (two workgroups per CU) instead of 32-deep (one): 39.6 against 40.7 ms at C4
     int opt_choldiag = 0;  // timing diagnostics of chol_solve_kernel (wrong results)
     int opt_chol = 1;      // Cholesky fast path of the safe inverse (0: always Jacobi)
     int opt_chol_mfma = 1; // k_pad = 256 per-row solves: blocked Cholesky on the matrix pipe (0: the rank-1 register kernel chol_solve_kernel<16>)
@@ -388,7 +389,12 @@ static int launch_gemm_pipe(cmf_ctx *c, const GemmArgs &a, const GemmPlan &pl) {
         hipLaunchKernelGGL((gemm_kernel<MODE, BN_, ROLE, PIPE>), grid, block, Cfg::LDS_BYTES, c->stream, a); \
     } while (0)
     if constexpr (MODE == MODE_NT) {
-        if (pl.bn != 128) return fail(CMF_EINVAL, "NT tile width must be 128");
+        if (pl.bn == 256 && pl.tile == 0) { // 256 x 256 x 32: the data passes' tile (twice the MFMA work per barrier and per LDS fill)
+            CMF_LAUNCH(256);
+            HIPCHK(hipGetLastError());
+            return CMF_OK;
+        }
+        if (pl.bn != 128) return fail(CMF_EINVAL, "NT tile width must be 128 or 256");
         if (pl.tile == 2) { // 256 x 128 x 16: two workgroups per CU (GemmCfg TILE 2)
             using Cfg = GemmCfg<MODE, 128, 2>;
             CHK(allow_big_lds(c, reinterpret_cast<const void *>(&gemm_kernel<MODE, 128, ROLE, PIPE, 2>), (int)Cfg::LDS_BYTES));
@@ -684,6 +690,9 @@ static int gemm_nt(cmf_ctx *c, const float *L, int64_t rows_pad, int64_t rows_va
     GemmPlan pl;
     pl.bn = 128; pl.ntiles_n = (int)(cols_pad / 128); pl.tiles_m = rows_pad / 256; pl.nsplit = 1; pl.klen = c->kp;
     pl.tile = c->opt_nt_tile16 ? 2 : 0;
+    if (c->opt_nt_bn256 && cols_pad % 256 == 0 && (rows_pad / 256) * (cols_pad / 256) >= 2 * (int64_t)c->num_cu) {
+        pl.bn = 256; pl.ntiles_n = (int)(cols_pad / 256); pl.tile = 0;
+    }
     int ras_rb = 0, ras_cb = 0;
     if (c->opt_nt_raster && pl.ntiles_n % 8 == 0 && pl.tiles_m * pl.ntiles_n >= 8 * 64) {
         const int per_x = pl.ntiles_n / 8;
@@ -870,6 +879,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_chol_mfma = value != 0;
     } else if (!strcmp(name, "side_gram")) {
         c->opt_side_gram = value != 0;
+    } else if (!strcmp(name, "nt_bn256")) {
+        c->opt_nt_bn256 = value != 0;
     } else if (!strcmp(name, "nt_raster")) {
         c->opt_nt_raster = value != 0;
     } else if (!strcmp(name, "nt_tile16")) {

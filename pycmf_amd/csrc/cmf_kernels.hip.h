@@ -12,7 +12,6 @@
 // contractions), :399-400/:436-440 (Newton residual products), :36-42 (error).
 #pragma once
 #include <hip/hip_runtime.h>
-#include <type_traits>
 #include <stdint.h>
 
 namespace cmfk {
@@ -361,38 +360,9 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
             }
         }
     };
-    // NT passes without a byte mask on the one-workgroup-per-CU tile: the targets of the wave tile (64 floats per lane, read once
-    // from HBM) are requested inside the FIRST K-step, behind its staging traffic, and wait in registers -- the epilogue then starts
-    // on data that arrived under the MFMAs instead of paying one HBM latency per tile (172 + 64 registers of the 256 a lane may use)
-    constexpr bool TPRE = (MODE == MODE_NT && TILE == 0);
-    float tpre[TPRE ? C::TM : 1][TPRE ? 16 : 1][TPRE ? C::TN : 1];
-    const bool want_tpre = TPRE && g.T != nullptr && g.mask == nullptr;
-    auto tprefetch = [&]() {
-        if constexpr (TPRE) {
-            // scalar base + ONE 32-bit per-lane offset (global_load saddr form): 64 address pairs in vector registers on top of the 64
-            // destinations would not fit beside the accumulators
-            const int widu = __builtin_amdgcn_readfirstlane(wid);
-            const int64_t wr_u = (widu / C::WN) * C::WTM, wc_u = (widu % C::WN) * C::WTN;
-            const int ldt_ = (int)g.ldt;
-            const float *Tb = g.T + (row0 + wr_u) * g.ldt + n0 + wc_u;           // wave-uniform
-            const unsigned voff = (unsigned)(4 * lh * ldt_ + l31) * 4u;           // bytes, per lane
-#pragma unroll
-            for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-#pragma unroll
-                    for (int j = 0; j < C::TN; ++j) {
-                        const float *ps = Tb + (32 * i + (r & 3) + 8 * (r >> 2)) * ldt_ + 32 * j;
-                        tpre[i][r][j] = __builtin_nontemporal_load(reinterpret_cast<const float *>(reinterpret_cast<const char *>(ps) + voff));
-                    }
-        }
-    };
     auto compute = [&](const float *As, const float *Bs, float *nAs, float *nBs, bool do_write, bool do_load,
-                       int64_t next_k0, bool do_tpre = false) {
+                       int64_t next_k0) {
         auto side = [&](int sidx) {
-            if constexpr (TPRE) {
-                if (sidx == 2 && do_tpre) tprefetch();
-            }
             if constexpr (PIPE == 0) {
                 if (sidx == 0 && do_load) gload(next_k0);
             } else if constexpr (PIPE == 10) {
@@ -546,11 +516,11 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
             float *nxt = smem + ((kt + 1) & 1) * C::STAGE;
             if constexpr (PIPE == 0) {
                 const bool more = kt + 1 < nkt;
-                compute(cur, cur + C::A_ELEMS, nxt, nxt + C::A_ELEMS, false, more, kbeg + (int64_t)(kt + 1) * C::BK, want_tpre && kt == 0);
+                compute(cur, cur + C::A_ELEMS, nxt, nxt + C::A_ELEMS, false, more, kbeg + (int64_t)(kt + 1) * C::BK);
                 if (more) lstore(nxt, nxt + C::A_ELEMS);
             } else {
                 compute(cur, cur + C::A_ELEMS, nxt, nxt + C::A_ELEMS, kt + 1 < nkt, kt + 2 < nkt,
-                        kbeg + (int64_t)(kt + 2) * C::BK, want_tpre && kt == 0);
+                        kbeg + (int64_t)(kt + 2) * C::BK);
             }
             __syncthreads();
         }
@@ -726,7 +696,8 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
             // first -- one latency for 64 loads in flight instead of 64 dependent load -> wait -> use rounds, which
             // made this epilogue longer than the 8 K-steps in front of it -- then the arithmetic
             // (TILE 2 -- two workgroups per CU, 128 registers per lane: one block row of the wave tile at a time, 32 loads in flight)
-            constexpr int IB = (TILE == 2) ? 1 : C::TM;   // block rows per batch
+            constexpr int IB = (TILE == 2 || BN == 256) ? 1 : C::TM;   // block rows per batch (256-wide tile: 64 of its 128 targets per lane at a time)
+            const float lkf = g.link ? 1.0f : 0.0f, nlk = 1.0f - lkf;
             const float slope = g.w_is_slope ? 1.0f : 0.0f, nslope = 1.0f - slope;
 #pragma unroll
             for (int i0 = 0; i0 < C::TM; i0 += IB) {
@@ -737,16 +708,7 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
                     for (int r = 0; r < 16; ++r)
 #pragma unroll
                         for (int j = 0; j < C::TN; ++j) tv[i][r][j] = 0.0f;
-                if constexpr (TPRE) {
-                    if (want_tpre && nkt > 0) {
-#pragma unroll
-                        for (int i = 0; i < IB; ++i)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r)
-#pragma unroll
-                                for (int j = 0; j < C::TN; ++j) tv[i][r][j] = tpre[i0 + i][r][j];
-                    }
-                } else if (Tp) {
+                if (Tp) {
 #pragma unroll
                     for (int i = 0; i < IB; ++i)
 #pragma unroll
@@ -755,27 +717,22 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
                             for (int j = 0; j < C::TN; ++j)   // read once: non-temporal, so that the targets do not push the operands out of L2
                                 tv[i][r][j] = __builtin_nontemporal_load(Tp + (32 * (i0 + i) + (r & 3) + 8 * (r >> 2)) * ldt + 32 * j);
                 }
-                // (the link is uniform over the launch: a branch, not a blend -- the blend paid v_exp + v_rcp per element of a LINEAR side too)
-                auto body = [&](auto is_logit) {
 #pragma unroll
-                    for (int i = 0; i < IB; ++i)
+                for (int i = 0; i < IB; ++i)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int rr = 32 * (i0 + i) + (r & 3) + 8 * (r >> 2);
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = 32 * (i0 + i) + (r & 3) + 8 * (r >> 2);
 #pragma unroll
-                            for (int j = 0; j < C::TN; ++j) {
-                                const float s = acc[i0 + i][j][r];
-                                const float f = decltype(is_logit)::value ? sigmoidf_(s) : s;
-                                const float mk = (rr < rlim && 32 * j < clim) ? 1.0f : 0.0f;
-                                const float res = f - tv[i][r][j];
-                                sq += mk * res * res;
-                                if (Rp) Rp[rr * ldr + 32 * j] = g.scale_r * mk * res;
-                                if (Wp) Wp[rr * ldr + 32 * j] = g.scale_w * mk * (slope * (f * (1.0f - f)) + nslope);
-                            }
+                        for (int j = 0; j < C::TN; ++j) {
+                            const float s = acc[i0 + i][j][r];
+                            const float f = lkf * sigmoidf_(s) + nlk * s; // exact: one of the two terms is zero
+                            const float mk = (rr < rlim && 32 * j < clim) ? 1.0f : 0.0f;
+                            const float res = f - tv[i][r][j];
+                            sq += mk * res * res;
+                            if (Rp) Rp[rr * ldr + 32 * j] = g.scale_r * mk * res;
+                            if (Wp) Wp[rr * ldr + 32 * j] = g.scale_w * mk * (slope * (f * (1.0f - f)) + nslope);
                         }
-                };
-                if (g.link) body(std::integral_constant<int, 1>{});
-                else body(std::integral_constant<int, 0>{});
+                    }
             }
         } else
 #pragma unroll
