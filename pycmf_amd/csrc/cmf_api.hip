@@ -121,7 +121,8 @@ struct cmf_ctx {
     int opt_ns = 1;        // flagged per-row Hessians at k_pad = 256: Newton-Schulz spectral clamp (0: Jacobi)
     bool hess_psd = true;  // the Hessians of the current step are positive semi-definite by construction (0 <= alpha <= 1)
     int opt_pipe_nt = 4;   // staging schedule of the NT (residual / error) GEMMs: 0 | 4
-    int opt_nt_bn256 = 1;  // NT passes on 256 x 256 tiles where the column extent allows (else 256 x 128)
+    int opt_nt_debug = 0;  // measurement only (tools/r05_nt_probe.py): bit 0 = the error pass without its targets
+    int opt_nt_bn256 = 0;  // NT passes on 256 x 256 tiles where the column extent allows (A/B option: 39.9 ms at C4 against 39.7 for the 256 x 128 x 16 tile)
     int opt_nt_raster = 0; // NT passes: XCD-aware tile order (blocks of 4 x 8 tiles per XCD; gemm_kernel) -- measured no gain at C4 (40.9 against 40.6 ms): the operands beyond L2 are not the bound
     int opt_nt_tile16 = 1; // 256 x 128 NT passes on the 16-deep K-step (two workgroups per CU) instead of 32-deep (one): 39.6 against 40.7 ms at C4
     int opt_choldiag = 0;  // timing diagnostics of chol_solve_kernel (wrong results)
@@ -879,6 +880,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_chol_mfma = value != 0;
     } else if (!strcmp(name, "side_gram")) {
         c->opt_side_gram = value != 0;
+    } else if (!strcmp(name, "nt_debug")) {
+        c->opt_nt_debug = (int)value;
     } else if (!strcmp(name, "nt_bn256")) {
         c->opt_nt_bn256 = value != 0;
     } else if (!strcmp(name, "nt_raster")) {
@@ -1721,7 +1724,7 @@ extern "C" int cmf_residual_sq(cmf_ctx *c, int x_link, int y_link, double *ex2, 
             CHK(sparse_residual_sq(c, 0, c->dscalar, x_link));
         } else {
             CHK(need_dense(c, 0));
-            NtOut o; o.T = c->X; o.ldt = c->dp; o.sq = c->dscalar; o.link = x_link;
+            NtOut o; o.T = c->opt_nt_debug & 1 ? nullptr : c->X; o.ldt = c->dp; o.sq = c->dscalar; o.link = x_link;
             CHK(gemm_nt(c, c->F[CMF_U], c->mp, c->m, c->F[CMF_V], c->dp, c->d, o));
         }
     }
@@ -1730,7 +1733,7 @@ extern "C" int cmf_residual_sq(cmf_ctx *c, int x_link, int y_link, double *ex2, 
             CHK(sparse_residual_sq(c, 1, c->dscalar + 1, y_link));
         } else {
             CHK(need_dense(c, 1));
-            NtOut o; o.T = c->Y; o.ldt = c->pp; o.sq = c->dscalar + 1; o.link = y_link;
+            NtOut o; o.T = c->opt_nt_debug & 1 ? nullptr : c->Y; o.ldt = c->pp; o.sq = c->dscalar + 1; o.link = y_link;
             CHK(gemm_nt(c, c->F[CMF_V], c->dp, c->d, c->F[CMF_Z], c->pp, c->p, o));
         }
     }

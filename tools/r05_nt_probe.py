@@ -20,9 +20,10 @@ def run(m, d, p, k, reps=6, link="linear"):
         ctx.fill_factor_synthetic(w, seed, 0, sc)
     out = {}
     for rnd in range(2):
-        for opt in (0, 1, 2):
+        for opt in (0, 1, 2, 4, 6):
             ctx.set_option("nt_tile16", opt & 1)
-            ctx.set_option("nt_bn256", opt >> 1)
+            ctx.set_option("nt_bn256", (opt >> 1) & 1)
+            ctx.set_option("nt_debug", opt >> 2)
             val = ctx.residual_sq(link, link)
             ctx.sync()
             t0 = time.perf_counter()
@@ -32,7 +33,7 @@ def run(m, d, p, k, reps=6, link="linear"):
             ms = (time.perf_counter() - t0) / reps * 1e3
             flops = 2.0 * k * d * (m + p)
             out.setdefault(opt, []).append(ms)
-            print("m,d,p,k=%s link=%s nt_tile16 + 2 nt_bn256 = %d round %d: %.3f ms per metric, %.1f TF/s = %.3f of the fp32 MFMA peak; values %r"
+            print("m,d,p,k=%s link=%s nt_tile16 + 2 nt_bn256 + 4 no_targets = %d round %d: %.3f ms per metric, %.1f TF/s = %.3f of the fp32 MFMA peak; values %r"
                   % ((m, d, p, k), link, opt, rnd, ms, flops / ms / 1e9, flops / ms / 1e9 / 157.3, val), flush=True)
     ctx.close()
     return out
@@ -40,6 +41,4 @@ def run(m, d, p, k, reps=6, link="linear"):
 
 if __name__ == "__main__":
     run(65536, 65536, 65536, 256)
-    run(65536, 65536, 65536, 256, link="logit")
-    run(16384, 8192, 4096, 128, reps=50)
     run(32768, 16384, 8192, 256, reps=20)
