@@ -295,9 +295,6 @@ def main():
     newton = w["solver"] == "newton"
     sharded_ok = (not newton) or (w["x_link"] == "linear" and w["y_link"] == "linear" and w["ratio"] == 1.0)
     rows_mode = newton and not sharded_ok and use_dist
-    if rows_mode and "nnz_per_row" in w:
-        raise SystemExit("bench.py: --workload %s is a single-GPU bench line (the row-sharded Newton of a CSR X needs its column "
-                         "blocks as well: use CMF(n_gpus=N), pycmf_amd/multi_gpu.py)" % args.workload)
     bounds_fn = block_bounds if rows_mode else shard_bounds   # the row-sharded Newton all-gathers equal blocks
     r0, r1 = bounds_fn(m, world, rank)
     c0, c1 = bounds_fn(p, world, rank)
@@ -318,10 +315,22 @@ def main():
         # notebook) and kept native on the device
         import scipy.sparse as sp
         npr = w["nnz_per_row"]
-        rng = np.random.default_rng(42 + rank)
-        rows = r1 - r0
-        X = sp.csr_matrix((np.ones(rows * npr), rng.integers(0, d, size=rows * npr, dtype=np.int32),
-                           np.arange(0, rows * npr + 1, npr, dtype=np.int64)), shape=(rows, d))
+        X_cols_block = None
+        if rows_mode:
+            # the row-sharded Newton (y logit: BASELINE configs[4] with the reference's own settings is an 8-GPU configuration) holds
+            # X by rows AND by columns: every rank draws the WHOLE synthetic matrix from the same stream and cuts its two blocks
+            rng = np.random.default_rng(42)
+            Xall = sp.csr_matrix((np.ones(m * npr), rng.integers(0, d, size=m * npr, dtype=np.int32),
+                                  np.arange(0, m * npr + 1, npr, dtype=np.int64)), shape=(m, d))
+            X = Xall[r0:r1]
+            q0_, q1_ = block_bounds(d, world, rank)
+            X_cols_block = Xall[:, q0_:q1_].tocsr()
+            del Xall
+        else:
+            rng = np.random.default_rng(42 + rank)
+            rows = r1 - r0
+            X = sp.csr_matrix((np.ones(rows * npr), rng.integers(0, d, size=rows * npr, dtype=np.int32),
+                               np.arange(0, rows * npr + 1, npr, dtype=np.int64)), shape=(rows, d))
         ctx.set_option("sparse_mode", 2)
         ctx.set_data(0, X)
         del X
@@ -364,7 +373,12 @@ def main():
             name, _, val = kv.partition("=")
             ctx_v.set_option(name, int(val))
         ctx_v.set_problem(m, q1 - q0, p, k)
-        ctx_v.fill_data_synthetic(0, 42, 0, q0, w.get("x_kind", 0))
+        if "nnz_per_row" in w:
+            ctx_v.set_option("sparse_mode", 2)
+            ctx_v.set_data(0, X_cols_block)
+            del X_cols_block
+        else:
+            ctx_v.fill_data_synthetic(0, 42, 0, q0, w.get("x_kind", 0))
         ctx_v.fill_data_synthetic(1, 43, q0, 0, w.get("y_kind", 0), w.get("y_param", 0.0))
         ctx_v.fill_factor_synthetic(_lib.CMF_U, 101, 0, scale)
         ctx_v.fill_factor_synthetic(_lib.CMF_V, 102, q0, scale)
@@ -553,7 +567,7 @@ def main():
         roof["mfma_executed_tflops"] = achieved * (36 * 2048.0 + 4 * kp) / (kp * (kp + 1.0) + 4 * kp)
     roof["traffic_provenance"] = (None if roof.get("traffic") is None else
                                   "stored: profiles/traffic_%s.json, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                  "command (tools/refresh_r04.sh, gfx950 corrections of MI355X_MICROARCH.md); PMC collection cannot run "
+                                  "command (tools/refresh_r05.sh, gfx950 corrections of MI355X_MICROARCH.md); PMC collection cannot run "
                                   "inside a timed bench run, so this figure is NOT measured by the run that printed this line" % args.workload)
     roof["per_class_ms_per_step"] = {c: v[0] / extra for c, v in other.items() if v[1]}
     roof["per_class_note"] = ("%d extra iterations after the timed region with HIP events around every launch; inside the timed region "

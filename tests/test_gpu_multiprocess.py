@@ -154,7 +154,7 @@ def _run_bench(args, env_extra, timeout=1800):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("workload", ["tiny", "tiny3", "tiny5"])
+@pytest.mark.parametrize("workload", ["tiny", "tiny3", "tiny5", "tiny5l"])
 def test_bench_launches_its_own_ranks(workload):
     """`python bench.py --gpus 2` as the driver calls it -- no launcher, no WORLD_SIZE in the environment: bench.py
     starts the two rank processes itself (before any GPU call in the parent) and prints rank 0's JSON line.  The test
@@ -169,11 +169,12 @@ def test_bench_launches_its_own_ranks(workload):
     assert coll["ranks_seen"] == 2 and coll["rank_seen"] == 0 and "exposed_ms_per_iteration" in coll and coll["per_kind"]
     # MU (--mu-collective rsag): the one sum cut in two (reduce-scatter, all-gather) + the two k^2 Grams, as TWO groups; per-row
     # Newton: 3 all-gathers of factor rows; linear Newton: the k^2 float64 Gram + ONE d x k partial
-    assert coll["calls_per_iteration"] == {"tiny": 4, "tiny3": 3, "tiny5": 2}[workload]
-    assert coll["launch_points_per_iteration"] == {"tiny": 2, "tiny3": 3, "tiny5": 2}[workload]
+    # (tiny5l = the shape of --workload c5l: native CSR X with a logit Y goes through the ROW-sharded driver, X held by rows and by columns)
+    assert coll["calls_per_iteration"] == {"tiny": 4, "tiny3": 3, "tiny5": 2, "tiny5l": 3}[workload]
+    assert coll["launch_points_per_iteration"] == {"tiny": 2, "tiny3": 3, "tiny5": 2, "tiny5l": 3}[workload]
     if workload == "tiny":
         assert coll["protocol"] == "rsag" and set(coll["per_kind"]) == {"all_reduce_f32", "reduce_scatter_f32", "all_gather_f32"}
-    if workload != "tiny3":
+    if workload not in ("tiny3", "tiny5l"):
         assert coll["replicas"]["identical"], coll["replicas"]     # every rank ends with the same V, bit for bit
     one = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", workload, "--no-cpu-baseline"], {})
     assert one["n_gpus"] == 1 and "collective" not in one
