@@ -463,9 +463,11 @@ def main():
     for c_ in ctxs:
         c_.kernel_timing(1)
         c_.kernel_timing_reset()
+    t_extra = time.perf_counter()
     for it in range(extra):
         do_step(args.warmup + args.steps + it)
     sync_all()
+    t_extra = (time.perf_counter() - t_extra) / max(extra, 1) * 1e3
     other = {c: tuple(sum(v) for v in zip(*(c_.kernel_time(c) for c_ in ctxs))) for c in names}
     for c_ in ctxs:
         c_.kernel_timing(False)
@@ -570,6 +572,8 @@ def main():
                                   "command (tools/refresh_r05.sh, gfx950 corrections of MI355X_MICROARCH.md); PMC collection cannot run "
                                   "inside a timed bench run, so this figure is NOT measured by the run that printed this line" % args.workload)
     roof["per_class_ms_per_step"] = {c: v[0] / extra for c, v in other.items() if v[1]}
+    roof["per_class_launches_per_step"] = {c: v[1] / extra for c, v in other.items() if v[1]}
+    roof["instrumented_ms_per_step"] = t_extra
     roof["per_class_note"] = ("%d extra iterations after the timed region with HIP events around every launch; inside the timed region "
                               "only the data-pass classes carry events (what achieved / avg_launch_ms are computed from)" % extra)
     out = {

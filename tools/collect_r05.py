@@ -29,7 +29,7 @@ if LINES_ONLY:
     for w in ("c3z", "c3x"):
         shutil.copy(os.path.join(SRC, "%s.json" % w), os.path.join(DST, "%s_%s_n1_bench.json" % (TAG, w)))
     sys.exit(0)
-for f_, t_ in (("c4_tol.json", "%s_c4_n1_tol_bench.json"), ("c4q_n8_same_device_auto.json", "%s_c4q_n8_same_device_auto.json")):
+for f_, t_ in (("c4_tol.json", "%s_c4_n1_tol_bench.json"), ("c3z_norefine.json", "%s_c3z_n1_bench_refine_rows_0.json"), ("c4q_n8_same_device_auto.json", "%s_c4q_n8_same_device_auto.json")):
     shutil.copy(os.path.join(SRC, f_), os.path.join(DST, t_ % TAG))
 for mode in ("allreduce", "rsag"):
     shutil.copy(os.path.join(SRC, "c4_n8_same_device_%s.json" % mode), os.path.join(DST, "%s_c4_n8_same_device_%s.json" % (TAG, mode)))

@@ -13,7 +13,11 @@ MODE=${1:-all}
 python3 bench.py --steps 20 --warmup 5 > $O/c4.json 2> $O/c4.err
 python3 bench.py --workload c2 --steps 200 --warmup 20 > $O/c2.json 2> $O/c2.err
 python3 bench.py --workload c3 --steps 5 --warmup 2 > $O/c3.json 2> $O/c3.err
-python3 bench.py --workload c3z --steps 5 --warmup 2 > $O/c3z.json 2> $O/c3z.err
+# c3z (the reference's default l2 = 0): the regime changes after ~7 iterations -- from then on the clamp of `_safe_invert` acts on every row
+# of U and every one of them is redone in float64 -- so the line is taken BEHIND the transition; beside it the same run with the
+# float64 refinement switched off (float32 spectral clamp only)
+python3 bench.py --workload c3z --steps 3 --warmup 9 > $O/c3z.json 2> $O/c3z.err
+python3 bench.py --workload c3z --steps 3 --warmup 9 --no-cpu-baseline --option refine_rows=0 > $O/c3z_norefine.json 2> $O/c3z_norefine.err
 python3 bench.py --workload c3x --steps 3 --warmup 1 > $O/c3x.json 2> $O/c3x.err
 # the reference's default stopping test (tol = 1e-4: the error metric every 10th iteration) INSIDE the timed region
 python3 bench.py --steps 20 --warmup 5 --tol 1e-4 --no-cpu-baseline > $O/c4_tol.json 2> $O/c4_tol.err
