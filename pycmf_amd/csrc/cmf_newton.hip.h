@@ -1438,7 +1438,11 @@ static int refine_rows64_batched(cmf_ctx *c, int which, const RowSide &s1, const
             nq = std::min(std::max(nq, 4), 48);
             const dim3 gg((unsigned)(kp / 32), (unsigned)(kp / 32), (unsigned)ncl);
             auto mm = [&](const double *A, const double *B, double *Cc, const double *D, double al, double be, double ga) {
-                hipLaunchKernelGGL((gemm64_kernel<false>), gg, dim3(256), 0, c->stream, A, B, Cc, D, al, be, ga, kp, (float *)nullptr, 0, (const int *)nullptr, 0, kk);
+                if (c->opt_gemm64_tile128 && kp % 128 == 0 &&
+                    allow_big_lds(c, reinterpret_cast<const void *>(&gemm64_tile128_kernel), GEMM64_TILE128_LDS) == CMF_OK)
+                    hipLaunchKernelGGL(gemm64_tile128_kernel, dim3((unsigned)(kp / 128), (unsigned)(kp / 128), (unsigned)ncl), dim3(512), GEMM64_TILE128_LDS, c->stream, A, B, Cc, D, al, be, ga, kp, (int64_t)kk);
+                else
+                    hipLaunchKernelGGL((gemm64_kernel<false>), gg, dim3(256), 0, c->stream, A, B, Cc, D, al, be, ga, kp, (float *)nullptr, 0, (const int *)nullptr, 0, kk);
             };
             for (int it = 0; it < nq; ++it) {
                 mm(X, X, Y, nullptr, 1.0, 0.0, 0.0);

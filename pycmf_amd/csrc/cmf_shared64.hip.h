@@ -638,6 +638,85 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const double *A, const doub
     }
 }
 
+// ------------------------------------------------------------------------------------------ batched 256-wide float64 product
+// C_b = alpha A_b B_b + beta D_b + gamma I for stacked kp x kp float64 matrices (kp a multiple of 128), bstride doubles apart:
+// the Newton-Schulz polynomials of the batched float64 refinement (cmf_newton.hip.h, refine_rows64_batched: ~74 such products
+// per clamped row).  gemm64_kernel gives a workgroup a 32 x 32 tile -- 4 flop per byte it stages, 8 MB of L2 -> LDS traffic per
+// 256^3 product: the refinement of C3's 32768 rows of U at l2 = 0 moved 19 TB per iteration through it (26 TF/s).  Here a
+// workgroup of eight waves owns a 128 x 128 tile (wave tile 32 x 64 = 2 x 4 blocks of v_mfma_f64_16x16x4_f64, six fragment reads
+// per eight MFMAs, 16 flop per staged byte), 32-deep K-steps, the next step's operands waiting in registers under the MFMAs.
+// LDS: A tile [128][34] doubles (k contiguous), B tile [32][144] doubles (n contiguous): 71 KB, two workgroups per CU.
+constexpr int GEMM64_TILE128_LDS = (128 * 34 + 32 * 144) * (int)sizeof(double);
+__global__ __launch_bounds__(512, 4) void gemm64_tile128_kernel(const double *A, const double *B, double *C, const double *D, double alpha,
+                                                                double beta, double gamma, int kp, int64_t bstride) {
+    constexpr int LA = 34, LB = 144;
+    extern __shared__ __attribute__((aligned(16))) double g64sm[];   // GEMM64_TILE128_LDS bytes (dynamic: above the 64 KB static limit)
+    double *As = g64sm, *Bs = g64sm + 128 * LA;
+    {
+        const int64_t off = (int64_t)blockIdx.z * bstride;
+        A += off; B += off; C += off;
+        if (D) D += off;
+    }
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wi = w >> 1, wj = w & 1;               // wave rows wi * 32 .., columns wj * 64 ..
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    f64x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+    // staging: A tile 128 rows x 16 double2, B tile 32 rows x 64 double2: four of each per thread
+    f64x2 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = t + 512 * q;
+            ra[q] = *reinterpret_cast<const f64x2 *>(A + (int64_t)(m0 + (idx >> 4)) * kp + k0 + 2 * (idx & 15));
+            rb[q] = *reinterpret_cast<const f64x2 *>(B + (int64_t)(k0 + (idx >> 6)) * kp + n0 + 2 * (idx & 63));
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = t + 512 * q;
+            *reinterpret_cast<f64x2 *>(As + (idx >> 4) * LA + 2 * (idx & 15)) = ra[q];
+            *reinterpret_cast<f64x2 *>(Bs + (idx >> 6) * LB + 2 * (idx & 63)) = rb[q];
+        }
+    };
+    gload(0);
+    for (int k0 = 0; k0 < kp; k0 += 32) {
+        __syncthreads();            // the previous step's fragment reads are done
+        lstore();
+        __syncthreads();
+        if (k0 + 32 < kp) gload(k0 + 32);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            double a[2], b[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[(wi * 32 + 16 * i + l15) * LA + 4 * s + lk];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[(4 * s + lk) * LB + wj * 64 + 16 * j + l15];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = m0 + wi * 32 + 16 * i + lk + 4 * reg, c = n0 + wj * 64 + 16 * j + l15;
+                double v = alpha * acc[i][j][reg];
+                if (D) v += beta * D[(int64_t)r * kp + c];
+                if (r == c) v += gamma;
+                C[(int64_t)r * kp + c] = v;
+            }
+}
+
 // ------------------------------------------------------------------------------------------ factor times float64 matrix
 // O32[rows x kp] = scale * A32[rows x kp] * B64[kp x kp], float64 products and sums on v_mfma_f64_16x16x4_f64, rounded ONCE to
 // float32.  This is the "pre-conditioned operand" of the re-associated Newton sweep (cmf_newton.hip.h): with the safe inverse
