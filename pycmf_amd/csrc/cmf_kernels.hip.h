@@ -1257,6 +1257,20 @@ __global__ __launch_bounds__(64) void clamp_stats_kernel(const float *H, const i
 }
 
 
+// The matrices listed for the float64 refinement (list[0 .. nb)) leave the float32 clamp path: their flag is cleared -- the spectral
+// clamp by Newton-Schulz products (49 float32 256^3 products per matrix) would be thrown away when refine_rows64 overwrites the step --
+// and their step row is zeroed, so that a row the refinement could not finish (a failed factorisation: not reached for positive
+// semi-definite Hessians) stays where it was instead of moving by a half-finished solve.
+__global__ __launch_bounds__(64) void unflag_listed_kernel(int *flags, const int *list, int nb, float *step, int kp) {
+    const int q = blockIdx.x;
+    if (q >= nb) return;
+    const int b = list[q];
+    if (!flags[b]) return; // a plain solve listed by its condition estimate: its float32 step stands until the refinement replaces it
+    for (int c = threadIdx.x; c < kp; c += 64) step[(int64_t)b * kp + c] = 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) flags[b] = 0;
+}
+
 // B = H - pert I for flagged matrix b (valid n x n block; padding: c on the diagonal, 0 elsewhere),
 // c = min(||B||_F, ||B||_inf) >= rho(B), X0 = B / c.  One workgroup per matrix; thread t owns column t
 // (H is symmetric, so column sums are row sums and the reads are coalesced).  cmax collects max c (float bits).

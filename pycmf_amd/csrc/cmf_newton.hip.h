@@ -55,8 +55,8 @@ static int jacobi_chipwide(cmf_ctx *c, const float *Hin, float *Hout, int *flags
 // note the matrices the float32 spectral clamp is about to act on (see clamp_stats_kernel).  refine: those with ||H||_F / pert above
 // the refinement ratio are not recorded but collected (chunk-relative, ascending) in c->bad_host for refine_rows64 -- one 4-byte
 // read-back per call; a list that would take the sweep over opt_refine_max is declined and recorded instead.
-static int clamp_stats(cmf_ctx *c, const float *Hc, const int *flags, int64_t nmat, int n, int kp, int64_t stride, double pert,
-                       bool refine = false, const float *condest = nullptr) {
+static int clamp_stats(cmf_ctx *c, const float *Hc, int *flags, int64_t nmat, int n, int kp, int64_t stride, double pert,
+                       bool refine = false, const float *condest = nullptr, float *step = nullptr) {
     c->bad_host.clear();
     if (nmat <= 0) return CMF_OK;
     if (!c->clampstat.p) {
@@ -91,6 +91,11 @@ static int clamp_stats(cmf_ctx *c, const float *Hc, const int *flags, int64_t nm
     }
     c->bad_host.resize((size_t)nb);
     HIPCHK(hipMemcpyAsync(c->bad_host.data(), bad + 1, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    // the listed matrices skip the float32 spectral clamp (refine_rows64 redoes them from scratch; at C3 with l2 = 0 that clamp was
+    // 0.75 s per iteration of work thrown away): only where the batched refinement will take them
+    if (step && c->opt_refine_batched && c->k > 64 && c->k <= 256 && c->hess_psd)
+        hipLaunchKernelGGL(unflag_listed_kernel, dim3((unsigned)nb), dim3(64), 0, c->stream, flags, (const int *)(bad + 1), nb, step, kp);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     std::sort(c->bad_host.begin(), c->bad_host.end());
     c->refined_sweep += nb;
@@ -189,7 +194,7 @@ static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat,
         need = (const int *)c->eigflag.p;
         Hin = src;
     }
-    CHK(clamp_stats(c, Hin, need, nmat, n, kp, stride, pert, refine));
+    CHK(clamp_stats(c, Hin, const_cast<int *>(need), nmat, n, kp, stride, pert, refine));
     const size_t lds_need = (size_t)(2 * n * n + n) * sizeof(float);
     if (lds_need <= 150 * 1024) {
         CHK(allow_big_lds(c, reinterpret_cast<const void *>(&jacobi_safe_inverse_kernel<true>), 150 * 1024));
@@ -342,7 +347,7 @@ static int safe_solve_rows(cmf_ctx *c, float *Hc, const float *grad, float *step
         else hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag,
                                 (const int *)nullptr, 1, cert.flags, cert.rows, cert.split, condest);
         HIPCHK(hipGetLastError());
-        CHK(clamp_stats(c, Hc, flags, nr, n, kp, stride, pert, refine, condest));
+        CHK(clamp_stats(c, Hc, flags, nr, n, kp, stride, pert, refine, condest, step));
         // flagged matrices, k_pad = 128 / 256, Hessians positive semi-definite by construction (weights >= 0):
         // spectral clamp by Newton-Schulz (MFMA) + a second Cholesky solve; clears the flags it serves
         if ((kp == 256 || kp == 128) && c->opt_ns && c->hess_psd) CHK(ns_clamp_solve_rows(c, Hc, grad, step, flags, nr, n, kp, pert));
@@ -1450,7 +1455,7 @@ static int refine_rows64_batched(cmf_ctx *c, int which, const RowSide &s1, const
                 mm(X, Z, X2, nullptr, 1.0, 0.0, 0.0);
                 std::swap(X, X2);
             }
-            for (int it = 0; it < 8; ++it) {
+            for (int it = 0; it < 6; ++it) { // from |x| in [0.7, 1.2]: 0.3 -> 0.14 -> 2.7e-2 -> 1.1e-3 -> 1.8e-6 -> 5e-12 -> below the float64 unit roundoff
                 mm(X, X, Y, nullptr, 1.0, 0.0, 0.0);
                 mm(X, Y, X2, X, -0.5, 1.5, 0.0);
                 std::swap(X, X2);
