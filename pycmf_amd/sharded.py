@@ -450,12 +450,16 @@ def make_sharded_mu(ctx, coll, chunks=1, mode=None):
     if mode not in ("auto", "rsag", "allreduce"):
         raise ValueError("MU collective mode must be 'auto', 'rsag' or 'allreduce', got %r" % (mode,))
     trial = None
-    if mode in ("auto", "rsag") and hasattr(coll, "self_test") and not coll.self_test():
-        import warnings
-        warnings.warn("pycmf_amd: the known-answer test of the in-place reduce-scatter / all-gather failed on this communicator; "
-                      "falling back to the single all-reduce of the MU iteration", RuntimeWarning)
-        trial = {"chosen": "allreduce", "reason": "known-answer test of the grouped reduce-scatter / all-gather failed"}
-        mode = "allreduce"
+    if mode in ("auto", "rsag") and hasattr(coll, "self_test"):
+        try:
+            ok, why = bool(coll.self_test()), "known-answer test of the grouped reduce-scatter / all-gather failed"
+        except Exception as e:      # an RCCL error inside the grouped forms: every rank sees it at the same call
+            ok, why = False, "known-answer test of the grouped reduce-scatter / all-gather raised %r" % (e,)
+        if not ok:
+            import warnings
+            warnings.warn("pycmf_amd: %s on this communicator; falling back to the single all-reduce of the MU iteration" % why, RuntimeWarning)
+            trial = {"chosen": "allreduce", "reason": why}
+            mode = "allreduce"
     if mode == "auto":
         cands = {"allreduce": _build_mu_driver(ctx, backend, coll, "allreduce"), "rsag": _build_mu_driver(ctx, backend, coll, "rsag")}
         ms = time_mu_protocols(ctx, coll, cands)
