@@ -110,6 +110,29 @@ class HipShardBackend:
         kp = self.ctx.geometry()[3]
         return _lib.DeviceArray(self.ctx, rows, kp, _ptr=self.ctx.factor_dev_ptr(_lib.CMF_V), _owner=None)
 
+    # the three factors saved / restored on the device (the protocol trial of make_sharded_mu runs real iterations)
+    def snapshot(self):
+        from . import _lib
+        m_pad, d_pad, p_pad, kp = self.ctx.geometry()
+        saved = []
+        for which, rows in ((_lib.CMF_U, m_pad), (_lib.CMF_V, d_pad), (_lib.CMF_Z, p_pad)):
+            a = _lib.DeviceArray(self.ctx, max(rows, 1), kp)
+            self.ctx.export_factor_rows(which, a.data_ptr())
+            saved.append((which, a))
+        return saved
+
+    def restore(self, saved):
+        for which, a in saved:
+            self.ctx.import_factor_rows(which, a.data_ptr())
+        self.ctx.sync()
+
+    def drop_snapshot(self, saved):
+        for _, a in saved:
+            a.release()
+
+    def sync(self):
+        self.ctx.sync()
+
     def row_blocks(self, chunks):
         """256-aligned blocks of the d_pad rows of the partial, at most `chunks` of them."""
         _, dp, _, kp = self.ctx.geometry()
@@ -399,36 +422,32 @@ def _release_mu_driver(drv):
             b.release()
 
 
-def time_mu_protocols(ctx, coll, drivers, iterations=TRIAL_ITERATIONS):
-    """Milliseconds per iteration of each driver in `drivers` (name -> ShardedMU) on the LIVE ranks: the factors are saved on
-    the device, every candidate runs one untimed and `iterations` timed iterations from the same state (stream drained and ranks
-    met on both sides of the timed region, the slowest rank's clock), the factors are restored.  Every rank returns the same
-    numbers (they are max-reduced), so every rank takes the same decision."""
+def time_mu_protocols(backend, coll, drivers, iterations=TRIAL_ITERATIONS):
+    """Milliseconds per iteration of each driver in `drivers` (name -> ShardedMU) on the LIVE ranks: the factors are saved
+    (``backend.snapshot()``), every candidate runs one untimed and `iterations` timed iterations from the same state (stream drained
+    and ranks met on both sides of the timed region, the slowest rank's clock), the factors are restored.  Every rank returns the
+    same numbers (they are max-reduced), so every rank takes the same decision."""
     import time
-    from . import _lib
-    m_pad, d_pad, p_pad, kp = ctx.geometry()
-    saved = []
-    for which, rows in ((_lib.CMF_U, m_pad), (_lib.CMF_V, d_pad), (_lib.CMF_Z, p_pad)):
-        a = _lib.DeviceArray(ctx, max(rows, 1), kp)
-        ctx.export_factor_rows(which, a.data_ptr())
-        saved.append((which, a))
+    saved = backend.snapshot()
     out = {}
     for name, drv in drivers.items():
         drv.step(0.0, 0.0, 7)
-        ctx.sync()
+        backend.sync()
         coll.barrier()
         t0 = time.perf_counter()
         for _ in range(iterations):
             drv.step(0.0, 0.0, 7)
-        ctx.sync()
+        backend.sync()
         dt = time.perf_counter() - t0
         out[name] = float(coll.all_reduce_host([dt], "max")[0]) / iterations * 1e3
-        for which, a in saved:
-            ctx.import_factor_rows(which, a.data_ptr())
-        ctx.sync()
-    for _, a in saved:
-        a.release()
+        backend.restore(saved)
+    backend.drop_snapshot(saved)
     return out
+
+
+def choose_mu_protocol(ms, margin=TRIAL_MARGIN):
+    """The trial's decision rule: the row-blocked protocol only when it beats north_star's single all-reduce by more than `margin`."""
+    return "rsag" if ms["rsag"] < ms["allreduce"] * (1.0 - margin) else "allreduce"
 
 
 def make_sharded_mu(ctx, coll, chunks=1, mode=None):
@@ -462,8 +481,8 @@ def make_sharded_mu(ctx, coll, chunks=1, mode=None):
             mode = "allreduce"
     if mode == "auto":
         cands = {"allreduce": _build_mu_driver(ctx, backend, coll, "allreduce"), "rsag": _build_mu_driver(ctx, backend, coll, "rsag")}
-        ms = time_mu_protocols(ctx, coll, cands)
-        mode = "rsag" if ms["rsag"] < ms["allreduce"] * (1.0 - TRIAL_MARGIN) else "allreduce"
+        ms = time_mu_protocols(backend, coll, cands)
+        mode = choose_mu_protocol(ms)
         trial = {"chosen": mode, "ms_per_iteration": ms, "timed_iterations": TRIAL_ITERATIONS, "margin": TRIAL_MARGIN,
                  "rule": "rsag only if faster than allreduce by more than the margin (tie-break: north_star's single all-reduce)"}
         drv = cands.pop(mode)

@@ -317,10 +317,47 @@ class OracleBlocked:
             self.U *= O.mu_ratio(self.X @ self.V, self.U @ G2, l1, l2, self.U)
         if mask & 4:
             self.Z *= O.mu_ratio(self.Y.T @ self.V, self.Z @ G2, l1, l2, self.Z)
+    # the single all-reduce protocol on the same shard (buffer = [P (d x k) | G (k x k)], like cmf_mu_v_partials / _v_apply / _uz_update)
+    def buf_elems(self):
+        return (self.d + self.k) * self.k
+    def partials(self, buf):
+        b = buf.numpy().reshape(self.d + self.k, self.k)
+        b[: self.d] = self.X.T @ self.U + self.Y @ self.Z
+        b[self.d:] = self.U.T @ self.U + self.Z.T @ self.Z
+    def apply_v(self, buf, l1, l2):
+        b = buf.numpy().reshape(self.d + self.k, self.k)
+        self.V *= O.mu_ratio(b[: self.d], self.V @ b[self.d:], l1, l2, self.V)
+    def update_uz(self, l1, l2, mask):
+        G2 = self.V.T @ self.V
+        if mask & 1:
+            self.U *= O.mu_ratio(self.X @ self.V, self.U @ G2, l1, l2, self.U)
+        if mask & 4:
+            self.Z *= O.mu_ratio(self.Y.T @ self.V, self.Z @ G2, l1, l2, self.Z)
+    # what the protocol trial needs of a backend
+    def snapshot(self):
+        return (self.U.copy(), self.Vfull.clone(), self.Z.copy())
+    def restore(self, saved):
+        self.U[...] = saved[0]; self.Vfull.copy_(saved[1]); self.Z[...] = saved[2]
+    def drop_snapshot(self, saved):
+        pass
+    def sync(self):
+        pass
 
 class GlooColl:
     def __init__(self, rank, world):
         self.rank, self.world, self.log = rank, world, []
+        self.groups = 0
+    def group(self):
+        import contextlib
+        self.groups += 1
+        self.log.append(("group",))
+        return contextlib.nullcontext()
+    def barrier(self):
+        dist.barrier()
+    def all_reduce_host(self, values, op="sum"):
+        t = torch.tensor(list(values), dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX)
+        return t.numpy()
     def all_reduce(self, t):
         self.log.append(("ar", t.numel()))
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -352,7 +389,8 @@ drv = ShardedMU(be, buf, world, coll.all_reduce, coll=coll, mode="rsag", rank=ra
 for _ in range(3):
     drv.step(0.1, 0.2, 7)
 n = world * be.B * k
-assert coll.log == [("ar", k * k), ("rs", n), ("ar", k * k), ("ag", n)] * 3, coll.log
+# two groups per iteration: {k^2 all-reduce, reduce-scatter}, {k^2 all-reduce, all-gather}
+assert coll.log == [("group",), ("ar", k * k), ("rs", n), ("group",), ("ar", k * k), ("ag", n)] * 3, coll.log
 Ur, Vr, Zr = U.copy(), V.copy(), Z.copy()
 for _ in range(3):
     O.mu_update_step(X, Y, Ur, Vr, Zr, 0.1, 0.2)
@@ -365,6 +403,28 @@ drv.step(0.1, 0.2, 5)
 O.mu_update_step(X, Y, Ur, Vr, Zr, 0.1, 0.2, update_V=False)
 np.testing.assert_allclose(be.U, Ur[r0:r1], rtol=1e-10)
 np.testing.assert_allclose(be.V, Vr, rtol=1e-10)
+# the protocol trial (make_sharded_mu(mode='auto') runs exactly this): both drivers timed on the live ranks from the same saved
+# state, every rank reads the SAME max-reduced timings and so takes the same decision, and the factors come back untouched
+from pycmf_amd.sharded import time_mu_protocols, choose_mu_protocol
+before = (be.U.copy(), be.V.copy(), be.Z.copy())
+ar = ShardedMU(be, torch.zeros(be.buf_elems(), dtype=torch.float64), world, coll.all_reduce, coll=coll)
+ms = time_mu_protocols(be, coll, {"allreduce": ar, "rsag": drv}, iterations=2)
+assert set(ms) == {"allreduce", "rsag"} and all(v > 0 for v in ms.values())
+agree = torch.tensor([ms["allreduce"], ms["rsag"]], dtype=torch.float64)
+lo, hi = agree.clone(), agree.clone()
+dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+assert torch.equal(lo, hi)                                     # identical numbers on every rank
+assert choose_mu_protocol(ms) in ("allreduce", "rsag")
+assert choose_mu_protocol({"allreduce": 1.0, "rsag": 0.99}) == "allreduce" and choose_mu_protocol({"allreduce": 1.0, "rsag": 0.97}) == "rsag"
+for a, b in zip(before, (be.U, be.V, be.Z)):
+    np.testing.assert_array_equal(a, b)
+# and the two protocols are the same iteration: one more step through each from the same state
+ar.step(0.1, 0.2, 7)
+V_ar, U_ar = be.V.copy(), be.U.copy()
+be.restore((before[0], torch.cat([torch.from_numpy(before[1]), torch.zeros(world * be.B - d, k, dtype=torch.float64)]), before[2]))
+drv.step(0.1, 0.2, 7)
+np.testing.assert_allclose(be.V, V_ar, rtol=1e-12)
+np.testing.assert_allclose(be.U, U_ar, rtol=1e-12)
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
