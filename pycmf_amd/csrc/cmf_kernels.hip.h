@@ -697,7 +697,6 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
             // made this epilogue longer than the 8 K-steps in front of it -- then the arithmetic
             // (TILE 2 -- two workgroups per CU, 128 registers per lane: one block row of the wave tile at a time, 32 loads in flight)
             constexpr int IB = (TILE == 2 || BN == 256) ? 1 : C::TM;   // block rows per batch (256-wide tile: 64 of its 128 targets per lane at a time)
-            const float lkf = g.link ? 1.0f : 0.0f, nlk = 1.0f - lkf;
             const float slope = g.w_is_slope ? 1.0f : 0.0f, nslope = 1.0f - slope;
 #pragma unroll
             for (int i0 = 0; i0 < C::TM; i0 += IB) {
@@ -722,10 +721,19 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int rr = 32 * (i0 + i) + (r & 3) + 8 * (r >> 2);
+                        // the link is uniform over the launch: a scalar branch around the sigmoids of this register row (the blend
+                        // lkf * sigmoid(s) + nlk * s paid v_exp + v_rcp, quarter-rate instructions, for every element of a LINEAR side)
+                        float fv[C::TN];
+#pragma unroll
+                        for (int j = 0; j < C::TN; ++j) fv[j] = acc[i0 + i][j][r];
+                        if (__builtin_amdgcn_readfirstlane(g.link)) {
+#pragma unroll
+                            for (int j = 0; j < C::TN; ++j) fv[j] = sigmoidf_(fv[j]);
+                            asm volatile("" ::: "memory"); // keep the branch: do not speculate the transcendentals into a select
+                        }
 #pragma unroll
                         for (int j = 0; j < C::TN; ++j) {
-                            const float s = acc[i0 + i][j][r];
-                            const float f = lkf * sigmoidf_(s) + nlk * s; // exact: one of the two terms is zero
+                            const float f = fv[j];
                             const float mk = (rr < rlim && 32 * j < clim) ? 1.0f : 0.0f;
                             const float res = f - tv[i][r][j];
                             sq += mk * res * res;
