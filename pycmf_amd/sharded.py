@@ -564,7 +564,11 @@ def fit_mu_sharded(X_rows, Y_cols, U_rows, V, Z_rows, l1_reg=0.0, l2_reg=0.0, ma
     for which, F in ((_lib.CMF_U, U_rows), (_lib.CMF_V, V), (_lib.CMF_Z, Z_rows)):
         ctx.set_factor(which, F)
     coll, rank, world = _collectives_for(ctx, rank, world)
-    drv = make_sharded_mu(ctx, coll)
+    # a fit of a few iterations is over before a protocol trial (2 x (1 + TRIAL_ITERATIONS) iterations) could pay for itself:
+    # north_star's single all-reduce then, unless the environment pins a protocol
+    import os
+    short = max_iter < 8 * (1 + TRIAL_ITERATIONS) and "PYCMF_AMD_MU_COLLECTIVE" not in os.environ
+    drv = make_sharded_mu(ctx, coll, mode="allreduce" if short else None)
 
     def global_sq():
         sq = np.array(ctx.residual_sq("linear", "linear"))
