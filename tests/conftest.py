@@ -16,6 +16,7 @@ FILE_ORDER = [
     "test_gpu_mu.py",              # golden MU steps (g2, g6), ragged / signed / CSR cases
     "test_gpu_newton.py",          # golden Newton steps (g3, g7), per-row kernels, solves
     "test_gpu_integration_doc.py", # INTEGRATION.md's stub against g2
+    "test_gpu_c_consumer.py",      # a plain-C host of the C ABI against g2
     "test_gpu_estimator.py",       # g1, g4, g5: the reference's fit-level contracts
     "test_gpu_fullsize.py",        # BASELINE configs at full size
     "test_gpu_midrange.py",

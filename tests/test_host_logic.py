@@ -712,3 +712,38 @@ def test_host_staged_collectives_world2(tmp_path):
         assert "rank %d ok" % r in o
     left = [f for f in os.listdir(str(tmp_path)) if f.startswith("cmf_host_hs_") and "done" not in f]
     assert left == [], left
+
+
+def test_c_consumer_compiles_links_and_fails_loudly_without_a_gpu(tmp_path):
+    """tests/c/abi_consumer.c -- a plain C99 host of the C ABI -- compiles with -Wall -Wextra -Werror against include/cmfhip.h (the
+    header is valid C, not only C++), links against libcmfhip.so (every entry point it uses is exported with C linkage), and on a box
+    without a GPU exits with an error instead of computing anything on the CPU (the GPU run against the golden fixture is
+    tests/test_gpu_c_consumer.py)."""
+    import shutil
+    import numpy as np
+    if shutil.which("gcc") is None:
+        _pytest.skip("no gcc here")
+    from pycmf_amd import build as b
+    assert os.path.exists(b.LIB)
+    exe = str(tmp_path / "abi_consumer")
+    q = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "c", "abi_consumer.c"), "-L", os.path.dirname(b.LIB), "-lcmfhip",
+                        "-Wl,-rpath," + os.path.dirname(b.LIB), "-o", exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert q.returncode == 0, q.stdout.decode()
+    prob = tmp_path / "prob.bin"
+    rng = np.random.RandomState(0)
+    with open(prob, "wb") as f:
+        f.write(np.array([5, 4, 3, 2, 1], dtype=np.int64).tobytes())
+        f.write(np.zeros(2).tobytes())
+        for shape in ((5, 4), (4, 3), (5, 2), (4, 2), (3, 2)):
+            f.write(np.abs(rng.randn(*shape)).tobytes())
+    from pycmf_amd import _lib
+    try:
+        have_gpu = _lib.device_count() > 0
+    except Exception:
+        have_gpu = False
+    q = subprocess.run([exe, str(prob), str(tmp_path / "res.bin")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if have_gpu:
+        assert q.returncode == 0, q.stdout.decode()
+    else:
+        assert q.returncode in (3, 4) and not os.path.exists(str(tmp_path / "res.bin")), q.stdout.decode()
