@@ -237,3 +237,49 @@ def test_graph_replay_matches_eager(lib, solver):
         ctx.close()
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("solver", ["mu", "newton"])
+def test_in_place_updates_on_column_tiles_are_deterministic(lib, solver):
+    """a fused factor update with few row tiles runs on 256 x 64 column tiles (option narrow_update, default on).  Where
+    the update is IN PLACE -- the MU epilogue F <- F * P / reg(F G) (pycmf/cmf_solvers.py:212-228) and the re-associated Newton sweep
+    F <- clamp(F E + ...) -- the column workgroups of a row tile all stream the whole rows of F, so they must not see each other's
+    output: the launch writes a scratch image that is copied over F afterwards.  2048 / 1536 / 1024 rows at k = 200 (k_pad = 256: 8 / 6 /
+    4 row tiles, four column tiles each): twenty repetitions, each compared BIT FOR BIT with the one-column-tile form, on a busy device
+    (a second context hammers another stream)."""
+    rng = np.random.RandomState(11)
+    m, d, p, k = 2048, 1536, 1024, 200
+    X, Y = np.abs(rng.randn(m, d)), np.abs(rng.randn(d, p))
+    s = np.sqrt(X.mean() / k)
+    U0, V0, Z0 = s * np.abs(rng.randn(m, k)), s * np.abs(rng.randn(d, k)), s * np.abs(rng.randn(p, k))
+    noise = lib.Context(0)                    # keeps the CUs busy from another stream while the updates run
+    noise.set_problem(4096, 4096, 4096, 200)
+    noise.fill_data_synthetic(0, 1, 0, 0); noise.fill_data_synthetic(1, 2, 0, 0)
+    for w, seed in ((0, 3), (1, 4), (2, 5)):
+        noise.fill_factor_synthetic(w, seed, 0, 0.05)
+
+    def run(narrow):
+        ctx = lib.Context(0)
+        ctx.set_problem(m, d, p, k)
+        ctx.set_option("narrow_update", narrow)
+        ctx.set_data(0, X); ctx.set_data(1, Y)
+        for w, F in enumerate((U0, V0, Z0)):
+            ctx.set_factor(w, F)
+        for _ in range(3):
+            noise.mu_step(0.0, 0.0, 7)        # asynchronous: runs beside what follows
+            if solver == "mu":
+                ctx.mu_step(0.01, 0.02, 7)
+            else:                             # linear links, clamp active (non-negative factors, small l2): F E + T (O Hinv) in place
+                ctx.newton_step(0.5, 0.0, 0.001, "linear", "linear", 7, 7, 0.2, 1.0)
+        out = [ctx.get_factor(w) for w in range(3)]
+        ctx.close()
+        return out
+
+    ref = run(0)
+    assert all(np.isfinite(F).all() for F in ref)
+    for rep in range(20):
+        got = run(1)
+        for name, a, b in zip("UVZ", got, ref):
+            assert np.array_equal(a, b), "repetition %d: %s differs from the one-column-tile form in %d entries" % (rep, name, int((a != b).sum()))
+    noise.sync()
+    noise.close()
