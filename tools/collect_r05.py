@@ -26,6 +26,8 @@ for w in ("c4", "c2", "c3", "c5", "c5l"):
 for w in ("c3z", "c3x"):
     shutil.copy(os.path.join(SRC, "%s.json" % w), os.path.join(DST, "%s_%s_n1_bench.json" % (TAG, w)))
 if LINES_ONLY:
+    shutil.copy(os.path.join(SRC, "c4_tol.json"), os.path.join(DST, "%s_c4_n1_tol_bench.json" % TAG))
+    shutil.copy(os.path.join(SRC, "c3z_norefine.json"), os.path.join(DST, "%s_c3z_n1_bench_refine_rows_0.json" % TAG))
     for w in ("c3z", "c3x"):
         shutil.copy(os.path.join(SRC, "%s.json" % w), os.path.join(DST, "%s_%s_n1_bench.json" % (TAG, w)))
     sys.exit(0)
