@@ -490,13 +490,6 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
         }
     };
 
-    // NT passes without a byte mask on the 32-deep tile (one workgroup per CU, registers to spare): the targets of the wave tile -- 64
-    // floats per lane, read once from HBM -- are requested in front of the LAST K-step and arrive under its MFMAs instead of costing
-    // every tile one HBM latency at the top of the epilogue.  (Requested at the FIRST K-step they stay live across the whole loop and
-    // the allocator spills: 64 ms against 40.7, profiles/HISTORY.md section 10.)
-    constexpr bool TPRE = (MODE == MODE_NT && TILE == 0 && BN == 128 && PIPE != 0);
-    float tpre[TPRE ? C::TM : 1][TPRE ? 16 : 1][TPRE ? C::TN : 1];
-    const bool want_tpre = TPRE && g.T != nullptr && g.mask == nullptr && nkt > 1;
     if constexpr (GLDS) {
         static_assert(MODE != MODE_NT, "direct-to-LDS staging is wired for the NN / TN forms");
         if (nkt > 0) {
@@ -518,8 +511,7 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
         // (asking for tiles 0 and 1 together through a second set of staging registers: no change at C2's 16-64 K-steps per
         //  workgroup, 0.172 ms either way in the interleaved A/B)
         __syncthreads();
-        const int nloop = want_tpre ? nkt - 1 : nkt;
-        for (int kt = 0; kt < nloop; ++kt) {
+        for (int kt = 0; kt < nkt; ++kt) {
             float *cur = smem + (kt & 1) * C::STAGE;
             float *nxt = smem + ((kt + 1) & 1) * C::STAGE;
             if constexpr (PIPE == 0) {
@@ -531,23 +523,6 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
                         kbeg + (int64_t)(kt + 2) * C::BK);
             }
             __syncthreads();
-        }
-        if constexpr (TPRE) {
-            if (want_tpre) { // the peeled last K-step: nothing left to stage, the targets travel under its 64 MFMAs
-                const float *Tq = g.T + (row0 + wrow0 + 4 * lh) * g.ldt + n0 + wcol0 + l31;
-                const int ldt_ = (int)g.ldt;
-#pragma unroll
-                for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-#pragma unroll
-                        for (int j = 0; j < C::TN; ++j)
-                            tpre[i][r][j] = __builtin_nontemporal_load(Tq + (32 * i + (r & 3) + 8 * (r >> 2)) * ldt_ + 32 * j);
-                const int kt = nkt - 1;
-                float *cur = smem + (kt & 1) * C::STAGE;
-                compute(cur, cur + C::A_ELEMS, cur, cur + C::A_ELEMS, false, false, 0);
-                __syncthreads();
-            }
         }
     }
 
@@ -732,19 +707,7 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
                     for (int r = 0; r < 16; ++r)
 #pragma unroll
                         for (int j = 0; j < C::TN; ++j) tv[i][r][j] = 0.0f;
-                bool have_t = false;
-                if constexpr (TPRE) {
-                    if (want_tpre) {
-                        have_t = true;
-#pragma unroll
-                        for (int i = 0; i < IB; ++i)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r)
-#pragma unroll
-                                for (int j = 0; j < C::TN; ++j) tv[i][r][j] = tpre[i0 + i][r][j];
-                    }
-                }
-                if (Tp && !have_t) {
+                if (Tp) {
 #pragma unroll
                     for (int i = 0; i < IB; ++i)
 #pragma unroll
