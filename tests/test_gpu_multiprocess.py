@@ -501,3 +501,24 @@ def test_bench_under_torch_distributed_run():
     assert out["n_gpus"] == 2 and coll["ranks"] == 2 and coll["replicas"]["identical"]
     assert coll["protocol_trial"]["chosen"] == coll["protocol"]          # the default: both protocols timed on the two live ranks
     assert coll["launch_points_per_iteration"] == (2 if coll["protocol"] == "rsag" else 1)
+
+
+def test_bench_under_torch_distributed_run_with_real_rccl_one_rank():
+    """The same launch line with REAL RCCL (all a one-GPU box can offer it: one rank, CMF_BENCH_FORCE_DIST=1 takes the sharded driver
+    anyway): the unique id travels through the launcher-keyed file under torchrun's environment (its agent is the ranks' parent, it sets
+    MASTER_PORT and TORCHELASTIC_RESTART_COUNT), ncclCommInitRank runs inside libcmfhip, the protocol trial times both MU protocols
+    -- grouped collectives included -- on the live communicator."""
+    import json
+    port = _free_port()
+    env = dict(os.environ, CMF_BENCH_FORCE_DIST="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "CMF_COMM_KEY", "CMF_COMM_DIR", "CMF_COMM_BACKEND", "CMF_BENCH_SAME_DEVICE"):
+        env.pop(k, None)
+    q = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--workload", "tiny", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert q.returncode == 0, q.stderr.decode()[-3000:]
+    lines = [ln for ln in q.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    coll = json.loads(lines[0])["collective"]
+    assert coll["backend"] == "rccl" and coll["ranks_seen"] == 1 and coll["replicas"]["identical"]
+    assert set(coll["protocol_trial"]["ms_per_iteration"]) == {"allreduce", "rsag"}
