@@ -248,13 +248,21 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
 
     const float *Bbase = (ROLE == 2) ? g.B + (int64_t)blockIdx.x * g.b_batch : g.B;
     f32x4 ra[C::A_LD], rb[C::B_LD];
+    // Row of a k-contiguous tile that staging slot `q` (= thread index / chunks per row) carries.  16-deep tiles (TILE 2: 80-byte
+    // rows, four 16-byte chunks each): the sixteen lanes a ds_write_b128 serves together would write rows q .. q + 3, whose 64-byte
+    // pieces overlap mod 256 bytes (80 n mod 256 = 0, 80, 160, 240: 1.6e9 bank-conflict cycles at C4, PMC); rows q, q + 4, q + 8,
+    // q + 12 sit at 0, 64, 128, 192 mod 256.  So the slots of each group of 16 rows are dealt out transposed (4 x 4).
+    auto krow = [](int q) -> int {
+        if constexpr (TILE == 2) return (q & ~15) | ((q & 3) << 2) | ((q >> 2) & 3);
+        else return q;
+    };
 
     auto gload = [&](int64_t k0) {
 #pragma unroll
         for (int p = 0; p < C::A_LD; ++p) {
             const int idx = t + C::NT * p;
             if constexpr (C::A_KC) {
-                const int r = idx >> ilog2(F4K), c4 = idx & (F4K - 1);
+                const int r = krow(idx >> ilog2(F4K)), c4 = idx & (F4K - 1);
                 ra[p] = *reinterpret_cast<const f32x4 *>(g.A + (row0 + r) * g.lda + k0 + 4 * c4);
             } else {
                 // branch-free: a conditional load makes hipcc wait for the loads it has just
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
             const int idx = t + C::NT * p;
             if (C::B_F4 >= C::NT || idx < C::B_F4) {
                 if constexpr (C::B_KC) {
-                    const int r = idx >> ilog2(F4K), c4 = idx & (F4K - 1);
+                    const int r = krow(idx >> ilog2(F4K)), c4 = idx & (F4K - 1);
                     rb[p] = *reinterpret_cast<const f32x4 *>(Bbase + (n0 + r) * g.ldb + k0 + 4 * c4);
                 } else {
                     constexpr int F4R = BN / 4;
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
         if (p < C::A_LD) {
             const int idx = t + C::NT * p;
             if constexpr (C::A_KC) {
-                const int r = idx >> ilog2(F4K), c4 = idx & (F4K - 1);
+                const int r = krow(idx >> ilog2(F4K)), c4 = idx & (F4K - 1);
                 *reinterpret_cast<f32x4 *>(As + r * C::PADK + 4 * c4) = ra[p];
             } else {
                 const int r = idx >> ilog2(F4M), c4 = idx & (F4M - 1);
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
             const int idx = t + C::NT * pb;
             if (C::B_F4 >= C::NT || idx < C::B_F4) {
                 if constexpr (C::B_KC) {
-                    const int r = idx >> ilog2(F4K), c4 = idx & (F4K - 1);
+                    const int r = krow(idx >> ilog2(F4K)), c4 = idx & (F4K - 1);
                     *reinterpret_cast<f32x4 *>(Bs + r * C::PADK + 4 * c4) = rb[pb];
                 } else {
                     constexpr int F4R = BN / 4;
