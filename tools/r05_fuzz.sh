@@ -3,8 +3,8 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
-python3 tests/tools/fuzz_campaign.py --minutes ${1:-10} --seed 505 > gpurun_out/fuzz_r05.jsonl 2> gpurun_out/fuzz_r05.err
-python3 tests/tools/fuzz_campaign.py --minutes ${2:-4} --seed 55 --focus pair > gpurun_out/fuzz_r05_pair.jsonl 2> gpurun_out/fuzz_r05_pair.err
+python3 tests/tools/fuzz_campaign.py --minutes ${1:-10} --seed ${3:-505} > gpurun_out/fuzz_r05.jsonl 2> gpurun_out/fuzz_r05.err
+python3 tests/tools/fuzz_campaign.py --minutes ${2:-4} --seed ${4:-55} --focus pair > gpurun_out/fuzz_r05_pair.jsonl 2> gpurun_out/fuzz_r05_pair.err
 python3 - <<'PY'
 import json, collections
 out = {}
