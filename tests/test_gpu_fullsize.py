@@ -261,7 +261,7 @@ def test_c4_full_size_mu_sampled_rows_vs_fp64(lib):
     ctx.mu_step(0.0, 0.0, lib.CMF_UPD_V)
     V1 = ctx.get_factor(1)
     G = U0.T @ U0 + Z0.T @ Z0                                    # :245
-    for j in _spread(d, 6, rng):
+    for j in _spread(d, 30, rng):
         xcol = ctx.get_data_block(0, 0, m, j, 1)[:, 0].astype(np.float64)
         yrow = ctx.get_data_block(1, j, 1, 0, p)[0].astype(np.float64)
         num = xcol @ U0 + yrow @ Z0                              # :244
@@ -271,12 +271,12 @@ def test_c4_full_size_mu_sampled_rows_vs_fp64(lib):
     ctx.mu_step(0.0, 0.0, lib.CMF_UPD_U | lib.CMF_UPD_Z)
     U1, Z1 = ctx.get_factor(0), ctx.get_factor(2)
     G2 = V1.T @ V1
-    for i in _spread(m, 6, rng):
+    for i in _spread(m, 30, rng):
         xrow = ctx.get_data_block(0, i, 1, 0, d)[0].astype(np.float64)
         den = U0[i] @ G2                                         # (U V^T) V, :233
         den[den == 0] = eps
         np.testing.assert_allclose(U1[i], U0[i] * (xrow @ V1) / den, rtol=2e-4, atol=0, err_msg="U row %d" % i)
-    for c in _spread(p, 6, rng):
+    for c in _spread(p, 30, rng):
         ycol = ctx.get_data_block(1, 0, d, c, 1)[:, 0].astype(np.float64)
         den = Z0[c] @ G2                                         # :239
         den[den == 0] = eps
@@ -414,7 +414,7 @@ def test_c3_full_size_newton_sampled_rows_vs_fp64(lib, monkeypatch, x_link):
 
     ctx.newton_step_device_sampled(alpha, l1, l2, x_link, "logit", 0, lib.CMF_UPD_U, pert, ratio, seed)
     U1 = ctx.get_factor(0)
-    rows = _spread(m, 3, rng)
+    rows = _spread(m, 14, rng)
     lists = [ctx.sample_lists(0, seed, ratio, i, 1)[0] for i in rows]
     assert all(len(s) == int(d * ratio) and len(np.unique(s)) == len(s) for s in lists)
     Xs = np.vstack([ctx.get_data_block(0, i, 1, 0, d) for i in rows]).astype(np.float64)
@@ -426,7 +426,7 @@ def test_c3_full_size_newton_sampled_rows_vs_fp64(lib, monkeypatch, x_link):
 
     ctx.newton_step_device_sampled(alpha, l1, l2, x_link, "logit", 0, lib.CMF_UPD_Z, pert, ratio, seed)
     Z1 = ctx.get_factor(2)
-    cols = _spread(p, 3, rng)
+    cols = _spread(p, 14, rng)
     lists = [ctx.sample_lists(1, seed, ratio, c, 1)[0] for c in cols]
     Ys = np.hstack([ctx.get_data_block(1, 0, d, c, 1) for c in cols]).astype(np.float64)
     Zs = Z0[cols].copy()
@@ -436,7 +436,7 @@ def test_c3_full_size_newton_sampled_rows_vs_fp64(lib, monkeypatch, x_link):
 
     ctx.newton_step_device_sampled(alpha, l1, l2, x_link, "logit", 0, lib.CMF_UPD_V, pert, ratio, seed)
     V1 = ctx.get_factor(1)
-    rows = _spread(d, 3, rng)
+    rows = _spread(d, 10, rng)
     lists = []
     for q in rows:
         lists += [ctx.sample_lists(2, seed, ratio, q, 1)[0], ctx.sample_lists(3, seed, ratio, q, 1)[0]]
