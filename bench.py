@@ -674,7 +674,8 @@ def main():
                           cb["iters"], cb["seconds"], cb["its"], cb["threads"],
                           "reference-order flop" if full else "algorithmic-work", cb["ratio"])),
         }
-    print(json.dumps(out))
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -108,6 +108,10 @@ extern "C" int cmf_comm_init(cmf_ctx *c, int rank, int world, const char *id128)
         delete cm;
         return fail(CMF_ERCCL, "ncclCommInitRank(rank %d of %d, device %d): %s", rank, world, c->device, g_rccl.GetErrorString(r));
     }
+    // RCCL prints a version banner through C stdio on its first communicator; on a pipe that text would sit in the stdio buffer until
+    // the process exits and land BEHIND whatever the host program prints through its own buffers (bench.py's one JSON line): out now
+    (void)fflush(stdout);
+    (void)fflush(stderr);
     if (hipMalloc((void **)&cm->dscratch, 16 * sizeof(double)) != hipSuccess) {
         (void)g_rccl.CommDestroy(cm->comm);
         delete cm;

@@ -519,6 +519,10 @@ def test_bench_under_torch_distributed_run_with_real_rccl_one_rank():
     assert q.returncode == 0, q.stderr.decode()[-3000:]
     lines = [ln for ln in q.stdout.decode().splitlines() if ln.startswith("{")]
     assert len(lines) == 1
+    # the JSON line is the LAST thing on stdout: RCCL's version banner (C stdio, buffered on a pipe) is flushed when the communicator
+    # is created, not at exit behind the line a driver may read as "the last line"
+    nonempty = [ln for ln in q.stdout.decode().splitlines() if ln.strip()]
+    assert nonempty[-1] == lines[0], nonempty[-3:]
     coll = json.loads(lines[0])["collective"]
     assert coll["backend"] == "rccl" and coll["ranks_seen"] == 1 and coll["replicas"]["identical"]
     assert set(coll["protocol_trial"]["ms_per_iteration"]) == {"allreduce", "rsag"}
