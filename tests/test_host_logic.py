@@ -747,3 +747,71 @@ def test_c_consumer_compiles_links_and_fails_loudly_without_a_gpu(tmp_path):
         assert q.returncode == 0, q.stdout.decode()
     else:
         assert q.returncode in (3, 4) and not os.path.exists(str(tmp_path / "res.bin")), q.stdout.decode()
+
+
+def test_job_files_are_float32_and_written_from_any_layout(tmp_path):
+    """``CMF(n_gpus=N)`` from a process that already holds a GPU runtime hands X and Y to its ranks ONCE, as float32 files written in
+    row slabs straight from the caller's array (C order, Fortran order, a strided view): half the bytes of the float64 input, the
+    values the upload shim would have produced anyway."""
+    import numpy as np
+    from pycmf_amd import multi_gpu
+    rng = np.random.RandomState(0)
+    base = rng.rand(700, 300)
+    for tag, A in (("c", base), ("f", np.asfortranarray(base)), ("view", rng.rand(1400, 600)[::2, ::2])):
+        path = str(tmp_path / tag)
+        multi_gpu._save(path, A)
+        B = multi_gpu._load(path)
+        assert B.dtype == np.float32 and B.shape == A.shape and os.path.getsize(path + ".npy") < 0.51 * A.size * 8 + 256
+        np.testing.assert_array_equal(np.asarray(B), A.astype(np.float32))
+    import scipy.sparse as sp
+    S = sp.random(50, 40, density=0.1, format="csc", random_state=1)
+    multi_gpu._save(str(tmp_path / "s"), S)
+    np.testing.assert_array_equal(multi_gpu._load(str(tmp_path / "s")).toarray(), S.toarray())
+
+
+def test_ranks_are_forked_only_off_a_process_without_a_gpu_runtime(monkeypatch):
+    """The zero-copy hand-over (ranks forked off the caller) is taken only while this process has made no HIP call through pycmf_amd,
+    and never when the environment forbids it."""
+    from pycmf_amd import _lib, multi_gpu
+    monkeypatch.setattr(_lib, "_gpu_touched", False)
+    monkeypatch.delenv("PYCMF_AMD_FORK_RANKS", raising=False)
+    assert multi_gpu.can_fork_ranks()
+    monkeypatch.setenv("PYCMF_AMD_FORK_RANKS", "0")
+    assert not multi_gpu.can_fork_ranks()
+    monkeypatch.delenv("PYCMF_AMD_FORK_RANKS")
+    monkeypatch.setattr(_lib, "_gpu_touched", True)
+    assert not multi_gpu.can_fork_ranks()
+
+
+def test_compare_rows_tool(tmp_path):
+    """tools/compare_rows.py (the N = 8 dress rehearsal against N = 1): merges per-rank dumps by global row index, passes within the
+    tolerance, fails on a wrong row and on a missing one."""
+    import numpy as np
+    rng = np.random.RandomState(3)
+    rows = {"U": np.array([0, 5, 9, 12]), "V": np.array([1, 2, 3]), "Z": np.array([4, 7])}
+    vals = {k: rng.rand(len(v), 6) for k, v in rows.items()}
+
+    def dump(prefix, parts, tweak=None, drop=None):
+        for r, (lo, hi) in enumerate(parts):
+            out = {}
+            for name in "UVZ":
+                keep = (rows[name] >= lo) & (rows[name] < hi) if name != "V" else (np.ones(len(rows[name]), bool) if r == 0 else np.zeros(len(rows[name]), bool))
+                if drop == (name, r):
+                    keep = keep & (rows[name] != rows[name][keep][0]) if keep.any() else keep
+                v = vals[name][keep].copy()
+                if tweak and tweak[0] == name and keep.any():
+                    v[0, 0] += tweak[1]
+                out[name + "_rows"], out[name], out[name + "_absmax"] = rows[name][keep], v, np.array([1.0])
+            np.savez(prefix + ".rank%d.npz" % r, **out)
+
+    tool = os.path.join(ROOT, "tools", "compare_rows.py")
+    dump(str(tmp_path / "one"), [(0, 100)])
+    dump(str(tmp_path / "two"), [(0, 6), (6, 100)], tweak=("U", 5e-6))
+    q = subprocess.run([sys.executable, tool, str(tmp_path / "one"), str(tmp_path / "two"), "--tol", "1e-5"], stdout=subprocess.PIPE)
+    assert q.returncode == 0 and b'"ok": true' in q.stdout
+    dump(str(tmp_path / "bad"), [(0, 6), (6, 100)], tweak=("Z", 1e-3))
+    q = subprocess.run([sys.executable, tool, str(tmp_path / "one"), str(tmp_path / "bad"), "--tol", "1e-5"], stdout=subprocess.PIPE)
+    assert q.returncode == 1
+    dump(str(tmp_path / "miss"), [(0, 6), (6, 100)], drop=("U", 1))
+    q = subprocess.run([sys.executable, tool, str(tmp_path / "one"), str(tmp_path / "miss"), "--tol", "1e-5"], stdout=subprocess.PIPE)
+    assert q.returncode == 1
