@@ -121,6 +121,7 @@ struct cmf_ctx {
     int opt_ns = 1;        // flagged per-row Hessians at k_pad = 256: Newton-Schulz spectral clamp (0: Jacobi)
     bool hess_psd = true;  // the Hessians of the current step are positive semi-definite by construction (0 <= alpha <= 1)
     int opt_pipe_nt = 4;   // staging schedule of the NT (residual / error) GEMMs: 0 | 4
+    int opt_refine_map = 1;     // batched float64 clamp: spectral map (lambda - pert) / (lambda + pert) in front of the sign iteration (refine_rows64_batched)
     int opt_gemm64_tile128 = 1; // batched float64 256^3 products of the refinement on 128 x 128 tiles (gemm64_tile128_kernel); 0: 32 x 32 tiles
     int opt_nt_debug = 0;  // measurement only (tools/r05_nt_probe.py): bit 0 = the error pass without its targets
     int opt_nt_bn256 = 0;  // NT passes on 256 x 256 tiles where the column extent allows (A/B option: 39.9 ms at C4 against 39.7 for the 256 x 128 x 16 tile)
@@ -881,6 +882,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_chol_mfma = value != 0;
     } else if (!strcmp(name, "side_gram")) {
         c->opt_side_gram = value != 0;
+    } else if (!strcmp(name, "refine_spectral_map")) {
+        c->opt_refine_map = value != 0;
     } else if (!strcmp(name, "gemm64_tile128")) {
         c->opt_gemm64_tile128 = value != 0;
     } else if (!strcmp(name, "nt_debug")) {

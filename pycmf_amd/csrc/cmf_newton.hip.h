@@ -1442,9 +1442,37 @@ static int refine_rows64_batched(cmf_ctx *c, int which, const RowSide &s1, const
             // that eigen-direction at worst, two growth steps fewer than the single-matrix path's 1e-6 (every step is three 256^3
             // float64 products PER ROW here)
             const double delta = 1e-5 * pert;
-            int nq = (int)std::ceil(std::log(hmax / delta) / std::log(3.4445));
-            nq = std::min(std::max(nq, 4), 48);
             const dim3 gg((unsigned)(kp / 32), (unsigned)(kp / 32), (unsigned)ncl);
+            // Spectral map in front of the sign iteration (option refine_spectral_map).  H is positive semi-definite, so B = H - pert I
+            // has its spectrum in [-pert, ||H||]: ||H|| / pert is 1e3 ... 1e4 here, and the growth phase spends log_3.44 of that ratio
+            // in steps just to bring the eigenvalues near the threshold up from delta / ||H||.  f(lambda) = (lambda - pert) /
+            // (lambda + pert) is increasing with f(pert) = 0, so sign(f(H)) = sign(B), and it maps [0, inf) into [-1, 1): the start
+            // X0 = f(H) = I - 2 pert (H + pert I)^-1 needs no scaling and resolves |lambda - pert| >= delta as |x| >= delta / (2 pert).
+            // Cost: one batched register Cholesky of H + pert I, its triangular inverse, one product -- against six growth steps
+            // (eighteen products) saved at ||H|| / pert = 2600.
+            bool mapped = false;
+            if (c->opt_refine_map && n > 64) {
+                int *mflag0 = dflag; // (the flags of the threshold test were read above)
+                if (n <= 128) hipLaunchKernelGGL((chol64_reg_kernel<4>), dim3((unsigned)ncl), dim3(1024), 0, c->stream, (const double *)Hc, n, kp, Y, kk, kp, -pert, -pert, mflag0, kk, 1);
+                else hipLaunchKernelGGL((chol64_reg_kernel<8>), dim3((unsigned)ncl), dim3(1024), 0, c->stream, (const double *)Hc, n, kp, Y, kk, kp, -pert, -pert, mflag0, kk, 1);
+                HIPCHK(hipGetLastError());
+                std::vector<int> f0((size_t)ncl);
+                HIPCHK(hipMemcpyAsync(f0.data(), mflag0, f0.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                bool all_ok = true;
+                for (int v : f0) all_ok = all_ok && v == 0;
+                if (all_ok) {
+                    if (kp <= 128) hipLaunchKernelGGL((tri_inverse64_reg_kernel<8>), dim3((unsigned)(kp / 16), (unsigned)ncl), dim3(256), 0, c->stream, (const double *)Y, n, kp, Z, kp, kp, (int64_t)kk, (int64_t)kk);
+                    else hipLaunchKernelGGL((tri_inverse64_reg_kernel<16>), dim3((unsigned)(kp / 16), (unsigned)ncl), dim3(256), 0, c->stream, (const double *)Y, n, kp, Z, kp, kp, (int64_t)kk, (int64_t)kk);
+                    // X0 = I - 2 pert Xt Xt^T  (Xt = L^-1 transposed, zero beyond the valid block: identity on the padding)
+                    hipLaunchKernelGGL((gemm64_kernel<true>), gg, dim3(256), 0, c->stream, (const double *)Z, (const double *)Z, X, (const double *)nullptr, -2.0 * pert, 0.0, 1.0, kp,
+                                       (float *)nullptr, 0, (const int *)nullptr, 0, kk);
+                    HIPCHK(hipGetLastError());
+                    mapped = true;
+                }
+            }
+            int nq = (int)std::ceil(std::log(mapped ? 2.0 * pert / delta : hmax / delta) / std::log(3.4445));
+            nq = std::min(std::max(nq, 4), 48);
             auto mm = [&](const double *A, const double *B, double *Cc, const double *D, double al, double be, double ga) {
                 if (c->opt_gemm64_tile128 && kp % 128 == 0 &&
                     allow_big_lds(c, reinterpret_cast<const void *>(&gemm64_tile128_kernel), GEMM64_TILE128_LDS) == CMF_OK)

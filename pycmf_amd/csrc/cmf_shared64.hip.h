@@ -542,7 +542,11 @@ __device__ __forceinline__ double group16_sum_f64_dpp(double v) {
 // multiply-adds, four DPP additions and one multiplication by the pre-inverted diagonal -- no barrier inside a panel
 // (the 16 lanes of a column sit in one wave), ~250 cycles per row instead of ~2000.
 template <int NM>
-__global__ __launch_bounds__(256) void tri_inverse64_reg_kernel(const double *L, int n, int ld, double *Xt, int ldx, int kp) {
+__global__ __launch_bounds__(256) void tri_inverse64_reg_kernel(const double *L, int n, int ld, double *Xt, int ldx, int kp, int64_t lstride = 0,
+                                                               int64_t xstride = 0) {
+    // batched (grid y): matrix images lstride / xstride doubles apart
+    L += (int64_t)blockIdx.y * lstride;
+    Xt += (int64_t)blockIdx.y * xstride;
     constexpr int RP = 32;
     __shared__ __attribute__((aligned(16))) double Ls[RP * (16 * NM + 2)];
     __shared__ double dinv[RP];
