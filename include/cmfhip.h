@@ -238,6 +238,12 @@ int cmf_data_sq(cmf_ctx *ctx, double *x2, double *y2);  /* ||X||^2, ||Y||^2 */
 /* ---- batched safe inverse (exposed for tests): _safe_invert :346-356 --- */
 /* H: n symmetric k x k float64 matrices (host), out: Q diag(1/max(|l|,pert)) Q^T */
 int cmf_safe_invert_batch(cmf_ctx *ctx, const double *H, double *out, int n, int k, double pert);
+/* The step of _row_newton_update (:321-326) for n independent rows: out_b = g_b * safe_inverse(H_b) (H: n symmetric k x k
+ * float64 host matrices, g / out: n x k), through the float32 path the per-row sweeps take.  method 0: the sweeps' own dispatch
+ * (Cholesky where lambda_min >= pert, the clamp path for the rest); 1: every matrix through the tridiagonal eigen-solve
+ * (cmf_eigclamp.hip.h; 64 < k <= 256), lam (nullable, n x k) receives its eigenvalues in the order the QL iteration left them. */
+int cmf_safe_solve_batch(cmf_ctx *ctx, const double *H, const double *g, double *out, double *lam, int n, int k,
+                         double pert, int method);
 
 /* Conditioning record of the per-row Newton sweeps.  The spectral clamp of _safe_invert (pycmf/cmf_solvers.py:346-356) acts on a
  * row's Hessian only when its smallest eigenvalue is below `pert`; on the device that Hessian is a float32 matrix, whose

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "cmf_data_sq": [_vp, _pd, _pd],
     "cmf_safe_invert_batch": [_vp, _pd, _pd, _i32, _i32, _dbl],
     "cmf_safe_invert_f64": [_vp, _pd, _pd, _i32, _dbl],
+    "cmf_safe_solve_batch": [_vp, _pd, _pd, _pd, _pd, _i32, _i32, _dbl, _i32],
     "cmf_debug_clock": [_vp, _pd, _pd],
     "cmf_kernel_timing": [_vp, _i32],
     "cmf_kernel_time": [_vp, _i32, _pd, _pi64, _pd],
@@ -525,6 +526,18 @@ class Context:
         out = np.empty_like(H)
         check(self._lib.cmf_safe_invert_batch(self._h, H.ctypes.data_as(_pd), out.ctypes.data_as(_pd), n, k, pert))
         return out
+
+    def safe_solve_batch(self, H, g, pert, method=0, eigenvalues=False):
+        """g_b * safe_inverse(H_b) for a batch (the step of a per-row sweep), float32 device path; method 1: all through the
+        tridiagonal eigen-solve.  eigenvalues=True also returns the eigenvalues the QL iteration found (method 1)."""
+        H = np.ascontiguousarray(H, dtype=np.float64)
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        n, k, _ = H.shape
+        out = np.empty((n, k), dtype=np.float64)
+        lam = np.empty((n, k), dtype=np.float64) if eigenvalues else None
+        check(self._lib.cmf_safe_solve_batch(self._h, H.ctypes.data_as(_pd), g.ctypes.data_as(_pd), out.ctypes.data_as(_pd),
+                                             lam.ctypes.data_as(_pd) if eigenvalues else None, n, k, pert, method))
+        return (out, lam) if eigenvalues else out
 
     def safe_invert_f64(self, H, pert):
         """float64 path of the shared Hessian: H is k x k with k = this context's n_components."""

@@ -12,6 +12,7 @@
 #include "cmf_rowhess6.hip.h"
 #include "cmf_shared64.hip.h"
 #include "cmf_refine64.hip.h"
+#include "cmf_eigclamp.hip.h"
 
 #include <hip/hip_runtime.h>
 
@@ -205,11 +206,16 @@ struct cmf_ctx {
     int opt_refine = 1;                   // redo clamped rows with ||H||_F / pert > refine_ratio in float64 (0: float32 only, recorded)
     double opt_refine_ratio = 3.0e3;       // clamped rows: ||H||_F / pert above this (campaign: 2.7e3 -> 3e-4 off the float64 reference, 9.8e3 -> 1.9e-3)
     double opt_refine_cond = 1.0e3;        // plain Cholesky solves: max H_ii / min L_ii^2 (a LOWER bound of cond H) above this
+    double opt_refine_tol = 2.0e-5;        // ... and only if eps32 * ratio * ||step_i|| > tol * ||F_i||: the float32 error bound of the row's update against the tolerance on the factor row (0: the ratio alone decides, round 5)
     int64_t opt_refine_max = (int64_t)1 << 40; // cap on the rows redone per sweep (no cap since the refinement is batched; the option remains); beyond: float32, recorded
     int64_t refined_sweep = 0, refined_total = 0;
     DevBuf bfp[2][2], bff;                // gemm_arith = 1: bf16 planes of X / Y (normal, transposed) and of the factor operand
     bool bfp_valid[2][2] = {{false, false}, {false, false}};
     DevBuf nsidx, nsws;                   // Newton-Schulz clamp: flagged-row list + counters, matrix workspaces
+    DevBuf eigcl_snap;                    // snapshot of a chunk's flags (which matrices the clamp acted on) for the refinement's error-bound test
+    DevBuf eigcl_ws, eigcl_log, eigcl_fail; // tridiagonal eigen-clamp (cmf_eigclamp.hip.h): d / e / Q^T g / tau, rotation logs, per-matrix give-up flags
+    int opt_eig_clamp = 1;                // flagged per-row Hessians at k_pad 128 / 256: Householder + QL solve on the vector units (0: Newton-Schulz polynomials / Jacobi)
+    int64_t eig_clamp_rows = 0;           // matrices served by it since the context was created (tests / bench)
     DevBuf g64a, g64b, gmix64, h64;       // float64 Grams / shared Hessian of the linear-link Newton sweeps (cmf_shared64.hip.h)
     DevBuf gslab64, w64, ns64;            // their split slabs, Cholesky workspaces + L^-1 image, Newton-Schulz images
     bool gmix64_valid = false;            // gmix64 = alpha U^T U + (1 - alpha) Z^T Z of the partials just formed (single-GPU step)
@@ -816,7 +822,7 @@ static void release_problem(cmf_ctx *c) {
     c->hclass = DevBuf(); c->certimg = DevBuf(); c->certflag = DevBuf();
     c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf(); c->clampstat = DevBuf(); c->badbuf = DevBuf(); c->rw64 = DevBuf(); c->rh64 = DevBuf(); c->bad_host.clear();
     c->ref_w = DevBuf(); c->ref_w2 = DevBuf(); c->ref_g = DevBuf(); c->ref_i = DevBuf(); c->ref_ns = DevBuf();
-    c->nsidx = DevBuf(); c->nsws = DevBuf();
+    c->nsidx = DevBuf(); c->nsws = DevBuf(); c->eigcl_ws = DevBuf(); c->eigcl_log = DevBuf(); c->eigcl_fail = DevBuf(); c->eigcl_snap = DevBuf();
     c->spmm_bar = DevBuf();
     c->g64a = DevBuf(); c->g64b = DevBuf(); c->gmix64 = DevBuf(); c->h64 = DevBuf();
     c->gslab64 = DevBuf(); c->w64 = DevBuf(); c->ns64 = DevBuf();
@@ -939,6 +945,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_arith = (int)value;
     } else if (!strcmp(name, "gemm_arith_min_tiles")) {
         c->opt_arith_min_tiles = (int)std::max<int64_t>(1, value);
+    } else if (!strcmp(name, "eig_clamp")) {
+        c->opt_eig_clamp = (int)value;
     } else if (!strcmp(name, "newton_schulz")) {
         c->opt_ns = value != 0;
     } else if (!strcmp(name, "chol_diag")) {
@@ -968,6 +976,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_refine_ratio = (double)std::max<int64_t>(1, value);
     } else if (!strcmp(name, "refine_rows_cond")) {
         c->opt_refine_cond = (double)std::max<int64_t>(1, value);
+    } else if (!strcmp(name, "refine_rows_tol_ppm")) {
+        c->opt_refine_tol = 1e-6 * (double)std::max<int64_t>(0, value);
     } else if (!strcmp(name, "refine_rows_max")) {
         c->opt_refine_max = std::max<int64_t>(0, value);
     } else if (!strcmp(name, "row_split")) {

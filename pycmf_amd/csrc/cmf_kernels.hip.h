@@ -1232,9 +1232,15 @@ __global__ __launch_bounds__(256) void compact_flags_kernel(const int *flags, in
 // flags is null) count it and keep the largest ||H_b||_F / pert.  The clamp max(|lambda|, pert) of a float32 Hessian resolves
 // eigenvalues only to about eps32 * ||H||, i.e. to a RELATIVE error of eps32 * ||H|| / pert in the clamped directions of the
 // inverse: the ratio says when that leaves the stated tolerance.  One wave per matrix, H is not modified.
+// step / Frows / tol (round 6; all or none): the float32 result of matrix b and the factor row it updates.  A matrix above its
+// ratio threshold is LISTED only if the float32 error can matter: eps32 * ratio * ||step_b|| > tol * ||F_b|| -- eps32 * ratio bounds
+// the relative error of the clamped (or ill-conditioned) directions of the inverse, so the left side bounds the error of this
+// row's update and the right side is the tolerance on the factor row.  One that passes is certified by the bound: counted as
+// clamped, not entered in the maximum ratio "left in float32".
 __global__ __launch_bounds__(64) void clamp_stats_kernel(const float *H, const int *flags, int n, int kp, int64_t stride, float pert,
                                                          unsigned long long *count, unsigned *maxratio, float thr, int mode, int *bad,
-                                                         const float *condest, float thr_plain) {
+                                                         const float *condest, float thr_plain, const float *step = nullptr,
+                                                         const float *Frows = nullptr, float tol = 0.f, int clamp_sens = 0) {
     // mode 0: record every clamped matrix.  mode 1 (float64 refinement on): matrices with ratio > thr are LISTED in bad[1 ..]
     // (bad[0] = how many; they will be redone in float64) and only the others recorded.  mode 2: record only those above thr
     // (a chunk whose list the host declined to refine).
@@ -1254,13 +1260,30 @@ __global__ __launch_bounds__(64) void clamp_stats_kernel(const float *H, const i
             }
         for (int off = 32; off > 0; off >>= 1) fro += __shfl_xor(fro, off, 64);
     }
+    float s2 = 0.f, f2 = 0.f;
+    if (step && Frows && tol > 0.f) {
+        for (int q = threadIdx.x; q < n; q += 64) {
+            const float sv = step[(int64_t)b * kp + q], fv = Frows[(int64_t)b * kp + q];
+            s2 += sv * sv;
+            f2 += fv * fv;
+        }
+        for (int off = 32; off > 0; off >>= 1) { s2 += __shfl_xor(s2, off, 64); f2 += __shfl_xor(f2, off, 64); }
+    }
     if (threadIdx.x == 0) {
         float ratio = clamped ? sqrtf(fro) / pert : condest[b];
         if (!(ratio == ratio)) ratio = 3.0e38f;
         ratio = fminf(ratio, 3.0e38f);
         if (!clamped && mode != 2) atomicMax(maxratio + 1, __float_as_uint(ratio)); // largest estimate over ALL plain solves (diagnostic)
         // an overflowed Hessian (inf / NaN: a diverged iteration) is recorded, never listed: float64 cannot repair it
-        const bool above = ratio > (clamped ? thr : thr_plain);
+        bool above = ratio > (clamped ? thr : thr_plain);
+        // clamp_sens: for the matrices the clamp acted on, condest[b] holds the eigen-solve's own sensitivity estimate (relative error
+        // of its step: cmf_eigclamp.hip.h) -- sharper than eps32 * ratio, which prices every clamped matrix as if an eigenvalue sat
+        // right at the threshold
+        const float relerr = (clamped && clamp_sens && condest) ? condest[b] : 1.1920929e-7f * ratio;
+        if (above && step && Frows && tol > 0.f && ratio < 1.0e30f && !(relerr * sqrtf(s2) > tol * sqrtf(f2))) {
+            if (clamped) atomicAdd(count, 1ull); // certified by the error bound: float32 is enough for this row
+            return;
+        }
         if (mode == 1 && above && ratio < 1.0e30f) {
             bad[1 + atomicAdd(bad, 1)] = b;
             return;

@@ -55,8 +55,11 @@ static int jacobi_chipwide(cmf_ctx *c, const float *Hin, float *Hout, int *flags
 // note the matrices the float32 spectral clamp is about to act on (see clamp_stats_kernel).  refine: those with ||H||_F / pert above
 // the refinement ratio are not recorded but collected (chunk-relative, ascending) in c->bad_host for refine_rows64 -- one 4-byte
 // read-back per call; a list that would take the sweep over opt_refine_max is declined and recorded instead.
+// Frows (round 6): the factor rows the matrices update.  With it (and the float32 steps already in `step`) a matrix is listed only
+// when the float32 error bound of its row's update exceeds opt_refine_tol (clamp_stats_kernel); the caller then ran the float32
+// clamp path for every flagged matrix BEFORE this call, `flags` is its snapshot of the flags, and nothing is unflagged here.
 static int clamp_stats(cmf_ctx *c, const float *Hc, int *flags, int64_t nmat, int n, int kp, int64_t stride, double pert,
-                       bool refine = false, const float *condest = nullptr, float *step = nullptr) {
+                       bool refine = false, const float *condest = nullptr, float *step = nullptr, const float *Frows = nullptr) {
     c->bad_host.clear();
     if (nmat <= 0) return CMF_OK;
     if (!c->clampstat.p) {
@@ -66,6 +69,8 @@ static int clamp_stats(cmf_ctx *c, const float *Hc, int *flags, int64_t nmat, in
     unsigned long long *cnt = (unsigned long long *)c->clampstat.p;
     unsigned *mx = (unsigned *)((char *)c->clampstat.p + 8);
     const float thr = (float)c->opt_refine_ratio, thrp = (float)c->opt_refine_cond;
+    const float tol = Frows ? (float)c->opt_refine_tol : 0.f;
+    const float *bstep = Frows ? step : nullptr;
     const bool want = refine && c->opt_refine && c->hess_psd && c->refined_sweep < c->opt_refine_max;
     if (!want) {
         hipLaunchKernelGGL(clamp_stats_kernel, dim3((unsigned)nmat), dim3(64), 0, c->stream, Hc, flags, n, kp, stride, (float)pert, cnt, mx, thr, 0,
@@ -76,7 +81,7 @@ static int clamp_stats(cmf_ctx *c, const float *Hc, int *flags, int64_t nmat, in
     CHK(ensure(c, c->badbuf, (size_t)(nmat + 1) * sizeof(int)));
     int *bad = (int *)c->badbuf.p;
     HIPCHK(hipMemsetAsync(bad, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL(clamp_stats_kernel, dim3((unsigned)nmat), dim3(64), 0, c->stream, Hc, flags, n, kp, stride, (float)pert, cnt, mx, thr, 1, bad, condest, thrp);
+    hipLaunchKernelGGL(clamp_stats_kernel, dim3((unsigned)nmat), dim3(64), 0, c->stream, Hc, flags, n, kp, stride, (float)pert, cnt, mx, thr, 1, bad, condest, thrp, bstep, Frows, tol, Frows ? 1 : 0);
     HIPCHK(hipGetLastError());
     int nb = 0;
     HIPCHK(hipMemcpyAsync(&nb, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -84,7 +89,7 @@ static int clamp_stats(cmf_ctx *c, const float *Hc, int *flags, int64_t nmat, in
     if (nb <= 0) return CMF_OK;
     if (c->refined_sweep + nb > c->opt_refine_max) { // too many for this sweep: they stay float32 and are recorded as such
         hipLaunchKernelGGL(clamp_stats_kernel, dim3((unsigned)nmat), dim3(64), 0, c->stream, Hc, flags, n, kp, stride, (float)pert, cnt, mx, thr, 2,
-                           (int *)nullptr, condest, thrp);
+                           (int *)nullptr, condest, thrp, bstep, Frows, tol, Frows ? 1 : 0);
         HIPCHK(hipGetLastError());
         c->refined_sweep = c->opt_refine_max;
         return CMF_OK;
@@ -93,7 +98,7 @@ static int clamp_stats(cmf_ctx *c, const float *Hc, int *flags, int64_t nmat, in
     HIPCHK(hipMemcpyAsync(c->bad_host.data(), bad + 1, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     // the listed matrices skip the float32 spectral clamp (refine_rows64 redoes them from scratch; at C3 with l2 = 0 that clamp was
     // 0.75 s per iteration of work thrown away): only where the batched refinement will take them
-    if (step && c->opt_refine_batched && c->k > 64 && c->k <= 256 && c->hess_psd)
+    if (step && !Frows && c->opt_refine_batched && c->k > 64 && c->k <= 256 && c->hess_psd)
         hipLaunchKernelGGL(unflag_listed_kernel, dim3((unsigned)nb), dim3(64), 0, c->stream, flags, (const int *)(bad + 1), nb, step, kp);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -278,6 +283,74 @@ static int ns_clamp_images(cmf_ctx *c, const float *Hc, const int *idx, int nf, 
     return CMF_OK;
 }
 
+// step_b = grad_b * safe_inverse(H_b) for the matrices idx[0 .. nf) of a chunk (idx null: all of 0 .. nf) by the tridiagonal
+// eigen-solve of cmf_eigclamp.hip.h (H is not modified).  Serves any symmetric H (|lambda| as
+// pycmf/cmf_solvers.py:353), k_pad 128 / 256.  flags (nullable): cleared for every matrix served; one the QL iteration gave up on
+// keeps its flag for the caller's fallback.
+static bool eig_clamp_ok(const cmf_ctx *c, int n, int kp) { return c->opt_eig_clamp && (kp == 256 || kp == 128) && n > 64; }
+static int eig_clamp_solve(cmf_ctx *c, const float *Hc, const int *idx, int nf, const float *grad, float *step, int *flags, int n, int kp,
+                           double pert, float *lam_out = nullptr, float *sens_out = nullptr) {
+    if (nf <= 0) return CMF_OK;
+    Timed tm(c, CMF_K_EIGEN);
+    const int64_t stride = (int64_t)kp * kp;
+    const int64_t cap = std::max<int64_t>(1024, (int64_t)n * n);       // PAIRS of sweep steps logged per wave of 64 matrices (measured: 0.3 .. 0.6 n^2)
+    const int sw_cap = 8 * kp;                                          // sweeps per wave (measured: ~1.8 n)
+    const int64_t per_mat = cap * (int64_t)sizeof(float4) + stride * (int64_t)sizeof(float);
+    // scratch: reflectors (k_pad^2 floats) + rotation log (1 MB at n = 256) per matrix, kept under 12 GiB: a whole 8192-row chunk
+    // of C3 is one batch
+    const int bmax = (int)std::min<int64_t>(rup(nf, 64), std::max<int64_t>(64, ((int64_t)12 << 30) / per_mat / 64 * 64));
+    const int64_t NB = bmax;
+    CHK(ensure(c, c->eigcl_ws, eig_ws_floats(kp, NB) * sizeof(float)));
+    CHK(ensure(c, c->eigcl_log, (size_t)NB * (size_t)per_mat + (size_t)(NB / 64) * sw_cap * sizeof(EigSweep)));
+    CHK(ensure(c, c->eigcl_fail, (size_t)NB * sizeof(int)));
+    float *ws = (float *)c->eigcl_ws.p;
+    float *refl = (float *)c->eigcl_log.p;
+    float4 *lg = (float4 *)(refl + (size_t)NB * stride);
+    const size_t ql_lds = (size_t)2 * kp * 64 * sizeof(float);
+    EigSweep *sw = (EigSweep *)(lg + (size_t)NB * cap);
+    int *failf = (int *)c->eigcl_fail.p;
+    static const bool want_stats = getenv("CMF_EIG_STATS") != nullptr; // (measurement: sweeps / trips per wave on stderr)
+    long long *qstats = nullptr;
+    if (want_stats) HIPCHK(hipMalloc((void **)&qstats, (size_t)(NB / 64) * 6 * sizeof(long long)));
+    for (int b0 = 0; b0 < nf; b0 += bmax) {
+        const int nb = std::min(bmax, nf - b0);
+        const int *ib = idx ? idx + b0 : nullptr;
+        const float *Hb = idx ? Hc : Hc + (int64_t)b0 * stride;
+        const float *gb = idx ? grad : grad + (int64_t)b0 * kp;
+        float *sb = idx ? step : step + (int64_t)b0 * kp;
+        int *fb = (idx || !flags) ? flags : flags + b0;
+        float *lam = lam_out ? lam_out + (int64_t)b0 * kp : (float *)nullptr;
+        // (the QL kernel reads d, e, gt of all 64 lanes of its last wave: clear the slots past nb)
+        if (nb % 64) HIPCHK(hipMemsetAsync(ws, 0, eig_ws_floats(kp, NB) * sizeof(float), c->stream));
+        if (kp == 256) {
+            CHK(allow_big_lds(c, reinterpret_cast<const void *>(&eig_ql_kernel<256>), (int)ql_lds));
+            hipLaunchKernelGGL(eig_tridiag_kernel<256>, dim3((unsigned)nb), dim3(512), 0, c->stream, Hb, ib, gb, n, stride, ws, NB, refl);
+            hipLaunchKernelGGL(eig_ql_kernel<256>, dim3((unsigned)((nb + 63) / 64)), dim3(64), ql_lds, c->stream, ws, NB, nb, n, (float)pert, lg, cap, sw, sw_cap, failf, lam, qstats);
+            hipLaunchKernelGGL(eig_backtransform_kernel<256>, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, c->stream, (const float *)refl, ib, nb, n,
+                               (const float *)ws, NB, (const int *)failf, sb, fb, idx ? sens_out : (sens_out ? sens_out + b0 : (float *)nullptr));
+        } else {
+            CHK(allow_big_lds(c, reinterpret_cast<const void *>(&eig_ql_kernel<128>), (int)ql_lds));
+            hipLaunchKernelGGL(eig_tridiag_kernel<128>, dim3((unsigned)nb), dim3(512), 0, c->stream, Hb, ib, gb, n, stride, ws, NB, refl);
+            hipLaunchKernelGGL(eig_ql_kernel<128>, dim3((unsigned)((nb + 63) / 64)), dim3(64), ql_lds, c->stream, ws, NB, nb, n, (float)pert, lg, cap, sw, sw_cap, failf, lam, qstats);
+            hipLaunchKernelGGL(eig_backtransform_kernel<128>, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, c->stream, (const float *)refl, ib, nb, n,
+                               (const float *)ws, NB, (const int *)failf, sb, fb, idx ? sens_out : (sens_out ? sens_out + b0 : (float *)nullptr));
+        }
+        HIPCHK(hipGetLastError());
+        if (qstats) {
+            const int nw = (nb + 63) / 64;
+            std::vector<long long> hs((size_t)nw * 6);
+            HIPCHK(hipMemcpyAsync(hs.data(), qstats, hs.size() * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            long long a = 0, t = 0, r = 0, tmax = 0, c1 = 0, c2 = 0, c3 = 0;
+            for (int w = 0; w < nw; ++w) { a += hs[6 * w]; t += hs[6 * w + 1]; r += hs[6 * w + 2]; tmax = std::max(tmax, hs[6 * w + 1]); c1 += hs[6 * w + 3]; c2 += hs[6 * w + 4]; c3 += hs[6 * w + 5]; }
+            fprintf(stderr, "[cmf eig] %d matrices, %d waves: sweeps/wave %.1f, trips/wave %.0f (max %lld), own rotations/matrix %.0f; cycles/wave: QL %.0f, forward %.0f, scale + backward %.0f\n", nb, nw, (double)a / nw, (double)t / nw, tmax, (double)r / nb, (double)c1 / nw, (double)c2 / nw, (double)c3 / nw);
+        }
+    }
+    if (qstats) (void)hipFree(qstats);
+    c->eig_clamp_rows += nf;
+    return CMF_OK;
+}
+
 static int ns_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, float *step, int *flags, int64_t nr, int n, int kp,
                                double pert) {
     CHK(ensure(c, c->nsidx, (size_t)(nr + 1) * sizeof(int)));
@@ -308,6 +381,22 @@ static int ns_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, f
     return CMF_OK;
 }
 
+// the flagged matrices of a chunk through eig_clamp_solve (compacted list; one 4-byte read-back)
+static int eig_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, float *step, int *flags, int64_t nr, int n, int kp, double pert,
+                                float *sens_out = nullptr) {
+    CHK(ensure(c, c->nsidx, (size_t)(nr + 1) * sizeof(int)));
+    int *idx = (int *)c->nsidx.p, *count = idx + nr;
+    HIPCHK(hipMemsetAsync(count, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(compact_flags_kernel, dim3(32), dim3(256), 0, c->stream, (const int *)flags, (int)nr, idx, count);
+    HIPCHK(hipGetLastError());
+    int nf = 0;
+    HIPCHK(hipMemcpyAsync(&nf, count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (nf <= 0) return CMF_OK;
+    if (nf == nr) return eig_clamp_solve(c, Hc, nullptr, nf, grad, step, flags, n, kp, pert, nullptr, sens_out); // every row: no indirection
+    return eig_clamp_solve(c, Hc, (const int *)idx, nf, grad, step, flags, n, kp, pert, nullptr, sens_out);
+}
+
 // step_i = grad_i * safe_inverse(H_i) for a chunk of per-row Hessians (H is clobbered):
 // register-resident Cholesky solve for the rows with lambda_min >= pert, Jacobi + row product
 // for the flagged rest.
@@ -316,7 +405,7 @@ struct RowCert { // per-group positive-definiteness certificates of a chunk (fus
     int rows = 1, split = 0;    // rows per group, rows in its first half
 };
 static int safe_solve_rows(cmf_ctx *c, float *Hc, const float *grad, float *step, int64_t nr, int n, int kp, double pert,
-                           const RowCert &cert = RowCert(), bool refine = false) {
+                           const RowCert &cert = RowCert(), bool refine = false, const float *Frows = nullptr) {
     if (nr <= 0) return CMF_OK;
     const int64_t stride = (int64_t)kp * kp;
     if (!c->opt_chol || n > 256) { // general path only
@@ -347,9 +436,21 @@ static int safe_solve_rows(cmf_ctx *c, float *Hc, const float *grad, float *step
         else hipLaunchKernelGGL((chol_solve_kernel<16>), grid, block, 0, c->stream, (const float *)Hc, grad, step, flags, n, kp, stride, (float)pert, (int)nr, c->opt_choldiag,
                                 (const int *)nullptr, 1, cert.flags, cert.rows, cert.split, condest);
         HIPCHK(hipGetLastError());
-        CHK(clamp_stats(c, Hc, flags, nr, n, kp, stride, pert, refine, condest, step));
-        // flagged matrices, k_pad = 128 / 256, Hessians positive semi-definite by construction (weights >= 0):
-        // spectral clamp by Newton-Schulz (MFMA) + a second Cholesky solve; clears the flags it serves
+        // Round 6: where the tridiagonal eigen-solve serves the flagged matrices (cheap: every one of them gets its float32 step)
+        // the float64 refinement is decided AFTERWARDS, per row, by the error bound of that step (clamp_stats); otherwise (round 5)
+        // by the ratio alone, before the clamp path, whose work on the listed matrices would be thrown away.
+        const bool bound_first = refine && Frows && c->opt_refine && c->hess_psd && c->opt_refine_tol > 0.0 && eig_clamp_ok(c, n, kp);
+        if (bound_first) {
+            CHK(ensure(c, c->eigcl_snap, (size_t)nr * sizeof(int)));
+            HIPCHK(hipMemcpyAsync(c->eigcl_snap.p, flags, (size_t)nr * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+            CHK(eig_clamp_solve_rows(c, Hc, grad, step, flags, nr, n, kp, pert, condest)); // (condest of a clamped row <- the solve's sensitivity)
+            CHK(clamp_stats(c, Hc, (int *)c->eigcl_snap.p, nr, n, kp, stride, pert, refine, condest, step, Frows));
+        } else {
+            CHK(clamp_stats(c, Hc, flags, nr, n, kp, stride, pert, refine, condest, step));
+            if (eig_clamp_ok(c, n, kp)) CHK(eig_clamp_solve_rows(c, Hc, grad, step, flags, nr, n, kp, pert));
+        }
+        // flagged matrices the eigen-solve did not serve (option, or its iteration gave up), k_pad = 128 / 256, Hessians positive
+        // semi-definite by construction (weights >= 0): spectral clamp by Newton-Schulz (MFMA) + a second Cholesky solve
         if ((kp == 256 || kp == 128) && c->opt_ns && c->hess_psd) CHK(ns_clamp_solve_rows(c, Hc, grad, step, flags, nr, n, kp, pert));
         // whatever is still flagged: |lambda| / clamp by Jacobi, in place (the solve kernel does not modify H)
         const size_t lds_need = (size_t)(2 * n * n + n) * sizeof(float);
@@ -400,6 +501,47 @@ extern "C" int cmf_safe_invert_batch(cmf_ctx *c, const double *H, double *out, i
 
 // ---- shared-Hessian building blocks ------------------------------------------------------
 // float64 Gram of a factor (cmf_shared64.hip.h): G64 = F^T F, optional float32 copy for the F G product
+extern "C" int cmf_safe_solve_batch(cmf_ctx *c, const double *H, const double *g, double *out, double *lam, int n, int k, double pert, int method) {
+    if (!c || !H || !g || !out || n < 0 || k <= 0 || method < 0 || method > 1) return fail(CMF_EINVAL, "bad argument");
+    DeviceGuard dg(c->device);
+    const int kp = pad_k(k);
+    if (method == 1 && !((kp == 128 || kp == 256) && k > 64)) return fail(CMF_EINVAL, "the eigen-solve serves 64 < k <= 256");
+    if (n == 0) return CMF_OK;
+    const size_t me = (size_t)n * kp * kp, ve = (size_t)n * kp;
+    std::vector<float> hm(me, 0.f), hv(3 * ve, 0.f);
+    for (int i = 0; i < n; ++i) {
+        for (int r = 0; r < k; ++r)
+            for (int q = 0; q < k; ++q) hm[((size_t)i * kp + r) * kp + q] = (float)H[((size_t)i * k + r) * k + q];
+        for (int q = 0; q < k; ++q) hv[(size_t)i * kp + q] = (float)g[(size_t)i * k + q];
+    }
+    float *dH = nullptr, *dv = nullptr;
+    HIPCHK(hipMalloc((void **)&dH, me * sizeof(float)));
+    if (hipMalloc((void **)&dv, 3 * ve * sizeof(float)) != hipSuccess) { (void)hipFree(dH); return fail(CMF_ENOMEM, "hipMalloc failed"); }
+    float *dgr = dv, *dstep = dv + ve, *dlam = dv + 2 * ve;
+    int rc = CMF_OK;
+    do {
+        if (hipMemcpyAsync(dH, hm.data(), me * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(dv, hv.data(), 3 * ve * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(CMF_EHIP, "H2D failed"); break; }
+        const int save_refine = c->opt_refine;
+        c->opt_refine = 0; // (no factors / data behind these matrices: nothing the float64 refinement could recompute)
+        if (method == 1) rc = eig_clamp_solve(c, dH, nullptr, n, dgr, dstep, nullptr, k, kp, pert, dlam);
+        else rc = safe_solve_rows(c, dH, dgr, dstep, n, k, kp, pert);
+        c->opt_refine = save_refine;
+        if (rc != CMF_OK) break;
+        if (hipMemcpyAsync(hv.data(), dv, 3 * ve * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail(CMF_EHIP, "D2H failed"); break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(CMF_EHIP, "sync failed"); break; }
+    } while (0);
+    (void)hipFree(dH);
+    (void)hipFree(dv);
+    if (rc != CMF_OK) return rc;
+    for (int i = 0; i < n; ++i)
+        for (int q = 0; q < k; ++q) {
+            out[(size_t)i * k + q] = (double)hv[ve + (size_t)i * kp + q];
+            if (lam) lam[(size_t)i * k + q] = (double)hv[2 * ve + (size_t)i * kp + q];
+        }
+    return CMF_OK;
+}
+
 static int gram64(cmf_ctx *c, const float *F, int64_t rows_pad, double *G64, float *G32) {
     const int kp = c->kp;
     const int ts = kp >= 64 ? 64 : 32, T = kp / ts, ntile = T * (T + 1) / 2;
@@ -989,7 +1131,7 @@ static int per_row_finish(cmf_ctx *c, int which, const RowHess &h, double pert, 
             have = true;
         }
         CHK(launch_ew(c, hessian_finalize_kernel, nr_pad * kk, Hc, h.S, (float)h.diag, nr_pad, c->kp, c->k, have ? 1 : 0));
-        CHK(safe_solve_rows(c, Hc, grad + r0 * c->kp, step + r0 * c->kp, nr, c->k, c->kp, pert, RowCert(), rf.on));
+        CHK(safe_solve_rows(c, Hc, grad + r0 * c->kp, step + r0 * c->kp, nr, c->k, c->kp, pert, RowCert(), rf.on, c->F[which] + r0 * c->kp));
         if (rf.on) CHK(refine_rows64(c, which, rf.s1, rf.s2, rf.shared, rf.shs.active ? &rf.shs : nullptr, h.diag, rf.l1, rf.l2, r0, step + r0 * c->kp, pert));
     }
     return launch_ew(c, newton_apply_kernel, rows_pad * c->kp, c->F[which], (const float *)step, rows, c->kp, c->k,
@@ -1737,7 +1879,7 @@ static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const Row
                                (float *)nullptr, (int *)c->certflag.p, c->k, c->kp, kk, (float)(pert - diag), (int)ncert, 1);
             HIPCHK(hipGetLastError());
         }
-        CHK(safe_solve_rows(c, Hc, grad + r0 * c->kp, step + r0 * c->kp, nr, c->k, c->kp, pert, cert, true));
+        CHK(safe_solve_rows(c, Hc, grad + r0 * c->kp, step + r0 * c->kp, nr, c->k, c->kp, pert, cert, true, c->F[which] + r0 * c->kp));
         CHK(refine_rows64(c, which, s1, s2, shared, shside, diag, l1, l2, r0, step + r0 * c->kp, pert));
     }
     return launch_ew(c, newton_apply_kernel, rows_pad * c->kp, c->F[which], (const float *)step, rows, c->kp, c->k, rows_pad * c->kp,

@@ -102,11 +102,40 @@ def _nbytes(A):
     return np.asarray(A).nbytes
 
 
+def _job_nbytes(A):
+    """Bytes `_save` writes for one matrix: dense inputs travel as float32 whatever the caller's dtype, sparse ones as they are."""
+    if sp.issparse(A):
+        return _nbytes(A)
+    return int(A.shape[0]) * int(A.shape[1]) * 4
+
+
+def _gpu_runtime_present():
+    """Has ANYTHING in this process opened the GPU -- not only pycmf_amd?  An open descriptor on /dev/kfd or a DRM render node
+    means some HIP / HSA runtime is initialised (torch, cupy, hip-python, another ctypes library, rocprofv3's preloaded tool
+    library with --pmc): a forked child would inherit state it must not.  (A runtime library that is merely mapped has opened
+    neither: HIP initialises on the first call.)"""
+    try:
+        for fd in os.listdir("/proc/self/fd"):
+            try:
+                target = os.readlink("/proc/self/fd/" + fd)
+            except OSError:
+                continue
+            if target == "/dev/kfd" or target.startswith("/dev/dri/renderD"):
+                return True
+    except OSError:
+        return True      # cannot tell: assume the worst
+    return False
+
+
 def can_fork_ranks():
     """May the ranks be forked off this process (they then read the caller's X, Y, U, V, Z in place -- no copy of the job at all)?
-    Only while this process has never initialised a GPU runtime: a forked child must not inherit one.  PYCMF_AMD_FORK_RANKS=0
-    forces the file path, =1 is the default behaviour."""
-    if os.environ.get("PYCMF_AMD_FORK_RANKS", "1") == "0" or not hasattr(os, "fork"):
+    OPT-IN: PYCMF_AMD_FORK_RANKS=1 (the default is the fresh-child path with float32 job files).  Even then only while
+    this process (i) has never initialised or even loaded a GPU runtime -- pycmf_amd's own flag, torch's, AND what the process
+    table shows: no descriptor on /dev/kfd or a render node (a runtime brought up by any other library or by a profiler's
+    preloaded tool is seen there) -- and (ii) runs a single Python thread.  (Native pools Python cannot see are the
+    opting-in caller's statement: OpenBLAS registers fork handlers for its own; a parent with a live OpenMP team or RCCL proxy
+    threads must not opt in.)"""
+    if os.environ.get("PYCMF_AMD_FORK_RANKS", "0") != "1" or not hasattr(os, "fork"):
         return False
     from . import _lib
     if _lib.gpu_touched():
@@ -116,6 +145,11 @@ def can_fork_ranks():
         if torch is not None and torch.cuda.is_initialized():
             return False
     except Exception:
+        return False
+    if _gpu_runtime_present():
+        return False
+    import threading
+    if threading.active_count() > 1:
         return False
     return True
 
@@ -195,7 +229,7 @@ def fit_multi_gpu(X, Y, U, V, Z, solver, n_gpus, params, timeout=None):
     if solver == "newton" and sparse_y and not _linear(params):
         Y = Y.toarray()
     fork = can_fork_ranks()
-    job = tempfile.mkdtemp(prefix="pycmf_amd_job_", dir=None if fork else _job_base((_nbytes(X) + _nbytes(Y)) // (1 if sp.issparse(X) else 2) + U.nbytes + V.nbytes + Z.nbytes))
+    job = tempfile.mkdtemp(prefix="pycmf_amd_job_", dir=None if fork else _job_base(_job_nbytes(X) + _job_nbytes(Y) + U.nbytes + V.nbytes + Z.nbytes))
     last_fit_info.clear()
     last_fit_info.update(forked=fork, job_bytes=0)
     try:

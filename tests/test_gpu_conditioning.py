@@ -82,7 +82,7 @@ def test_batched_refinement_equals_row_by_row(lib, k, pert):
     args = (0.6, 0.01, 0.05, "linear", "logit", 0, 7, pert, 1.0)
     outs = []
     for batched in (1, 0):
-        got, (rows, ratio, refined) = _step(lib, X, Y, U, V, Z, k, args, [("refine_rows_batched", batched), ("refine_rows_ratio", 1), ("refine_rows_cond", 1)])
+        got, (rows, ratio, refined) = _step(lib, X, Y, U, V, Z, k, args, [("refine_rows_batched", batched), ("refine_rows_ratio", 1), ("refine_rows_cond", 1), ("refine_rows_tol_ppm", 0)])   # (tol 0: the ratios alone decide -- every row)
         assert refined >= d + p                      # every Z and V row (logit / two-sided sweeps) went through the float64 path
         outs.append(got)
     for a, b in zip(*outs):

@@ -1,0 +1,105 @@
+"""The tridiagonal eigen-solve of `_safe_invert`'s clamp (csrc/cmf_eigclamp.hip.h) against the oracle's float64 `safe_invert`
+(pycmf/cmf_solvers.py:346-356 applied as :321-326 applies it: step = g . H^-1), through the C ABI (`cmf_safe_solve_batch`).
+
+Tolerances: the device works on the float32 image of H; eigenvalues of a float32 matrix are defined to eps32 * ||H||, so a
+direction whose eigenvalue sits within that distance of the threshold may be clamped on one side and not on the other -- the clamp is
+continuous, the step differs by the eigenvalue's relative distance.  Stated per case below."""
+import numpy as np
+import pytest
+
+from oracle import cmf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _spectrum_matrix(rng, ev):
+    n = len(ev)
+    Q, _ = np.linalg.qr(rng.randn(n, n))
+    return (Q * ev) @ Q.T
+
+
+def _cases(rng):
+    out = {}
+    # the C3 regime at the reference's default l2 = 0 (tools/r06_spectrum_probe.py): one outlier, the bulk just below pert
+    out["c3z"] = [_spectrum_matrix(rng, np.concatenate([np.sort(rng.uniform(0.10, 0.199, 255)), [2087.0]])) for _ in range(3)]
+    # C3X: the bulk straddles the threshold (140 below, 85 within 10 % of it)
+    out["c3x"] = [_spectrum_matrix(rng, np.concatenate([np.sort(rng.uniform(0.133, 0.27, 255)), [2.27]])) for _ in range(3)]
+    # Gram matrices (what the sweeps produce), some rank deficient
+    g = []
+    for s in (40, 200, 300, 2000):
+        B = rng.randn(s, 256) * 0.05
+        g.append(B.T @ B)
+    out["gram"] = g
+    # indefinite: |lambda| as the reference takes it
+    out["indef"] = [_spectrum_matrix(rng, rng.uniform(-3, 3, 256)) for _ in range(2)]
+    out["diag"] = [np.diag(rng.uniform(0.01, 5.0, 256)), 0.05 * np.eye(256), 7.0 * np.eye(256)]
+    return out
+
+
+def _check(ctx, Hs, pert, tol, rng, k=None):
+    H = np.stack(Hs)
+    g = rng.randn(H.shape[0], H.shape[1])
+    got, lam = ctx.safe_solve_batch(H, g, pert, method=1, eigenvalues=True)
+    H32 = H.astype(np.float32).astype(np.float64)
+    for b in range(H.shape[0]):
+        ref = g[b] @ O.safe_invert(H32[b], pert)
+        err = np.abs(got[b] - ref).max() / np.abs(ref).max()
+        assert err < tol, (b, err)
+        ev = np.linalg.eigvalsh(H32[b])
+        assert np.abs(np.sort(lam[b]) - ev).max() <= 2e-5 * max(1.0, np.abs(ev).max()), b
+    return got
+
+
+@pytest.mark.parametrize("name,tol", [("c3z", 5e-4), ("c3x", 5e-6), ("gram", 5e-6), ("indef", 5e-6), ("diag", 1e-6)])
+def test_eigen_solve_matches_float64_safe_invert(name, tol):
+    """k = 256.  c3z: ||H|| / pert = 1e4, eigenvalues resolved to eps32 ||H|| = 2.5e-4 = 1.2e-3 pert -- the bulk within that distance of
+    the threshold moves by as much; everything else is float32 round-off."""
+    from pycmf_amd import _lib
+    rng = np.random.RandomState(5)
+    ctx = _lib.Context(0)
+    try:
+        _check(ctx, _cases(rng)[name], 0.2, tol, rng)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("k", [65, 100, 128, 129, 200, 255])
+def test_eigen_solve_other_orders(k):
+    """n < k_pad (padding rows / columns must stay inert), the k_pad = 128 instance, odd orders; 70 matrices: two QL workgroups,
+    a partly filled second one."""
+    from pycmf_amd import _lib
+    rng = np.random.RandomState(k)
+    Hs = []
+    for i in range(70):
+        s = rng.randint(k // 2, 3 * k)
+        B = rng.randn(s, k) * rng.uniform(0.02, 0.3)
+        Hs.append(B.T @ B)
+    ctx = _lib.Context(0)
+    try:
+        _check(ctx, Hs, 0.2, 5e-4, rng)
+    finally:
+        ctx.close()
+
+
+def test_sweep_dispatch_uses_the_eigen_solve_and_agrees_with_newton_schulz():
+    """The sweeps' own dispatch (method 0: Cholesky where lambda_min >= pert, the clamp path for the rest) with the eigen-solve on
+    (default) and off (round 5's Newton-Schulz polynomials): both against float64; unclamped matrices never reach either."""
+    from pycmf_amd import _lib
+    rng = np.random.RandomState(11)
+    cases = _cases(rng)
+    Hs = cases["c3x"] + cases["gram"] + [7.0 * np.eye(256) + cases["gram"][3]]
+    H = np.stack(Hs)
+    g = rng.randn(len(Hs), 256)
+    H32 = H.astype(np.float32).astype(np.float64)
+    ref = np.stack([g[b] @ O.safe_invert(H32[b], 0.2) for b in range(len(Hs))])
+    res = {}
+    for eig in (1, 0):
+        ctx = _lib.Context(0)
+        try:
+            ctx.set_option("eig_clamp", eig)
+            res[eig] = ctx.safe_solve_batch(H, g, 0.2, method=0)
+        finally:
+            ctx.close()
+    for eig, tol in ((1, 2e-5), (0, 2e-3)):
+        err = np.abs(res[eig] - ref).max(axis=1) / np.abs(ref).max(axis=1)
+        assert err.max() < tol, (eig, err)

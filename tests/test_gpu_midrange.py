@@ -29,8 +29,14 @@ def _one_thread():
     return threadpool_limits(limits=1)
 
 
-def _synthetic(lib, m, d, p, k, signed=False):
+def _synthetic(lib, m, d, p, k, signed=False, options=()):
     ctx = lib.Context(0)
+    for name, val in options:
+        ctx.set_option(name, val)
+    import os
+    for kv in os.environ.get("CMF_TEST_OPTIONS", "").split(","):   # (A/B runs of a whole test file: name=value,...)
+        if kv:
+            ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     ctx.set_problem(m, d, p, k)
     ctx.fill_data_synthetic(0, 42, 0, 0)
     ctx.fill_data_synthetic(1, 43, 0, 0, 1)            # targets of the logit side: sigmoid(N(0,1)), as bench.py's c3

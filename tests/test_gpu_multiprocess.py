@@ -449,6 +449,8 @@ sys.path.insert(0, %(root)r)
 from pycmf_amd import CMF, multi_gpu, _lib
 rng = np.random.RandomState(3)
 X, Y = np.abs(rng.randn(300, 170)), np.abs(rng.randn(170, 90))
+assert not multi_gpu.can_fork_ranks()             # opt-in only (ADVICE r5)
+os.environ["PYCMF_AMD_FORK_RANKS"] = "1"
 assert multi_gpu.can_fork_ranks() and not _lib.gpu_touched()
 two = CMF(n_components=6, solver="mu", x_init="random", y_init="random", random_state=0, max_iter=30, n_gpus=2).fit(X, Y)
 assert multi_gpu.last_fit_info == {"forked": True, "job_bytes": 0}, multi_gpu.last_fit_info   # the ranks read X, Y in place

@@ -770,17 +770,63 @@ def test_job_files_are_float32_and_written_from_any_layout(tmp_path):
 
 
 def test_ranks_are_forked_only_off_a_process_without_a_gpu_runtime(monkeypatch):
-    """The zero-copy hand-over (ranks forked off the caller) is taken only while this process has made no HIP call through pycmf_amd,
-    and never when the environment forbids it."""
+    """The zero-copy hand-over (ranks forked off the caller) is OPT-IN and even then taken only while this process has
+    no GPU runtime of ANYBODY's -- pycmf_amd's flag, an open /dev/kfd or render-node descriptor, a mapped HIP / HSA library -- and a
+    single Python thread."""
+    import threading
     from pycmf_amd import _lib, multi_gpu
     monkeypatch.setattr(_lib, "_gpu_touched", False)
+    monkeypatch.setattr(multi_gpu, "_gpu_runtime_present", lambda: False)
     monkeypatch.delenv("PYCMF_AMD_FORK_RANKS", raising=False)
-    assert multi_gpu.can_fork_ranks()
+    assert not multi_gpu.can_fork_ranks()            # default: fresh children + float32 job files
     monkeypatch.setenv("PYCMF_AMD_FORK_RANKS", "0")
     assert not multi_gpu.can_fork_ranks()
-    monkeypatch.delenv("PYCMF_AMD_FORK_RANKS")
+    monkeypatch.setenv("PYCMF_AMD_FORK_RANKS", "1")
+    assert multi_gpu.can_fork_ranks()
     monkeypatch.setattr(_lib, "_gpu_touched", True)
     assert not multi_gpu.can_fork_ranks()
+    monkeypatch.setattr(_lib, "_gpu_touched", False)
+    monkeypatch.setattr(multi_gpu, "_gpu_runtime_present", lambda: True)   # somebody else's runtime
+    assert not multi_gpu.can_fork_ranks()
+    monkeypatch.setattr(multi_gpu, "_gpu_runtime_present", lambda: False)
+    stop = threading.Event()
+    t = threading.Thread(target=stop.wait)
+    t.start()
+    try:
+        assert not multi_gpu.can_fork_ranks()        # a second Python thread
+    finally:
+        stop.set()
+        t.join()
+    assert multi_gpu.can_fork_ranks()
+
+
+def test_gpu_runtime_probe_sees_foreign_descriptors(monkeypatch):
+    """`_gpu_runtime_present` reads the process table, not pycmf_amd's own bookkeeping: a descriptor on /dev/kfd or a render node
+    counts whoever opened it."""
+    from pycmf_amd import multi_gpu
+    real_listdir, real_readlink = os.listdir, os.readlink
+    fds = {"0": "/dev/pts/0", "5": "/tmp/x"}
+    monkeypatch.setattr(os, "listdir", lambda p: list(fds) if p == "/proc/self/fd" else real_listdir(p))
+    monkeypatch.setattr(os, "readlink", lambda p: fds[p.rsplit("/", 1)[1]] if p.startswith("/proc/self/fd/") else real_readlink(p))
+    assert not multi_gpu._gpu_runtime_present()
+    fds["9"] = "/dev/kfd"
+    assert multi_gpu._gpu_runtime_present()
+    fds["9"] = "/dev/dri/renderD128"
+    assert multi_gpu._gpu_runtime_present()
+    fds["9"] = "/dev/null"
+    assert not multi_gpu._gpu_runtime_present()
+
+
+def test_job_size_estimate_counts_float32_files(tmp_path):
+    """the scratch-space estimate is what `_save` writes -- rows x cols x 4 for dense inputs of any dtype, the stored
+    arrays for sparse ones."""
+    import numpy as np
+    import scipy.sparse as sp
+    from pycmf_amd import multi_gpu
+    assert multi_gpu._job_nbytes(np.zeros((10, 7), dtype=np.float64)) == 280
+    assert multi_gpu._job_nbytes(np.zeros((10, 7), dtype=np.float32)) == 280
+    S = sp.random(50, 40, density=0.1, format="csr", random_state=1)
+    assert multi_gpu._job_nbytes(S) == S.data.nbytes + S.indices.nbytes + S.indptr.nbytes
 
 
 def test_compare_rows_tool(tmp_path):
