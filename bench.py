@@ -43,26 +43,33 @@ WORKLOADS = {
     "c2": dict(m=16384, d=8192, p=4096, k=128, solver="mu",
                desc="BASELINE configs[1]: CMF(n_components=128, solver='mu', linear link), dense "
                     "16384x8192 X, 8192x4096 Y, non-negative synthetic"),
-    "c3": dict(m=32768, d=16384, p=8192, k=256, solver="newton", x_link="linear", y_link="logit", ratio=0.5, y_kind=1,
-               desc="BASELINE configs[2]: CMF(n_components=256, solver='newton', y_link='logit', "
-                    "sg_sample_ratio=0.5, device sampler) on dense 32768x16384 X, 16384x8192 Y"),
-    "c3z": dict(m=32768, d=16384, p=8192, k=256, solver="newton", x_link="linear", y_link="logit", ratio=0.5, y_kind=1, l2=0.0,
-                desc="BASELINE configs[2] with the reference's default l2_reg = 0 (pycmf/cmf.py:622): CMF(n_components=256, solver='newton', "
-                     "y_link='logit', sg_sample_ratio=0.5, device sampler) on dense 32768x16384 X, 16384x8192 Y"),
-    "c3x": dict(m=32768, d=16384, p=8192, k=256, solver="newton", x_link="logit", y_link="logit", ratio=0.5, x_kind=1, y_kind=1,
-                desc="BASELINE configs[2] with the sigmoid link on BOTH sides: CMF(n_components=256, solver='newton', x_link='logit', "
+    "c3": dict(m=32768, d=16384, p=8192, k=256, solver="newton", x_link="linear", y_link="logit", ratio=0.5, y_kind=1, l2=0.0,
+               desc="BASELINE configs[2] at the reference's defaults (l2_reg = 0, pycmf/cmf.py:622): CMF(n_components=256, solver='newton', "
+                    "y_link='logit', sg_sample_ratio=0.5, device sampler) on dense 32768x16384 X, 16384x8192 Y"),
+    "c3r": dict(m=32768, d=16384, p=8192, k=256, solver="newton", x_link="linear", y_link="logit", ratio=0.5, y_kind=1, l2=0.1,
+                desc="BASELINE configs[2] with l2_reg = 0.1 (NOT the reference's default: rounds 1-5 quoted this as 'c3'; with it "
+                     "_safe_invert's clamp never acts): CMF(n_components=256, solver='newton', y_link='logit', sg_sample_ratio=0.5, device "
+                     "sampler) on dense 32768x16384 X, 16384x8192 Y"),
+    "c3x": dict(m=32768, d=16384, p=8192, k=256, solver="newton", x_link="logit", y_link="logit", ratio=0.5, x_kind=1, y_kind=1, l2=0.0,
+                desc="BASELINE configs[2] with the sigmoid link on BOTH sides, the reference's default l2_reg = 0: CMF(n_components=256, solver='newton', x_link='logit', "
                      "y_link='logit', sg_sample_ratio=0.5, device sampler) on dense 32768x16384 X, 16384x8192 Y (sigmoid(N(0,1)) targets)"),
     "c5": dict(m=1000000, d=100000, p=64, k=256, solver="newton", x_link="linear", y_link="linear", ratio=1.0,
                nnz_per_row=100,
                desc="BASELINE configs[4]: CSR X 1e6 x 1e5 at 0.1% nnz (100 per row, values 1.0, native CSR), "
                     "dense Y 1e5 x 64, n_components=256, newton solver, linear links"),
     "c5l": dict(m=1000000, d=100000, p=64, k=256, solver="newton", x_link="linear", y_link="logit", ratio=1.0,
-                nnz_per_row=100, l1=2.0, l2=50.0, nn_mask=3, y_kind=2, y_param=0.1,
+                nnz_per_row=100, l1=2.0, l2=5.0, nn_mask=3, y_kind=2, y_param=0.1, may_diverge=True,
                 desc="BASELINE configs[4] with the reference's own Newton settings (samples/toxic_comments.ipynb:853-856: "
-                     "x_link='linear', y_link='logit', l1_reg=2, U and V non-negative; l2_reg = 50 = the notebook's 5 scaled by d / 1e4, "
-                     "the number of rows each Z gradient sums over -- with l2 = 5 the reference's undamped iteration itself diverges on "
-                     "this unstructured synthetic Y by iteration 3, profiles/r05_c5l_probe.txt): CSR X 1e6 x 1e5 at 0.1% nnz "
-                     "(values 1.0, native CSR), dense Y 1e5 x 64 in {0,1} (10% ones), n_components=256"),
+                     "x_link='linear', y_link='logit', l1_reg=2, l2_reg=5, U and V non-negative): CSR X 1e6 x 1e5 at 0.1% nnz "
+                     "(values 1.0, native CSR), dense Y 1e5 x 64 in {0,1} (10% ones), n_components=256.  On this unstructured synthetic Y "
+                     "the reference's undamped iteration itself diverges by iteration 3 (profiles/r05_c5l_probe.txt): the line is a "
+                     "throughput figure, rel_residual says where the iterates are; c5l_l2x10 is the same on bounded iterates"),
+    "c5l_l2x10": dict(m=1000000, d=100000, p=64, k=256, solver="newton", x_link="linear", y_link="logit", ratio=1.0,
+                      nnz_per_row=100, l1=2.0, l2=50.0, nn_mask=3, y_kind=2, y_param=0.1,
+                      desc="c5l with l2_reg = 50 INSTEAD OF the notebook's 5 (5 scaled by d / 1e4, the number of rows each Z gradient sums "
+                           "over -- a deviation from the reference's settings, made because every iterate then stays finite): CSR X 1e6 x "
+                           "1e5 at 0.1% nnz (values 1.0, native CSR), dense Y 1e5 x 64 in {0,1} (10% ones), n_components=256, newton, "
+                           "x linear / y logit, l1_reg=2, U and V non-negative"),
     "tiny5l": dict(m=20000, d=3000, p=64, k=64, solver="newton", x_link="linear", y_link="logit", ratio=1.0,
                    nnz_per_row=30, l1=2.0, l2=5.0, nn_mask=3, y_kind=2, y_param=0.1,
                    desc="debug shape (native CSR X, y logit newton; the notebook's l1 = 2, l2 = 5, on which the iteration stays bounded at this size)"),
@@ -72,6 +79,7 @@ WORKLOADS = {
     "tiny5": dict(m=20000, d=3000, p=64, k=64, solver="newton", x_link="linear", y_link="linear", ratio=1.0,
                   nnz_per_row=30, desc="debug shape (native CSR X, linear newton)"),
 }
+WORKLOADS["c3z"] = WORKLOADS["c3"]   # rounds 4-5 named the l2 = 0 configuration c3z: kept as an alias
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 (v_mfma_f32_32x32x16_bf16)
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec
@@ -141,19 +149,12 @@ def cpu_baseline(w, budget_s=20.0):
         Y = 1.0 / (1.0 + np.exp(-rng.randn(ds, ps)))
     sc = np.sqrt(max(X.mean(), 1e-12) / ks)
     U, V, Z = (sc * np.abs(rng.randn(n, ks)) for n in (ms, ds, ps))
-    limit = None
     if w["solver"] == "mu":
         def step():
             O.mu_update_step(X, Y, U, V, Z)
         warm, timed = 3, 5
     else:
-        np.random.seed(0)
-        if per_row:
-            try:
-                from threadpoolctl import threadpool_limits
-                limit = threadpool_limits(limits=1)
-            except Exception:
-                limit = None
+        np.random.seed(0)   # (oracle.safe_invert pins ITS eigh calls to one BLAS thread; the GEMMs of the step keep every thread -- ADVICE r5)
 
         def step():
             nnm = w.get("nn_mask", 0)
@@ -180,9 +181,6 @@ def cpu_baseline(w, budget_s=20.0):
             blas = ", ".join(sorted({"%s %s" % (i.get("internal_api", "?"), i.get("version", "?")) for i in info}))
     except Exception:
         pass
-    if limit is not None:
-        threads = 1
-        limit.restore_original_limits() if hasattr(limit, "restore_original_limits") else None
     if w["solver"] == "mu":   # reference-order flops: 8 k d (m + p) (+ Grams / applies, the same order in both shapes)
         ref = lambda m_, d_, p_, k_: 8.0 * k_ * d_ * (m_ + p_) + 4.0 * k_ * k_ * (m_ + d_ + p_)
         ratio = ref(ms, ds, ps, ks) / ref(w["m"], w["d"], w["p"], k)
@@ -255,6 +253,9 @@ def main():
                          "protocol); 'rsag' = reduce-scatter of the partial, V epilogue on the rank's row block, all-gather of V, the two "
                          "k^2 Grams in the same two RCCL groups; 'auto' (default) = both timed on the live ranks before the warm-up, the "
                          "faster kept (rsag only when it wins by > 2 %%), decision and timings in collective.protocol_trial")
+    ap.add_argument("--max-warmup", type=int, default=40,
+                    help="per-row Newton workloads: upper limit of the extra warm-up iterations run until the clamp / refinement counts "
+                         "of two consecutive iterations agree (steady state)")
     ap.add_argument("--tol", type=float, default=0.0,
                     help="> 0: the reference's convergence check (pycmf/cmf_solvers.py:175-187: the error metric every 10th iteration, "
                          "default tol of pycmf.CMF 1e-4) runs INSIDE the timed region -- the device error pass, its 16-byte read-back and, "
@@ -412,6 +413,28 @@ def main():
 
     for it in range(args.warmup):
         do_step(it)
+    # Per-row Newton: the work of an iteration depends on the iterate -- how many rows _safe_invert's clamp acts on, how many the
+    # float64 refinement redoes (C3 at l2 = 0: none for six iterations, every row of U from the seventh on; round 4 and round 5 each
+    # quoted a line from BEFORE such a change).  Warm up until two consecutive iterations record the same clamp / refinement
+    # counts (at most --max-warmup more), and say how long that took; the line is checked again after the timed region.
+    warm_extra = 0
+    if newton and not sharded_ok and not use_dist:
+        def clamp_counts():
+            ctx.sync()
+            st = ctx.newton_clamp_stats(full=True)
+            return (st[0], st[2])
+        prev = clamp_counts()
+        last = None
+        while warm_extra < args.max_warmup:
+            do_step(args.warmup + warm_extra)
+            warm_extra += 1
+            cur = clamp_counts()
+            delta = (cur[0] - prev[0], cur[1] - prev[1])
+            prev = cur
+            if last is not None and delta == last:
+                break
+            last = delta
+        args.warmup += warm_extra
     for c_ in ctxs:
         c_.kernel_timing(2)        # HIP events around the data-pass launches only (the class the roofline prices): an event pair per
         c_.kernel_timing_reset()   # launch serialises the stream for a few microseconds, 7 % of a C2 iteration when every launch has one
@@ -421,9 +444,14 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     ctx.marker()
+    fused_check = args.tol > 0 and not newton and not use_dist   # cmf_mu_step_error: the step and the error of its result, no pass over X / Y
     for it in range(args.steps):
-        do_step(args.warmup + it)
-        maybe_check(it)
+        if fused_check and (it + 1) % 10 == 0:
+            ex2_, ey2_ = ctx.mu_step_error(0.0, 0.0, 7)
+            checks.append(float(0.5 * ex2_ ** 0.5 + 0.5 * ey2_ ** 0.5))
+        else:
+            do_step(args.warmup + it)
+            maybe_check(it)
         ctx.marker()               # one event per iteration on the launch stream: the auditable time series
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -629,6 +657,8 @@ def main():
                                      "rank's copy of V compared after the run"}
     if args.tol > 0:
         out["convergence_check"] = {"tol": args.tol, "every": 10, "checks_in_timed_region": len(checks), "errors": checks,
+                                    "form": ("cmf_mu_step_error: ||X||^2 - 2 <U, X V> + <U^T U, V^T V> from the step's own products (NT error pass only "
+                                             "where the expansion would cancel)" if fused_check else "cmf_residual_sq: NT error pass over X and Y"),
                                     "note": "the reference's stopping test (pycmf/cmf_solvers.py:175-187) evaluated inside the timed region; "
                                             "the stop is not taken, so that exactly `steps` iterations are timed"}
     for key in ("x_link", "y_link", "ratio", "l1", "l2", "nn_mask"):
@@ -636,9 +666,9 @@ def main():
             out["config"][key] = w[key]
     if newton:
         out["config"]["l1"], out["config"]["l2"] = l1_reg, l2_reg
-        if "l2" not in w:
-            out["config"]["l2_note"] = ("l2_reg = 0.1 is this bench's choice, not BASELINE.json's (which names no regularisation) nor the "
-                                        "reference's default (0, pycmf/cmf.py:622): --workload c3z is the same configuration at l2 = 0")
+        if args.workload == "c3r" or "l2" not in w:
+            out["config"]["l2_note"] = ("l2_reg = 0.1 is this bench's choice, not BASELINE.json's (which names no regularisation: the "
+                                        "reference's default is 0, pycmf/cmf.py:622)" + ("; --workload c3 is the configuration at the default" if args.workload == "c3r" else ""))
         out["config"]["workload"] += "; l1_reg = %g, l2_reg = %g" % (l1_reg, l2_reg)
     if args.option:
         out["config"]["options"] = list(args.option)
@@ -656,26 +686,39 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline(w)
         full = w["solver"] == "mu"
+        per_row = bool(cb.get("per_row"))
         out["cpu_baseline"] = {
             "value": cb["its"] * cb["ratio"],
             "unit": "it/s",
             "cores": cb["threads"],
             "host_cpu_count": cb["cpu_count"],
             "blas": cb["blas"],
-            "kind": "port",
-            "cores_note": ("one BLAS thread: the per-row sweeps call LAPACK's eigh on one k x k matrix at a time, which a many-threaded "
-                           "OpenBLAS runs an order of magnitude slower" if cb.get("per_row") else
+            # "port" = the oracle timed on the configuration itself (C2 in full) or scaled by a flop ratio of order 1e-2 (C4 from
+            # C2); "extrapolated" = ONE reduced-shape step scaled by 1e-3 .. 1e-2 of the algorithmic work (per-row Newton)
+            "kind": "extrapolated" if (newton and per_row) else "port",
+            "cores_note": ("eigh: 1 BLAS thread (oracle.safe_invert pins LAPACK's k x k eigh, an order of magnitude slower on a many-threaded "
+                           "OpenBLAS); GEMMs of the step: %d" % cb["threads"] if per_row else
                            "all host cores" if cb["threads"] >= cb["cpu_count"] else
                            "the BLAS under NumPy (%s) is built for at most %d threads: that is every thread this build can use on the "
                            "%d-CPU host" % (cb["blas"], cb["threads"], cb["cpu_count"])),
             "sample": ("oracle/cmf_oracle %s update_step (NumPy float64, reference operation order) at m,d,p,k=%s%s: %d timed "
-                       "iterations in %.1f s = %.3f it/s on %d BLAS threads; scaled to the bench shape by the %s ratio %.3g"
+                       "iterations in %.1f s = %.3f it/s on %d BLAS threads%s; scaled to the bench shape by the %s ratio %.3g"
                        % (w["solver"], cb["shape"], " (BASELINE config C2 in full)" if full and cb["shape"][0] == 16384 else "",
-                          cb["iters"], cb["seconds"], cb["its"], cb["threads"],
+                          cb["iters"], cb["seconds"], cb["its"], cb["threads"], " (eigh on 1)" if per_row else "",
                           "reference-order flop" if full else "algorithmic-work", cb["ratio"])),
         }
+    if newton:
+        out["steady_state"] = {"extra_warmup_iterations": warm_extra, "instrumented_over_timed": t_extra / ms_per_step if ms_per_step > 0 else None,
+                               "note": "warm-up continued until two consecutive iterations recorded the same clamp / refinement counts; the "
+                                       "iterations after the timed region (instrumented_ms_per_step) must not cost more than 1.25 x the timed "
+                                       "ones, else the line is refused (exit code 3)"}
     sys.stdout.flush()
     print(json.dumps(out), flush=True)
+    if newton and ms_per_step > 0 and t_extra > 1.25 * ms_per_step and extra > 0 and not w.get("may_diverge"):
+        sys.stderr.write("bench.py: NOT a steady-state line: the %d iterations after the timed region took %.1f ms each against %.1f ms "
+                         "inside it (a regime change of the solver behind the timed window); raise --warmup / --max-warmup\n"
+                         % (extra, t_extra, ms_per_step))
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -157,6 +157,12 @@ int cmf_get_factor_f64(cmf_ctx *ctx, int which, double *ptr, int64_t rs, int64_t
 
 /* ---- MU solver: MUSolver.update_step, pycmf/cmf_solvers.py:248-263 ----- */
 int cmf_mu_step(cmf_ctx *ctx, double l1, double l2, int update_mask);
+/* cmf_mu_step AND the error metric of the factors it leaves (compute_factorization_error, cmf_solvers.py:36-42, as the loop
+ * evaluates it every 10th iteration, :175-187) from the products of the step itself: ||X||^2 - 2 <U, X V> + <U^T U, V^T V> (the
+ * expansion of sklearn's sparse path, :40) -- no pass over X and Y.  Falls back to cmf_residual_sq per side where the expansion
+ * would cancel (e^2 < 1e-3 ||.||^2), the side is not dense or its factor is not updated.  *ex2 / *ey2 (nullable): squared
+ * Frobenius residuals of the local shard, as cmf_residual_sq.                                                              */
+int cmf_mu_step_error(cmf_ctx *ctx, double l1, double l2, int update_mask, double *ex2, double *ey2);
 
 /* sharded form: rank g holds rows of X/U and columns of
  * Y/Z, V replicated.  buf is a DEVICE buffer of cmf_v_buf_elems() floats:

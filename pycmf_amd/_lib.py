@@ -53,6 +53,7 @@ PROTOTYPES = {
     "cmf_set_factor_f64": [_vp, _i32, _pd, _i64, _i64],
     "cmf_get_factor_f64": [_vp, _i32, _pd, _i64, _i64],
     "cmf_mu_step": [_vp, _dbl, _dbl, _i32],
+    "cmf_mu_step_error": [_vp, _dbl, _dbl, _i32, _pd, _pd],
     "cmf_v_buf_elems": [_vp, _pi64],
     "cmf_mu_v_partials": [_vp, _vp],
     "cmf_mu_v_apply": [_vp, _vp, _dbl, _dbl],
@@ -408,6 +409,12 @@ class Context:
     # ---- MU
     def mu_step(self, l1, l2, mask=7):
         check(self._lib.cmf_mu_step(self._h, l1, l2, mask))
+
+    def mu_step_error(self, l1, l2, mask=7):
+        """One MU iteration and the squared residuals (ex2, ey2) of the factors it leaves, from the step's own products."""
+        ex2, ey2 = C.c_double(0), C.c_double(0)
+        check(self._lib.cmf_mu_step_error(self._h, l1, l2, mask, C.byref(ex2), C.byref(ey2)))
+        return ex2.value, ey2.value
 
     def v_buf_elems(self):
         n = C.c_int64(0)

@@ -68,7 +68,9 @@ def run_rank(job, meta, X, Y, factors=None):
     common = dict(max_iter=P["max_iter"], tol=P["tol"], device=local, verbose=P["verbose"] if rank == 0 else 0, stats=stats,
                   rank=rank, world=world, update_mask=int(P.get("update_mask", 7)))
     if meta["solver"] == "mu":
-        U, V, Z, n_iter = fit_mu_sharded(Xr, Yc, U, V, Z, l1_reg=P["l1_reg"], l2_reg=P["l2_reg"], **common)
+        # a seeded fit is run-to-run reproducible: no wall-clock choice between protocols that differ in summation order
+        U, V, Z, n_iter = fit_mu_sharded(Xr, Yc, U, V, Z, l1_reg=P["l1_reg"], l2_reg=P["l2_reg"],
+                                         collective="allreduce" if P.get("random_state") is not None else None, **common)
     elif linear_newton(P):
         U, V, Z, n_iter = fit_newton_linear_sharded(
             Xr, Yc, U, V, Z, alpha=P["alpha"], l1_reg=P["l1_reg"], l2_reg=P["l2_reg"], U_non_negative=P["U_non_negative"],

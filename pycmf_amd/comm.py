@@ -159,34 +159,39 @@ class _ProtocolCheck:
         """Known-answer run of the in-place reduce-scatter and all-gather on this communicator (every rank must call it): True when
         every rank saw the sums / the gathered chunks it had to see.  `make_sharded_mu` falls back to the single all-reduce
         otherwise -- a wrong result of the row-blocked protocol would otherwise only show as a strange residual."""
-        from . import _lib
-        w, r, per = self.world, self.rank, 64
-        buf = _lib.DeviceArray(self.ctx, w * per, 1)
-        i = np.arange(w * per, dtype=np.float32)
-        self.ctx.copy_from_host(buf, (r + 1) + i)
-        self.reduce_scatter(buf)
-        got = self.ctx.copy_to_host(buf).reshape(-1)[r * per:(r + 1) * per]
-        ok = np.array_equal(got, w * (w + 1) / 2 + w * i[r * per:(r + 1) * per])
-        mine = np.full(w * per, -1.0, dtype=np.float32)
-        mine[r * per:(r + 1) * per] = 100.0 * (r + 1) + np.arange(per)
-        self.ctx.copy_from_host(buf, mine)
-        self.all_gather(buf)
-        want = np.concatenate([100.0 * (q + 1) + np.arange(per) for q in range(w)]).astype(np.float32)
-        ok = ok and np.array_equal(self.ctx.copy_to_host(buf).reshape(-1), want)
-        # the two grouped pairs of the row-blocked MU iteration: {small all-reduce, reduce-scatter}, {small all-reduce, all-gather}
-        small = _lib.DeviceArray(self.ctx, 16, 1)
-        for second in (self.reduce_scatter, self.all_gather):
-            self.ctx.copy_from_host(small, np.arange(16, dtype=np.float32) + r)
-            self.ctx.copy_from_host(buf, mine if second == self.all_gather else (r + 1) + i)
-            with self.group():
-                self.all_reduce(small)
-                second(buf)
-            ok = ok and np.array_equal(self.ctx.copy_to_host(small).reshape(-1), w * np.arange(16, dtype=np.float32) + w * (w - 1) / 2)
-            got = self.ctx.copy_to_host(buf).reshape(-1)
-            ok = ok and (np.array_equal(got, want) if second == self.all_gather else
-                         np.array_equal(got[r * per:(r + 1) * per], w * (w + 1) / 2 + w * i[r * per:(r + 1) * per]))
-        small.release()
-        buf.release()
+        ok = True
+        try:
+            from . import _lib
+            w, r, per = self.world, self.rank, 64
+            buf = _lib.DeviceArray(self.ctx, w * per, 1)
+            i = np.arange(w * per, dtype=np.float32)
+            self.ctx.copy_from_host(buf, (r + 1) + i)
+            self.reduce_scatter(buf)
+            got = self.ctx.copy_to_host(buf).reshape(-1)[r * per:(r + 1) * per]
+            ok = np.array_equal(got, w * (w + 1) / 2 + w * i[r * per:(r + 1) * per])
+            mine = np.full(w * per, -1.0, dtype=np.float32)
+            mine[r * per:(r + 1) * per] = 100.0 * (r + 1) + np.arange(per)
+            self.ctx.copy_from_host(buf, mine)
+            self.all_gather(buf)
+            want = np.concatenate([100.0 * (q + 1) + np.arange(per) for q in range(w)]).astype(np.float32)
+            ok = ok and np.array_equal(self.ctx.copy_to_host(buf).reshape(-1), want)
+            # the two grouped pairs of the row-blocked MU iteration: {small all-reduce, reduce-scatter}, {small all-reduce, all-gather}
+            small = _lib.DeviceArray(self.ctx, 16, 1)
+            for second in (self.reduce_scatter, self.all_gather):
+                self.ctx.copy_from_host(small, np.arange(16, dtype=np.float32) + r)
+                self.ctx.copy_from_host(buf, mine if second == self.all_gather else (r + 1) + i)
+                with self.group():
+                    self.all_reduce(small)
+                    second(buf)
+                ok = ok and np.array_equal(self.ctx.copy_to_host(small).reshape(-1), w * np.arange(16, dtype=np.float32) + w * (w - 1) / 2)
+                got = self.ctx.copy_to_host(buf).reshape(-1)
+                ok = ok and (np.array_equal(got, want) if second == self.all_gather else
+                             np.array_equal(got[r * per:(r + 1) * per], w * (w + 1) / 2 + w * i[r * per:(r + 1) * per]))
+            small.release()
+            buf.release()
+        except Exception as e:   # (ADVICE r5: a rank that raises must still reach the agreement below, or the others wait for it)
+            ok = False
+            self.self_test_error = repr(e)
         return bool(self.all_reduce_host([0.0 if ok else 1.0], "max")[0] == 0.0)
 
 

@@ -224,6 +224,11 @@ struct cmf_ctx {
     int opt_reassoc = 1;                  // 1: shared sweeps as F E + T (O Hinv) (cmf_newton.hip.h) | 0: gradient form F - grad Hinv
     bool v_plain = false;                 // cmf_newton_v_products -> cmf_newton_v_finish: the inverse was not clamped (E = 0)
     DevBuf dpart;                         // double partial sums
+    int opt_trace_error_off = 0;          // 1: cmf_mu_step_error always takes the NT error pass (A/B, tests)
+    bool mu_dots = false;                 // this MU step also leaves <U, X V> / <Z, Y^T V> in dscalar[2] / [3] (cmf_mu_step_error)
+    DevBuf trace64;                       // float64 Grams of U, V, Z for the trace form of the error metric
+    double dsq_cache[2] = {0.0, 0.0};     // ||X||^2, ||Y||^2 of the dense images (cmf_mu_step_error), valid while dsq_valid
+    bool dsq_valid[2] = {false, false};
     double *dscalar = nullptr;            // 8 slots of 8 bytes; slot 7: sample rows gathered by class launches (unsigned long long)
     double rh_credited = 0.0, rh_gathered = 0.0; // per-row Newton accounting while timing is on: sample rows of the algorithm / gathered by row launches
     std::vector<void *> owned;            // problem-scoped allocations (released by the next cmf_set_problem)
@@ -822,6 +827,7 @@ static void release_problem(cmf_ctx *c) {
     c->hclass = DevBuf(); c->certimg = DevBuf(); c->certflag = DevBuf();
     c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf(); c->clampstat = DevBuf(); c->badbuf = DevBuf(); c->rw64 = DevBuf(); c->rh64 = DevBuf(); c->bad_host.clear();
     c->ref_w = DevBuf(); c->ref_w2 = DevBuf(); c->ref_g = DevBuf(); c->ref_i = DevBuf(); c->ref_ns = DevBuf();
+    c->trace64 = DevBuf(); c->dsq_valid[0] = c->dsq_valid[1] = false;
     c->nsidx = DevBuf(); c->nsws = DevBuf(); c->eigcl_ws = DevBuf(); c->eigcl_log = DevBuf(); c->eigcl_fail = DevBuf(); c->eigcl_snap = DevBuf();
     c->spmm_bar = DevBuf();
     c->g64a = DevBuf(); c->g64b = DevBuf(); c->gmix64 = DevBuf(); c->h64 = DevBuf();
@@ -945,6 +951,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_arith = (int)value;
     } else if (!strcmp(name, "gemm_arith_min_tiles")) {
         c->opt_arith_min_tiles = (int)std::max<int64_t>(1, value);
+    } else if (!strcmp(name, "trace_error")) {
+        c->opt_trace_error_off = value == 0;
     } else if (!strcmp(name, "eig_clamp")) {
         c->opt_eig_clamp = (int)value;
     } else if (!strcmp(name, "newton_schulz")) {
@@ -1067,6 +1075,7 @@ static int data_dims(cmf_ctx *c, int which, int64_t *rows, int64_t *cols, int64_
 
 static int ensure_dense(cmf_ctx *c, int which) {
     invalidate_graphs(c);
+    c->dsq_valid[which] = false;
     c->bfp_valid[which][0] = c->bfp_valid[which][1] = false; // the dense image is about to be (re)written
     int64_t r, cc, rp, cp; float **slot;
     CHK(data_dims(c, which, &r, &cc, &rp, &cp, &slot));
@@ -1587,7 +1596,18 @@ extern "C" int cmf_mu_gram_v_rows(cmf_ctx *c, int64_t row0, int64_t nrows, float
 }
 static int mu_uz_update_with(cmf_ctx *c, const float *G2, double l1, double l2, int mask) {
     const PairSide xv{0, false, c->F[CMF_V]}, ytv{1, true, c->F[CMF_V]};
-    if ((mask & CMF_UPD_U) && (mask & CMF_UPD_Z) && pair_ok(c, xv, ytv)) {
+    // c->mu_dots (cmf_mu_step_error): the numerators X V and Y^T V are wanted whole in c->num behind the updates -- no pair launch,
+    // no partial tiles left to the update kernel
+    auto factor_dot = [&](const float *F, int64_t n, double *out) -> int {
+        const int blocks = 1024;
+        CHK(ensure(c, c->dpart, blocks * sizeof(double)));
+        Timed tm(c, CMF_K_ELEMWISE);
+        hipLaunchKernelGGL(dot_kernel, dim3(blocks), dim3(256), 0, c->stream, F, (const float *)c->num, n / 4, (double *)c->dpart.p);
+        hipLaunchKernelGGL(sum_doubles_kernel, dim3(1), dim3(256), 0, c->stream, (const double *)c->dpart.p, (int64_t)blocks, out);
+        HIPCHK(hipGetLastError());
+        return CMF_OK;
+    };
+    if (!c->mu_dots && (mask & CMF_UPD_U) && (mask & CMF_UPD_Z) && pair_ok(c, xv, ytv)) {
         // X V and Y^T V (cmf_solvers.py:232, :238) read the same V: one balanced launch, then the two updates
         SlabRef su, sz;
         CHK(data_times_pair(c, xv, ytv, &su, &sz));
@@ -1604,16 +1624,18 @@ static int mu_uz_update_with(cmf_ctx *c, const float *G2, double l1, double l2, 
     if (mask & CMF_UPD_U) {
         if (!have_data(c, 0)) { (void)side_join(c); return fail(CMF_EINVAL, "X must be set before a U update"); }
         SlabRef sl;
-        CHK(data_times(c, 0, false, c->F[CMF_V], c->num, false, small_tile_ok(c, c->mp) ? &sl : nullptr));
+        CHK(data_times(c, 0, false, c->F[CMF_V], c->num, false, (small_tile_ok(c, c->mp) && !c->mu_dots) ? &sl : nullptr));
         CHK(side_join(c)); // G2 (when it was formed on the side stream)
         CHK(mu_update(c, c->F[CMF_U], G2, c->num, c->mp, l1, l2, &sl));
+        if (c->mu_dots) CHK(factor_dot(c->F[CMF_U], c->mp * c->kp, c->dscalar + 2));
     }
     if (mask & CMF_UPD_Z) {
         if (!have_data(c, 1)) { (void)side_join(c); return fail(CMF_EINVAL, "Y must be set before a Z update"); }
         SlabRef sl;
-        CHK(data_times(c, 1, true, c->F[CMF_V], c->num, false, small_tile_ok(c, c->pp) ? &sl : nullptr));
+        CHK(data_times(c, 1, true, c->F[CMF_V], c->num, false, (small_tile_ok(c, c->pp) && !c->mu_dots) ? &sl : nullptr));
         CHK(side_join(c));
         CHK(mu_update(c, c->F[CMF_Z], G2, c->num, c->pp, l1, l2, &sl));
+        if (c->mu_dots) CHK(factor_dot(c->F[CMF_Z], c->pp * c->kp, c->dscalar + 3));
     }
     return side_join(c);
 }

@@ -1183,6 +1183,36 @@ __global__ void sumsq_kernel(const float *A, int64_t n4, double *partials) {
     if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
 }
 
+// partial sums of <A, B> (float32 operands, float64 products and sums); n4 = elements / 4
+__global__ void dot_kernel(const float *A, const float *B, int64_t n4, double *partials) {
+    double v = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 a = reinterpret_cast<const f32x4 *>(A)[i], b = reinterpret_cast<const f32x4 *>(B)[i];
+        v += (double)a[0] * b[0] + (double)a[1] * b[1] + (double)a[2] * b[2] + (double)a[3] * b[3];
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+// <A, B> of two n-element float64 arrays (single block)
+__global__ void frob_inner64_kernel(const double *A, const double *B, int n, double *out) {
+    __shared__ double red[256];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v += A[i] * B[i];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+
 // ------------------------------------------------------------------ synthetic data
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;

@@ -2266,6 +2266,62 @@ extern "C" int cmf_data_matmul_f64(cmf_ctx *c, int which, int trans, const doubl
 // Newton configurations is replayed from a hipGraph (option "graph": -1 = inside cmf_run only, the default).
 // err_trace (nullable, trace_cap entries): [0] = error at init, then one entry per check; time_trace (nullable): seconds since
 // the call started at the same points (what the reference's verbose lines print, :178-181).
+// One MU iteration AND the error metric of the factors it leaves (compute_factorization_error, pycmf/cmf_solvers.py:36-42, linear
+// link) from what the iteration forms anyway -- the expansion sklearn's own sparse path takes (:40):
+//   ||X - U V^T||^2 = ||X||^2 - 2 <U, X V> + <U^T U, V^T V>,
+// X V being the numerator of the U update (:232) taken with the NEW V, <.,.> float64 sums over float32 operands, the three k x k
+// Grams on the float64 matrix pipe, ||X||^2 once per data set.  No pass over X or Y: the NT error pass costs 38.7 ms at C4 (6 % of
+// a fit at the reference's default tol = 1e-4), this costs two dot products of m k elements and three Grams.  The expansion
+// subtracts numbers of size ||X||^2: where the fit is close (e^2 < 1e-3 ||X||^2: float32 rounding of X V would show in the fifth
+// digit of the error) -- or the side is not dense, its factor not part of this update -- the side falls back to the NT pass.
+// *ex2, *ey2: squared Frobenius residuals as cmf_residual_sq returns them.
+extern "C" int cmf_mu_step_error(cmf_ctx *c, double l1, double l2, int mask, double *ex2, double *ey2) {
+    NEED_PROBLEM(c);
+    DeviceGuard dg(c->device);
+    const bool tx = ex2 && c->X && (mask & CMF_UPD_U) && !c->opt_trace_error_off, ty = ey2 && c->Y && (mask & CMF_UPD_Z) && !c->opt_trace_error_off;
+    c->mu_dots = tx || ty;
+    const int rc = mu_step_eager(c, l1, l2, mask);
+    c->mu_dots = false;
+    CHK(rc);
+    double sq[2] = {-1.0, -1.0};
+    if (tx || ty) {
+        for (int w = 0; w < 2; ++w)
+            if ((w == 0 ? tx : ty) && !c->dsq_valid[w]) {
+                double x2 = 0.0, y2 = 0.0;
+                CHK(cmf_data_sq(c, &x2, &y2));
+                c->dsq_cache[0] = x2; c->dsq_cache[1] = y2;
+                c->dsq_valid[0] = c->X != nullptr; c->dsq_valid[1] = c->Y != nullptr;
+            }
+        const int64_t kk = (int64_t)c->kp * c->kp;
+        CHK(ensure(c, c->trace64, (size_t)3 * kk * sizeof(double)));
+        double *GU = (double *)c->trace64.p, *GV = GU + kk, *GZ = GV + kk;
+        CHK(gram64(c, c->F[CMF_V], c->dp, GV, nullptr));
+        if (tx) CHK(gram64(c, c->F[CMF_U], c->mp, GU, nullptr));
+        if (ty) CHK(gram64(c, c->F[CMF_Z], c->pp, GZ, nullptr));
+        {
+            Timed tm(c, CMF_K_ELEMWISE);
+            if (tx) hipLaunchKernelGGL(frob_inner64_kernel, dim3(1), dim3(256), 0, c->stream, (const double *)GU, (const double *)GV, (int)kk, c->dscalar + 4);
+            if (ty) hipLaunchKernelGGL(frob_inner64_kernel, dim3(1), dim3(256), 0, c->stream, (const double *)GZ, (const double *)GV, (int)kk, c->dscalar + 5);
+            HIPCHK(hipGetLastError());
+        }
+        double h[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(h, c->dscalar + 2, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (tx) { const double e2 = c->dsq_cache[0] - 2.0 * h[0] + h[2]; if (e2 >= 1e-3 * c->dsq_cache[0]) sq[0] = e2; }
+        if (ty) { const double e2 = c->dsq_cache[1] - 2.0 * h[1] + h[3]; if (e2 >= 1e-3 * c->dsq_cache[1]) sq[1] = e2; }
+    }
+    const bool nx = ex2 && sq[0] < 0.0 && have_data(c, 0), ny = ey2 && sq[1] < 0.0 && have_data(c, 1);
+    if (nx || ny) {
+        double a = 0.0, b = 0.0;
+        CHK(cmf_residual_sq(c, CMF_LINK_LINEAR, CMF_LINK_LINEAR, nx ? &a : nullptr, ny ? &b : nullptr));
+        if (nx) sq[0] = a;
+        if (ny) sq[1] = b;
+    }
+    if (ex2) *ex2 = sq[0] < 0.0 ? 0.0 : sq[0];
+    if (ey2) *ey2 = sq[1] < 0.0 ? 0.0 : sq[1];
+    return CMF_OK;
+}
+
 extern "C" int cmf_run(cmf_ctx *c, const cmf_run_params *p, int max_iter, double tol, int check_every, int *n_iter_out,
                        double *err_trace, double *time_trace, int trace_cap, int *n_trace) {
     NEED_PROBLEM(c);
@@ -2296,7 +2352,24 @@ extern "C" int cmf_run(cmf_ctx *c, const cmf_run_params *p, int max_iter, double
     CHK(error(&at_init));
     prev = at_init;
     int it = 0;
+    auto record = [&](double e) {
+        if (nt < trace_cap) {
+            if (err_trace) err_trace[nt] = e;
+            if (time_trace) time_trace[nt] = elapsed();
+        }
+        ++nt;
+    };
     for (it = 1; it <= max_iter; ++it) {
+        if (p->solver == CMF_SOLVER_MU && tol > 0.0 && it % check_every == 0) {
+            // the check iteration: the step and the error metric of its result in one call, without a pass over X and Y
+            double ex2 = 0.0, ey2 = 0.0;
+            CHK(cmf_mu_step_error(c, p->l1, p->l2, p->update_mask, hx ? &ex2 : nullptr, hy ? &ey2 : nullptr));
+            const double e = p->alpha_err * (hx ? std::sqrt(ex2) : 0.0) + (1.0 - p->alpha_err) * (hy ? std::sqrt(ey2) : 0.0);
+            record(e);
+            if ((prev - e) / at_init < tol) break;
+            prev = e;
+            continue;
+        }
         if (p->solver == CMF_SOLVER_MU) CHK(cmf_mu_step(c, p->l1, p->l2, p->update_mask));
         else if (p->sg_ratio < 1.0)
             CHK(cmf_newton_step_device_sampled(c, p->alpha, p->l1, p->l2, p->x_link, p->y_link, p->nn_mask, p->update_mask, p->hessian_pertubation,

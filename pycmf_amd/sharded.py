@@ -425,24 +425,54 @@ def _release_mu_driver(drv):
 def time_mu_protocols(backend, coll, drivers, iterations=TRIAL_ITERATIONS):
     """Milliseconds per iteration of each driver in `drivers` (name -> ShardedMU) on the LIVE ranks: the factors are saved
     (``backend.snapshot()``), every candidate runs one untimed and `iterations` timed iterations from the same state (stream drained
-    and ranks met on both sides of the timed region, the slowest rank's clock), the factors are restored.  Every rank returns the
-    same numbers (they are max-reduced), so every rank takes the same decision."""
+    and ranks met on both sides of the timed region, the slowest rank's clock), the factors are restored -- also when a candidate
+    raises.  Every rank returns the same numbers (they are max-reduced), so every rank takes the same decision."""
     import time
     saved = backend.snapshot()
     out = {}
-    for name, drv in drivers.items():
-        drv.step(0.0, 0.0, 7)
-        backend.sync()
-        coll.barrier()
-        t0 = time.perf_counter()
-        for _ in range(iterations):
-            drv.step(0.0, 0.0, 7)
-        backend.sync()
-        dt = time.perf_counter() - t0
-        out[name] = float(coll.all_reduce_host([dt], "max")[0]) / iterations * 1e3
-        backend.restore(saved)
-    backend.drop_snapshot(saved)
+    try:
+        for name, drv in drivers.items():
+            try:
+                drv.step(0.0, 0.0, 7)
+                backend.sync()
+                coll.barrier()
+                t0 = time.perf_counter()
+                for _ in range(iterations):
+                    drv.step(0.0, 0.0, 7)
+                backend.sync()
+                dt = time.perf_counter() - t0
+                out[name] = float(coll.all_reduce_host([dt], "max")[0]) / iterations * 1e3
+            finally:
+                backend.restore(saved)
+    finally:
+        backend.drop_snapshot(saved)
     return out
+
+
+def decide_mu_protocol(backend, coll, drivers, iterations=TRIAL_ITERATIONS):
+    """The protocol of a sharded MU fit, by the timed trial -- and north_star's single all-reduce WHENEVER THE TRIAL DOES NOT COME
+    THROUGH: a candidate that raises (an RCCL error of the grouped forms shows on every rank at the same call),
+    a wait that runs into CMF_COMM_TIMEOUT, ranks that cannot agree on the outcome.  Every rank max-reduces a failure flag after
+    its trial, so a failure seen by ONE rank decides for all.  Returns (name, record); the record carries the trial's wall-clock
+    cost in seconds (it runs 2 x (1 + iterations) iterations and saves / restores the factors: a fit pays it once)."""
+    import time
+    t0 = time.perf_counter()
+    failed, why, ms = 0.0, None, None
+    try:
+        ms = time_mu_protocols(backend, coll, drivers, iterations)
+    except Exception as e:
+        failed, why = 1.0, "the timed trial raised %r" % (e,)
+    try:
+        failed = float(coll.all_reduce_host([failed], "max")[0])
+    except Exception as e:
+        failed, why = 1.0, why or "the ranks could not agree on the trial's outcome (%r)" % (e,)
+    seconds = time.perf_counter() - t0
+    if failed:
+        return "allreduce", {"chosen": "allreduce", "reason": why or "the timed trial failed on another rank", "seconds": seconds,
+                             "timed_iterations": iterations}
+    mode = choose_mu_protocol(ms)
+    return mode, {"chosen": mode, "ms_per_iteration": ms, "timed_iterations": iterations, "margin": TRIAL_MARGIN, "seconds": seconds,
+                  "rule": "rsag only if faster than allreduce by more than the margin (tie-break: north_star's single all-reduce)"}
 
 
 def choose_mu_protocol(ms, margin=TRIAL_MARGIN):
@@ -457,9 +487,12 @@ def make_sharded_mu(ctx, coll, chunks=1, mode=None):
       the buffer reduced in that many row blocks, overlapped with the partials of the next block);
     * ``'rsag'``: reduce-scatter -> epilogue on the rank's row block of V -> all-gather, the two k^2 Grams in the same two groups;
     * ``'auto'`` (default; ``PYCMF_AMD_MU_COLLECTIVE`` overrides): both are built, ``TRIAL_ITERATIONS`` iterations of each are timed
-      on the live ranks from the same saved state (``time_mu_protocols``) and the faster one is kept -- the row-blocked form only
-      when it wins by more than ``TRIAL_MARGIN`` and passes the communicator's known-answer test; the decision and both timings
-      are left in ``drv.protocol_trial``."""
+      on the live ranks from the same saved state (``decide_mu_protocol``) and the faster one is kept -- the row-blocked form only
+      when it wins by more than ``TRIAL_MARGIN`` and passes the communicator's known-answer test, the single all-reduce whenever
+      the trial raises, times out or the ranks disagree; the decision, both timings and the trial's cost in seconds are left in
+      ``drv.protocol_trial``.  The choice depends on a wall clock: two fits of the same data may take different protocols, whose
+      results differ by float32 summation order (1e-6); ``PYCMF_AMD_MU_COLLECTIVE=allreduce`` (or the recorded choice) pins it --
+      ``CMF(random_state=...)`` with ``n_gpus > 1`` does so by itself (pycmf_amd/_worker.py)."""
     import os
     backend = HipShardBackend(ctx)
     if coll is None:
@@ -480,11 +513,14 @@ def make_sharded_mu(ctx, coll, chunks=1, mode=None):
             trial = {"chosen": "allreduce", "reason": why}
             mode = "allreduce"
     if mode == "auto":
+        import time
+        t0 = time.perf_counter()
         cands = {"allreduce": _build_mu_driver(ctx, backend, coll, "allreduce"), "rsag": _build_mu_driver(ctx, backend, coll, "rsag")}
-        ms = time_mu_protocols(backend, coll, cands)
-        mode = choose_mu_protocol(ms)
-        trial = {"chosen": mode, "ms_per_iteration": ms, "timed_iterations": TRIAL_ITERATIONS, "margin": TRIAL_MARGIN,
-                 "rule": "rsag only if faster than allreduce by more than the margin (tie-break: north_star's single all-reduce)"}
+        mode, trial = decide_mu_protocol(backend, coll, cands)
+        trial["seconds"] = time.perf_counter() - t0          # the candidates' workspaces included
+        if "reason" in trial:
+            import warnings
+            warnings.warn("pycmf_amd: %s; falling back to the single all-reduce of the MU iteration" % trial["reason"], RuntimeWarning)
         drv = cands.pop(mode)
         for other in cands.values():
             _release_mu_driver(other)
@@ -547,7 +583,7 @@ def _collectives_for(ctx, rank, world):
 
 
 def fit_mu_sharded(X_rows, Y_cols, U_rows, V, Z_rows, l1_reg=0.0, l2_reg=0.0, max_iter=200, tol=1e-4,
-                   device=0, verbose=0, stats=None, rank=None, world=None, update_mask=7):
+                   device=0, verbose=0, stats=None, rank=None, world=None, update_mask=7, collective=None):
     """Data-parallel MU fit: call from every rank (one process per GPU; RANK / WORLD_SIZE from the environment unless given).
 
     Rank g passes its row block of X (and the matching rows of U), the matching column block of Y (and rows
@@ -568,7 +604,16 @@ def fit_mu_sharded(X_rows, Y_cols, U_rows, V, Z_rows, l1_reg=0.0, l2_reg=0.0, ma
     # north_star's single all-reduce then, unless the environment pins a protocol
     import os
     short = max_iter < 8 * (1 + TRIAL_ITERATIONS) and "PYCMF_AMD_MU_COLLECTIVE" not in os.environ
-    drv = make_sharded_mu(ctx, coll, mode="allreduce" if short else None)
+    # ``collective``: a protocol pinned by the caller (the front end pins 'allreduce' for a fit with a random_state: the trial's
+    # choice hangs on a wall clock, and the two protocols differ in float32 summation order -- a seeded fit must not); the
+    # environment variable still wins
+    if collective is not None and "PYCMF_AMD_MU_COLLECTIVE" not in os.environ:
+        drv = make_sharded_mu(ctx, coll, mode=collective)
+    else:
+        drv = make_sharded_mu(ctx, coll, mode="allreduce" if short else None)
+    if stats is not None:
+        stats["mu_protocol"] = getattr(drv, "mode", None)
+        stats["mu_protocol_trial"] = getattr(drv, "protocol_trial", None)
 
     def global_sq():
         sq = np.array(ctx.residual_sq("linear", "linear"))

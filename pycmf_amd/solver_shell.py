@@ -159,6 +159,11 @@ class _HipIterativeSolver:
         self._device_step(l1_reg, l2_reg, alpha)
         self._pull_factors(U, V, Z)
 
+    def _device_step_error(self, l1_reg, l2_reg, alpha):
+        """One update step AND (||X - f(UV^T)||_F, ||Y - f(VZ^T)||_F) of its result in one device call, or None where the solver has
+        no such call (then the caller runs the step and the error pass separately)."""
+        return None
+
     def _device_error(self):
         ex2, ey2 = self._ctx.residual_sq(self.x_link, self.y_link)
         X, Y = self._XY
@@ -202,7 +207,7 @@ class _HipIterativeSolver:
                 every = int(params.get("check_every", 10))
                 for i, (e, t) in enumerate(zip(errs[1:], secs[1:]), start=1):
                     print("Epoch %02d reached after %.3f seconds, error: %f" % (every * i, before_run + t, e))
-                if self.tol == 0 or n_iter % 10 != 0:
+                if self.tol == 0 or n_iter % every != 0:
                     print("Epoch %02d reached after %.3f seconds." % (n_iter, time.time() - start_time))
             self._fit_end()
             self._pull_factors(U, V, Z)
@@ -212,9 +217,14 @@ class _HipIterativeSolver:
 
         n_iter = 0
         for n_iter in range(1, self.max_iter + 1):
-            self._device_step(self.l1_reg, self.l2_reg, self.alpha)
-            if self.tol > 0 and n_iter % 10 == 0:
-                ex, ey = self._device_error()
+            check = self.tol > 0 and n_iter % 10 == 0
+            # (MU: the check iteration is ONE call -- the step and the error of its result from the step's own products,
+            # cmf_mu_step_error -- exactly what the C loop runs, so the two loops stay launch for launch the same)
+            fused = self._device_step_error(self.l1_reg, self.l2_reg, self.alpha) if check else None
+            if fused is None:
+                self._device_step(self.l1_reg, self.l2_reg, self.alpha)
+            if check:
+                ex, ey = fused if fused is not None else self._device_error()
                 error = self.alpha * ex + (1 - self.alpha) * ey
                 if self.verbose:
                     print("Epoch %02d reached after %.3f seconds, error: %f" %
@@ -246,6 +256,11 @@ class HipMUSolver(_HipIterativeSolver):
 
     def _device_step(self, l1_reg, l2_reg, alpha):
         self._ctx.mu_step(l1_reg, l2_reg, self._update_mask())
+
+    def _device_step_error(self, l1_reg, l2_reg, alpha):
+        ex2, ey2 = self._ctx.mu_step_error(l1_reg, l2_reg, self._update_mask())
+        X, Y = self._XY
+        return (np.sqrt(ex2) if X is not None else 0.0), (np.sqrt(ey2) if Y is not None else 0.0)
 
     def _run_params(self):
         return dict(solver="mu", l1=self.l1_reg, l2=self.l2_reg, alpha_err=self.alpha, update_mask=self._update_mask())

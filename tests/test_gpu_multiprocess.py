@@ -323,6 +323,27 @@ def test_dress_rehearsal_eight_ranks_match_one(tmp_path, mode):
         assert np.isfinite(eight["rel_residual"][key]) and abs(eight["rel_residual"][key] - one["rel_residual"][key]) < 0.05 * one["rel_residual"][key]
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_dress_rehearsal_two_and_four_ranks_with_the_default_protocol_trial(tmp_path, world):
+    """the rehearsal at the OTHER rank counts the driver's scaling run takes (N = 2, 4), through the DEFAULT
+    protocol selection -- the timed trial on the live ranks, whose cost is in the line (`protocol_trial.seconds`) -- on one GPU with the
+    host-staged collectives: replicas identical, 16 rows of each factor equal to the single-GPU run's to 1e-5 of the largest entry."""
+    base = ["--steps", "2", "--warmup", "0", "--workload", "c4q", "--no-cpu-baseline"]
+    one = _run_bench(["--gpus", "1", "--dump-rows", str(tmp_path / "one")] + base, {})
+    many = _run_bench(["--gpus", str(world), "--dump-rows", str(tmp_path / "many")] + base,
+                      {"CMF_BENCH_SAME_DEVICE": "1", "CMF_COMM_BACKEND": "host", "CMF_COMM_TIMEOUT": "300"})
+    coll = many["collective"]
+    assert coll["ranks"] == world and coll["replicas"]["identical"], coll
+    trial = coll["protocol_trial"]
+    assert trial["chosen"] == coll["protocol"] and trial["seconds"] > 0 and set(trial["ms_per_iteration"]) == {"allreduce", "rsag"}, trial
+    assert coll["launch_points_per_iteration"] == (1 if coll["protocol"] == "allreduce" else 2)
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "compare_rows.py"), str(tmp_path / "one"), str(tmp_path / "many"),
+                        "--tol", "1e-5"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert q.returncode == 0, q.stdout.decode() + q.stderr.decode()[-2000:]
+    for key in ("x", "y"):
+        assert np.isfinite(many["rel_residual"][key]) and abs(many["rel_residual"][key] - one["rel_residual"][key]) < 0.05 * one["rel_residual"][key]
+
+
 @pytest.mark.parametrize("solver,kw", [("mu", {}), ("newton", dict(y_link="logit", U_non_negative=False, V_non_negative=False,
                                                                  Z_non_negative=False, l2_reg=0.05, alpha=0.4))])
 def test_cmf_n_gpus_through_the_drop_in_api(solver, kw, monkeypatch):

@@ -102,3 +102,58 @@ def test_reference_benchmark_shape_solve_time():
     ctx.close()
     print("solve time, 10 iterations at 2000 x 150 / 150 x 10, k = 10: mu %.2f ms, newton %.2f ms" % (best["mu"] * 1e3, best["newton"] * 1e3))
     assert best["mu"] < 0.02 and best["newton"] < 0.03
+
+
+@pytest.mark.parametrize("k,mask", [(12, 7), (100, 7), (256, 7), (40, 5), (40, 3)])
+def test_step_with_trace_form_error_equals_step_and_error_pass(k, mask):
+    """cmf_mu_step_error: the error metric of the loop's check (pycmf/cmf_solvers.py:36-42, :175-187) from the
+    step's own products, ||X||^2 - 2 <U, X V> + <U^T U, V^T V>, against the NT error pass over X and Y on the same factors --
+    1e-6 relative on the squared residuals (float32 products, float64 sums) -- and the factors of the step itself against the plain
+    step's.  mask 5 / 3: a factor that is not updated has no numerator product to reuse: that side takes the NT pass."""
+    from pycmf_amd import _lib
+    X, Y, F0 = _problem(3, 700, 330, 210, k)
+    res = {}
+    for fused in (1, 0):
+        ctx = _lib.Context(0)
+        ctx.set_problem(700, 330, 210, k)
+        ctx.set_data(0, X); ctx.set_data(1, Y)
+        for w, F in enumerate(F0):
+            ctx.set_factor(w, F)
+        for _ in range(3):
+            ctx.mu_step(0.01, 0.02, 7)
+        if fused:
+            sq = ctx.mu_step_error(0.01, 0.02, mask)
+        else:
+            ctx.mu_step(0.01, 0.02, mask)
+            sq = ctx.residual_sq("linear", "linear")
+        res[fused] = (sq, [ctx.get_factor(w) for w in range(3)])
+        ctx.close()
+    for a, b in zip(res[1][0], res[0][0]):
+        assert abs(a - b) <= 1e-6 * b, (res[1][0], res[0][0])
+    for a, b in zip(res[1][1], res[0][1]):
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-6 * np.abs(b).max())
+
+
+def test_trace_form_falls_back_where_the_expansion_would_cancel():
+    """An (almost) exact fit: e^2 << 1e-3 ||X||^2 -- the expansion's three terms of size ||X||^2 cannot resolve it in float32; the
+    call must return what the NT pass returns (it IS the NT pass then)."""
+    from pycmf_amd import _lib
+    rng = np.random.RandomState(2)
+    U, V, Z = np.abs(rng.randn(300, 5)), np.abs(rng.randn(200, 5)), np.abs(rng.randn(120, 5))
+    X, Y = U @ V.T, V @ Z.T
+    out = {}
+    for fused in (1, 0):
+        ctx = _lib.Context(0)
+        ctx.set_problem(300, 200, 120, 5)
+        ctx.set_data(0, X); ctx.set_data(1, Y)
+        for w, F in enumerate((U * 1.001, V, Z * 0.999)):
+            ctx.set_factor(w, F)
+        if fused:
+            out[fused] = ctx.mu_step_error(0.0, 0.0, 7)
+        else:
+            ctx.set_option("trace_error", 0)
+            out[fused] = ctx.mu_step_error(0.0, 0.0, 7)
+        ctx.close()
+    assert out[1][0] < 1e-3 * (X ** 2).sum()
+    for a, b in zip(out[1], out[0]):
+        assert abs(a - b) <= 1e-5 * b + 1e-12, out
