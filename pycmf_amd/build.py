@@ -65,7 +65,7 @@ def needs_build():
 
 def build(force=False, verbose=False, diag=False):
     """diag: also compile the timing-only diagnostic kernel variants (row_diag / chol_diag / cmf_debug_clock: wrong results,
-    tools/archive/probe_*.py); the default product build does not carry them."""
+    their probe scripts left the tree in round 6: git history); the default product build does not carry them."""
     if not force and not diag and not needs_build():
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",

@@ -450,6 +450,73 @@ def test_c3_full_size_newton_sampled_rows_vs_fp64(lib, monkeypatch, x_link):
     ctx.close()
 
 
+def test_c3_full_size_in_the_clamp_regime_rows_vs_fp64(lib, monkeypatch):
+    """BASELINE configs[2] at the reference's DEFAULT l2_reg = 0 (pycmf/cmf.py:622) where it actually lives: from
+    iteration 7 on `_safe_invert`'s clamp (pycmf/cmf_solvers.py:346-356) acts on EVERY row of U and Z -- 255 of 256 eigenvalues
+    of each Hessian below the perturbation (tools/r06_spectrum_probe.py).  Ten iterations on the device, then the sweeps of the
+    eleventh one by one: 12 rows of each factor against the oracle's per-row float64 arithmetic on the lists the device drew, at
+    the full-size tolerance (2e-3 of the factor's largest entry: float32 Hessians of ||H|| / pert = 1e4), the clamp asserted to
+    have acted on every row of the U and Z sweeps (in float32, or redone in float64 where the error bound asked for it)."""
+    from oracle import cmf_oracle as O
+    from threadpoolctl import threadpool_limits
+    m, d, p, k = 32768, 16384, 8192, 256
+    alpha, l1, l2, pert, ratio = 0.5, 0.0, 0.0, 0.2, 0.5
+    rng = np.random.RandomState(2)
+    ctx = _synthetic(lib, m, d, p, k)
+    ctx.fill_data_synthetic(1, 43, 0, 0, 1)
+    for it in range(10):
+        ctx.newton_step_device_sampled(alpha, l1, l2, "linear", "logit", 0, 7, pert, ratio, 1000 + it)
+    before = ctx.newton_clamp_stats(full=True)
+    seed = 1010
+    limit = threadpool_limits(limits=1)
+    U0, V0, Z0 = (ctx.get_factor(w) for w in range(3))
+
+    def tol(ref):
+        return dict(rtol=0, atol=2e-3 * np.abs(ref).max())
+
+    ctx.newton_step_device_sampled(alpha, l1, l2, "linear", "logit", 0, lib.CMF_UPD_U, pert, ratio, seed)
+    after_u = ctx.newton_clamp_stats(full=True)
+    assert (after_u[0] - before[0]) + (after_u[2] - before[2]) == m, (before, after_u)     # every row of U: clamped (float32) or refined
+    U1 = ctx.get_factor(0)
+    rows = _spread(m, 12, rng)
+    lists = [ctx.sample_lists(0, seed, ratio, i, 1)[0] for i in rows]
+    Xs = np.vstack([ctx.get_data_block(0, i, 1, 0, d) for i in rows]).astype(np.float64)
+    Us = U0[rows].copy()
+    _feed(monkeypatch, O, lists)
+    O.newton_sweep_U(Us, V0, Xs, alpha, l1, l2, "linear", False, ratio, pert)
+    np.testing.assert_allclose(U1[rows], Us, **tol(Us))
+    below = [int((np.linalg.eigvalsh(alpha * V0[s].T @ V0[s]) < pert).sum()) for s in lists[:2]]
+    assert min(below) >= 200, below                        # the regime itself: nearly the whole spectrum under the threshold
+    assert np.abs(U1[rows] - U0[rows]).max() > 1e-4 * np.abs(U0).max()
+
+    ctx.newton_step_device_sampled(alpha, l1, l2, "linear", "logit", 0, lib.CMF_UPD_Z, pert, ratio, seed)
+    after_z = ctx.newton_clamp_stats(full=True)
+    assert (after_z[0] - after_u[0]) + (after_z[2] - after_u[2]) == p, (after_u, after_z)
+    Z1 = ctx.get_factor(2)
+    cols = _spread(p, 12, rng)
+    lists = [ctx.sample_lists(1, seed, ratio, c, 1)[0] for c in cols]
+    Ys = np.hstack([ctx.get_data_block(1, 0, d, c, 1) for c in cols]).astype(np.float64)
+    Zs = Z0[cols].copy()
+    _feed(monkeypatch, O, lists)
+    O.newton_sweep_Z(Zs, V0, Ys, alpha, l1, l2, "logit", False, ratio, pert)
+    np.testing.assert_allclose(Z1[cols], Zs, **tol(Zs))
+
+    ctx.newton_step_device_sampled(alpha, l1, l2, "linear", "logit", 0, lib.CMF_UPD_V, pert, ratio, seed)
+    V1 = ctx.get_factor(1)
+    rows = _spread(d, 12, rng)
+    lists = []
+    for q in rows:
+        lists += [ctx.sample_lists(2, seed, ratio, q, 1)[0], ctx.sample_lists(3, seed, ratio, q, 1)[0]]
+    Xs = np.hstack([ctx.get_data_block(0, 0, m, q, 1) for q in rows]).astype(np.float64)
+    Ys = np.vstack([ctx.get_data_block(1, q, 1, 0, p) for q in rows]).astype(np.float64)
+    Vs = V0[rows].copy()
+    _feed(monkeypatch, O, lists)
+    O.newton_sweep_V(Vs, U1, Z1, Xs, Ys, alpha, l1, l2, "linear", "logit", False, ratio, pert)
+    np.testing.assert_allclose(V1[rows], Vs, **tol(Vs))
+    limit.restore_original_limits()
+    ctx.close()
+
+
 def _c5_problem(lib, y_kind=0, y_param=0.0):
     import scipy.sparse as sp
     m, d, p, k, npr = 1000000, 100000, 64, 256, 100

@@ -151,3 +151,59 @@ def test_sub_problem_residual_parity_4_iterations(lib, monkeypatch, x_link, l2):
         assert st[0] + st[2] > 0, "l2 = 0: the clamp of _safe_invert never acted (neither in float32 nor in the float64 refinement)"
     print("sub-problem, x %s, l2 %g: residuals X %.6f / %.6f, Y %.6f / %.6f (device / oracle), factors within %.2e of max |ref|; "
           "clamped rows %d, refined %d" % (x_link, l2, out[0][0], out[0][1], out[1][0], out[1][1], fac, st[0], st[2]))
+
+
+def test_sub_problem_twelve_iterations_refinement_on_and_off(lib, monkeypatch):
+    """the sub-problem at the reference's default l2 = 0 along TWELVE iterations of the float64 oracle's
+    trajectory (x linear, y logit; every per-row Hessian under `_safe_invert`'s clamp), the device run with the float64 refinement
+    on (default: decided per row by the error bound of its float32 step) AND off.  Iteration by iteration from the ORACLE's
+    iterate: the undamped iteration of this problem (288 samples for 256 components, no regularisation) doubles any perturbation
+    per iteration -- float32 rounding of the data passes alone (3e-5 on the factors after one step) reaches 0.2 after twelve, with
+    round 5's kernels exactly as with these (tests/tools/r06_subproblem_trace.py) -- so a free-running comparison over twelve
+    iterations says nothing about the clamp; twelve single steps through the clamp regime do.  Bars: both relative residuals within
+    1e-4 relative of the oracle's after every step (north_star), factors within 2e-3 of the largest entry."""
+    from oracle import cmf_oracle as O
+    m, d, p, k = 640, 576, 320, 256
+    alpha, l1, l2, pert, ratio, iters = 0.5, 0.0, 0.0, 0.2, 0.5, 12
+    names = ("default", "refine_rows=0")
+    ctxs = {"default": _synthetic(lib, m, d, p, k), "refine_rows=0": _synthetic(lib, m, d, p, k, options=(("refine_rows", 0),))}
+    X = ctxs["default"].get_data(0).astype(np.float64)
+    Y = ctxs["default"].get_data(1).astype(np.float64)
+    U, V, Z = (ctxs["default"].get_factor(w) for w in range(3))
+    sig = lambda t: 1.0 / (1.0 + np.exp(-t))
+    ident = lambda t: t
+    worst = {n: [0.0, 0.0] for n in names}
+    for it in range(1, iters + 1):
+        seed = 700 + it
+        got = {}
+        for n in names:
+            for w, F in enumerate((U, V, Z)):
+                ctxs[n].set_factor(w, F)                  # from the oracle's iterate
+            ctxs[n].newton_step_device_sampled(alpha, l1, l2, "linear", "logit", 0, 7, pert, ratio, seed)
+            got[n] = [ctxs[n].get_factor(w) for w in range(3)]
+        c = ctxs["default"]
+        lists = [row for row in c.sample_lists(0, seed, ratio, 0, m)] + [row for row in c.sample_lists(1, seed, ratio, 0, p)]
+        lx, ly = c.sample_lists(2, seed, ratio, 0, d), c.sample_lists(3, seed, ratio, 0, d)
+        for q in range(d):
+            lists += [lx[q], ly[q]]
+        _feed(monkeypatch, O, lists)
+        with _one_thread():
+            O.newton_update_step(X, Y, U, V, Z, alpha, l1, l2, "linear", "logit", False, False, False, ratio=ratio, pert=pert)
+        for n in names:
+            Ug, Vg, Zg = got[n]
+            for T, L, R, Lo, Ro, f in ((X, Ug, Vg, U, V, ident), (Y, Vg, Zg, V, Z, sig)):
+                rg = np.linalg.norm(T - f(L @ R.T)) / np.linalg.norm(T)
+                ro = np.linalg.norm(T - f(Lo @ Ro.T)) / np.linalg.norm(T)
+                worst[n][0] = max(worst[n][0], abs(rg - ro) / ro)
+                assert abs(rg - ro) <= 1e-4 * ro, "%s, iteration %d: relative residual %.8f (device) vs %.8f (float64 oracle)" % (n, it, rg, ro)
+            fac = max(np.abs(a - b).max() / np.abs(b).max() for a, b in ((Ug, U), (Vg, V), (Zg, Z)))
+            worst[n][1] = max(worst[n][1], fac)
+            assert fac <= 2e-3, "%s, iteration %d: factors %.2e of max |ref|" % (n, it, fac)
+    for n in names:
+        st = ctxs[n].newton_clamp_stats(full=True)
+        assert st[0] + st[2] > 0, "the clamp never acted"
+        if n != "default":
+            assert st[2] == 0
+        print("sub-problem, 12 steps along the oracle's trajectory, %s: residuals within %.1e, factors within %.1e of max |ref|; clamped rows %d, "
+              "refined %d" % (n, worst[n][0], worst[n][1], st[0], st[2]))
+        ctxs[n].close()
