@@ -57,6 +57,17 @@ WORKLOADS = {
                nnz_per_row=100,
                desc="BASELINE configs[4]: CSR X 1e6 x 1e5 at 0.1% nnz (100 per row, values 1.0, native CSR), "
                     "dense Y 1e5 x 64, n_components=256, newton solver, linear links"),
+    "c5z": dict(m=1000000, d=100000, p=64, k=256, solver="newton", x_link="linear", y_link="linear", ratio=1.0,
+                nnz_per_row=100, zipf=1.1,
+                desc="BASELINE configs[4] with bag-of-words column statistics: CSR X 1e6 x 1e5, 100 non-zeros per row (values 1.0, native "
+                     "CSR) whose columns follow Zipf(1.1) popularity over a randomly ordered vocabulary (samples/toxic_comments.ipynb:"
+                     "446-465: word counts are Zipfian; uniformly scattered columns, workload c5, are the worst case for the SpMM's "
+                     "gathers), dense Y 1e5 x 64, n_components=256, newton solver, linear links"),
+    "c5zs": dict(m=1000000, d=100000, p=64, k=256, solver="newton", x_link="linear", y_link="linear", ratio=1.0,
+                 nnz_per_row=100, zipf=1.1, zipf_sorted=True,
+                 desc="c5z with the vocabulary ordered by popularity (hot columns first): what a relabelling of V's rows at upload would "
+                      "give the SpMM; CSR X 1e6 x 1e5, 100 non-zeros per row, Zipf(1.1) columns, dense Y 1e5 x 64, n_components=256, "
+                      "newton solver, linear links"),
     "c5l": dict(m=1000000, d=100000, p=64, k=256, solver="newton", x_link="linear", y_link="logit", ratio=1.0,
                 nnz_per_row=100, l1=2.0, l2=5.0, nn_mask=3, y_kind=2, y_param=0.1, may_diverge=True,
                 desc="BASELINE configs[4] with the reference's own Newton settings (samples/toxic_comments.ipynb:853-856: "
@@ -330,8 +341,29 @@ def main():
         else:
             rng = np.random.default_rng(42 + rank)
             rows = r1 - r0
-            X = sp.csr_matrix((np.ones(rows * npr), rng.integers(0, d, size=rows * npr, dtype=np.int32),
-                               np.arange(0, rows * npr + 1, npr, dtype=np.int64)), shape=(rows, d))
+            if "zipf" in w:
+                # columns by popularity rank ~ Zipf(s) (inverse CDF), duplicates inside a row re-drawn uniformly (binary bag of words:
+                # a word counts once per document), the vocabulary in random order unless zipf_sorted
+                wgt = 1.0 / np.arange(1, d + 1, dtype=np.float64) ** w["zipf"]
+                cdf = np.cumsum(wgt)
+                cdf /= cdf[-1]
+                cols = np.empty(rows * npr, dtype=np.int32)
+                step = 1 << 24
+                for a in range(0, rows * npr, step):
+                    cols[a:a + step] = np.searchsorted(cdf, rng.random(min(step, rows * npr - a)), side="right").astype(np.int32)
+                np.minimum(cols, d - 1, out=cols)
+                cols = cols.reshape(rows, npr)
+                cols.sort(axis=1)
+                dup = np.zeros(cols.shape, dtype=bool)
+                dup[:, 1:] = cols[:, 1:] == cols[:, :-1]
+                cols[dup] = rng.integers(0, d, size=int(dup.sum()), dtype=np.int32)
+                if not w.get("zipf_sorted"):
+                    cols = np.random.default_rng(7).permutation(d).astype(np.int32)[cols]
+                X = sp.csr_matrix((np.ones(rows * npr), cols.reshape(-1), np.arange(0, rows * npr + 1, npr, dtype=np.int64)), shape=(rows, d))
+                del cols, dup
+            else:
+                X = sp.csr_matrix((np.ones(rows * npr), rng.integers(0, d, size=rows * npr, dtype=np.int32),
+                                   np.arange(0, rows * npr + 1, npr, dtype=np.int64)), shape=(rows, d))
         ctx.set_option("sparse_mode", 2)
         ctx.set_data(0, X)
         del X
@@ -424,16 +456,19 @@ def main():
             st = ctx.newton_clamp_stats(full=True)
             return (st[0], st[2])
         prev = clamp_counts()
-        last = None
+        last, same = None, 0
         while warm_extra < args.max_warmup:
             do_step(args.warmup + warm_extra)
             warm_extra += 1
             cur = clamp_counts()
             delta = (cur[0] - prev[0], cur[1] - prev[1])
             prev = cur
-            if last is not None and delta == last:
-                break
+            same = same + 1 if (last is not None and delta == last) else 0
             last = delta
+            # (C3 idles at "8192 rows of Z clamped" for iterations 3-6 before every row of U joins at the seventh: two equal
+            # iterations in a row are no steady state -- at least 12 iterations in all, then three alike)
+            if same >= 2 and args.warmup + warm_extra >= min(12, args.max_warmup):
+                break
         args.warmup += warm_extra
     for c_ in ctxs:
         c_.kernel_timing(2)        # HIP events around the data-pass launches only (the class the roofline prices): an event pair per

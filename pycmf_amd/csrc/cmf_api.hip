@@ -214,7 +214,7 @@ struct cmf_ctx {
     DevBuf nsidx, nsws;                   // Newton-Schulz clamp: flagged-row list + counters, matrix workspaces
     DevBuf eigcl_snap;                    // snapshot of a chunk's flags (which matrices the clamp acted on) for the refinement's error-bound test
     DevBuf eigcl_ws, eigcl_log, eigcl_fail; // tridiagonal eigen-clamp (cmf_eigclamp.hip.h): d / e / Q^T g / tau, rotation logs, per-matrix give-up flags
-    int opt_eig_clamp = 1;                // flagged per-row Hessians at k_pad 128 / 256: Householder + QL solve on the vector units (0: Newton-Schulz polynomials / Jacobi)
+    int opt_eig_clamp = 1;                // flagged per-row Hessians at k_pad 128 / 256: Householder + QL solve on the vector units (0: Newton-Schulz polynomials / Jacobi; 3: without the early exit of the QL iteration)
     int64_t eig_clamp_rows = 0;           // matrices served by it since the context was created (tests / bench)
     DevBuf g64a, g64b, gmix64, h64;       // float64 Grams / shared Hessian of the linear-link Newton sweeps (cmf_shared64.hip.h)
     DevBuf gslab64, w64, ns64;            // their split slabs, Cholesky workspaces + L^-1 image, Newton-Schulz images

@@ -263,7 +263,7 @@ struct EigSweep { int ihi, ilo; int64_t pos; };
 
 template <int NP>
 __global__ __launch_bounds__(64) void eig_ql_kernel(float *ws, int64_t NB, int nb, int n, float pert, float4 *lg, int64_t cap, EigSweep *sw_all,
-                                                    int sw_cap, int *fail, float *lam_out, long long *stats) {
+                                                    int sw_cap, int *fail, float *lam_out, long long *stats, int early_exit) {
     constexpr int CH = 16, RC = 32; // elements read ahead of the sweep (LDS), trips of log read ahead of a replay (global)
     extern __shared__ float eig_lds[];
     const int lane = threadIdx.x, b = blockIdx.x * 64 + lane;
@@ -293,6 +293,45 @@ __global__ __launch_bounds__(64) void eig_ql_kernel(float *ws, int64_t NB, int n
         if (q_ >= n - 1) return true;
         return negl(E[q_ * 64], D[q_ * 64], D[(q_ + 1) * 64]);
     };
+    // ---- how much of the spectrum does the solve need?  f(x) = 1 / max(|x|, pert) is CONSTANT on (-pert, pert) and 1 / x above: once
+    // the eigenvalues still to be found (those of the trailing block [l, n): QL deflates at the top) all lie inside (-pert, pert),
+    // f of that block is I / pert, and once they all lie above pert it is the block's inverse, a positive definite tridiagonal solve
+    // -- either way the iteration can stop.  Sturm counts at +-pert say how many eigenvalues are inside / above / below; every
+    // eigenvalue the iteration finds is taken off its count.  (A count and the iteration can disagree only about an eigenvalue within
+    // round-off of the threshold, where the two treatments agree to round-off: f is continuous.)  While one side is a small
+    // minority its eigenvalues are looked for FIRST: the first sweep for a new eigenvalue takes a bound of the spectrum (or zero) as
+    // its shift instead of Wilkinson's.  C3 at the reference's default l2 = 0 (one eigenvalue of 2e3, 255 under the threshold):
+    // three sweeps instead of 320.
+    int rem_in = 0, rem_pos = 0, rem_neg = 0;
+    auto sturm = [&](int l0, float sg, int &below_pos, int &below_neg) { // eigenvalues of T[l0:n, l0:n] below +sg / below -sg
+        float qp = D[l0 * 64] - sg, qm = D[l0 * 64] + sg;
+        int cp = qp < 0.f, cm = qm < 0.f;
+        for (int i = l0 + 1; i < n; ++i) {
+            const float di = D[i * 64], e2 = E[(i - 1) * 64] * E[(i - 1) * 64];
+            if (fabsf(qp) < 1e-30f) qp = -1e-30f;
+            if (fabsf(qm) < 1e-30f) qm = -1e-30f;
+            qp = di - sg - e2 / qp;
+            qm = di + sg - e2 / qm;
+            cp += qp < 0.f;
+            cm += qm < 0.f;
+        }
+        below_pos = cp; below_neg = cm;
+    };
+    {
+        int cp, cm;
+        sturm(0, pert, cp, cm);
+        rem_neg = cm; rem_in = cp - cm; rem_pos = n - cp;
+    }
+    bool seed_ok_top = true;
+    float top = anorm; // upper bound of the eigenvalues still to be found above pert: the last one found there
+    auto take = [&](float lam) { // an eigenvalue found: off its count
+        if (lam > pert && seed_ok_top) top = fminf(top, lam);
+        if (lam > pert) --rem_pos;
+        else if (lam < -pert) --rem_neg;
+        else --rem_in;
+    };
+    int mode = 0, lstop = n;     // mode 1: the block [lstop, n) is left tridiagonal, all its eigenvalues inside (-pert, pert); 2: all above pert
+    bool seed_ok = true;
     int l = 0, m = -1, mlow = -1, iter = 0, nsw = 0;
     int64_t pos = 0;
     long long lane_rot = 0, wave_trips = 0;
@@ -301,21 +340,35 @@ __global__ __launch_bounds__(64) void eig_ql_kernel(float *ws, int64_t NB, int n
     for (;;) {
         // ---- per lane: advance over converged eigenvalues, settle the block [l, m] of the next sweep
         if (!done) {
-            if (conv) { ++l; iter = 0; conv = false; }
+            if (conv) { take(D[l * 64]); ++l; iter = 0; conv = false; }
             for (;;) {
                 if (l >= n) { done = true; break; }
+                if (early_exit && rem_neg <= 0 && (rem_pos <= 0 || rem_in <= 0)) {
+                    // by the bookkeeping the rest of the spectrum is one-sided.  COUNT AGAIN on the block itself before stopping: an
+                    // eigenvalue within round-off of the threshold may have been booked on the other side than the first count had
+                    // it -- harmless for that eigenvalue, but it leaves the wrong side one short, and the eigenvalue that then
+                    // remains (any value at all) would get the wrong treatment
+                    int cp, cm;
+                    sturm(l, pert, cp, cm);
+                    rem_neg = cm; rem_in = cp - cm; rem_pos = (n - l) - cp;
+                    if (rem_neg == 0 && (rem_pos == 0 || rem_in == 0)) {
+                        mode = rem_pos == 0 ? 1 : 2; lstop = l; done = true;
+                        break;
+                    }
+                }
                 if (l > m) { // a new block: first negligible off-diagonal element at or after l
                     int q_ = l;
                     while (!negl_mem(q_)) ++q_;
                     m = q_; mlow = -1;
                 }
-                if (l == m) { ++l; iter = 0; continue; } // e[l] negligible: d[l] is an eigenvalue
+                if (l == m) { take(D[l * 64]); ++l; iter = 0; continue; } // e[l] negligible: d[l] is an eigenvalue
                 if (mlow >= 0 && mlow < l) mlow = -1;
-                if (iter == 0 && (mlow == l || negl_mem(l))) { ++l; continue; }
+                if (iter == 0 && (mlow == l || negl_mem(l))) { take(D[l * 64]); ++l; continue; }
                 if (mlow > l) { m = mlow; mlow = -1; }
                 break;
             }
             if (!done && ++iter > 60) { bad = true; done = true; }
+            if (iter > 10) seed_ok = false; // a bound as shift did not single out an eigenvalue (no gap): Wilkinson shifts from now on
         }
         const bool active = !done;
         int ihi = active ? m - 1 : -1, ilo = active ? l : n;
@@ -342,7 +395,17 @@ __global__ __launch_bounds__(64) void eig_ql_kernel(float *ws, int64_t NB, int n
             const float dl = D[l * 64], el = E[l * 64];
             g = (D[(l + 1) * 64] - dl) * __builtin_amdgcn_rcpf(2.0f * el);
             const float r = __builtin_amdgcn_sqrtf(g * g + 1.0f);
-            g = D[m * 64] - dl + el * __builtin_amdgcn_rcpf(g + copysignf(r, g));
+            const float gw = g, dm = D[m * 64];
+            g = dm - dl + el * __builtin_amdgcn_rcpf(gw + copysignf(r, gw)); // Wilkinson: the eigenvalue of the top 2 x 2 block nearer d[l]
+            const int outside = rem_pos + rem_neg, minority = min(rem_in, outside);
+            if (early_exit && seed_ok && minority > 0 && minority * 8 <= n - l) { // the minority side first (see above)
+                // first sweep: a bound of the spectrum (or zero) as shift; then the eigenvalue of the top 2 x 2 block on the WANTED
+                // side (Wilkinson's choice, the one nearer d[l], wanders off to whatever the block happens to be near)
+                const float target = outside <= rem_in ? (rem_pos > 0 ? top : -anorm) : 0.f; // (found in descending order: the last one bounds the rest)
+                const float k1 = dl - el * __builtin_amdgcn_rcpf(gw + r), k2 = dl - el * __builtin_amdgcn_rcpf(gw - r);
+                const float ks = fabsf(k1 - target) <= fabsf(k2 - target) ? k1 : k2;
+                g = dm - (iter == 1 ? target : ks);
+            }
         }
         mlow = -1;
         // ---- the sweep: i = ihi .. ilo for the whole wave.  One trip is straight-line code: every lane computes the rotation,
@@ -414,6 +477,24 @@ __global__ __launch_bounds__(64) void eig_ql_kernel(float *ws, int64_t NB, int n
         if (uflow) { m = l - 1; --iter; }                 // underflow: the next settle re-scans from l
     }
     const long long t_ql = stats ? (long long)__builtin_readcyclecounter() : 0;
+    // ---- a block left tridiagonal with its spectrum above pert: factor it now (T = L diag(q) L^T, positive definite: no pivoting),
+    // pivots over d, multipliers to global memory (e's place in LDS is about to hold r)
+    const float delta = 4.0f * 1.1920929e-7f * anorm;
+    float rest_low = 3.0e38f; // smallest |eigenvalue| the block [lstop, n) may hold that is not safely clamped
+    if (mode == 2) {
+        float q = D[lstop * 64];
+        for (int i = lstop + 1; i < n; ++i) {
+            const float ei = E[(i - 1) * 64], mi = ei / q;
+            eT[(size_t)i * NB] = mi;
+            q = D[i * 64] - mi * ei;
+            D[i * 64] = q;
+        }
+        rest_low = pert;
+    } else if (mode == 1) { // inside (-pert, pert): all of it safely (by delta) inside?
+        int cp, cm;
+        sturm(lstop, pert - delta, cp, cm);
+        if (cp - cm != n - lstop) rest_low = pert - delta;
+    }
     // ---- r = Z^T gt (forward replay), scale by f(lambda), y = Z r (backward replay); r takes e's place in LDS
     float *Rv = E;
     for (int q = 0; q < n; ++q) Rv[q * 64] = gT[(size_t)q * NB];
@@ -448,14 +529,31 @@ __global__ __launch_bounds__(64) void eig_ql_kernel(float *ws, int64_t NB, int n
     // so the relative error of the step is bounded by delta / (smallest |lambda| that is NOT safely clamped) -- and by zero when
     // every eigenvalue is: then max(H, pert I) = pert I whatever the rounding.  (C3 at the reference's default l2 = 0, steady state:
     // one eigenvalue of 2e3 and 255 below pert: 1e-6, although ||H|| / pert = 1e4.)
-    const float delta = 4.0f * 1.1920929e-7f * anorm;
-    float minabove = 3.0e38f;
-    for (int q = 0; q < n; ++q) {
+    float minabove = rest_low;
+    for (int q = 0; q < lstop; ++q) {
         const float lam = D[q * 64], al = fabsf(lam);
         if (al >= pert - delta) minabove = fminf(minabove, al);
         Rv[q * 64] = Rv[q * 64] / fmaxf(al, pert);
         if (lam_out && live) lam_out[(size_t)b * NP + q] = lam;
     }
+    if (mode == 1) {
+        const float ip = 1.0f / pert;
+        for (int q = lstop; q < n; ++q) Rv[q * 64] *= ip;
+    } else if (mode == 2) { // L z = r, y = L^-T diag(1 / q) z
+        float z = Rv[lstop * 64];
+        for (int i = lstop + 1; i < n; ++i) {
+            z = Rv[i * 64] - eT[(size_t)i * NB] * z;
+            Rv[i * 64] = z;
+        }
+        float y = Rv[(n - 1) * 64] / D[(n - 1) * 64];
+        Rv[(n - 1) * 64] = y;
+        for (int i = n - 2; i >= lstop; --i) {
+            y = Rv[i * 64] / D[i * 64] - eT[(size_t)(i + 1) * NB] * y;
+            Rv[i * 64] = y;
+        }
+    }
+    if (lam_out && live)
+        for (int q = lstop; q < n; ++q) lam_out[(size_t)b * NP + q] = __int_as_float(0x7fc00000); // (not computed: the iteration stopped)
     if (live) ws[(size_t)4 * NP * NB + b] = minabove < 3.0e38f ? delta / fmaxf(minabove, 1e-30f) : 0.f;
     for (int t = nsw - 1; t >= 0; --t) {
         // ascending i = ilo .. ihi: trip index ihi - i descends; chunks of RC trips aligned to the pairs of the forward order
@@ -493,8 +591,11 @@ __global__ __launch_bounds__(64) void eig_ql_kernel(float *ws, int64_t NB, int n
     if (stats) { // (measurement: sweeps and trips of the wave, rotations of the lane's own blocks)
         for (int off = 32; off > 0; off >>= 1) lane_rot += __shfl_xor(lane_rot, off, 64);
         const long long t_end = (long long)__builtin_readcyclecounter();
-        if (lane == 0) { stats[6 * blockIdx.x] = nsw; stats[6 * blockIdx.x + 1] = wave_trips; stats[6 * blockIdx.x + 2] = lane_rot;
-                         stats[6 * blockIdx.x + 3] = t_ql - t_start; stats[6 * blockIdx.x + 4] = t_fwd - t_ql; stats[6 * blockIdx.x + 5] = t_end - t_fwd; }
+        long long n1 = live && mode == 1, n2 = live && mode == 2, ls = live ? lstop : 0;
+        for (int off = 32; off > 0; off >>= 1) { n1 += __shfl_xor(n1, off, 64); n2 += __shfl_xor(n2, off, 64); ls += __shfl_xor(ls, off, 64); }
+        if (lane == 0) { stats[9 * blockIdx.x] = nsw; stats[9 * blockIdx.x + 1] = wave_trips; stats[9 * blockIdx.x + 2] = lane_rot;
+                         stats[9 * blockIdx.x + 3] = t_ql - t_start; stats[9 * blockIdx.x + 4] = t_fwd - t_ql; stats[9 * blockIdx.x + 5] = t_end - t_fwd;
+                         stats[9 * blockIdx.x + 6] = n1; stats[9 * blockIdx.x + 7] = n2; stats[9 * blockIdx.x + 8] = ls; }
     }
 }
 

@@ -287,7 +287,7 @@ static int ns_clamp_images(cmf_ctx *c, const float *Hc, const int *idx, int nf, 
 // eigen-solve of cmf_eigclamp.hip.h (H is not modified).  Serves any symmetric H (|lambda| as
 // pycmf/cmf_solvers.py:353), k_pad 128 / 256.  flags (nullable): cleared for every matrix served; one the QL iteration gave up on
 // keeps its flag for the caller's fallback.
-static bool eig_clamp_ok(const cmf_ctx *c, int n, int kp) { return c->opt_eig_clamp && (kp == 256 || kp == 128) && n > 64; }
+static bool eig_clamp_ok(const cmf_ctx *c, int n, int kp) { return (c->opt_eig_clamp & 1) && (kp == 256 || kp == 128) && n > 64; }
 static int eig_clamp_solve(cmf_ctx *c, const float *Hc, const int *idx, int nf, const float *grad, float *step, int *flags, int n, int kp,
                            double pert, float *lam_out = nullptr, float *sens_out = nullptr) {
     if (nf <= 0) return CMF_OK;
@@ -311,7 +311,7 @@ static int eig_clamp_solve(cmf_ctx *c, const float *Hc, const int *idx, int nf, 
     int *failf = (int *)c->eigcl_fail.p;
     static const bool want_stats = getenv("CMF_EIG_STATS") != nullptr; // (measurement: sweeps / trips per wave on stderr)
     long long *qstats = nullptr;
-    if (want_stats) HIPCHK(hipMalloc((void **)&qstats, (size_t)(NB / 64) * 6 * sizeof(long long)));
+    if (want_stats) HIPCHK(hipMalloc((void **)&qstats, (size_t)(NB / 64) * 9 * sizeof(long long)));
     for (int b0 = 0; b0 < nf; b0 += bmax) {
         const int nb = std::min(bmax, nf - b0);
         const int *ib = idx ? idx + b0 : nullptr;
@@ -325,25 +325,30 @@ static int eig_clamp_solve(cmf_ctx *c, const float *Hc, const int *idx, int nf, 
         if (kp == 256) {
             CHK(allow_big_lds(c, reinterpret_cast<const void *>(&eig_ql_kernel<256>), (int)ql_lds));
             hipLaunchKernelGGL(eig_tridiag_kernel<256>, dim3((unsigned)nb), dim3(512), 0, c->stream, Hb, ib, gb, n, stride, ws, NB, refl);
-            hipLaunchKernelGGL(eig_ql_kernel<256>, dim3((unsigned)((nb + 63) / 64)), dim3(64), ql_lds, c->stream, ws, NB, nb, n, (float)pert, lg, cap, sw, sw_cap, failf, lam, qstats);
+            hipLaunchKernelGGL(eig_ql_kernel<256>, dim3((unsigned)((nb + 63) / 64)), dim3(64), ql_lds, c->stream, ws, NB, nb, n, (float)pert, lg, cap, sw, sw_cap, failf, lam, qstats, (c->opt_eig_clamp & 2) ? 0 : 1);
             hipLaunchKernelGGL(eig_backtransform_kernel<256>, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, c->stream, (const float *)refl, ib, nb, n,
                                (const float *)ws, NB, (const int *)failf, sb, fb, idx ? sens_out : (sens_out ? sens_out + b0 : (float *)nullptr));
         } else {
             CHK(allow_big_lds(c, reinterpret_cast<const void *>(&eig_ql_kernel<128>), (int)ql_lds));
             hipLaunchKernelGGL(eig_tridiag_kernel<128>, dim3((unsigned)nb), dim3(512), 0, c->stream, Hb, ib, gb, n, stride, ws, NB, refl);
-            hipLaunchKernelGGL(eig_ql_kernel<128>, dim3((unsigned)((nb + 63) / 64)), dim3(64), ql_lds, c->stream, ws, NB, nb, n, (float)pert, lg, cap, sw, sw_cap, failf, lam, qstats);
+            hipLaunchKernelGGL(eig_ql_kernel<128>, dim3((unsigned)((nb + 63) / 64)), dim3(64), ql_lds, c->stream, ws, NB, nb, n, (float)pert, lg, cap, sw, sw_cap, failf, lam, qstats, (c->opt_eig_clamp & 2) ? 0 : 1);
             hipLaunchKernelGGL(eig_backtransform_kernel<128>, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, c->stream, (const float *)refl, ib, nb, n,
                                (const float *)ws, NB, (const int *)failf, sb, fb, idx ? sens_out : (sens_out ? sens_out + b0 : (float *)nullptr));
         }
         HIPCHK(hipGetLastError());
         if (qstats) {
             const int nw = (nb + 63) / 64;
-            std::vector<long long> hs((size_t)nw * 6);
+            std::vector<long long> hs((size_t)nw * 9);
             HIPCHK(hipMemcpyAsync(hs.data(), qstats, hs.size() * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
-            long long a = 0, t = 0, r = 0, tmax = 0, c1 = 0, c2 = 0, c3 = 0;
-            for (int w = 0; w < nw; ++w) { a += hs[6 * w]; t += hs[6 * w + 1]; r += hs[6 * w + 2]; tmax = std::max(tmax, hs[6 * w + 1]); c1 += hs[6 * w + 3]; c2 += hs[6 * w + 4]; c3 += hs[6 * w + 5]; }
-            fprintf(stderr, "[cmf eig] %d matrices, %d waves: sweeps/wave %.1f, trips/wave %.0f (max %lld), own rotations/matrix %.0f; cycles/wave: QL %.0f, forward %.0f, scale + backward %.0f\n", nb, nw, (double)a / nw, (double)t / nw, tmax, (double)r / nb, (double)c1 / nw, (double)c2 / nw, (double)c3 / nw);
+            long long a = 0, t = 0, r = 0, tmax = 0, c1 = 0, c2 = 0, c3 = 0, n1 = 0, n2 = 0, ls = 0;
+            for (int w = 0; w < nw; ++w) {
+                const long long *q = hs.data() + 9 * w;
+                a += q[0]; t += q[1]; r += q[2]; tmax = std::max(tmax, q[1]); c1 += q[3]; c2 += q[4]; c3 += q[5]; n1 += q[6]; n2 += q[7]; ls += q[8];
+            }
+            fprintf(stderr, "[cmf eig] %d matrices, %d waves: sweeps/wave %.1f, trips/wave %.0f (max %lld), own rotations/matrix %.0f; cycles/wave: QL %.0f, "
+                            "forward %.0f, scale + backward %.0f; stopped early: %lld inside, %lld above, eigenvalues found per matrix %.1f\n",
+                    nb, nw, (double)a / nw, (double)t / nw, tmax, (double)r / nb, (double)c1 / nw, (double)c2 / nw, (double)c3 / nw, n1, n2, (double)ls / nb);
         }
     }
     if (qstats) (void)hipFree(qstats);

@@ -36,7 +36,7 @@ def _cases(rng):
     return out
 
 
-def _check(ctx, Hs, pert, tol, rng, k=None):
+def _check(ctx, Hs, pert, tol, rng, k=None, full_spectrum=False):
     H = np.stack(Hs)
     g = rng.randn(H.shape[0], H.shape[1])
     got, lam = ctx.safe_solve_batch(H, g, pert, method=1, eigenvalues=True)
@@ -46,19 +46,51 @@ def _check(ctx, Hs, pert, tol, rng, k=None):
         err = np.abs(got[b] - ref).max() / np.abs(ref).max()
         assert err < tol, (b, err)
         ev = np.linalg.eigvalsh(H32[b])
-        assert np.abs(np.sort(lam[b]) - ev).max() <= 2e-5 * max(1.0, np.abs(ev).max()), b
-    return got
+        found = lam[b][~np.isnan(lam[b])]    # (the iteration stops once the rest of the spectrum is one-sided: NaN = not computed)
+        assert all(np.abs(ev - v).min() <= 2e-5 * max(1.0, np.abs(ev).max()) for v in found), b
+        if full_spectrum:
+            assert len(found) == len(ev) and np.abs(np.sort(found) - ev).max() <= 2e-5 * max(1.0, np.abs(ev).max()), b
+    return got, lam
 
 
-@pytest.mark.parametrize("name,tol", [("c3z", 5e-4), ("c3x", 5e-6), ("gram", 5e-6), ("indef", 5e-6), ("diag", 1e-6)])
+@pytest.mark.parametrize("name,tol", [("c3z", 5e-4), ("c3x", 5e-6), ("gram", 5e-6), ("indef", 1e-5), ("diag", 1e-6)])
 def test_eigen_solve_matches_float64_safe_invert(name, tol):
     """k = 256.  c3z: ||H|| / pert = 1e4, eigenvalues resolved to eps32 ||H|| = 2.5e-4 = 1.2e-3 pert -- the bulk within that distance of
     the threshold moves by as much; everything else is float32 round-off."""
     from pycmf_amd import _lib
     rng = np.random.RandomState(5)
+    for early_exit in (1, 0):
+        ctx = _lib.Context(0)
+        try:
+            ctx.set_option("eig_clamp", 1 if early_exit else 3)
+            _, lam = _check(ctx, _cases(np.random.RandomState(5))[name], 0.2, tol, rng, full_spectrum=not early_exit)
+            if early_exit and name == "c3z":      # one eigenvalue above the threshold, found first: the other 255 are never computed
+                assert (np.isnan(lam).sum(axis=1) >= 250).all(), np.isnan(lam).sum(axis=1)
+        finally:
+            ctx.close()
+
+
+def test_early_exit_regimes():
+    """The three ways the QL iteration ends (cmf_eigclamp.hip.h): (i) the rest of the spectrum inside (-pert, pert): I / pert;
+    (ii) the rest above pert: a positive definite tridiagonal solve (a well-conditioned matrix with a few eigenvalues under the
+    threshold -- the usual reason a row fails the Cholesky test); (iii) mixed to the end.  Each against float64, with the number
+    of eigenvalues the iteration needed."""
+    from pycmf_amd import _lib
+    rng = np.random.RandomState(9)
+    few_below = [_spectrum_matrix(rng, np.concatenate([rng.uniform(0.01, 0.19, r), rng.uniform(0.5, 30.0, 256 - r)])) for r in (1, 3, 12)]
+    few_above = [_spectrum_matrix(rng, np.concatenate([rng.uniform(0.0, 0.15, 256 - r), rng.uniform(1.0, 900.0, r)])) for r in (1, 4, 10)]
+    none_below = [_spectrum_matrix(rng, rng.uniform(0.3, 9.0, 256))]
+    all_below = [_spectrum_matrix(rng, rng.uniform(0.0, 0.19, 256))]
+    mixed = [_spectrum_matrix(rng, rng.uniform(0.05, 0.6, 256))]
     ctx = _lib.Context(0)
     try:
-        _check(ctx, _cases(rng)[name], 0.2, tol, rng)
+        for name, Hs, tol, max_found in (("few below", few_below, 2e-5, 40), ("few above", few_above, 2e-4, 40), ("none below", none_below, 1e-5, 0),
+                                         ("all below", all_below, 1e-6, 0), ("mixed", mixed, 1e-5, 256)):
+            _, lam = _check(ctx, Hs, 0.2, tol, rng)
+            found = (~np.isnan(lam)).sum(axis=1)
+            assert (found <= max_found).all(), (name, found)
+            if name == "mixed":
+                assert (found >= 50).all(), found    # (at least the minority side: 27 % of a uniform spectrum lies under the threshold)
     finally:
         ctx.close()
 
@@ -77,6 +109,8 @@ def test_eigen_solve_other_orders(k):
     ctx = _lib.Context(0)
     try:
         _check(ctx, Hs, 0.2, 5e-4, rng)
+        ctx.set_option("eig_clamp", 3)
+        _check(ctx, Hs, 0.2, 5e-4, np.random.RandomState(k + 1), full_spectrum=True)
     finally:
         ctx.close()
 
