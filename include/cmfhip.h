@@ -121,6 +121,10 @@ int cmf_set_data_csr(cmf_ctx *ctx, int which, const int64_t *indptr, const int32
  * global matrix land in the local matrix.  Used by bench.py.                 */
 /* representation of X / Y on the device: *dense = a dense float32 image exists, *native = the CSR pair (A, A^T) is resident */
 int cmf_data_layout(cmf_ctx *ctx, int which, int *dense, int *native);
+/* layout of the column-blocked SpMM images of a native sparse X / Y (the products safe_sparse_dot runs at cmf_solvers.py:232, :244):
+ * out[0..3] = row groups, rows cut into pieces (more non-zeros than a wave's share of a group), pieces, accumulator rows per group --
+ * of A; out[4..7] the same of A^T.  Zeros where an orientation has no blocked image.                                          */
+int cmf_sparse_layout(cmf_ctx *ctx, int which, int64_t *out8);
 /* rows x cols block of the dense device image into a packed host array (parity tests at full BASELINE sizes) */
 int cmf_get_data_block_f32(cmf_ctx *ctx, int which, int64_t row0, int64_t nrows, int64_t col0, int64_t ncols, float *host_dst);
 int cmf_fill_data_synthetic(cmf_ctx *ctx, int which, uint64_t seed, int64_t row0, int64_t col0);

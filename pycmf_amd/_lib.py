@@ -43,6 +43,7 @@ PROTOTYPES = {
     "cmf_fill_data_synthetic_kind": [_vp, _i32, C.c_uint64, _i64, _i64, _i32, _dbl],
     "cmf_get_data_f32": [_vp, _i32, _pf, _i64, _i64],
     "cmf_data_layout": [_vp, _i32, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "cmf_sparse_layout": [_vp, _i32, _pi64],
     "cmf_get_data_block_f32": [_vp, _i32, _i64, _i64, _i64, _i64, _pf],
     "cmf_sample_lists": [_vp, _i32, C.c_uint64, _dbl, _i64, _i64, _pi32],
     "cmf_newton_clamp_stats": [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), _i32],
@@ -355,6 +356,13 @@ class Context:
         sx, sy = C.c_double(0), C.c_double(0)
         check(self._lib.cmf_data_sum(self._h, C.byref(sx), C.byref(sy)))
         return sx.value, sy.value
+
+    def sparse_layout(self, which):
+        """(groups, split rows, pieces, accumulator rows per group) of the blocked SpMM image of A and of A^T."""
+        out = (C.c_int64 * 8)()
+        check(self._lib.cmf_sparse_layout(self._h, which, out))
+        v = [int(x) for x in out]
+        return tuple(v[:4]), tuple(v[4:])
 
     def data_layout(self, which):
         """(dense image exists, native CSR pair resident) of X (0) / Y (1)."""

@@ -75,6 +75,11 @@ struct CsrDev {
     int64_t *b_seg = nullptr;
     int32_t *b_grow = nullptr;
     int b_ngroups = 0, b_nblocks = 0, b_rows_per_group = 0, b_nsync = 1;
+    // r06: a row with far more than a wave's share of non-zeros (the hot words of a bag-of-words matrix in X^T U) is cut into pieces,
+    // each an accumulator row of its own; b_vmap: accumulator row -> output row (>= 0) or -(1 + slot) of the partial buffer, whose
+    // slots b_pfirst[i] .. + b_pcnt[i] are summed into output row b_prow[i] behind the launch
+    int32_t *b_vmap = nullptr, *b_prow = nullptr, *b_pfirst = nullptr, *b_pcnt = nullptr;
+    int b_nsplit = 0, b_nslots = 0;
 };
 
 // A captured update step: replayed with hipGraphLaunch while the key (hyper-parameters baked into
@@ -150,6 +155,8 @@ struct cmf_ctx {
     int64_t opt_spmm_block_cols = 0;  // gathered rows per column block (0: 3 MB worth)
     int64_t opt_spmm_stretch = 0;     // entries of a group between two re-alignments of its XCD class (0: 8192)
     DevBuf spmm_bar;                  // rendezvous counters of the blocked SpMM (8 x 16 bytes)
+    DevBuf spmm_part;                 // partial output rows of split rows (spmm_blocked_kernel)
+    int opt_spmm_split = 1;           // cut rows with far more than a wave's share of non-zeros into pieces, waves by longest-piece-first (0: round 5's layout)
     float *F[3] = {nullptr, nullptr, nullptr};
     int64_t frows[3] = {0, 0, 0}, frows_pad[3] = {0, 0, 0};
     int64_t v_rows_alloc = 0;         // rows allocated behind F[CMF_V] (>= dp: the row-blocked MU driver all-gathers world equal blocks in place)
@@ -829,7 +836,7 @@ static void release_problem(cmf_ctx *c) {
     c->ref_w = DevBuf(); c->ref_w2 = DevBuf(); c->ref_g = DevBuf(); c->ref_i = DevBuf(); c->ref_ns = DevBuf();
     c->trace64 = DevBuf(); c->dsq_valid[0] = c->dsq_valid[1] = false;
     c->nsidx = DevBuf(); c->nsws = DevBuf(); c->eigcl_ws = DevBuf(); c->eigcl_log = DevBuf(); c->eigcl_fail = DevBuf(); c->eigcl_snap = DevBuf();
-    c->spmm_bar = DevBuf();
+    c->spmm_bar = DevBuf(); c->spmm_part = DevBuf();
     c->g64a = DevBuf(); c->g64b = DevBuf(); c->gmix64 = DevBuf(); c->h64 = DevBuf();
     c->gslab64 = DevBuf(); c->w64 = DevBuf(); c->ns64 = DevBuf();
     c->hinv64 = DevBuf(); c->opr = DevBuf(); c->v_plain = false;
@@ -998,6 +1005,8 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "spmm_blocked")) {
         if (value < 0 || value > 2) return fail(CMF_EINVAL, "spmm_blocked must be 0 (never), 1 (auto) or 2 (always); set before cmf_set_data_csr");
         c->opt_spmm_blocked = (int)value;
+    } else if (!strcmp(name, "spmm_split")) {
+        c->opt_spmm_split = value != 0;
     } else if (!strcmp(name, "spmm_stretch")) {
         c->opt_spmm_stretch = std::max<int64_t>(0, value);
     } else if (!strcmp(name, "spmm_block_cols")) {
@@ -1238,6 +1247,7 @@ extern "C" int cmf_set_data_csr(cmf_ctx *c, int which, const int64_t *indptr, co
         CsrDev &old = c->sp[which][t];
         dev_free(c, old.indptr); dev_free(c, old.idx); dev_free(c, old.val);
         dev_free(c, old.b_ent); dev_free(c, old.b_seg); dev_free(c, old.b_grow);
+        dev_free(c, old.b_vmap); dev_free(c, old.b_prow); dev_free(c, old.b_pfirst); dev_free(c, old.b_pcnt);
         old = CsrDev();
     }
     c->sparse[which] = false;
@@ -1280,6 +1290,21 @@ extern "C" int cmf_data_layout(cmf_ctx *c, int which, int *dense, int *native) {
     if (which != 0 && which != 1) return fail(CMF_EINVAL, "which must be 0 (X) or 1 (Y)");
     if (dense) *dense = (which == 0 ? c->X : c->Y) != nullptr ? 1 : 0;
     if (native) *native = c->sparse[which] ? 1 : 0;
+    return CMF_OK;
+}
+
+// layout of the column-blocked SpMM images of a native sparse X / Y: out[0..3] = (row groups, split rows, pieces, accumulator rows per
+// group) of A, out[4..7] the same of A^T; zeros where an orientation has no blocked image
+extern "C" int cmf_sparse_layout(cmf_ctx *c, int which, int64_t *out) {
+    NEED_PROBLEM(c);
+    if ((which != 0 && which != 1) || !out) return fail(CMF_EINVAL, "bad argument");
+    for (int t = 0; t < 2; ++t) {
+        const CsrDev &A = c->sp[which][t];
+        out[4 * t] = A.b_ent ? A.b_ngroups : 0;
+        out[4 * t + 1] = A.b_ent ? A.b_nsplit : 0;
+        out[4 * t + 2] = A.b_ent ? A.b_nslots : 0;
+        out[4 * t + 3] = A.b_ent ? A.b_rows_per_group : 0;
+    }
     return CMF_OK;
 }
 

@@ -129,10 +129,19 @@ struct BcsrEntry {
 struct BcsrView {
     const BcsrEntry *ent;
     const int64_t *seg;     // [(g * 8 + w) * nsync + i] -> first entry of stretch i of wave w's list for group g; one extra at the end
-    const int32_t *grow;    // first row of group g; ngroups + 1 entries
+    const int32_t *grow;    // first accumulator row of group g; ngroups + 1 entries
     int ngroups;
     int nsync;              // stretches per list: the class re-aligns between stretches (every few column blocks)
+    const int32_t *vmap;    // accumulator row -> output row (>= 0), or -(1 + slot): a piece of a split row, written to part[slot]
+    float *part;            // partial output rows of the pieces (summed by spmm_partial_sum_kernel)
 };
+// Round 6: accumulator rows are no longer output rows one to one.  A row whose non-zeros exceed a wave's fair share of a group (the hot
+// words of a bag-of-words matrix: Zipf(1.1) columns put 13 % of the documents on the first word, and X^T U has the words as rows) is cut
+// into pieces of at most that share; every piece is an accumulator row of its own, possibly in another group (another workgroup),
+// and the waves of a group take its accumulator rows longest-first (the host's greedy assignment: the wave of a row is that of its
+// entries, no longer row % 8).  Pieces write to a partial buffer; spmm_partial_sum_kernel adds the pieces of a row in order:
+// deterministic, no atomics.  Measured on the Zipf(1.1) variant of C5 (c5z): 72 -> see DESIGN.md section 8 ms per launch; uniform
+// columns (c5) have nothing to split and keep their layout.
 
 constexpr int BCSR_NW = 8;  // waves per workgroup (host layout and kernel agree on it)
 template <int VEC> // floats per lane; k_pad = 64 * VEC
@@ -228,9 +237,15 @@ __global__ __launch_bounds__(64 * BCSR_NW) void spmm_blocked_kernel(BcsrView A, 
         }
         }
         flush();
+        __syncthreads(); // (an accumulator row is summed by the wave the host gave it to, written back by wave r % 8)
         for (int r = w; r < nrows; r += BCSR_NW) {
             vec v = *reinterpret_cast<const vec *>(lacc + r * KP + lane * VEC);
-            vec *dst = reinterpret_cast<vec *>(out + (int64_t)(r0 + r) * KP + lane * VEC);
+            const int orow = A.vmap[r0 + r];
+            if (orow < 0) { // a piece of a split row: the partial sum as it is
+                *reinterpret_cast<vec *>(A.part + (int64_t)(-orow - 1) * KP + lane * VEC) = v;
+                continue;
+            }
+            vec *dst = reinterpret_cast<vec *>(out + (int64_t)orow * KP + lane * VEC);
             if (accumulate & 1) v += *dst;
             if (kvalid > 0 || (accumulate & 2)) {
 #pragma unroll
@@ -242,6 +257,29 @@ __global__ __launch_bounds__(64 * BCSR_NW) void spmm_blocked_kernel(BcsrView A, 
             *dst = v;
         }
     }
+}
+
+// out[prow[i]] (+)= sum of the partial rows first[i] .. first[i] + cnt[i] (in that order), with the epilogue of spmm_blocked_kernel
+template <int VEC>
+__global__ __launch_bounds__(64) void spmm_partial_sum_kernel(const float *part, const int32_t *prow, const int32_t *first, const int32_t *cnt, float *out,
+                                                              int accumulate, int kvalid) {
+    typedef float vec __attribute__((ext_vector_type(VEC)));
+    constexpr int KP = 64 * VEC;
+    const int i = blockIdx.x, lane = threadIdx.x;
+    vec v;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = 0.f;
+    for (int s = 0; s < cnt[i]; ++s) v += *reinterpret_cast<const vec *>(part + (int64_t)(first[i] + s) * KP + lane * VEC);
+    vec *dst = reinterpret_cast<vec *>(out + (int64_t)prow[i] * KP + lane * VEC);
+    if (accumulate & 1) v += *dst;
+    if (kvalid > 0 || (accumulate & 2)) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            if (kvalid > 0 && lane * VEC + e >= kvalid) v[e] = 0.f;
+            else if ((accumulate & 2) && v[e] < 0.f) v[e] = 0.f;
+        }
+    }
+    *dst = v;
 }
 
 // cross[wg] = sum over the nonzeros of this workgroup's rows of  a_ij * (L_i . R_j)

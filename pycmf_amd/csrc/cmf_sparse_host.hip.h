@@ -15,32 +15,90 @@ static int csr_upload(cmf_ctx *c, CsrDev &dst, const int64_t *indptr, const int3
     return CMF_OK;
 }
 
-// Regroup a host CSR matrix for spmm_blocked_kernel (see cmf_sparse.hip.h): row groups of at most G rows, closed early
-// once a group holds twice the average share of non-zeros (nnz-balanced work items: a few very long rows do not make
-// one workgroup the straggler of its round); column blocks of B gathered rows; counting sort by (group, block, wave).
+// Regroup a host CSR matrix for spmm_blocked_kernel (see cmf_sparse.hip.h): accumulator rows = the matrix rows, a row with more
+// non-zeros than a wave's fair share of a group cut into pieces (r06); groups of at most G accumulator rows, closed once they hold
+// their share of non-zeros (nnz-balanced work items: the workgroups of an XCD class re-align in front of every stretch, so a round
+// lasts as long as its slowest group); the accumulator rows of a group dealt to its eight waves longest-first; column blocks of B
+// gathered rows; counting sort by (group, wave, block).
 static int bcsr_build_upload(cmf_ctx *c, CsrDev &dst, const int64_t *indptr, const int32_t *indices, const float *vals, int64_t rows,
                              int64_t cols, int64_t nnz, int G, int64_t B) {
-    std::vector<int32_t> grow;
-    grow.push_back(0);
-    const double cap = std::max(64.0, 2.0 * (double)nnz / (double)std::max<int64_t>(rows, 1) * G);
-    int64_t gn = 0;
-    int cnt = 0;
+    // entries q0 + i * stride < q1 of the CSR arrays; slot: of the partial buffer (a piece of a split row), or -1.  The pieces of a row
+    // INTERLEAVE (piece i takes every np-th entry from the i-th on): each spans the row's whole column range, so that it has work in every
+    // stretch of the lockstep sweep over the column blocks -- contiguous pieces would each sit in one or two blocks and wait out the rest
+    struct Piece { int32_t row; int32_t slot; int64_t q0, q1, stride; int64_t n() const { return q1 > q0 ? (q1 - q0 + stride - 1) / stride : 0; } };
+    const bool split = c->opt_spmm_split != 0;
+    const double avg_group = (double)nnz / (double)std::max<int64_t>(rows, 1) * G;          // non-zeros of G average rows
+    // a piece: a quarter of one wave's fair share of a group (a wave then holds several, and longest-first evens the waves out to
+    // ~10 %; at a whole share a group of ten pieces left two waves with double the work)
+    const int64_t share = std::max<int64_t>(1024, (int64_t)(avg_group / (4 * cmfk::BCSR_NW)));
+    std::vector<Piece> pc;
+    pc.reserve((size_t)rows + 64);
+    std::vector<int32_t> prow, pfirst, pcnt;      // split rows: output row, first slot, number of pieces
+    int32_t nslots = 0;
     for (int64_t r = 0; r < rows; ++r) {
         const int64_t rn = indptr[r + 1] - indptr[r];
-        if (cnt > 0 && (cnt == G || (double)(gn + rn) > cap)) { grow.push_back((int32_t)r); gn = 0; cnt = 0; }
+        if (split && rn > share + share / 4) {
+            const int64_t np = (rn + share - 1) / share;
+            prow.push_back((int32_t)r); pfirst.push_back(nslots); pcnt.push_back((int32_t)np);
+            for (int64_t i = 0; i < np; ++i) pc.push_back(Piece{(int32_t)r, nslots + (int32_t)i, indptr[r] + i, indptr[r + 1], np});
+            nslots += (int32_t)np;
+        } else
+            pc.push_back(Piece{(int32_t)r, -1, indptr[r], indptr[r + 1], 1});
+    }
+    const int64_t nacc = (int64_t)pc.size();
+    // Accumulator rows need not follow the matrix's row order (vmap says where each one goes): heaviest first.  A group then holds
+    // rows of like weight, and consecutive groups -- the ones the workgroups of an XCD class take in the same round, re-aligning at
+    // every stretch -- weigh alike: with the rows in matrix order a group of 136 random words held one hot word or none, and every
+    // round waited for its heaviest group (c5z, X^T U: 55 ms per launch against 7 for uniform columns).
+    if (split) std::stable_sort(pc.begin(), pc.end(), [](const Piece &x, const Piece &y) { return x.n() > y.n(); });
+    std::vector<int32_t> grow;
+    grow.push_back(0);
+    // (round 5: closed at twice the average share; with pieces no row exceeds a quarter of a group, and equal groups are what the
+    // rendezvous wants)
+    const double cap = std::max(64.0, (split ? 1.25 : 2.0) * avg_group);
+    int64_t gn = 0;
+    int cnt = 0;
+    for (int64_t a = 0; a < nacc; ++a) {
+        const int64_t rn = pc[a].n();
+        if (cnt > 0 && (cnt == G || (double)(gn + rn) > cap)) { grow.push_back((int32_t)a); gn = 0; cnt = 0; }
         gn += rn; ++cnt;
     }
-    grow.push_back((int32_t)rows);
+    grow.push_back((int32_t)nacc);
     const int64_t ngroups = (int64_t)grow.size() - 1;
     const int64_t nblocks = std::max<int64_t>(1, (cols + B - 1) / B);
     if (ngroups * nblocks * cmfk::BCSR_NW > ((int64_t)1 << 31)) return CMF_EUNSUPPORTED; // sort table too large: keep the plain CSR kernel
-    // counting sort by key (group, wave, block); inside a key the CSR order (row, column) is kept
+    // wave of every accumulator row: longest first onto the least loaded wave of its group (round 5: row % 8)
+    std::vector<uint8_t> wave_of((size_t)nacc);
+    std::vector<int32_t> vmap((size_t)nacc);
+    {
+        std::vector<int32_t> order;
+        for (int64_t a = 0; a < nacc; ++a) vmap[(size_t)a] = pc[a].slot >= 0 ? -(1 + pc[a].slot) : pc[a].row;
+        for (int64_t g = 0; g < ngroups; ++g) {
+            const int32_t a0 = grow[g], a1 = grow[g + 1];
+            if (!split) {
+                for (int32_t a = a0; a < a1; ++a) wave_of[(size_t)a] = (uint8_t)((a - a0) & (cmfk::BCSR_NW - 1));
+                continue;
+            }
+            order.resize((size_t)(a1 - a0));
+            for (int32_t a = a0; a < a1; ++a) order[(size_t)(a - a0)] = a;
+            std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return pc[x].n() > pc[y].n(); });
+            int64_t load[cmfk::BCSR_NW] = {0};
+            for (int32_t a : order) {
+                int best = 0;
+                for (int w = 1; w < cmfk::BCSR_NW; ++w)
+                    if (load[w] < load[best]) best = w;
+                wave_of[(size_t)a] = (uint8_t)best;
+                load[best] += pc[a].n();
+            }
+        }
+    }
+    // counting sort by key (group, wave, block); inside a key the order (accumulator row, column) is kept
     const int64_t nkey = ngroups * cmfk::BCSR_NW * nblocks;
     std::vector<int64_t> kcnt((size_t)nkey + 1, 0);
     for (int64_t g = 0; g < ngroups; ++g)
-        for (int64_t r = grow[g]; r < grow[g + 1]; ++r) {
-            const int64_t base = (g * cmfk::BCSR_NW + ((r - grow[g]) & (cmfk::BCSR_NW - 1))) * nblocks;
-            for (int64_t q = indptr[r]; q < indptr[r + 1]; ++q) kcnt[(size_t)(base + indices[q] / B) + 1]++;
+        for (int64_t a = grow[g]; a < grow[g + 1]; ++a) {
+            const int64_t base = (g * cmfk::BCSR_NW + wave_of[(size_t)a]) * nblocks;
+            for (int64_t q = pc[a].q0; q < pc[a].q1; q += pc[a].stride) kcnt[(size_t)(base + indices[q] / B) + 1]++;
         }
     for (int64_t i = 0; i < nkey; ++i) kcnt[i + 1] += kcnt[i];
     // stretches between two re-alignments of an XCD class: about 8k entries of a group (~80 us; 16k: +0.5 ms on X^T U at C5, 32k: +1.7 ms), whole blocks
@@ -54,22 +112,29 @@ static int bcsr_build_upload(cmf_ctx *c, CsrDev &dst, const int64_t *indptr, con
     seg[(size_t)(ngroups * cmfk::BCSR_NW * nsync)] = nnz;
     std::vector<cmfk::BcsrEntry> ent((size_t)std::max<int64_t>(nnz, 1));
     for (int64_t g = 0; g < ngroups; ++g)
-        for (int64_t r = grow[g]; r < grow[g + 1]; ++r) {
-            const int32_t rl = (int32_t)(r - grow[g]);
-            const int64_t base = (g * cmfk::BCSR_NW + (rl & (cmfk::BCSR_NW - 1))) * nblocks;
-            for (int64_t q = indptr[r]; q < indptr[r + 1]; ++q) {
+        for (int64_t a = grow[g]; a < grow[g + 1]; ++a) {
+            const int32_t rl = (int32_t)(a - grow[g]);
+            const int64_t base = (g * cmfk::BCSR_NW + wave_of[(size_t)a]) * nblocks;
+            for (int64_t q = pc[a].q0; q < pc[a].q1; q += pc[a].stride) {
                 const int64_t pos = kcnt[(size_t)(base + indices[q] / B)]++;
                 ent[pos] = cmfk::BcsrEntry{indices[q], rl, vals[q], 0};
             }
         }
-    CHK(dev_alloc(c, (void **)&dst.b_ent, ent.size() * sizeof(cmfk::BcsrEntry), false));
-    CHK(dev_alloc(c, (void **)&dst.b_seg, seg.size() * sizeof(int64_t), false));
-    CHK(dev_alloc(c, (void **)&dst.b_grow, grow.size() * sizeof(int32_t), false));
-    HIPCHK(hipMemcpyAsync(dst.b_ent, ent.data(), ent.size() * sizeof(cmfk::BcsrEntry), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dst.b_seg, seg.data(), seg.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dst.b_grow, grow.data(), grow.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    auto up = [&](void **dptr, const void *src, size_t bytes) -> int {
+        CHK(dev_alloc(c, dptr, std::max<size_t>(bytes, 16), false));
+        if (bytes) HIPCHK(hipMemcpyAsync(*dptr, src, bytes, hipMemcpyHostToDevice, c->stream));
+        return CMF_OK;
+    };
+    CHK(up((void **)&dst.b_ent, ent.data(), ent.size() * sizeof(cmfk::BcsrEntry)));
+    CHK(up((void **)&dst.b_seg, seg.data(), seg.size() * sizeof(int64_t)));
+    CHK(up((void **)&dst.b_grow, grow.data(), grow.size() * sizeof(int32_t)));
+    CHK(up((void **)&dst.b_vmap, vmap.data(), vmap.size() * sizeof(int32_t)));
+    CHK(up((void **)&dst.b_prow, prow.data(), prow.size() * sizeof(int32_t)));
+    CHK(up((void **)&dst.b_pfirst, pfirst.data(), pfirst.size() * sizeof(int32_t)));
+    CHK(up((void **)&dst.b_pcnt, pcnt.data(), pcnt.size() * sizeof(int32_t)));
     HIPCHK(hipStreamSynchronize(c->stream));
     dst.b_ngroups = (int)ngroups; dst.b_nblocks = (int)nblocks; dst.b_rows_per_group = G; dst.b_nsync = (int)nsync;
+    dst.b_nsplit = (int)prow.size(); dst.b_nslots = (int)nslots;
     return CMF_OK;
 }
 
@@ -180,7 +245,8 @@ static int spmm(cmf_ctx *c, const CsrDev &A, const float *F, float *out, int64_t
     if (A.b_ent && width == c->kp) { // column-blocked, output-stationary form
         CHK(ensure(c, c->spmm_bar, 8 * 16));
         HIPCHK(hipMemsetAsync(c->spmm_bar.p, 0, 8 * 16, c->stream));
-        BcsrView bv{A.b_ent, A.b_seg, A.b_grow, A.b_ngroups, A.b_nsync};
+        if (A.b_nslots > 0) CHK(ensure(c, c->spmm_part, (size_t)A.b_nslots * width * sizeof(float)));
+        BcsrView bv{A.b_ent, A.b_seg, A.b_grow, A.b_ngroups, A.b_nsync, A.b_vmap, (float *)c->spmm_part.p};
         const unsigned grid = (unsigned)std::max(8, (c->num_cu / 8) * 8);
         const size_t lds = (size_t)A.b_rows_per_group * width * sizeof(float);
 #define CMF_SPMMB(V_)                                                                                                     \
@@ -188,6 +254,10 @@ static int spmm(cmf_ctx *c, const CsrDev &A, const float *F, float *out, int64_t
         CHK(allow_big_lds(c, reinterpret_cast<const void *>(&spmm_blocked_kernel<V_>), 156 * 1024));                      \
         hipLaunchKernelGGL((spmm_blocked_kernel<V_>), dim3(grid), dim3(64 * cmfk::BCSR_NW), lds, c->stream, bv, F, out,                   \
                            (accumulate ? 1 : 0) | (update == 2 ? 2 : 0), (unsigned *)c->spmm_bar.p, update ? c->k : 0);                \
+        if (A.b_nsplit > 0)                                                                                               \
+            hipLaunchKernelGGL((spmm_partial_sum_kernel<V_>), dim3((unsigned)A.b_nsplit), dim3(64), 0, c->stream, (const float *)c->spmm_part.p, \
+                               (const int32_t *)A.b_prow, (const int32_t *)A.b_pfirst, (const int32_t *)A.b_pcnt, out,           \
+                               (accumulate ? 1 : 0) | (update == 2 ? 2 : 0), update ? c->k : 0);                                  \
     } while (0)
         if (width == 256) CMF_SPMMB(4);
         else if (width == 128) CMF_SPMMB(2);

@@ -184,9 +184,16 @@ class CMF(BaseEstimator, TransformerMixin):
     attributes ``reconstruction_err_``, ``n_components_``, ``x_weights``,
     ``components``, ``y_weights``, ``n_iter_`` (:697-704).
 
-    Extra keywords: ``device`` (GPU ordinal, default 0), ``sg_sampler`` and ``n_gpus`` (default 1; N > 1 = ``fit`` runs
-    data-parallel on N GPUs of the node, one worker process per GPU, V reassembled by one sum over the ranks per iteration
-    -- RCCL reduce-scatter + all-gather around the row-blocked V update; ``transform`` always uses one GPU).
+    Extra keywords: ``device`` (GPU ordinal, default 0), ``sg_sampler`` and ``n_gpus`` (default 1; N > 1 = ``fit`` and
+    ``transform`` run data-parallel on N GPUs of the node, one worker process per GPU; MU: V reassembled by ONE sum over the
+    ranks per iteration -- a single RCCL all-reduce, or reduce-scatter + all-gather around a row-blocked V update when a timed
+    trial on the live ranks finds that faster; a fit with a ``random_state`` pins the single all-reduce, so that it is
+    reproducible run to run).
+
+    ``n_gpus > 1`` with ``sg_sample_ratio < 1``: the samples come from the DEVICE sampler whatever ``sg_sampler`` says -- NumPy's
+    stream (pycmf/cmf_solvers.py:328-344) is global and sequential, one draw per row in sweep order, and cannot be cut across
+    ranks that sweep their rows concurrently.  Such a fit reproduces the reference's sampling STATISTICS (exactly
+    ``int(n * ratio)`` distinct uniform indices per row), not its iterates; ``n_gpus=1, sg_sampler='numpy'`` does.
 
     ``sg_sampler`` (only read when ``sg_sample_ratio < 1``): ``'numpy'`` (default) draws every row's sample from NumPy's global
     stream on the host, in the reference's order -- results reproduce the reference's for the same ``random_state``, but the

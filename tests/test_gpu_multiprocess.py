@@ -176,7 +176,9 @@ def test_bench_launches_its_own_ranks(workload):
         assert coll["protocol"] == "rsag" and set(coll["per_kind"]) == {"all_reduce_f32", "reduce_scatter_f32", "all_gather_f32"}
     if workload not in ("tiny3", "tiny5l"):
         assert coll["replicas"]["identical"], coll["replicas"]     # every rank ends with the same V, bit for bit
-    one = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", workload, "--no-cpu-baseline"], {})
+    # (--max-warmup 0: the single-GPU per-row Newton line would otherwise warm up to its steady state, and the two runs would no
+    # longer be the same iterations)
+    one = _run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", workload, "--no-cpu-baseline", "--max-warmup", "0"], {})
     assert one["n_gpus"] == 1 and "collective" not in one
     # same synthetic problem, same iteration count: the sharded run ends at the same residuals (rank 0's shard of X / Y
     # for the sharded run, so compare loosely: both are far from the starting residual and close to each other)

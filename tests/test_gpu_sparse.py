@@ -262,3 +262,48 @@ def test_blocked_spmm_writes_the_newton_update_itself(lib, k, nn):
     for a, b, o in zip(got[2], got[0], (U, V, Z)):
         np.testing.assert_allclose(a, b, rtol=0, atol=2e-5 * np.abs(b).max())
         np.testing.assert_allclose(a, o, rtol=0, atol=5e-5 * np.abs(o).max())
+
+
+@pytest.mark.parametrize("k", [100, 256])
+def test_blocked_spmm_splits_hot_rows(lib, k):
+    """Bag-of-words statistics (r06): a few words in most documents.  In X^T U those words are ROWS with far more non-zeros than a
+    wave's share of a row group; the blocked SpMM cuts them into pieces (accumulator rows of their own, possibly in different
+    workgroups, summed by a second kernel in a fixed order) and deals a group's rows to its waves longest-first.  Against the
+    one-wave-per-row CSR kernel and against the layout without pieces (option spmm_split=0): a MU and a linear Newton iteration; the
+    split layout asserted to be in effect; bit-identical when repeated."""
+    rng = np.random.RandomState(5 + k)
+    m, d, p = 9000, 1500, 200
+    prob = np.minimum(1.0, 2.5 / np.arange(1, d + 1) ** 1.1)      # word j in a document with probability ~ Zipf(1.1), the first three in all
+    rng.shuffle(prob[3:])
+    mask = rng.rand(m, d) < prob[None, :]
+    X = sp.csr_matrix(mask.astype(np.float64) * (np.abs(rng.randn(m, d)) + 0.1))
+    Y = sp.random(d, p, density=0.05, random_state=rng, format="csr", data_rvs=lambda n: np.abs(rng.randn(n)) + 0.1)
+    U0, V0, Z0 = (0.3 * np.abs(rng.randn(n, k)) for n in (m, d, p))
+    outs = {}
+    for name, opts in (("rows", dict(spmm_blocked=0)), ("blocked", dict(spmm_blocked=2)), ("nosplit", dict(spmm_blocked=2, spmm_split=0)), ("again", dict(spmm_blocked=2))):
+        ctx = lib.Context(0)
+        ctx.set_option("sparse_mode", 2)
+        ctx.set_option("spmm_block_cols", 256)
+        for o, v in opts.items():
+            ctx.set_option(o, v)
+        ctx.set_problem(m, d, p, k)
+        ctx.set_data(0, X); ctx.set_data(1, Y)
+        if name == "blocked":
+            a, at = ctx.sparse_layout(0)
+            assert at[1] >= 3 and at[2] >= 2 * at[1], (a, at)       # the rows of X^T that are whole documents-long were cut
+            assert a[1] == 0                                      # no document holds that many words
+        if name == "nosplit":
+            assert ctx.sparse_layout(0)[1][1] == 0
+        for w, F in enumerate((U0, V0, Z0)):
+            ctx.set_factor(w, F)
+        ctx.mu_step(0.01, 0.02, 7)
+        mu = [ctx.get_factor(w) for w in range(3)]
+        ctx.newton_step(0.4, 0.01, 0.1, "linear", "linear", 0, 7, 0.2, 1.0)
+        outs[name] = mu + [ctx.get_factor(w) for w in range(3)]
+        ctx.close()
+    for other in ("rows", "nosplit"):
+        for i, (a, b) in enumerate(zip(outs["blocked"], outs[other])):
+            tol = 2e-5 if i < 3 else 5e-3
+            np.testing.assert_allclose(a, b, rtol=tol, atol=tol * np.abs(b).max())
+    for a, b in zip(outs["blocked"], outs["again"]):
+        np.testing.assert_array_equal(a, b)
