@@ -26,7 +26,8 @@ OPTIONS = {"row_classes": [-1, 0, 2, 3, 5], "row_certificates": [0, 1], "lowrank
            "split_reduce_in_kernel": [0, 1], "spmm_blocked": [0, 1], "newton_schulz": [0, 1], "safe_inverse_cholesky": [0, 1],
            "factor_times_tile": [64, 128, 256], "graph": [0, 1], "chol_mfma": [0, 1], "refine_rows_batched": [0, 1], "narrow_update": [0, 1],
            "side_gram": [0, 1], "pair_passes": [0, 1, 2],
-           "nt_tile16": [0, 1], "nt_bn256": [0, 1], "nt_raster": [0, 1], "gemm64_tile128": [0, 1], "refine_spectral_map": [0, 1]}   # round 5
+           "nt_tile16": [0, 1], "nt_bn256": [0, 1], "nt_raster": [0, 1], "gemm64_tile128": [0, 1], "refine_spectral_map": [0, 1],   # round 5
+           "eig_clamp": [0, 1, 3], "refine_rows_tol_ppm": [0, 20, 1000], "spmm_split": [0, 1], "trace_error": [0, 1]}             # round 6
 
 
 def log_int(rng, lo, hi):
