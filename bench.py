@@ -628,8 +628,10 @@ def main():
         roof["peak"] = BF16_MFMA_PEAK_TFLOPS / 6.0
         roof["frac"] = roof["achieved"] / roof["peak"]
     elif dom == "rowhess" and kp == 256 and "row_symmetric=0" not in args.option:
-        # the MFMAs cover 36 whole 32x32 blocks (the diagonal blocks are computed in full)
-        roof["mfma_executed_tflops"] = achieved * (36 * 2048.0 + 4 * kp) / (kp * (kp + 1.0) + 4 * kp)
+        # the MFMAs cover 28 whole 32x32 blocks above the diagonal and three 16x16 sub-blocks of each of the 8 diagonal ones
+        # (34 block-equivalents; 36 with row_symmetric=1 / 3, which compute the diagonal blocks in full)
+        whole = 36 if any(o in args.option for o in ("row_symmetric=1", "row_symmetric=3")) else 34
+        roof["mfma_executed_tflops"] = achieved * (whole * 2048.0 + 4 * kp) / (kp * (kp + 1.0) + 4 * kp)
     roof["traffic_provenance"] = (None if roof.get("traffic") is None else
                                   "stored: profiles/traffic_%s.json, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                   "command (tools/refresh_r05.sh, gfx950 corrections of MI355X_MICROARCH.md); PMC collection cannot run "

@@ -1275,21 +1275,31 @@ static int launch_row_hess_kp(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
 #undef CMF_ROWDIAG
     } else
 #endif
-    if (KP == 256 && c->opt_rowsym == 3 && a.scale >= 0.f && a.cls_cnt && a.cls_upper) { // class launch, upper blocks only
+    if (KP == 256 && c->opt_rowsym >= 3 && a.scale >= 0.f && a.cls_cnt && a.cls_upper) { // class launch, upper blocks only
         constexpr int KS = KP == 256 ? 256 : 0;
         if constexpr (KS == 256) {
             constexpr size_t lds = Cfg::LDS_BYTES / 2; // one image per stage: two workgroups per CU
-            CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<256, 1, 0, 3, 1>), (int)lds));
-            hipLaunchKernelGGL((row_hess_kernel<256, 1, 0, 3, 1>), dim3((unsigned)nrows), dim3(512), lds, c->stream, a);
+            if (c->opt_rowsym == 3) {
+                CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<256, 1, 0, 3, 1>), (int)lds));
+                hipLaunchKernelGGL((row_hess_kernel<256, 1, 0, 3, 1>), dim3((unsigned)nrows), dim3(512), lds, c->stream, a);
+            } else { // diagonal blocks on the 16-wide instruction
+                CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<256, 1, 0, 4, 1>), (int)lds));
+                hipLaunchKernelGGL((row_hess_kernel<256, 1, 0, 4, 1>), dim3((unsigned)nrows), dim3(512), lds, c->stream, a);
+            }
         }
     } else if (KP == 256 && c->opt_arith == 1 && c->opt_rowsym && a.scale >= 0.f) { // optional arithmetic: bf16 planes, six products
         CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess6_kernel), R6_LDS_BYTES));
         hipLaunchKernelGGL(row_hess6_kernel, dim3((unsigned)nrows), dim3(512), R6_LDS_BYTES, c->stream, a);
-    } else if (KP == 256 && c->opt_rowsym == 3 && a.scale >= 0.f) { // non-negative weights: single sqrt-weighted image
+    } else if (KP == 256 && c->opt_rowsym >= 3 && a.scale >= 0.f) { // non-negative weights: single sqrt-weighted image
         constexpr int KS = KP == 256 ? 256 : 0;
         if constexpr (KS == 256) {
-            CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<256, 1, 0, 3>), (int)Cfg::LDS_BYTES));
-            hipLaunchKernelGGL((row_hess_kernel<256, 1, 0, 3>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
+            if (c->opt_rowsym == 3) {
+                CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<256, 1, 0, 3>), (int)Cfg::LDS_BYTES));
+                hipLaunchKernelGGL((row_hess_kernel<256, 1, 0, 3>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
+            } else {
+                CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<256, 1, 0, 4>), (int)Cfg::LDS_BYTES));
+                hipLaunchKernelGGL((row_hess_kernel<256, 1, 0, 4>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a);
+            }
         }
     } else if (KP == 256 && c->opt_rowsym) {
         constexpr int KS = KP == 256 ? 256 : 0; // only the k_pad = 256 instantiation exists
@@ -1736,7 +1746,7 @@ static int refine_rows64(cmf_ctx *c, int which, const RowSide &s1, const RowSide
 }
 
 // class images of the k_pad = 256 symmetric kernel hold their 36 upper 32 x 32 blocks only (cmf_rowhess.hip.h)
-static bool class_images_upper(const cmf_ctx *c, double scale) { return c->kp == 256 && c->opt_rowsym == 3 && scale >= 0.0 && c->opt_rowdiag == 0; }
+static bool class_images_upper(const cmf_ctx *c, double scale) { return c->kp == 256 && c->opt_rowsym >= 3 && scale >= 0.0 && c->opt_rowdiag == 0; }
 static int64_t class_image_floats(const cmf_ctx *c, double scale) { return class_images_upper(c, scale) ? 36 * CLS_BLOCK : (int64_t)c->kp * c->kp; }
 
 static int fused_rows_finish(cmf_ctx *c, int which, const RowSide &s1, const RowSide &s2, const float *S, double diag, bool grad_preloaded,

@@ -80,6 +80,15 @@ __host__ __device__ constexpr int sym_bi(int ty, int n) { return ty == 0 ? n : (
 __host__ __device__ constexpr int s3_nf(int ty) { return ty == 0 ? 5 : (ty == 1 ? 4 : 3); }
 __host__ __device__ constexpr int s3_ai(int ty, int n) { return ty == 0 ? 0 : (ty == 1 ? (n == 4 ? 3 : 0) : (n >= 3 ? 1 : 0)); }
 __host__ __device__ constexpr int s3_bi(int ty, int n) { return ty == 0 ? n + 1 : (ty == 1 ? (n == 4 ? 3 : n) : (n < 3 ? n : n - 2)); }
+// SYM = 4 (the default): SYM = 3 with the 8 DIAGONAL blocks accumulated as three 16 x 16 sub-blocks each -- (0,0), (0,1), (1,1) by
+// v_mfma_f32_16x16x4f32 over four samples: 3 x 8 passes against the 2 x 16 of two 32x32x2 steps, the lower sub-block is the
+// mirror image of (0,1).  A SIMD then runs 34 block-equivalents per k-pair and workgroup instead of 36 (the symmetric half is
+// 32.1): waves 0-3 keep their four off-diagonal blocks, waves 4-7 hold three off-diagonal blocks and two diagonal ones.
+// Fragment f of a wave as for SYM = 3 (type 0: block row w, then block columns 4..7; types 1, 2: their block columns).
+//   type 1 (base b): (b, b+1) (b, b+2) (b, b+3) + diagonal b, b+3      type 2: (b+1, b+2) (b+1, b+3) (b+2, b+3) + diagonal b+1, b+2
+__host__ __device__ constexpr int d16_np(int ty) { return ty == 0 ? 4 : 3; }                       // off-diagonal blocks of the wave
+__host__ __device__ constexpr int d16_ai(int ty, int n) { return (ty == 2 && n == 2) ? 1 : 0; }
+__host__ __device__ constexpr int d16_bi(int ty, int n) { return ty == 2 ? (n == 0 ? 1 : 2) : n + 1; }
 template <int V>
 struct IntC {
     static constexpr int value = V;
@@ -100,7 +109,9 @@ template <int KP, int STAGGER = 1, int DIAG = 0, int SYM = 0, int CLS = 0>
 __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs g) {
     using C = RowHessCfg<KP>;
     static_assert(!SYM || KP == 256, "the symmetric block map is laid out for k_pad = 256");
-    static_assert(!CLS || SYM == 3, "the class-only build exists for the single-image symmetric kernel");
+    static_assert(!CLS || SYM >= 3, "the class-only build exists for the single-image symmetric kernel");
+    constexpr bool ONE = SYM >= 3; // one staged image sqrt(w_j) o_j
+    constexpr bool D16 = SYM == 4; // ... and the 8 diagonal blocks as three 16 x 16 sub-blocks each (see d16_* above)
     const bool late = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >= 4;
     extern __shared__ __attribute__((aligned(16))) float rsm[];
     auto tile_of = [&](int b) { return rsm + (CLS ? 1 : 2) * b * C::TILE; }; // raw rows o_j      (B operand)
@@ -180,7 +191,9 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
     const float lk = g.link ? 1.0f : 0.0f, nlk = 1.0f - lk;
     const float cls_sq = __builtin_amdgcn_sqrtf(fmaxf(g.scale, 0.0f));
     auto stage = [&](int nb) {
-        float *rdst = tile_of(nb) + trow * KP + 4 * tl16;
+        // D16: odd sample rows keep the 16-column halves of every 32-column block swapped (16-byte chunk index ^ 4), so that the
+        // 16-wide fragments of the diagonal sub-blocks -- lanes l and l + 16 on consecutive sample rows -- fall on different banks
+        float *rdst = tile_of(nb) + trow * KP + 4 * (D16 ? (tl16 ^ ((trow & 1) << 2)) : tl16);
         float *wdst = wtile_of(nb) + trow * KP + 4 * tl16;
         if constexpr (CLS) { // linear link: every sample of the class weighs s
             const float sq = vv ? cls_sq : 0.0f;
@@ -214,7 +227,7 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
                 gacc[q] += wgt * rr[q];
                 continue;
             }
-            if constexpr (SYM == 3) {
+            if constexpr (ONE) {
                 *reinterpret_cast<f32x4 *>(rdst + 4 * q * C::LPR) = sqw * rr[q];
             } else {
                 *reinterpret_cast<f32x4 *>(rdst + 4 * q * C::LPR) = rr[q];
@@ -265,7 +278,7 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
         float a[2][2], b[2][5];
         auto ld_frag = [&](int sidx, float *da, float *db) {
             const int kk = 2 * sidx + lh;
-            if constexpr (SYM == 3) { // one image: db[f] = fragment f of this wave (da unused)
+            if constexpr (ONE) { // one image: db[f] = fragment f of this wave (da unused)
 #pragma unroll
                 for (int f = 0; f < s3_nf(TY); ++f) db[f] = Rt[kk * KP + 32 * (TY == 0 ? (f == 0 ? ablk[0] : bblk[f - 1]) : bblk[f])];
             } else {
@@ -289,7 +302,7 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int n = 0; n < NP; ++n) {
-                if constexpr (SYM == 3)
+                if constexpr (ONE)
                     hs[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[sidx & 1][s3_ai(TY, n)], b[sidx & 1][s3_bi(TY, n)], hs[n], 0, 0, 0);
                 else
                     hs[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sidx & 1][sym_ai(TY, n)], b[sidx & 1][sym_bi(TY, n)], hs[n], 0, 0, 0);
@@ -309,7 +322,7 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
         float a[2][2], b[2][5];
         auto ld_frag = [&](int sidx, float *da, float *db) {
             const int kk = 2 * sidx + lh;
-            if constexpr (SYM == 3) {
+            if constexpr (ONE) {
 #pragma unroll
                 for (int f = 0; f < s3_nf(TY); ++f) db[f] = Rt[kk * KP + 32 * (TY == 0 ? (f == 0 ? ablk[0] : bblk[f - 1]) : bblk[f])];
             } else {
@@ -322,7 +335,7 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
         auto mm = [&](const float *fa, const float *fb) {
 #pragma unroll
             for (int n = 0; n < NP; ++n) {
-                if constexpr (SYM == 3) hs[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[s3_ai(TY, n)], fb[s3_bi(TY, n)], hs[n], 0, 0, 0);
+                if constexpr (ONE) hs[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[s3_ai(TY, n)], fb[s3_bi(TY, n)], hs[n], 0, 0, 0);
                 else hs[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sym_ai(TY, n)], fb[sym_bi(TY, n)], hs[n], 0, 0, 0);
             }
         };
@@ -332,6 +345,85 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
             mm(a[0], b[0]);
             ld_frag(sidx + 2, a[0], b[0]);
             mm(a[1], b[1]);
+        }
+    };
+    // ---- SYM = 4: the same two loops with the diagonal blocks on the 16-wide instruction
+    f32x4 hd[2][3]; // diagonal block d of the wave: sub-blocks (0,0), (0,1), (1,1)
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int x = 0; x < 3; ++x) hd[d][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int dblk0 = wty == 1 ? sbase : sbase + 1, dblk1 = wty == 1 ? sbase + 3 : sbase + 2;
+    const int kq16 = lane >> 4, i16 = lane & 15, hx16 = (kq16 & 1) << 4;
+    // 32-wide fragment f at sample row kk = 2 sidx + lh (the swizzle: odd rows hold their halves swapped)
+    auto d16_frag = [&](auto typ, const float *Rt, int sidx, float *db) {
+        constexpr int TY = decltype(typ)::value;
+        const int kk = 2 * sidx + lh;
+#pragma unroll
+        for (int f = 0; f < s3_nf(TY); ++f) db[f] = Rt[kk * KP + 32 * (TY == 0 ? (f == 0 ? ablk[0] : bblk[f - 1]) : bblk[f])];
+    };
+    // 16-wide fragments of the two diagonal blocks over the samples 4 tq .. 4 tq + 3: lane 16 k + i holds sample 4 tq + k, column 16 h + i
+    auto d16_diag = [&](const float *R16, int tq, float (*de)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            de[0][h] = R16[4 * tq * KP + 32 * dblk0 + ((16 * h) ^ hx16)];
+            de[1][h] = R16[4 * tq * KP + 32 * dblk1 + ((16 * h) ^ hx16)];
+        }
+    };
+    auto d16_mm = [&](auto typ, const float *fb) {
+        constexpr int TY = decltype(typ)::value;
+#pragma unroll
+        for (int n = 0; n < d16_np(TY); ++n)
+            hs[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[d16_ai(TY, n)], fb[d16_bi(TY, n)], hs[n], 0, 0, 0);
+    };
+    auto d16_mmd = [&](int d, const float (*de)[2]) {
+        hd[d][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(de[d][0], de[d][0], hd[d][0], 0, 0, 0);
+        hd[d][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(de[d][0], de[d][1], hd[d][1], 0, 0, 0);
+        hd[d][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(de[d][1], de[d][1], hd[d][2], 0, 0, 0);
+    };
+    auto d16_tile = [&](auto typ, int cb, bool do_stage, int nb, bool do_gather, int tl_gather, bool do_idx, int tl_idx) {
+        constexpr int TY = decltype(typ)::value;
+        const float *Rt = tile_of(cb) + (l31 ^ (lh << 4));
+        const float *R16 = tile_of(cb) + kq16 * KP + i16;
+        float b[2][5], e[2][2][2];
+        d16_frag(typ, Rt, 0, b[0]);
+        if constexpr (TY != 0) d16_diag(R16, 0, e[0]);
+#pragma unroll
+        for (int sidx = 0; sidx < 16; ++sidx) {
+            if (sidx + 1 < 16) d16_frag(typ, Rt, sidx + 1, b[(sidx + 1) & 1]);
+            if constexpr (TY != 0) {
+                if ((sidx & 1) == 0 && sidx + 2 < 16) d16_diag(R16, sidx / 2 + 1, e[(sidx / 2 + 1) & 1]);
+            }
+            const int g0 = (STAGGER && late) ? 8 : 0;
+            if (sidx == g0) {
+                if (DIAG != 1 && DIAG != 3 && do_stage && loader) stage(nb);
+            } else if (sidx == g0 + 1) {
+                if (DIAG != 1 && DIAG != 2 && do_gather && loader) gather(tl_gather);
+                if (DIAG != 1 && DIAG != 2 && do_idx && loader) load_idx(tl_idx);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            d16_mm(typ, b[sidx & 1]);
+            if constexpr (TY != 0) d16_mmd(sidx & 1, e[(sidx / 2) & 1]); // diagonal block 0 on the even steps, 1 on the odd ones
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto d16_tail = [&](auto typ, int cb, int nsteps) {
+        constexpr int TY = decltype(typ)::value;
+        const float *Rt = tile_of(cb) + (l31 ^ (lh << 4));
+        const float *R16 = tile_of(cb) + kq16 * KP + i16;
+        float b[2][5], e[2][2];
+        d16_frag(typ, Rt, 0, b[0]);
+        if constexpr (TY != 0) d16_diag(R16, 0, e);
+        for (int sidx = 0; sidx < nsteps; sidx += 2) { // sidx + 2 <= 14 always (nsteps <= 14)
+            d16_frag(typ, Rt, sidx + 1, b[1]);
+            d16_mm(typ, b[0]);
+            if constexpr (TY != 0) d16_mmd(0, e);
+            d16_frag(typ, Rt, sidx + 2, b[0]);
+            d16_mm(typ, b[1]);
+            if constexpr (TY != 0) {
+                d16_mmd(1, e);
+                d16_diag(R16, sidx / 2 + 1, e);
+            }
         }
     };
     const int tail_steps = nt > 0 ? (ns - 32 * (nt - 1) + 1) / 2 : 0; // K-steps of the last tile that carry samples (1..16)
@@ -353,10 +445,14 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
             auto run = [&](auto typ) {
                 const int full = tail_steps <= 14 ? nt - 1 : nt;
                 for (int tl = 0; tl < full; ++tl) {
-                    sym_tile(typ, tl & 1, tl + 1 < nt, (tl + 1) & 1, tl + 2 < nt, tl + 2, tl + 3 < nt, tl + 3);
+                    if constexpr (D16) d16_tile(typ, tl & 1, tl + 1 < nt, (tl + 1) & 1, tl + 2 < nt, tl + 2, tl + 3 < nt, tl + 3);
+                    else sym_tile(typ, tl & 1, tl + 1 < nt, (tl + 1) & 1, tl + 2 < nt, tl + 2, tl + 3 < nt, tl + 3);
                     __syncthreads();
                 }
-                if (full < nt) sym_tail(typ, (nt - 1) & 1, tail_steps);
+                if (full < nt) {
+                    if constexpr (D16) d16_tail(typ, (nt - 1) & 1, tail_steps);
+                    else sym_tail(typ, (nt - 1) & 1, tail_steps);
+                }
             };
             if (wty == 0) run(IntC<0>{});
             else if (wty == 1) run(IntC<1>{});
@@ -380,9 +476,43 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
     if constexpr (SYM) {
         auto emit = [&](auto typ) {
             constexpr int TY = decltype(typ)::value;
+            if constexpr (D16 && TY != 0) { // the two diagonal blocks: sub-block (ha, hb) at rows 16 ha + 4 (lane / 16) + r, column 16 hb + lane % 16
 #pragma unroll
-            for (int n = 0; n < sym_np(TY); ++n) {
-                const int ba = ablk[sym_ai(TY, n)], bb = bblk[sym_bi(TY, n)];
+                for (int d = 0; d < 2; ++d) {
+                    const int bd = d == 0 ? dblk0 : dblk1;
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) {
+                        const int ha = x == 2 ? 1 : 0, hb = x == 0 ? 0 : 1;
+                        const int rloc = 16 * ha + 4 * kq16, cloc = 16 * hb + i16;
+                        if constexpr (CLS) {
+                            float *blk = Hi + cls_block(bd, bd) * cls_bstride;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) blk[(rloc + r) * 32 + cloc] = hd[d][x][r];
+                            if (x == 1) *reinterpret_cast<f32x4 *>(blk + cloc * 32 + rloc) = hd[d][x];
+                            continue;
+                        }
+                        float *dst = Hi + (32 * bd + rloc) * KP + 32 * bd + cloc;
+                        f32x4 v = hd[d][x];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 32 * bd + rloc + r, col = 32 * bd + cloc;
+                            if (g.accumulate & 1) v[r] += dst[r * KP];
+                            else {
+                                if (g.S) v[r] += g.S[row * KP + col];
+                                if (row == col && row < g.kvalid) v[r] += g.diag;
+                            }
+                            dst[r * KP] = v[r];
+                        }
+                        if (x == 1) *reinterpret_cast<f32x4 *>(Hi + (32 * bd + cloc) * KP + 32 * bd + rloc) = v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < (D16 ? d16_np(TY) : sym_np(TY)); ++n) {
+                const int ai_ = D16 ? d16_ai(TY, n) : 0, bi_ = D16 ? d16_bi(TY, n) : 0;
+                // (D16: operands are fragment indices -- type 0: fragment 0 = block row w, 1..4 = block columns 4..7; else block columns)
+                const int ba = D16 ? (TY == 0 ? ablk[0] : bblk[ai_]) : ablk[sym_ai(TY, n)];
+                const int bb = D16 ? (TY == 0 ? bblk[bi_ > 0 ? bi_ - 1 : 0] : bblk[bi_]) : bblk[sym_bi(TY, n)];
                 if constexpr (CLS) { // block-major image: upper block (ba, bb) is 4 KB in one piece, row-major inside
                     float *blk = Hi + cls_block(ba, bb) * cls_bstride + 4 * lh * 32 + l31;
 #pragma unroll

@@ -131,7 +131,8 @@ def test_c3_full_size_newton_properties(lib):
     args = (0.5, 0.0, 0.1, "linear", "logit", 0, 7, 0.2, 0.5)
     out = {}
     for name, sym, seed, classes, certs in (("a", 1, 1000, -1, 1), ("b", 1, 1000, -1, 1), ("full", 0, 1000, -1, 1), ("other", 1, 1001, -1, 1),
-                                            ("rows", 1, 1000, 0, 1), ("four", 1, 1000, 4, 1), ("nocert", 1, 1000, -1, 0)):
+                                            ("rows", 1, 1000, 0, 1), ("four", 1, 1000, 4, 1), ("nocert", 1, 1000, -1, 0),
+                                            ("one", 3, 1000, -1, 1), ("d16", 4, 1000, -1, 1), ("d16b", 4, 1000, -1, 1), ("d16rows", 4, 1000, 0, 1)):
         ctx = _synthetic(lib, m, d, p, k)
         ctx.set_option("row_symmetric", sym)
         ctx.set_option("row_classes", classes)
@@ -148,6 +149,10 @@ def test_c3_full_size_newton_properties(lib):
         # the same sums in another order (float32), then solved
         np.testing.assert_allclose(out["rows"][w], out["a"][w], rtol=0, atol=1e-4 * np.abs(out["a"][w]).max())
         np.testing.assert_allclose(out["four"][w], out["a"][w], rtol=0, atol=1e-4 * np.abs(out["a"][w]).max())
+        # the single-image kernel, and the default: its diagonal blocks as 16-wide sub-blocks (class images and row by row)
+        np.testing.assert_array_equal(out["d16"][w], out["d16b"][w])
+        for name in ("one", "d16", "d16rows"):
+            np.testing.assert_allclose(out[name][w], out["a"][w], rtol=0, atol=1e-4 * np.abs(out["a"][w]).max())
         # a certificate only replaces a test it implies: nothing changes
         np.testing.assert_array_equal(out["nocert"][w], out["a"][w])
 
