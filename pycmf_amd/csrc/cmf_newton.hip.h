@@ -1261,7 +1261,17 @@ static int launch_row_hess_kp(cmf_ctx *c, const RowHessArgs &a, int64_t nrows) {
         CHK(allow_big_lds(c, reinterpret_cast<const void *>(&row_hess_kernel<256, 1, D_, S_>), (int)Cfg::LDS_BYTES)); \
         hipLaunchKernelGGL((row_hess_kernel<256, 1, D_, S_>), dim3((unsigned)nrows), dim3(512), Cfg::LDS_BYTES, c->stream, a); \
     } while (0)
-        if (c->opt_rowsym) {
+        if (c->opt_rowsym >= 3 && a.scale >= 0.f && !a.cls_cnt) { // the default kernel of the logit launches (tools/r06_rowdiag.sh)
+            if (c->opt_rowdiag == 1) CMF_ROWDIAG(1, 4);
+            else if (c->opt_rowdiag == 4) CMF_ROWDIAG(4, 4);
+            else if (c->opt_rowdiag == 5) CMF_ROWDIAG(5, 4);
+            else if (c->opt_rowdiag == 6) CMF_ROWDIAG(6, 4);
+            else if (c->opt_rowdiag == 7) CMF_ROWDIAG(7, 4);
+            else if (c->opt_rowdiag == 9) CMF_ROWDIAG(9, 4);
+            else if (c->opt_rowdiag == 10) CMF_ROWDIAG(10, 4);
+            else if (c->opt_rowdiag == 11) CMF_ROWDIAG(11, 4);
+            else CMF_ROWDIAG(8, 4);
+        } else if (c->opt_rowsym) {
             if (c->opt_rowdiag == 1) CMF_ROWDIAG(1, 1);
             else if (c->opt_rowdiag == 2) CMF_ROWDIAG(2, 1);
             else if (c->opt_rowdiag == 4) CMF_ROWDIAG(4, 1);

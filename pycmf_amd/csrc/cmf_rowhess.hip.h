@@ -177,14 +177,26 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
     auto load_idx = [&](int tl) {
         const int q = 32 * tl + trow;
         const int qc = q < ns ? q : ns - 1;
-        jn = list ? list[qc] : qc + s0;
+        if constexpr (DIAG == 11) jn = trow + 32 * (int)(blockIdx.x & 63); // diagnostic: the same 32 rows every tile (cache hits), with the stage of DIAG 8
+        else if constexpr (DIAG == 7) jn = qc + s0; // diagnostic: consecutive rows, no index stream
+        else jn = list ? list[qc] : qc + s0;
     };
     auto gather = [&](int tl) {
         vv = 32 * tl + trow < ns;
         const float *src = g.O + (int64_t)jn * KP + 4 * tl16;
+        if constexpr (DIAG == 9) { // diagnostic: one dword per lane instead of the row (with the stage of DIAG 8)
+            rr[0][0] = src[0];
+            return;
+        }
+        if constexpr (DIAG == 10) { // diagnostic: the same number of loads, one dword each (with the stage of DIAG 8)
+#pragma unroll
+            for (int q = 0; q < C::CPT; ++q) rr[q][0] = src[4 * q * C::LPR];
+            tt = Ti[(int64_t)jn * g.t_col];
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < C::CPT; ++q) rr[q] = *reinterpret_cast<const f32x4 *>(src + 4 * q * C::LPR);
-        if constexpr (!CLS) tt = Ti[(int64_t)jn * g.t_col];
+        if constexpr (!CLS && DIAG != 6) tt = Ti[(int64_t)jn * g.t_col]; // (DIAG 6: no target load)
     };
     // registers -> (z, r, w, gradient) -> LDS tile.  Branch-free in the link:
     // f = lk sigmoid(z) + (1 - lk) z, w = lk f (1 - f) + (1 - lk), lk = 0 / 1 -- exact, one term is always zero.
@@ -199,6 +211,12 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
             const float sq = vv ? cls_sq : 0.0f;
 #pragma unroll
             for (int q = 0; q < C::CPT; ++q) *reinterpret_cast<f32x4 *>(rdst + 4 * q * C::LPR) = sq * rr[q];
+            return;
+        }
+        if constexpr (DIAG == 8 || DIAG == 9 || DIAG == 10 || DIAG == 11) { // diagnostic: wait for the gathered rows, nothing else
+#pragma unroll
+            for (int q = 0; q < C::CPT; ++q) gacc[0] += rr[q];
+            if constexpr (DIAG == 10) gacc[0][0] += tt;
             return;
         }
         if constexpr (DIAG == 4) { // diagnostic: LDS writes only
