@@ -450,6 +450,7 @@ def main():
     # quoted a line from BEFORE such a change).  Warm up until two consecutive iterations record the same clamp / refinement
     # counts (at most --max-warmup more), and say how long that took; the line is checked again after the timed region.
     warm_extra = 0
+    warm_ms = []
     if newton and not sharded_ok and not use_dist:
         def clamp_counts():
             ctx.sync()
@@ -458,16 +459,22 @@ def main():
         prev = clamp_counts()
         last, same = None, 0
         while warm_extra < args.max_warmup:
+            t_it = time.perf_counter()
             do_step(args.warmup + warm_extra)
             warm_extra += 1
             cur = clamp_counts()
+            warm_ms.append((time.perf_counter() - t_it) * 1e3)
             delta = (cur[0] - prev[0], cur[1] - prev[1])
             prev = cur
             same = same + 1 if (last is not None and delta == last) else 0
             last = delta
             # (C3 idles at "8192 rows of Z clamped" for iterations 3-6 before every row of U joins at the seventh: two equal
             # iterations in a row are no steady state -- at least 12 iterations in all, then three alike)
-            if same >= 2 and args.warmup + warm_extra >= min(12, args.max_warmup):
+            # (C3X: iterations 6-12 take 495 ms each, the 13th 625 ms once -- the eigen-solve of one sweep in a single iteration --
+            # then 493 ms for good: the counts do not show it.  At least 16 iterations in all, and the last three alike in TIME too.)
+            t3 = warm_ms[-3:]
+            steady_time = len(t3) == 3 and max(t3) <= 1.03 * min(t3)
+            if same >= 2 and steady_time and args.warmup + warm_extra >= min(16, args.max_warmup):
                 break
         args.warmup += warm_extra
     for c_ in ctxs:
@@ -746,7 +753,9 @@ def main():
         }
     if newton:
         out["steady_state"] = {"extra_warmup_iterations": warm_extra, "instrumented_over_timed": t_extra / ms_per_step if ms_per_step > 0 else None,
-                               "note": "warm-up continued until two consecutive iterations recorded the same clamp / refinement counts; the "
+                               "warmup_series_ms": [round(x, 1) for x in warm_ms] if warm_extra else [],
+                               "note": "warm-up continued until three consecutive iterations recorded the same clamp / refinement counts and took "
+                                       "the same time to 3 % (at least 16 iterations in all; warmup_series_ms: their wall clock, host-synchronised); the "
                                        "iterations after the timed region (instrumented_ms_per_step) must not cost more than 1.25 x the timed "
                                        "ones, else the line is refused (exit code 3)"}
     sys.stdout.flush()

@@ -19,6 +19,7 @@ def counters(path):
 
 
 LINES_ONLY = len(sys.argv) > 1 and sys.argv[1] == "lines"   # after `bash tools/refresh_r06.sh lines`: only the bench lines are new
+C3_ONLY = len(sys.argv) > 1 and sys.argv[1] == "c3"         # after `bash tools/refresh_r06b.sh`: the C3 family (row kernel changed late in the round)
 def copy(src, dst):
     if os.path.exists(src) and os.path.getsize(src) > 0:
         shutil.copy(src, dst)
@@ -26,23 +27,32 @@ def copy(src, dst):
         print("missing:", src)
 
 
-for w in ("c4", "c2", "c3", "c3r", "c3x", "c5", "c5z", "c5zs", "c5l", "c5l_l2x10"):
+for w in (("c3", "c3r", "c3x") if C3_ONLY else ("c4", "c2", "c3", "c3r", "c3x", "c5", "c5z", "c5zs", "c5l", "c5l_l2x10")):
     copy(os.path.join(SRC, "%s.json" % w), os.path.join(DST, "%s_%s_n1_bench.json" % (TAG, w)))
 for f_, t_ in (("c4_tol.json", "%s_c4_n1_tol_bench.json"), ("c4_notol40.json", "%s_c4_n1_bench_40_steps.json"),
                ("c3_norefine.json", "%s_c3_n1_bench_refine_rows_0.json"), ("c3_r05_clamp.json", "%s_c3_n1_bench_round5_clamp_path.json"),
-               ("c3_no_early_exit.json", "%s_c3_n1_bench_no_early_exit.json")):
+               ("c3_no_early_exit.json", "%s_c3_n1_bench_no_early_exit.json"),
+               ("c3_rowsym3.json", "%s_c3_n1_bench_row_symmetric_3.json"), ("c3x_rowsym3.json", "%s_c3x_n1_bench_row_symmetric_3.json")):
+    if C3_ONLY and not f_.startswith("c3"):
+        continue
     copy(os.path.join(SRC, f_), os.path.join(DST, t_ % TAG))
 if LINES_ONLY:
     sys.exit(0)
-for w in ("c4", "c2", "c3", "c3x", "c5"):
+for w in (("c3", "c3x") if C3_ONLY else ("c4", "c2", "c3", "c3x", "c5")):
     copy(os.path.join(SRC, "prof_%s" % w, "%s_kernel_stats.csv" % w), os.path.join(DST, "%s_%s_n1_kernel_stats.csv" % (TAG, w)))
-for w in ("c4", "c3", "c3x", "c5", "c5z", "c5zs"):
+for w in (("c3", "c3x") if C3_ONLY else ("c4", "c3", "c3x", "c5", "c5z", "c5zs")):
     for cnt, d, f in (("FETCH_SIZE", "fetch", "f"), ("WRITE_SIZE", "write", "w")):
         shutil.copy(os.path.join(SRC, "pmc_%s_%s" % (w, d), "%s_cmfk_counters.csv" % f), os.path.join(DST, "%s_%s_n1_pmc_%s.csv" % (TAG, w, cnt)))
-shutil.copy(os.path.join(SRC, "pmc_mfma_c4", "m_cmfk_counters.csv"), os.path.join(DST, "%s_c4_n1_pmc_MFMA.csv" % TAG))
+if not C3_ONLY:
+    shutil.copy(os.path.join(SRC, "pmc_mfma_c4", "m_cmfk_counters.csv"), os.path.join(DST, "%s_c4_n1_pmc_MFMA.csv" % TAG))
+for w in ("c3", "c3x"):   # (refresh_r06b.sh) matrix-pipe busy cycles of the row kernel; LDS counters of the C3X logit launches
+    copy(os.path.join(SRC, "pmc_mfma_%s" % w, "m_cmfk_counters.csv"), os.path.join(DST, "%s_%s_n1_pmc_MFMA.csv" % (TAG, w)))
+copy(os.path.join(SRC, "pmc_lds_c3x", "l_cmfk_counters.csv"), os.path.join(DST, "%s_c3x_n1_pmc_LDS.csv" % TAG))
+copy(os.path.join(SRC, "pmc_lds_c3x_sym3", "l_cmfk_counters.csv"), os.path.join(DST, "%s_c3x_n1_pmc_LDS_row_symmetric_3.csv" % TAG))
 
 # ---- C4: data-pass GEMMs
 m = d = 65536; k = 256
+# (in `c3` mode the blocks of the other workloads recompute their summaries from the PMC files already under profiles/: same numbers)
 alg = 4.0 * (m * d + m * k + d * k)
 f = counters(os.path.join(DST, "%s_c4_n1_pmc_FETCH_SIZE.csv" % TAG)); wr = counters(os.path.join(DST, "%s_c4_n1_pmc_WRITE_SIZE.csv" % TAG))
 out = {"_provenance": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/refresh_r06.sh) of `python3 bench.py --steps 2 "
@@ -68,7 +78,8 @@ for W3 in ("c3", "c3x"):
                           "--steps 1 --warmup 1 --no-cpu-baseline` (%s).  FETCH_SIZE KiB x1024 x2 (gfx950 correction) + WRITE_SIZE KiB x1024, averaged "
                           "over the launches of the row kernel.  Bytes past L2, Infinity-Cache hits included." % (W3, TAG), "unit": "bytes per launch"}
     allf, allw = [], []
-    for key, pred in (("class_launches", lambda n: "row_hess_kernel" in n and "3, 1>" in n), ("logit_launches", lambda n: "row_hess_kernel" in n and "3, 1>" not in n)):
+    for key, pred in (("class_launches", lambda n: "row_hess_kernel" in n and ("3, 1>" in n or "4, 1>" in n)),
+                      ("logit_launches", lambda n: "row_hess_kernel" in n and not ("3, 1>" in n or "4, 1>" in n))):
         fv = [v for (n, c), vs in f.items() if pred(n) and c == "FETCH_SIZE" for v, _ in vs]
         wv = [v for (n, c), vs in wr.items() if pred(n) and c == "WRITE_SIZE" for v, _ in vs]
         if fv and wv:
@@ -116,5 +127,31 @@ for key, sym in (("gemm_tn", "gemm_kernel<1, 256, 0,"), ("gemm_nn", "gemm_kernel
     if busy and act:
         b = sum(busy) / len(busy); a = sum(v for v, _ in act) / len(act); dd = sum(x for _, x in act) / len(act)
         util[key] = {"mfma_busy_cycles": b, "grbm_gui_active": a, "utilisation": b / (1024.0 * a / 8.0), "effective_clock_GHz": a / 8.0 / dd, "launches": len(busy)}
+# ---- ... and of the row kernel (tools/refresh_r06b.sh): class launches (two workgroups per CU) and logit launches (one) of C3, logit launches of C3X
+for w in ("c3", "c3x"):
+    pth = os.path.join(DST, "%s_%s_n1_pmc_MFMA.csv" % (TAG, w))
+    if not os.path.exists(pth):
+        continue
+    mm = counters(pth)
+    for key, pred in (("%s_rowhess_class_launches" % w, lambda n: "row_hess_kernel" in n and "4, 1>" in n),
+                      ("%s_rowhess_logit_launches" % w, lambda n: "row_hess_kernel" in n and "4, 0>" in n)):
+        busy = [v for (n, c), vs in mm.items() if pred(n) and c == "SQ_VALU_MFMA_BUSY_CYCLES" for v, _ in vs]
+        act = [(v, dd) for (n, c), vs in mm.items() if pred(n) and c == "GRBM_GUI_ACTIVE" for v, dd in vs]
+        if busy and act:
+            b = sum(busy) / len(busy); a = sum(v for v, _ in act) / len(act); dd = sum(x for _, x in act) / len(act)
+            util[key] = {"mfma_busy_cycles": b, "grbm_gui_active": a, "utilisation": b / (1024.0 * a / 8.0), "effective_clock_GHz": a / 8.0 / dd,
+                         "launches": len(busy), "avg_duration_ms_under_pmc": dd / 1e6}
+for tag_, fn in (("c3x_rowhess_lds", "%s_c3x_n1_pmc_LDS.csv" % TAG), ("c3x_rowhess_lds_row_symmetric_3", "%s_c3x_n1_pmc_LDS_row_symmetric_3.csv" % TAG)):
+    pth = os.path.join(DST, fn)
+    if os.path.exists(pth):
+        ll = counters(pth)
+        ent = {}
+        for cn in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"):
+            vals = [v for (n, c), vs in ll.items() if "row_hess_kernel" in n and c == cn for v, _ in vs]
+            if vals:
+                ent[cn] = sum(vals) / len(vals)
+        util[tag_] = ent
+util["_provenance_rowhess"] = ("rocprofv3 --pmc passes of `bench.py --workload c3|c3x --steps 1 --warmup 1` (tools/refresh_r06b.sh): the same quotients for "
+                               "row_hess_kernel<256, 1, 0, 4, *>; LDS counters are sums over the SIMDs, averaged over the launches")
 json.dump(util, open(os.path.join(DST, "mfma_util_%s.json" % TAG), "w"), indent=1)
 print(json.dumps(util, indent=1))
