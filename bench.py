@@ -724,6 +724,7 @@ def main():
         st = ctx.newton_clamp_stats(full=True)
         out["conditioning"] = {"clamped_rows_float32": st[0], "max_ratio_left_in_float32": st[1], "rows_refined_in_float64": st[2],
                                "max_condition_estimate_plain_solves": st[3],
+                               "clamp_routes": dict(zip(("tridiagonal_eigen_solve_rows", "rank_one_rows"), ctx.newton_clamp_routes())),
                                "note": "per-row sweeps since the context was created (cmf_newton_clamp_stats): rows whose float32 Hessian "
                                        "went through the spectral clamp, largest ||H||_F / pert left in float32, rows redone in float64, "
                                        "largest max H_ii / min L_ii^2 over all plain Cholesky solves"}

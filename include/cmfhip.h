@@ -268,6 +268,11 @@ int cmf_safe_solve_batch(cmf_ctx *ctx, const double *H, const double *g, double 
  * plain_cond: the largest condition estimate max H_ii / min L_ii^2 (<= cond(H)) over ALL rows solved by plain Cholesky -- rows above
  * the refinement ratio by that estimate are refined too; the ones left in float32 also enter max_ratio. */
 int cmf_newton_clamp_stats(cmf_ctx *ctx, int64_t *rows, double *max_ratio, int64_t *refined, double *plain_cond, int reset);
+/* Which route the rows flagged by the threshold test took through _safe_invert's clamp (pycmf/cmf_solvers.py:346-356) since the
+ * context was created: eigen_rows through the tridiagonal eigen-solve (Householder + QL, any spectrum), rank1_rows through the
+ * rank-one shortcut (one eigenvalue above pert, every other one certified below it by a Cholesky factorisation of
+ * (pert - delta) I - (H - lambda_1 q q^T); positive semi-definite Hessians at k_pad = 256; option "rank1_clamp", default on). */
+int cmf_newton_clamp_routes(cmf_ctx *ctx, int64_t *eigen_rows, int64_t *rank1_rows);
 
 /* float64 path of the ONE shared Hessian of a linear-link sweep (cmf_solvers.py:407-410, :448-450): H is k x k
  * float64 on the host, k = the problem's n_components; out = Q diag(1/max(|l|,pert)) Q^T computed in float64 on

@@ -47,6 +47,7 @@ PROTOTYPES = {
     "cmf_get_data_block_f32": [_vp, _i32, _i64, _i64, _i64, _i64, _pf],
     "cmf_sample_lists": [_vp, _i32, C.c_uint64, _dbl, _i64, _i64, _pi32],
     "cmf_newton_clamp_stats": [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), _i32],
+    "cmf_newton_clamp_routes": [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "cmf_data_matmul_f64": [_vp, _i32, _i32, _pd, _i64, _i32, _pd],
     "cmf_rsvd": [_vp, _i32, _i32, _i32, _i32, _i32, _pd, _pd, _pd, _pd],
     "cmf_data_sum": [_vp, _pd, _pd],
@@ -524,6 +525,12 @@ class Context:
         rows, ratio, refined, plain = C.c_int64(0), C.c_double(0), C.c_int64(0), C.c_double(0)
         check(self._lib.cmf_newton_clamp_stats(self._h, C.byref(rows), C.byref(ratio), C.byref(refined), C.byref(plain), 1 if reset else 0))
         return (rows.value, ratio.value, refined.value, plain.value) if full else (rows.value, ratio.value, refined.value)
+
+    def newton_clamp_routes(self):
+        """(rows served by the tridiagonal eigen-solve, rows served by the rank-one shortcut) since the context was created."""
+        e, r = C.c_int64(0), C.c_int64(0)
+        check(self._lib.cmf_newton_clamp_routes(self._h, C.byref(e), C.byref(r)))
+        return e.value, r.value
 
     def residual_sq(self, x_link="linear", y_link="linear"):
         ex, ey = C.c_double(0), C.c_double(0)

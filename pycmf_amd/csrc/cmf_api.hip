@@ -13,6 +13,7 @@
 #include "cmf_shared64.hip.h"
 #include "cmf_refine64.hip.h"
 #include "cmf_eigclamp.hip.h"
+#include "cmf_rank1clamp.hip.h"
 
 #include <hip/hip_runtime.h>
 
@@ -223,6 +224,10 @@ struct cmf_ctx {
     DevBuf eigcl_ws, eigcl_log, eigcl_fail; // tridiagonal eigen-clamp (cmf_eigclamp.hip.h): d / e / Q^T g / tau, rotation logs, per-matrix give-up flags
     int opt_eig_clamp = 1;                // flagged per-row Hessians at k_pad 128 / 256: Householder + QL solve on the vector units (0: Newton-Schulz polynomials / Jacobi; 3: without the early exit of the QL iteration)
     int64_t eig_clamp_rows = 0;           // matrices served by it since the context was created (tests / bench)
+    DevBuf r1_ws;                         // rank-one clamp (cmf_rank1clamp.hip.h): top eigenvectors, eigenvalues, convergence / certificate flags
+    int opt_rank1_clamp = 1;              // flagged PSD Hessians with ONE eigenvalue above the threshold: power iteration + Cholesky certificate (0: off)
+    int r1_skip = 0;                      // chunks to let pass after one where it served fewer than a quarter of the flagged rows
+    int64_t rank1_rows = 0;               // matrices served by it since the context was created
     DevBuf g64a, g64b, gmix64, h64;       // float64 Grams / shared Hessian of the linear-link Newton sweeps (cmf_shared64.hip.h)
     DevBuf gslab64, w64, ns64;            // their split slabs, Cholesky workspaces + L^-1 image, Newton-Schulz images
     bool gmix64_valid = false;            // gmix64 = alpha U^T U + (1 - alpha) Z^T Z of the partials just formed (single-GPU step)
@@ -835,7 +840,7 @@ static void release_problem(cmf_ctx *c) {
     c->idxbuf = DevBuf(); c->eigws = DevBuf(); c->eigflag = DevBuf(); c->eigcopy = DevBuf(); c->clampstat = DevBuf(); c->badbuf = DevBuf(); c->rw64 = DevBuf(); c->rh64 = DevBuf(); c->bad_host.clear();
     c->ref_w = DevBuf(); c->ref_w2 = DevBuf(); c->ref_g = DevBuf(); c->ref_i = DevBuf(); c->ref_ns = DevBuf();
     c->trace64 = DevBuf(); c->dsq_valid[0] = c->dsq_valid[1] = false;
-    c->nsidx = DevBuf(); c->nsws = DevBuf(); c->eigcl_ws = DevBuf(); c->eigcl_log = DevBuf(); c->eigcl_fail = DevBuf(); c->eigcl_snap = DevBuf();
+    c->nsidx = DevBuf(); c->nsws = DevBuf(); c->eigcl_ws = DevBuf(); c->eigcl_log = DevBuf(); c->eigcl_fail = DevBuf(); c->eigcl_snap = DevBuf(); c->r1_ws = DevBuf();
     c->spmm_bar = DevBuf(); c->spmm_part = DevBuf();
     c->g64a = DevBuf(); c->g64b = DevBuf(); c->gmix64 = DevBuf(); c->h64 = DevBuf();
     c->gslab64 = DevBuf(); c->w64 = DevBuf(); c->ns64 = DevBuf();
@@ -962,6 +967,9 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_trace_error_off = value == 0;
     } else if (!strcmp(name, "eig_clamp")) {
         c->opt_eig_clamp = (int)value;
+    } else if (!strcmp(name, "rank1_clamp")) {
+        c->opt_rank1_clamp = value != 0;
+        c->r1_skip = 0;
     } else if (!strcmp(name, "newton_schulz")) {
         c->opt_ns = value != 0;
     } else if (!strcmp(name, "chol_diag")) {

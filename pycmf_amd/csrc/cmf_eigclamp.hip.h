@@ -529,16 +529,29 @@ __global__ __launch_bounds__(64) void eig_ql_kernel(float *ws, int64_t NB, int n
     // so the relative error of the step is bounded by delta / (smallest |lambda| that is NOT safely clamped) -- and by zero when
     // every eigenvalue is: then max(H, pert I) = pert I whatever the rounding.  (C3 at the reference's default l2 = 0, steady state:
     // one eigenvalue of 2e3 and 255 below pert: 1e-6, although ||H|| / pert = 1e4.)
-    float minabove = rest_low;
+    // ... PLUS the rotation of the invariant subspaces against each other: a direction j that is not clamped leaks into the clamped
+    // subspace by an angle delta / (lambda_j - lambda_c), and f differs by up to 1 / pert - 1 / lambda_j between the two, so the
+    // step picks up an error of (delta / (pert lambda_j)) |g_j| = (delta / pert) |step_j| there -- small against ||step|| while the
+    // clamped part of the step (g / pert) dominates it (C3's steady state: 1e-4 of it), NOT small where the gradient lies along
+    // the large eigenvalues (second campaign of profiles/fuzz_r06.md: 6e-3 on V with the first term alone).  su2 / st2: squared
+    // norms of the step's part in the directions not safely clamped / of the whole step (in the eigenbasis: same norms).
+    float minabove = rest_low, su2 = 0.f, st2 = 0.f;
     for (int q = 0; q < lstop; ++q) {
         const float lam = D[q * 64], al = fabsf(lam);
-        if (al >= pert - delta) minabove = fminf(minabove, al);
-        Rv[q * 64] = Rv[q * 64] / fmaxf(al, pert);
+        const float y = Rv[q * 64] / fmaxf(al, pert);
+        if (al >= pert - delta) { minabove = fminf(minabove, al); su2 = fmaf(y, y, su2); }
+        st2 = fmaf(y, y, st2);
+        Rv[q * 64] = y;
         if (lam_out && live) lam_out[(size_t)b * NP + q] = lam;
     }
     if (mode == 1) {
         const float ip = 1.0f / pert;
-        for (int q = lstop; q < n; ++q) Rv[q * 64] *= ip;
+        for (int q = lstop; q < n; ++q) {
+            const float y = Rv[q * 64] * ip;
+            if (rest_low < 3.0e38f) su2 = fmaf(y, y, su2); // (not all of the rest is safely inside: priced as if none were)
+            st2 = fmaf(y, y, st2);
+            Rv[q * 64] = y;
+        }
     } else if (mode == 2) { // L z = r, y = L^-T diag(1 / q) z
         float z = Rv[lstop * 64];
         for (int i = lstop + 1; i < n; ++i) {
@@ -551,10 +564,15 @@ __global__ __launch_bounds__(64) void eig_ql_kernel(float *ws, int64_t NB, int n
             y = Rv[i * 64] / D[i * 64] - eT[(size_t)(i + 1) * NB] * y;
             Rv[i * 64] = y;
         }
+        for (int i = lstop; i < n; ++i) { // the whole block lies above the threshold
+            const float yi = Rv[i * 64];
+            su2 = fmaf(yi, yi, su2);
+            st2 = fmaf(yi, yi, st2);
+        }
     }
     if (lam_out && live)
         for (int q = lstop; q < n; ++q) lam_out[(size_t)b * NP + q] = __int_as_float(0x7fc00000); // (not computed: the iteration stopped)
-    if (live) ws[(size_t)4 * NP * NB + b] = minabove < 3.0e38f ? delta / fmaxf(minabove, 1e-30f) : 0.f;
+    if (live) ws[(size_t)4 * NP * NB + b] = minabove < 3.0e38f ? delta / fmaxf(minabove, 1e-30f) + (delta / pert) * sqrtf(su2 / fmaxf(st2, 1e-37f)) : 0.f;
     for (int t = nsw - 1; t >= 0; --t) {
         // ascending i = ilo .. ihi: trip index ihi - i descends; chunks of RC trips aligned to the pairs of the forward order
         const int ihi = __builtin_amdgcn_readfirstlane(sw[t].ihi), ilo = __builtin_amdgcn_readfirstlane(sw[t].ilo), len = ihi - ilo + 1, np_ = (len + 1) / 2;

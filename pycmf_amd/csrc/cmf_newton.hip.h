@@ -131,6 +131,14 @@ extern "C" int cmf_newton_clamp_stats(cmf_ctx *c, int64_t *rows, double *max_rat
     return CMF_OK;
 }
 
+// Which route the flagged rows of the per-row sweeps took since the context was created: tridiagonal eigen-solve, rank-one shortcut.
+extern "C" int cmf_newton_clamp_routes(cmf_ctx *c, int64_t *eigen_rows, int64_t *rank1_rows) {
+    if (!c) return fail(CMF_EINVAL, "null context");
+    if (eigen_rows) *eigen_rows = c->eig_clamp_rows;
+    if (rank1_rows) *rank1_rows = c->rank1_rows;
+    return CMF_OK;
+}
+
 static int safe_inverse_dev(cmf_ctx *c, const float *Hin, float *Hout, int nmat, int n, int kp, double pert, bool psd = false,
                             bool refine = false) {
     if (nmat <= 0) return CMF_OK;
@@ -386,6 +394,55 @@ static int ns_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, f
     return CMF_OK;
 }
 
+// The flagged matrices of a chunk whose spectrum is "one eigenvalue above the threshold, the rest below" (cmf_rank1clamp.hip.h): power
+// iteration, Cholesky certificate, closed-form step; a row that does not pass keeps its flag for the eigen-solve below.  Adaptive:
+// a chunk where fewer than a quarter of the flagged rows passed (mixed spectra: C3X, the transition iterations of C3) switches the
+// attempt off for the next 15 chunks -- a function of the iteration history only, so runs repeat bit for bit.
+static bool rank1_clamp_ok(const cmf_ctx *c, int n, int kp) {
+    return c->opt_rank1_clamp && c->hess_psd && kp == 256 && n > 128 && c->opt_chol_mfma && !c->opt_choldiag && eig_clamp_ok(c, n, kp);
+}
+static int rank1_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, float *step, int *flags, int64_t nr, int n, int kp, double pert,
+                                  float *sens_out) {
+    if (c->r1_skip > 0) {
+        --c->r1_skip;
+        return CMF_OK;
+    }
+    CHK(ensure(c, c->nsidx, (size_t)(nr + 1) * sizeof(int)));
+    int *idx = (int *)c->nsidx.p, *count = idx + nr;
+    HIPCHK(hipMemsetAsync(count, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(compact_flags_kernel, dim3(32), dim3(256), 0, c->stream, (const int *)flags, (int)nr, idx, count);
+    HIPCHK(hipGetLastError());
+    int nf = 0;
+    HIPCHK(hipMemcpyAsync(&nf, count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (nf <= 0) return CMF_OK;
+    Timed tm(c, CMF_K_EIGEN);
+    const int64_t stride = (int64_t)kp * kp;
+    CHK(ensure(c, c->eigcl_log, (size_t)nf * stride * sizeof(float)));                               // the certificate images
+    CHK(ensure(c, c->r1_ws, (size_t)nf * (kp + 3) * sizeof(float) + 16));                             // q | lambda | ok | cert | served (8-byte aligned)
+    float *A = (float *)c->eigcl_log.p;
+    float *q = (float *)c->r1_ws.p, *lam = q + (size_t)nf * kp;
+    int *ok = (int *)(lam + nf), *cert = ok + nf;
+    unsigned long long *served = (unsigned long long *)(((uintptr_t)(cert + nf) + 7) & ~(uintptr_t)7);
+    HIPCHK(hipMemsetAsync(cert, 1, (size_t)nf * sizeof(int), c->stream)); // non-zero: not certified
+    HIPCHK(hipMemsetAsync(served, 0, sizeof(unsigned long long), c->stream));
+    const int *ib = nf == nr ? (const int *)nullptr : (const int *)idx;
+    // four products: from the constant vector the iterate is converged after three when lambda_2 / lambda_1 < 1e-2; the fourth measures
+    hipLaunchKernelGGL(rank1_power_kernel, dim3((unsigned)nf), dim3(256), 0, c->stream, Hc, ib, n, kp, stride, (float)pert, 4, 1.0e-5f, A, q, lam, ok);
+    CHK(allow_big_lds(c, reinterpret_cast<const void *>(&chol_solve_mfma_kernel), (int)CholMfma::LDS_BYTES));
+    hipLaunchKernelGGL(chol_solve_mfma_kernel, dim3((unsigned)nf), dim3(256), CholMfma::LDS_BYTES, c->stream, (const float *)A, (const float *)nullptr,
+                       (float *)nullptr, cert, n, kp, stride, 0.0f, nf, (const int *)nullptr, (const int *)nullptr, 1, 0, (float *)nullptr);
+    hipLaunchKernelGGL(rank1_compose_kernel, dim3((unsigned)((nf + 3) / 4)), dim3(256), 0, c->stream, ib, nf, n, kp, (float)pert, (const float *)q,
+                       (const float *)lam, (const int *)ok, (const int *)cert, grad, step, flags, sens_out, served);
+    HIPCHK(hipGetLastError());
+    unsigned long long ns = 0;
+    HIPCHK(hipMemcpyAsync(&ns, served, sizeof(ns), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->rank1_rows += (int64_t)ns;
+    if (ns * 4 < (unsigned long long)nf) c->r1_skip = 15;
+    return CMF_OK;
+}
+
 // the flagged matrices of a chunk through eig_clamp_solve (compacted list; one 4-byte read-back)
 static int eig_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, float *step, int *flags, int64_t nr, int n, int kp, double pert,
                                 float *sens_out = nullptr) {
@@ -448,10 +505,12 @@ static int safe_solve_rows(cmf_ctx *c, float *Hc, const float *grad, float *step
         if (bound_first) {
             CHK(ensure(c, c->eigcl_snap, (size_t)nr * sizeof(int)));
             HIPCHK(hipMemcpyAsync(c->eigcl_snap.p, flags, (size_t)nr * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+            if (rank1_clamp_ok(c, n, kp)) CHK(rank1_clamp_solve_rows(c, Hc, grad, step, flags, nr, n, kp, pert, condest));
             CHK(eig_clamp_solve_rows(c, Hc, grad, step, flags, nr, n, kp, pert, condest)); // (condest of a clamped row <- the solve's sensitivity)
             CHK(clamp_stats(c, Hc, (int *)c->eigcl_snap.p, nr, n, kp, stride, pert, refine, condest, step, Frows));
         } else {
             CHK(clamp_stats(c, Hc, flags, nr, n, kp, stride, pert, refine, condest, step));
+            if (rank1_clamp_ok(c, n, kp)) CHK(rank1_clamp_solve_rows(c, Hc, grad, step, flags, nr, n, kp, pert, nullptr));
             if (eig_clamp_ok(c, n, kp)) CHK(eig_clamp_solve_rows(c, Hc, grad, step, flags, nr, n, kp, pert));
         }
         // flagged matrices the eigen-solve did not serve (option, or its iteration gave up), k_pad = 128 / 256, Hessians positive

@@ -455,13 +455,17 @@ def test_c3_full_size_newton_sampled_rows_vs_fp64(lib, monkeypatch, x_link):
     ctx.close()
 
 
-def test_c3_full_size_in_the_clamp_regime_rows_vs_fp64(lib, monkeypatch):
+@pytest.mark.parametrize("done", [10, 13])
+def test_c3_full_size_in_the_clamp_regime_rows_vs_fp64(lib, monkeypatch, done):
     """BASELINE configs[2] at the reference's DEFAULT l2_reg = 0 (pycmf/cmf.py:622) where it actually lives: from
     iteration 7 on `_safe_invert`'s clamp (pycmf/cmf_solvers.py:346-356) acts on EVERY row of U and Z -- 255 of 256 eigenvalues
     of each Hessian below the perturbation (tools/r06_spectrum_probe.py).  Ten iterations on the device, then the sweeps of the
     eleventh one by one: 12 rows of each factor against the oracle's per-row float64 arithmetic on the lists the device drew, at
     the full-size tolerance (2e-3 of the factor's largest entry: float32 Hessians of ||H|| / pert = 1e4), the clamp asserted to
-    have acted on every row of the U and Z sweeps (in float32, or redone in float64 where the error bound asked for it)."""
+    have acted on every row of the U and Z sweeps (in float32, or redone in float64 where the error bound asked for it).
+    done = 10: the transition (the bulk of U's spectrum is crossing the threshold; most rows are redone in float64).  done = 13: the
+    steady state every later iteration runs in -- all rows of U and Z through the rank-one route (csrc/cmf_rank1clamp.hip.h),
+    asserted via `cmf_newton_clamp_routes`."""
     from oracle import cmf_oracle as O
     from threadpoolctl import threadpool_limits
     m, d, p, k = 32768, 16384, 8192, 256
@@ -469,10 +473,11 @@ def test_c3_full_size_in_the_clamp_regime_rows_vs_fp64(lib, monkeypatch):
     rng = np.random.RandomState(2)
     ctx = _synthetic(lib, m, d, p, k)
     ctx.fill_data_synthetic(1, 43, 0, 0, 1)
-    for it in range(10):
+    for it in range(done):
         ctx.newton_step_device_sampled(alpha, l1, l2, "linear", "logit", 0, 7, pert, ratio, 1000 + it)
     before = ctx.newton_clamp_stats(full=True)
-    seed = 1010
+    routes0 = ctx.newton_clamp_routes()
+    seed = 1000 + done
     limit = threadpool_limits(limits=1)
     U0, V0, Z0 = (ctx.get_factor(w) for w in range(3))
 
@@ -482,6 +487,9 @@ def test_c3_full_size_in_the_clamp_regime_rows_vs_fp64(lib, monkeypatch):
     ctx.newton_step_device_sampled(alpha, l1, l2, "linear", "logit", 0, lib.CMF_UPD_U, pert, ratio, seed)
     after_u = ctx.newton_clamp_stats(full=True)
     assert (after_u[0] - before[0]) + (after_u[2] - before[2]) == m, (before, after_u)     # every row of U: clamped (float32) or refined
+    routes_u = ctx.newton_clamp_routes()
+    if done == 13:
+        assert routes_u[1] - routes0[1] == m and routes_u[0] == routes0[0] and after_u[2] == before[2], (routes0, routes_u, before, after_u)
     U1 = ctx.get_factor(0)
     rows = _spread(m, 12, rng)
     lists = [ctx.sample_lists(0, seed, ratio, i, 1)[0] for i in rows]
@@ -497,6 +505,8 @@ def test_c3_full_size_in_the_clamp_regime_rows_vs_fp64(lib, monkeypatch):
     ctx.newton_step_device_sampled(alpha, l1, l2, "linear", "logit", 0, lib.CMF_UPD_Z, pert, ratio, seed)
     after_z = ctx.newton_clamp_stats(full=True)
     assert (after_z[0] - after_u[0]) + (after_z[2] - after_u[2]) == p, (after_u, after_z)
+    if done == 13:
+        assert ctx.newton_clamp_routes()[1] - routes_u[1] == p
     Z1 = ctx.get_factor(2)
     cols = _spread(p, 12, rng)
     lists = [ctx.sample_lists(1, seed, ratio, c, 1)[0] for c in cols]

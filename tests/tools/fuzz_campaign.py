@@ -21,13 +21,14 @@ from oracle import cmf_oracle as O          # noqa: E402  (test infrastructure: 
 from pycmf_amd import _lib                  # noqa: E402
 
 OPTIONS = {"row_classes": [-1, 0, 2, 3, 5], "row_certificates": [0, 1], "lowrank_rows": [0, 1, 2], "row_split": [0, 1],
-           "row_chunk": [0, 256, 512], "small_gram": [0, 1], "gemm_split": [0, 1, 3], "row_symmetric": [0, 1, 3],
+           "row_chunk": [0, 256, 512], "small_gram": [0, 1], "gemm_split": [0, 1, 3], "row_symmetric": [0, 1, 3, 4],
            "row_kernel": [0, 1], "direct_newton_step": [0, 1], "small_tile_update": [0, 1], "fused_mu_update": [0, 1],
            "split_reduce_in_kernel": [0, 1], "spmm_blocked": [0, 1], "newton_schulz": [0, 1], "safe_inverse_cholesky": [0, 1],
            "factor_times_tile": [64, 128, 256], "graph": [0, 1], "chol_mfma": [0, 1], "refine_rows_batched": [0, 1], "narrow_update": [0, 1],
            "side_gram": [0, 1], "pair_passes": [0, 1, 2],
            "nt_tile16": [0, 1], "nt_bn256": [0, 1], "nt_raster": [0, 1], "gemm64_tile128": [0, 1], "refine_spectral_map": [0, 1],   # round 5
-           "eig_clamp": [0, 1, 3], "refine_rows_tol_ppm": [0, 20, 1000], "spmm_split": [0, 1], "trace_error": [0, 1]}             # round 6
+           "eig_clamp": [0, 1, 3], "refine_rows_tol_ppm": [0, 20, 1000], "spmm_split": [0, 1], "trace_error": [0, 1],               # round 6
+           "rank1_clamp": [0, 1]}
 
 
 def log_int(rng, lo, hi):

@@ -29,7 +29,7 @@ for tag in ("fuzz_r06", "fuzz_r06_pair"):
     opts = collections.Counter()
     for r in cases:
         for n, v in r["case"]["options"].items():
-            if n in ("eig_clamp", "refine_rows_tol_ppm", "spmm_split", "trace_error", "refine_rows_batched", "chol_mfma", "newton_schulz"):
+            if n in ("eig_clamp", "refine_rows_tol_ppm", "spmm_split", "trace_error", "refine_rows_batched", "chol_mfma", "newton_schulz", "rank1_clamp", "row_symmetric"):
                 opts["%s=%d" % (n, v)] += 1
     worst = sorted(cases, key=lambda r: -(max(r["err"]) if "err" in r else 9e9))[:3]
     out[tag] = {"groups": groups, "option_draws": dict(opts), "bad_cases": [r for r in cases if r["bad"]][:10],
