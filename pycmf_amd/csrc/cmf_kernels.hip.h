@@ -117,6 +117,16 @@ struct GemmCfg {
 
 // v_exp_f32 + v_rcp_f32 (1 ulp each) instead of the IEEE division sequence (11 dependent VALU instructions)
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// sigmoid and its slope WITHOUT cancellation: a = exp(-|x|) in (0, 1], s(|x|) = 1 / (1 + a), s(x) = x >= 0 ? s(|x|) : a s(|x|),
+// s'(x) = s (1 - s) = a s(|x|)^2.  (The product s (1 - s) loses the slope altogether beyond |x| = 17 in float32: the Hessian weights of
+// saturated rows came out as exact zeros where float64 has 1e-8 -- times |Z|^2 = 1e4 over 600 rows that is an eigenvalue above
+// pert = 0.01: third campaign of profiles/fuzz_r06.md.)
+__device__ __forceinline__ float sigmoid_slope_(float x, float &slope) {
+    const float a = __expf(-fabsf(x));
+    const float sp = __builtin_amdgcn_rcpf(1.0f + a);
+    slope = a * sp * sp;
+    return x >= 0.f ? sp : a * sp;
+}
 
 // Sum over aligned groups of GS lanes (8, 16, 32 or 64); every lane of a group receives the sum.
 // Pure VALU: v_add_f32_dpp for the in-row steps, v_permlane16/32_swap for the row exchanges -- the
@@ -734,10 +744,14 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
                         float fv[C::TN];
 #pragma unroll
                         for (int j = 0; j < C::TN; ++j) fv[j] = acc[i0 + i][j][r];
+                        float sl[C::TN]; // the link's slope at fv (cancellation-free for the sigmoid: sigmoid_slope_)
                         if (__builtin_amdgcn_readfirstlane(g.link)) {
 #pragma unroll
-                            for (int j = 0; j < C::TN; ++j) fv[j] = sigmoidf_(fv[j]);
+                            for (int j = 0; j < C::TN; ++j) fv[j] = sigmoid_slope_(fv[j], sl[j]);
                             asm volatile("" ::: "memory"); // keep the branch: do not speculate the transcendentals into a select
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < C::TN; ++j) sl[j] = fv[j] * (1.0f - fv[j]);
                         }
 #pragma unroll
                         for (int j = 0; j < C::TN; ++j) {
@@ -746,7 +760,7 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
                             const float res = f - tv[i][r][j];
                             sq += mk * res * res;
                             if (Rp) Rp[rr * ldr + 32 * j] = g.scale_r * mk * res;
-                            if (Wp) Wp[rr * ldr + 32 * j] = g.scale_w * mk * (slope * (f * (1.0f - f)) + nslope);
+                            if (Wp) Wp[rr * ldr + 32 * j] = g.scale_w * mk * (slope * sl[j] + nslope);
                         }
                     }
             }
@@ -771,14 +785,15 @@ __global__ __launch_bounds__(512, TILE == 2 ? 4 : 2) void gemm_kernel(GemmArgs g
 #pragma unroll
                 for (int j = 0; j < C::TN; ++j) {
                     const float s = acc[i][j][r];
-                    const float f = g.link ? sigmoidf_(s) : s;
+                    float slope = 1.0f;
+                    const float f = g.link ? sigmoid_slope_(s, slope) : s;
                     float mk = (rr < rlim && 32 * j < clim) ? 1.0f : 0.0f;
                     mk *= (float)mv[r][j];
                     const float res = f - tv[r][j];
                     if (g.sq_out) sq += mk * res * res;
                     if (Rp) Rp[rr * ldr + 32 * j] = g.scale_r * mk * res;
                     if (Wp) {
-                        const float w = g.w_is_slope ? f * (1.0f - f) : 1.0f;
+                        const float w = g.w_is_slope ? (g.link ? slope : f * (1.0f - f)) : 1.0f;
                         Wp[rr * ldr + 32 * j] = g.scale_w * mk * w;
                     }
                 }

@@ -232,11 +232,12 @@ __global__ __launch_bounds__(512, CLS ? 4 : 2) void row_hess_kernel(RowHessArgs 
         for (int q = 0; q < C::CPT; ++q)
             z += u4[q][0] * rr[q][0] + u4[q][1] * rr[q][1] + u4[q][2] * rr[q][2] + u4[q][3] * rr[q][3];
         z = group_sum<C::LPR>(z);
-        const float sg = sigmoidf_(z);
+        float slope;
+        const float sg = sigmoid_slope_(z, slope);   // (the slope without the cancellation of s (1 - s): cmf_kernels.hip.h)
         const float f = lk * sg + nlk * z;
         const float valid = vv ? g.scale : 0.0f;
         const float res = valid * (f - tt);
-        const float wgt = valid * (lk * (f * (1.0f - f)) + nlk);
+        const float wgt = valid * (lk * slope + nlk);
         const float sqw = __builtin_amdgcn_sqrtf(fmaxf(wgt, 0.0f)); // SYM == 3 only (launched when the weights are non-negative)
 #pragma unroll
         for (int q = 0; q < C::CPT; ++q) {

@@ -81,11 +81,12 @@ __global__ __launch_bounds__(512, 2) void row_hess6_kernel(RowHessArgs g) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) z += u4[q][0] * rr[q][0] + u4[q][1] * rr[q][1] + u4[q][2] * rr[q][2] + u4[q][3] * rr[q][3];
         z = group_sum<16>(z);
-        const float sg = sigmoidf_(z);
+        float slope;
+        const float sg = sigmoid_slope_(z, slope);   // (the slope without the cancellation of s (1 - s): cmf_kernels.hip.h)
         const float f = lk * sg + nlk * z;
         const float valid = vv ? g.scale : 0.0f;
         const float res = valid * (f - tt);
-        const float wgt = valid * (lk * (f * (1.0f - f)) + nlk);
+        const float wgt = valid * (lk * slope + nlk);
         const float sqw = __builtin_amdgcn_sqrtf(fmaxf(wgt, 0.0f));
         unsigned short *base = r6l + buf * R6_STAGE + trow * R6_PITCH + 4 * tl16;
 #pragma unroll
