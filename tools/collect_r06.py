@@ -32,7 +32,7 @@ for w in (("c3", "c3r", "c3x") if C3_ONLY else ("c4", "c2", "c3", "c3r", "c3x", 
 for f_, t_ in (("c4_tol.json", "%s_c4_n1_tol_bench.json"), ("c4_notol40.json", "%s_c4_n1_bench_40_steps.json"),
                ("c3_norefine.json", "%s_c3_n1_bench_refine_rows_0.json"), ("c3_r05_clamp.json", "%s_c3_n1_bench_round5_clamp_path.json"),
                ("c3_no_early_exit.json", "%s_c3_n1_bench_no_early_exit.json"),
-               ("c3_rowsym3.json", "%s_c3_n1_bench_row_symmetric_3.json"), ("c3x_rowsym3.json", "%s_c3x_n1_bench_row_symmetric_3.json")):
+               ("c3_rowsym3.json", "%s_c3_n1_bench_row_symmetric_3.json"), ("c3_norank1.json", "%s_c3_n1_bench_rank1_clamp_0.json"), ("c3x_rowsym3.json", "%s_c3x_n1_bench_row_symmetric_3.json")):
     if C3_ONLY and not f_.startswith("c3"):
         continue
     copy(os.path.join(SRC, f_), os.path.join(DST, t_ % TAG))

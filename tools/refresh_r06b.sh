@@ -14,6 +14,7 @@ $B --workload c3 --steps 5 --warmup 3 --no-cpu-baseline --option refine_rows=0 >
 $B --workload c3 --steps 5 --warmup 3 --no-cpu-baseline --option eig_clamp=0 --option refine_rows_tol_ppm=0 > $O/c3_r05_clamp.json 2> $O/c3_r05_clamp.err < /dev/null
 $B --workload c3 --steps 5 --warmup 3 --no-cpu-baseline --option eig_clamp=3 > $O/c3_no_early_exit.json 2> $O/c3_no_early_exit.err < /dev/null
 $B --workload c3 --steps 5 --warmup 3 --no-cpu-baseline --option row_symmetric=3 > $O/c3_rowsym3.json 2> $O/c3_rowsym3.err < /dev/null
+$B --workload c3 --steps 5 --warmup 3 --no-cpu-baseline --option rank1_clamp=0 > $O/c3_norank1.json 2> $O/c3_norank1.err < /dev/null
 $B --workload c3r --steps 5 --warmup 3 --no-cpu-baseline > $O/c3r.json 2> $O/c3r.err < /dev/null
 $B --workload c3x --steps 5 --warmup 3 > $O/c3x.json 2> $O/c3x.err < /dev/null
 $B --workload c3x --steps 5 --warmup 3 --no-cpu-baseline --option row_symmetric=3 > $O/c3x_rowsym3.json 2> $O/c3x_rowsym3.err < /dev/null
