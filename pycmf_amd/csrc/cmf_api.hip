@@ -226,7 +226,6 @@ struct cmf_ctx {
     int64_t eig_clamp_rows = 0;           // matrices served by it since the context was created (tests / bench)
     DevBuf r1_ws;                         // rank-one clamp (cmf_rank1clamp.hip.h): top eigenvectors, eigenvalues, convergence / certificate flags
     int opt_rank1_clamp = 1;              // flagged PSD Hessians with ONE eigenvalue above the threshold: power iteration + Cholesky certificate (0: off)
-    int r1_skip = 0;                      // chunks to let pass after one where it served fewer than a quarter of the flagged rows
     int64_t rank1_rows = 0;               // matrices served by it since the context was created
     DevBuf g64a, g64b, gmix64, h64;       // float64 Grams / shared Hessian of the linear-link Newton sweeps (cmf_shared64.hip.h)
     DevBuf gslab64, w64, ns64;            // their split slabs, Cholesky workspaces + L^-1 image, Newton-Schulz images
@@ -969,7 +968,6 @@ extern "C" int cmf_set_option(cmf_ctx *c, const char *name, int64_t value) {
         c->opt_eig_clamp = (int)value;
     } else if (!strcmp(name, "rank1_clamp")) {
         c->opt_rank1_clamp = value != 0;
-        c->r1_skip = 0;
     } else if (!strcmp(name, "newton_schulz")) {
         c->opt_ns = value != 0;
     } else if (!strcmp(name, "chol_diag")) {

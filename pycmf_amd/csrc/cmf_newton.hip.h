@@ -395,18 +395,14 @@ static int ns_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, f
 }
 
 // The flagged matrices of a chunk whose spectrum is "one eigenvalue above the threshold, the rest below" (cmf_rank1clamp.hip.h): power
-// iteration, Cholesky certificate, closed-form step; a row that does not pass keeps its flag for the eigen-solve below.  Adaptive:
-// a chunk where fewer than a quarter of the flagged rows passed (mixed spectra: C3X, the transition iterations of C3) switches the
-// attempt off for the next 15 chunks -- a function of the iteration history only, so runs repeat bit for bit.
+// iteration, Cholesky certificate, closed-form step; a row that does not pass keeps its flag for the eigen-solve below.  Every decision
+// is per row (a matrix without a dominant eigenvalue leaves the power iteration after one sweep; C3X: 0.4 ms per 8192 rows), so the
+// route a row takes does not depend on the chunk or the rank it is served in; a chunk in which no row converged skips the certificate.
 static bool rank1_clamp_ok(const cmf_ctx *c, int n, int kp) {
     return c->opt_rank1_clamp && c->hess_psd && kp == 256 && n > 128 && c->opt_chol_mfma && !c->opt_choldiag && eig_clamp_ok(c, n, kp);
 }
 static int rank1_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad, float *step, int *flags, int64_t nr, int n, int kp, double pert,
                                   float *sens_out) {
-    if (c->r1_skip > 0) {
-        --c->r1_skip;
-        return CMF_OK;
-    }
     CHK(ensure(c, c->nsidx, (size_t)(nr + 1) * sizeof(int)));
     int *idx = (int *)c->nsidx.p, *count = idx + nr;
     HIPCHK(hipMemsetAsync(count, 0, sizeof(int), c->stream));
@@ -426,20 +422,24 @@ static int rank1_clamp_solve_rows(cmf_ctx *c, const float *Hc, const float *grad
     unsigned long long *served = (unsigned long long *)(((uintptr_t)(cert + nf) + 7) & ~(uintptr_t)7);
     HIPCHK(hipMemsetAsync(cert, 1, (size_t)nf * sizeof(int), c->stream)); // non-zero: not certified
     HIPCHK(hipMemsetAsync(served, 0, sizeof(unsigned long long), c->stream));
+    unsigned long long ns = 0;
     const int *ib = nf == nr ? (const int *)nullptr : (const int *)idx;
-    // four products: from the constant vector the iterate is converged after three when lambda_2 / lambda_1 < 1e-2; the fourth measures
-    hipLaunchKernelGGL(rank1_power_kernel, dim3((unsigned)nf), dim3(256), 0, c->stream, Hc, ib, n, kp, stride, (float)pert, 4, 1.0e-5f, A, q, lam, ok);
+    // three products: the start (a normalised row of H) is one step already, two more converge when lambda_2 / lambda_1 < 1e-2, the third measures
+    hipLaunchKernelGGL(rank1_power_kernel, dim3((unsigned)nf), dim3(256), 0, c->stream, Hc, ib, n, kp, stride, (float)pert, 3, 1.0e-5f, A, q, lam, ok, served);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&ns, served, sizeof(ns), hipMemcpyDeviceToHost, c->stream));   // how many converged
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (ns == 0) return CMF_OK;
+    HIPCHK(hipMemsetAsync(served, 0, sizeof(unsigned long long), c->stream));
     CHK(allow_big_lds(c, reinterpret_cast<const void *>(&chol_solve_mfma_kernel), (int)CholMfma::LDS_BYTES));
     hipLaunchKernelGGL(chol_solve_mfma_kernel, dim3((unsigned)nf), dim3(256), CholMfma::LDS_BYTES, c->stream, (const float *)A, (const float *)nullptr,
                        (float *)nullptr, cert, n, kp, stride, 0.0f, nf, (const int *)nullptr, (const int *)nullptr, 1, 0, (float *)nullptr);
     hipLaunchKernelGGL(rank1_compose_kernel, dim3((unsigned)((nf + 3) / 4)), dim3(256), 0, c->stream, ib, nf, n, kp, (float)pert, (const float *)q,
                        (const float *)lam, (const int *)ok, (const int *)cert, grad, step, flags, sens_out, served);
     HIPCHK(hipGetLastError());
-    unsigned long long ns = 0;
     HIPCHK(hipMemcpyAsync(&ns, served, sizeof(ns), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->rank1_rows += (int64_t)ns;
-    if (ns * 4 < (unsigned long long)nf) c->r1_skip = 15;
     return CMF_OK;
 }
 

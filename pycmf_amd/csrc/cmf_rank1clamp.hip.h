@@ -10,9 +10,10 @@
 // mode) says every other eigenvalue lies below theta = pert - delta, delta = 4 * 2^-23 lambda_1 (the margin the tridiagonal solver's
 // error bound uses, cmf_eigclamp.hip.h: a row whose spectrum comes closer to the threshold than float32 resolves is not served).
 // A row that fails either test (the iteration has not converged: a second large eigenvalue; the certificate does not hold) keeps
-// its flag and goes through the tridiagonal eigen-solve as before.  Per 8192 rows at n = 256: ~ 3.5 ms against 19.5.
+// its flag and goes through the tridiagonal eigen-solve as before.  Every decision is the row's own: the route a row takes does not
+// depend on the batch it arrives in (row-sharded runs stay bit-identical to single-device ones).  Per 8192 rows at n = 256: ~ 3.5 ms against 19.5.
 //
-//   rank1_power_kernel   one workgroup per flagged matrix: power iteration from the constant vector (thread t owns column t; H is
+//   rank1_power_kernel   one workgroup per flagged matrix: power iteration from the row of the largest diagonal entry (thread t owns column t; H is
 //                        symmetric, so the product is a coalesced sweep down the rows), Rayleigh quotient and residual of the
 //                        last product, then the image A = theta I - H + lambda q q^T for the certificate
 //   rank1_compose_kernel rows whose certificate holds: step = (g - (q.g) q) / pert + (q.g) q / max(lambda, pert), flag cleared
@@ -33,13 +34,37 @@ __device__ __forceinline__ float r1_block_sum(float v, float *red, int t) { // 2
 // H: [.. x kp x kp] (stride floats apart), idx: the matrices served (null: 0 .. nf - 1); A: [nf][kp * kp] images; q: [nf][kp];
 // lam: [nf]; ok: [nf] (1: converged; the certificate is still to come)
 __global__ __launch_bounds__(256) void rank1_power_kernel(const float *H, const int *idx, int n, int kp, int64_t stride, float pert, int passes,
-                                                          float res_tol, float *A, float *qout, float *lam, int *ok) {
+                                                          float res_tol, float *A, float *qout, float *lam, int *ok, unsigned long long *nok) {
     __shared__ float x[256];
     __shared__ float red[8];
     const int b = blockIdx.x, t = threadIdx.x;
     const float *Hm = H + (int64_t)(idx ? idx[b] : b) * stride;
     const bool live = t < n;
-    x[t] = live ? __builtin_amdgcn_rsqf((float)n) : 0.f;
+    // start: the row of the largest diagonal entry, normalised -- one power step from e_j taken for free (H e_j is a contiguous row),
+    // and q_j^2 is largest where H_jj ~ lambda_1 q_j^2 is
+    __shared__ int jstar;
+    {
+        float dv = live ? Hm[(int64_t)t * kp + t] : -1.0f;
+        int di = t;
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(dv, off, 64);
+            const int oi = __shfl_xor(di, off, 64);
+            if (ov > dv || (ov == dv && oi < di)) { dv = ov; di = oi; }
+        }
+        if ((t & 63) == 0) { red[t >> 6] = dv; red[4 + (t >> 6)] = __int_as_float(di); }
+        __syncthreads();
+        if (t == 0) {
+            float bv = red[0];
+            int bi = __float_as_int(red[4]);
+            for (int w = 1; w < 4; ++w)
+                if (red[w] > bv || (red[w] == bv && __float_as_int(red[4 + w]) < bi)) { bv = red[w]; bi = __float_as_int(red[4 + w]); }
+            jstar = bi;
+        }
+        __syncthreads();
+        const float h = live ? Hm[(int64_t)jstar * kp + t] : 0.f;
+        const float n2 = r1_block_sum(h * h, red, t);
+        x[t] = n2 > 0.f ? h / sqrtf(n2) : 0.f;
+    }
     float p = 0.f, lambda = 0.f, res2 = 0.f, xt = 0.f;
     for (int it = 0; it < passes; ++it) {
         __syncthreads();
@@ -58,6 +83,19 @@ __global__ __launch_bounds__(256) void rank1_power_kernel(const float *H, const 
         }
         p = (a0 + a1) + (a2 + a3);
         const float nrm2 = r1_block_sum(p * p, red, t);
+        if (it == 0 && passes > 1) {
+            // screening, per matrix (so that WHICH route serves a row never depends on what else is in the batch): after the one step
+            // the start already took (tan of e_j's angle to q: up to sqrt(n)) an eigenvalue dominant enough for the final test
+            // (lambda_2 / lambda_1 < 9e-3: three steps to 1e-5) leaves a relative residual ~ tan(angle) < 0.15; a spectrum without one
+            // (C3X: lambda_2 / lambda_1 > 0.1) leaves more than 1 -- that matrix stops here, one sweep in instead of five
+            const float l1 = r1_block_sum(xt * p, red, t);
+            const float d1 = p - l1 * xt;
+            const float r1 = r1_block_sum(d1 * d1, red, t);
+            if (!(l1 > 0.f) || r1 > 0.09f * l1 * l1) {
+                if (t == 0) { lam[b] = l1; ok[b] = 0; }
+                return;
+            }
+        }
         if (it + 1 < passes) {
             __syncthreads();
             x[t] = nrm2 > 0.f ? p / sqrtf(nrm2) : 0.f;
@@ -71,6 +109,7 @@ __global__ __launch_bounds__(256) void rank1_power_kernel(const float *H, const 
     if (t == 0) {
         lam[b] = lambda;
         ok[b] = good ? 1 : 0;
+        if (good) atomicAdd(nok, 1ull);
     }
     if (t < kp) qout[(int64_t)b * kp + t] = live ? xt : 0.f;
     if (!good) return; // (wave-uniform: every thread holds the same sums) -- no image, the certificate is skipped by ok[b] = 0
