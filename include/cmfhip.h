@@ -83,7 +83,12 @@ int cmf_sync(cmf_ctx *ctx);
  * captured hipGraph; automatically off while cmf_kernel_timing is enabled),
  * "gemm_arith" 0 (fp32 MFMA, default) | 1 (k_pad = 256 data passes on the bf16 matrix pipe: every fp32 operand
  * split exactly into three bf16 planes, six cross products, fp32 accumulation; planes stay resident),
- * "row_symmetric" 1 | 0 (k_pad = 256 row kernel: upper block triangle of H_i only),
+ * "row_symmetric" 4 (default) | 3 | 1 | 0 (k_pad = 256 row kernel: 0 every 32 x 32 block of H_i | 1 the blocks on or above the block
+ * diagonal, raw and weighted sample images | 3 ... from one sqrt-weighted image | 4 ... with the 8 diagonal blocks as three 16 x 16
+ * sub-blocks each),
+ * "eig_clamp" 1 (default) | 0 | 3, "rank1_clamp" 1 (default) | 0, "refine_rows_tol_ppm" 20 (default): how the rows flagged by the
+ * threshold test of _safe_invert (cmf_solvers.py:346-356) are served (cmf_newton_clamp_routes below) and which of them are redone
+ * in float64 (cmf_newton_clamp_stats below),
  * "shared_hessian_f64" 1 (default) | 0: the single Hessian of a linear-link sweep is accumulated (float64 Grams on
  * the float64 matrix pipe) and inverted in float64 | float32 Grams and float32 inverse,
  * "newton_schulz" 1 | 0 (k_pad = 256: rows whose eigenvalue clamp acts go through the GEMM-only

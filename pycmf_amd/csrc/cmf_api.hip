@@ -138,7 +138,7 @@ struct cmf_ctx {
     int opt_chol = 1;      // Cholesky fast path of the safe inverse (0: always Jacobi)
     int opt_chol_mfma = 1; // k_pad = 256 per-row solves: blocked Cholesky on the matrix pipe (0: the rank-1 register kernel chol_solve_kernel<16>)
     int opt_zlogit_l2 = 1;  // 0: Cython-twin numerics (Z's logit Hessian without l2 I, pyx:287-290)
-    int opt_rowdiag = 0;    // diagnostic builds of row_hess_kernel<256> (1: no staging, 2: stage only, 3: gather only)
+    int opt_rowdiag = 0;    // diagnostic builds of row_hess_kernel<256> (CMF_DIAG_BUILD; 1: no staging, 2: stage only, 3: gather only, 4-11: cmf_rowhess.hip.h / tools/r06_rowdiag.sh)
     int opt_rowsym = 4;     // row_hess_kernel<256>: 0 full blocks | 1 upper block triangle, raw + weighted images | 3 ... one sqrt-weighted image | 4 ... and 16-wide diagonal sub-blocks
     int opt_rowstagger = 1; // row_hess_kernel: waves 4-7 stage half a K-step after waves 0-3
     int opt_rowkernel = 1; // per-row Newton sweeps: fused gather kernel (1) or masked-dense GEMMs (0)
